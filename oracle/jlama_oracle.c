@@ -1,0 +1,882 @@
+/*
+ * jlama_oracle.c -- CPU restatement of the Jlama hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This file is the parity ORACLE for jlama-hip.  It is NOT part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product path (libjlamahip.so) never links, loads or calls anything in here.
+ *
+ * Every function cites the reference file:line it restates.  Path abbreviations:
+ *   core/  = jlama-core/src/main/java/com/github/tjake/jlama/
+ *   nc/    = jlama-native/src/main/c/
+ *   PTO    = core/tensor/operations/PanamaTensorOperations.java
+ *
+ * Which Panama variant: the AVX-512 one (vectorType == AVX_512, FloatVector.SPECIES_512 = 16
+ * float lanes), because that is what core/util/MachineSpec.java:45-64 selects on any
+ * AVX-512 host.  `reduceLanes(ADD)` order is unspecified by the Vector API; we use the
+ * halving tree HotSpot emits on x86 (512->256->128->64->32), see jo_reduce16().
+ *
+ * Third-party arithmetic that is NOT in /root/reference: net.jafama:jafama:2.3.2
+ * (FastMath.exp/sqrt/pow/cos/sin).  All call sites evaluate in double and cast to float,
+ * so libm's correctly-rounded-in-practice double functions reproduce the float result
+ * except for rare double-rounding cases.  Pinned only by the RoPE KAT
+ * (jlama-tests/.../model/TestCorrectness.java:92-115); exp/sqrt are "parity unpinned"
+ * beyond the logit tolerance.
+ *
+ * Build: see oracle/Makefile (-O2 -ffp-contract=off: Java never contracts a*b+c; every
+ * FMA below is an explicit fmaf() where the reference calls FloatVector.fma()).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define JO_BLOCK 32
+#define JO_HALF 16
+
+int jo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+static inline int jo_thread_id(void) {
+#ifdef _OPENMP
+    return omp_get_thread_num();
+#else
+    return 0;
+#endif
+}
+
+/* dtype tags shared with include/jlama_hip.h */
+enum { JO_DT_F32 = 0, JO_DT_BF16 = 1, JO_DT_I8 = 2, JO_DT_Q4 = 3 };
+
+/* ------------------------------------------------------------------------------------
+ * scalar helpers
+ * ---------------------------------------------------------------------------------- */
+
+/* Java (byte)(float): float->int saturating (NaN->0), then keep the low 8 bits (JLS 5.1.3). */
+static inline int8_t jo_f2b(float f) {
+    int32_t i;
+    if (f != f) i = 0;
+    else if (f >= 2147483648.0f) i = INT32_MAX;
+    else if (f <= -2147483648.0f) i = INT32_MIN;
+    else i = (int32_t)f; /* truncation toward zero */
+    return (int8_t)(uint8_t)(i & 0xff);
+}
+
+/* core/math/FloatConversions.java:31-33 */
+float jo_bf16_to_f32(uint16_t raw) {
+    uint32_t u = ((uint32_t)raw) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* core/math/FloatConversions.java:35-60 (+ round() :71-90): round-to-nearest-even on the
+ * 16 dropped mantissa bits; the carry may ripple into the exponent field. */
+uint16_t jo_f32_to_bf16(float n) {
+    uint32_t nbits;
+    memcpy(&nbits, &n, 4);
+    int s = (nbits >> 16) & 0x8000;
+    int e = (nbits >> 16) & 0x7f80;
+    int m = (nbits & 0x7fffff);
+    if (e != 0x7f80) {
+        int shifts = 16, mid = 1 << (shifts - 1), mask = (1 << shifts) - 1;
+        int mshift = m >> shifts, masked = m & mask, cmp = masked - mid, m1;
+        if (cmp > 0) m1 = mshift + 1;
+        else if (cmp < 0) m1 = mshift;
+        else m1 = (mshift & 1) ? mshift + 1 : mshift;
+        return (uint16_t)(s | (e + m1));
+    }
+    return m != 0 ? (uint16_t)0x7fc0 : (uint16_t)(nbits >> 16);
+}
+
+/* HotSpot x86 lowering of FloatVector.reduceLanes(ADD) for a 512-bit species:
+ * add upper 256 to lower 256, upper 128 to lower 128, then 64, then 32.  (Order is
+ * unspecified by the API: last-bit differences vs. a real JVM are inherent.) */
+static inline float jo_reduce16(const float* v) {
+    float a[8], b[4], c[2];
+    for (int i = 0; i < 8; i++) a[i] = v[i] + v[i + 8];
+    for (int i = 0; i < 4; i++) b[i] = a[i] + a[i + 4];
+    for (int i = 0; i < 2; i++) c[i] = b[i] + b[i + 2];
+    return c[0] + c[1];
+}
+
+/* ------------------------------------------------------------------------------------
+ * a1. Q4 weight format -- core/tensor/Q4ByteBufferTensor.java
+ * ---------------------------------------------------------------------------------- */
+
+/* processBlock, Q4ByteBufferTensor.java:66-106.  x: [rows, cols] F32 row-major.
+ * nib: rows*cols/2 bytes, byte j of a block: low nibble = elem j, high = elem j+16.
+ * scales: [rows, cols/32] F32 ("blockF", :41,140). */
+void jo_q4_quantize(const float* x, int64_t rows, int cols, uint8_t* nib, float* scales) {
+    int nb = cols / JO_BLOCK;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; r++) {
+        for (int b = 0; b < nb; b++) {
+            const float* xb = x + r * (int64_t)cols + (int64_t)b * JO_BLOCK;
+            float max = 1.4e-45f /* Float.MIN_VALUE */, amax = 1.4e-45f;
+            for (int i = 0; i < JO_BLOCK; i++) {
+                float v = xb[i];
+                float absv = v < 0 ? -v : v;
+                if (absv > amax) { max = v; amax = absv; }
+            }
+            float scale = max / -8.0f;
+            float iscale = scale != 0.0f ? 1.0f / scale : 0.0f;
+            scales[r * nb + b] = scale;
+            uint8_t* ob = nib + (r * (int64_t)cols + (int64_t)b * JO_BLOCK) / 2;
+            for (int j = 0; j < JO_HALF; j++) {
+                float f0 = xb[j] * iscale;
+                float f1 = xb[j + JO_HALF] * iscale;
+                int8_t t0 = jo_f2b(f0 + 8.5f), t1 = jo_f2b(f1 + 8.5f);
+                int8_t fb0 = t0 < 15 ? t0 : 15; /* (byte) Math.min(15, (byte)(..)) */
+                int8_t fb1 = t1 < 15 ? t1 : 15;
+                ob[j] = (uint8_t)((fb0) | ((fb1) << 4)); /* (byte)((fb0) | ((fb1) << 4)) */
+            }
+        }
+    }
+}
+
+/* get(), Q4ByteBufferTensor.java:179-197: value = (nibble - 8) * scale. */
+static inline float jo_q4_get(const uint8_t* nib_row, const float* scale_row, int c) {
+    int blk = c / JO_BLOCK, in = c % JO_BLOCK;
+    uint8_t b0 = in < JO_HALF ? nib_row[blk * JO_HALF + in] : nib_row[blk * JO_HALF + in - JO_HALF];
+    int x = in < JO_HALF ? (b0 & 0x0F) - 8 : ((b0 >> 4) & 0x0F) - 8;
+    return (float)x * scale_row[blk];
+}
+
+void jo_q4_dequantize(const uint8_t* nib, const float* scales, int64_t rows, int cols, float* out) {
+    int nb = cols / JO_BLOCK;
+    for (int64_t r = 0; r < rows; r++)
+        for (int c = 0; c < cols; c++)
+            out[r * cols + c] = jo_q4_get(nib + r * (cols / 2), scales + r * nb, c);
+}
+
+/* ------------------------------------------------------------------------------------
+ * a2. dynamic activation quantizer F32 -> I8, Panama AVX-512
+ *     PTO:1684-1723 (quantizeQ8_512).  NOT the scalar ctor (Q8ByteBufferTensor.java:67-88).
+ * ---------------------------------------------------------------------------------- */
+void jo_q8_quantize(const float* x, int rows, int ldx, int offset, int length, int8_t* q, int ldq,
+                    float* d, int ldd) {
+    for (int b = 0; b < rows; b++) {
+        for (int i = offset; i < offset + length; i += JO_BLOCK) {
+            const float* xb = x + (int64_t)b * ldx + i;
+            float maxScalar = 0.0f; /* abs() lanes, reduceLanes(MAX) */
+            for (int t = 0; t < JO_BLOCK; t++) {
+                float a = fabsf(xb[t]);
+                if (a > maxScalar) maxScalar = a;
+            }
+            float dd = maxScalar / 127.0f;
+            float id = (maxScalar != 0.0f) ? 127.0f / maxScalar : 0.0f;
+            for (int t = 0; t < JO_BLOCK; t++) {
+                float v = xb[t] * id;  /* fv.mul(vid) */
+                v = v + 0.5f;          /* .add(F32_ROUND_UP_512) */
+                q[(int64_t)b * ldq + i + t] = jo_f2b(v); /* F2B: truncation, NOT round-to-nearest */
+            }
+            d[(int64_t)b * ldd + i / JO_BLOCK] = dd;
+        }
+    }
+}
+
+/* F32 -> BF16 activation quantizer: PTO:1624-1628 returns new BFloat16BufferTensor(ft)
+ * = element-wise FloatConversions.float32ToBFloat16 (RNE). */
+void jo_bf16_quantize(const float* x, int64_t n, uint16_t* out) {
+    for (int64_t i = 0; i < n; i++) out[i] = jo_f32_to_bf16(x[i]);
+}
+
+/* ------------------------------------------------------------------------------------
+ * a3-a6. batchDotProduct.  Semantics (core/tensor/operations/TensorOperations.java:62-72,
+ * NaiveTensorOperations.java:79-100, PTO:95-146):
+ *   result[i, j + rRowOff'] = sum_k a[i, aColOff+k] * b[j, bColOff+k],  i in [0,M),
+ *   j in [bRowOff, bRowOff+N).  Panama writes column (j + rOffset), rOffset = rRowOffset
+ *   (PTO:145,227); the model only uses bRowOff==0 or rRowOff==0 where Naive agrees.
+ * All variants below take dense row-major operands + leading dimensions.
+ * ---------------------------------------------------------------------------------- */
+
+/* I8 x Q4 -> F32, GemmerI8Q4_512 1x1 tile PTO:807-850 (1x4 :852-955 and 2x2 :958-1043 do
+ * the same per-element arithmetic).  Lane t of 16 accumulates over blocks in ascending K:
+ *   acc_t = fma(sa*sb, (float)(short)(lo[t]*a[t] + hi[t]*a[t+16]), acc_t). */
+void jo_gemm_i8q4(const int8_t* a, const float* af, int lda, int ldaf, const uint8_t* b,
+                  const float* bf, int ldb_bytes, int ldbf, float* r, int ldc, int M, int aColOff,
+                  int bColOff, int K, int rRowOff, int bRowOff, int N) {
+#pragma omp parallel for schedule(static) if (N >= 512)
+    for (int j = bRowOff; j < bRowOff + N; j++) {
+        for (int i = 0; i < M; i++) {
+            float acc[16];
+            for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+            int ao = aColOff, bo = bColOff;
+            for (int l = 0; l < K; l += JO_BLOCK, ao += JO_BLOCK, bo += JO_BLOCK) {
+                float scale = af[(int64_t)i * ldaf + ao / JO_BLOCK] * bf[(int64_t)j * ldbf + bo / JO_BLOCK];
+                const int8_t* ap = a + (int64_t)i * lda + ao;
+                const uint8_t* bp = b + (int64_t)j * ldb_bytes + bo / 2;
+                for (int t = 0; t < 16; t++) {
+                    int16_t lo = (int16_t)((bp[t] & 0x0F) - 8);
+                    int16_t hi = (int16_t)(((bp[t] >> 4) & 0x0F) - 8);
+                    int16_t isum = (int16_t)(lo * ap[t] + hi * ap[t + 16]); /* |.| <= 2032: exact */
+                    acc[t] = fmaf(scale, (float)isum, acc[t]);
+                }
+            }
+            r[(int64_t)i * ldc + j + rRowOff] = jo_reduce16(acc);
+        }
+    }
+}
+
+/* F32 x Q4 -> F32, GemmerF32Q4_512 1x1 PTO:336-374: dequantize first w = float(nib-8)*scale,
+ * then acc = fma(a_lo, w_lo, acc); acc = fma(a_hi, w_hi, acc) per block, 16 lanes. */
+void jo_gemm_f32q4(const float* a, int lda, const uint8_t* b, const float* bf, int ldb_bytes,
+                   int ldbf, float* r, int ldc, int M, int aColOff, int bColOff, int K, int rRowOff,
+                   int bRowOff, int N) {
+#pragma omp parallel for schedule(static) if (N >= 512)
+    for (int j = bRowOff; j < bRowOff + N; j++) {
+        for (int i = 0; i < M; i++) {
+            float acc[16];
+            for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+            int ao = aColOff, bo = bColOff;
+            for (int l = 0; l < K; l += JO_BLOCK, ao += JO_BLOCK, bo += JO_BLOCK) {
+                float scale = bf[(int64_t)j * ldbf + bo / JO_BLOCK];
+                const float* ap = a + (int64_t)i * lda + ao;
+                const uint8_t* bp = b + (int64_t)j * ldb_bytes + bo / 2;
+                for (int t = 0; t < 16; t++) {
+                    float low = (float)((bp[t] & 0x0F) - 8) * scale;
+                    acc[t] = fmaf(ap[t], low, acc[t]);
+                }
+                for (int t = 0; t < 16; t++) {
+                    float high = (float)(((bp[t] >> 4) & 0x0F) - 8) * scale;
+                    acc[t] = fmaf(ap[t + 16], high, acc[t]);
+                }
+            }
+            r[(int64_t)i * ldc + j + rRowOff] = jo_reduce16(acc);
+        }
+    }
+}
+
+/* F32 x F32 -> F32, GemmerF32 1x1 PTO:1086-1102: 16 lanes, one fma per 16-element step. */
+void jo_gemm_f32(const float* a, int lda, const float* b, int ldb, float* r, int ldc, int M,
+                 int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+#pragma omp parallel for schedule(static) if (N >= 512)
+    for (int j = bRowOff; j < bRowOff + N; j++) {
+        for (int i = 0; i < M; i++) {
+            float acc[16];
+            for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+            const float* ap = a + (int64_t)i * lda + aColOff;
+            const float* bp = b + (int64_t)j * ldb + bColOff;
+            for (int l = 0; l < K; l += 16)
+                for (int t = 0; t < 16; t++) acc[t] = fmaf(ap[l + t], bp[l + t], acc[t]);
+            r[(int64_t)i * ldc + j + rRowOff] = jo_reduce16(acc);
+        }
+    }
+}
+
+/* BF16 x BF16 -> F32, GemmerBF16 1x1 PTO:1279-1311: per 32-element step lanes t<16 take
+ * elements t then t+16 (convertShape part 0 / part 1), both operands widened by <<16. */
+void jo_gemm_bf16(const uint16_t* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
+                  int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+#pragma omp parallel for schedule(static) if (N >= 512)
+    for (int j = bRowOff; j < bRowOff + N; j++) {
+        for (int i = 0; i < M; i++) {
+            float acc[16];
+            for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+            const uint16_t* ap = a + (int64_t)i * lda + aColOff;
+            const uint16_t* bp = b + (int64_t)j * ldb + bColOff;
+            for (int l = 0; l < K; l += 32) {
+                for (int t = 0; t < 16; t++)
+                    acc[t] = fmaf(jo_bf16_to_f32(ap[l + t]), jo_bf16_to_f32(bp[l + t]), acc[t]);
+                for (int t = 0; t < 16; t++)
+                    acc[t] = fmaf(jo_bf16_to_f32(ap[l + 16 + t]), jo_bf16_to_f32(bp[l + 16 + t]), acc[t]);
+            }
+            r[(int64_t)i * ldc + j + rRowOff] = jo_reduce16(acc);
+        }
+    }
+}
+
+/* F32 x BF16 -> F32, GemmerF32BF16 1x1 PTO:1511-1538. */
+void jo_gemm_f32bf16(const float* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
+                     int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+#pragma omp parallel for schedule(static) if (N >= 512)
+    for (int j = bRowOff; j < bRowOff + N; j++) {
+        for (int i = 0; i < M; i++) {
+            float acc[16];
+            for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+            const float* ap = a + (int64_t)i * lda + aColOff;
+            const uint16_t* bp = b + (int64_t)j * ldb + bColOff;
+            for (int l = 0; l < K; l += 32) {
+                for (int t = 0; t < 16; t++) acc[t] = fmaf(ap[l + t], jo_bf16_to_f32(bp[l + t]), acc[t]);
+                for (int t = 0; t < 16; t++)
+                    acc[t] = fmaf(ap[l + 16 + t], jo_bf16_to_f32(bp[l + 16 + t]), acc[t]);
+            }
+            r[(int64_t)i * ldc + j + rRowOff] = jo_reduce16(acc);
+        }
+    }
+}
+
+/* The control implementation, NaiveTensorOperations.java:61-100: float s += a.get()*b.get()
+ * sequentially over k with every operand dequantized through get().  adt/bdt in JO_DT_*. */
+static inline float jo_get_a(int adt, const void* a, const float* af, int lda, int ldaf, int i, int c) {
+    switch (adt) {
+        case JO_DT_F32: return ((const float*)a)[(int64_t)i * lda + c];
+        case JO_DT_BF16: return jo_bf16_to_f32(((const uint16_t*)a)[(int64_t)i * lda + c]);
+        case JO_DT_I8: /* Q8ByteBufferTensor.get :140-146: b * d */
+            return (float)((const int8_t*)a)[(int64_t)i * lda + c] * af[(int64_t)i * ldaf + c / JO_BLOCK];
+        default: return jo_q4_get((const uint8_t*)a + (int64_t)i * (lda / 2), af + (int64_t)i * ldaf, c);
+    }
+}
+void jo_gemm_naive(int adt, const void* a, const float* af, int lda, int ldaf, int bdt, const void* b,
+                   const float* bf, int ldb, int ldbf, float* r, int ldc, int M, int aColOff, int bColOff,
+                   int K, int rRowOff, int bRowOff, int N) {
+    for (int i = 0; i < M; i++)
+        for (int j = bRowOff, rr = rRowOff; j < bRowOff + N; j++, rr++) {
+            float s = 0;
+            for (int k = 0; k < K; k++)
+                s += jo_get_a(adt, a, af, lda, ldaf, i, aColOff + k) * jo_get_a(bdt, b, bf, ldb, ldbf, j, bColOff + k);
+            r[(int64_t)i * ldc + rr] = s;
+        }
+}
+
+/* ------------------------------------------------------------------------------------
+ * element-wise ops behind TensorOperations
+ * ---------------------------------------------------------------------------------- */
+/* accumulateF32 PTO:2281-2295 */
+void jo_accumulate_f32(float* a, const float* b, int offset, int length) {
+    for (int i = offset; i < offset + length; i++) a[i] = a[i] + b[i];
+}
+/* accumulateF32Q4_256 PTO:2297-2325: a[t] += (float)(nib-8) * scale (mul then add). */
+void jo_accumulate_f32q4(float* a, const uint8_t* nib_row, const float* scale_row, int offset, int length) {
+    for (int i = offset; i < offset + length; i++) a[i] = a[i] + jo_q4_get(nib_row, scale_row, i);
+}
+/* maccumulateF32 PTO:2083-2097 */
+void jo_maccumulate_f32(float* a, const float* b, int offset, int length) {
+    for (int i = offset; i < offset + length; i++) a[i] = a[i] * b[i];
+}
+/* scaleF32 PTO:2499-2514 */
+void jo_scale_f32(float factor, float* a, int offset, int length) {
+    for (int i = offset; i < offset + length; i++) a[i] = a[i] * factor;
+}
+/* saxpyF32 PTO:2593-2611: vector body is x.fma(alpha, y) (limit is a multiple of 16 on the path);
+ * scalar tail :2607-2610 is y + alpha*x (two roundings) for limit % 16 leftovers. */
+void jo_saxpy_f32(float alpha, const float* x, float* y, int xoffset, int yoffset, int limit) {
+    int ub = limit - (limit % 16);
+    int t = 0;
+    for (; t < ub; t++) y[yoffset + t] = fmaf(x[xoffset + t], alpha, y[yoffset + t]);
+    for (; t < limit; t++) y[yoffset + t] = y[yoffset + t] + (alpha * x[xoffset + t]);
+}
+/* batched saxpy PTO:2648-2698: 4 rows at a time chained fma, then singles; per element this
+ * is one fma chain over rows in ascending order. x: [rows, ldx]. */
+void jo_saxpy_batch_f32(const float* alpha, const float* x, int ldx, float* y, int xoffset, int yoffset,
+                        int limit, int aOffset, int xRowOffset, int batchSize) {
+    for (int n = 0; n < batchSize; n++)
+        jo_saxpy_f32(alpha[aOffset + n], x + (int64_t)(xRowOffset + n) * ldx, y, xoffset, yoffset, limit);
+}
+
+/* ------------------------------------------------------------------------------------
+ * a10. RMSNorm.forward -- core/model/RMSNorm.java:33-56
+ * ---------------------------------------------------------------------------------- */
+void jo_rmsnorm(const float* x, const float* w, float weight_adj, int E, float eps, float* out) {
+    double ss = 0.0;
+    for (int j = 0; j < E; j++) {
+        float v = x[j];
+        ss += v * v; /* float product, double accumulate */
+    }
+    ss /= E;
+    ss += eps; /* float eps widened */
+    ss = 1.0 / sqrt(ss); /* FastMath.sqrt */
+    for (int j = 0; j < E; j++) out[j] = (weight_adj + w[j]) * ((float)ss * x[j]);
+}
+
+/* ------------------------------------------------------------------------------------
+ * a8. RoPE table -- core/math/VectorMath.java:148-165 (precomputeFreqsCis)
+ * out: [end * dim/2][2] = (cos, sin)
+ * ---------------------------------------------------------------------------------- */
+void jo_rope_table(int dim, int end, double theta, double scaling, float* out) {
+    int half = dim / 2;
+    float* freqs = (float*)malloc(sizeof(float) * half);
+    float step = 0.0f;
+    for (int i = 0; i < half; i++, step = (float)(step + 2.0))
+        freqs[i] = (float)((1.0 / pow(theta, (double)(step / dim))) / scaling);
+    for (int p = 0; p < end; p++) {
+        float t = (float)p;
+        for (int i = 0; i < half; i++) {
+            float ang = t * freqs[i]; /* outerProduct: float product */
+            out[((int64_t)p * half + i) * 2 + 0] = (float)cos((double)ang);
+            out[((int64_t)p * half + i) * 2 + 1] = (float)sin((double)ang);
+        }
+    }
+    free(freqs);
+}
+
+/* softMax -- core/math/VectorMath.java:69-90 */
+void jo_softmax(float* x, int offset, int length) {
+    int size = offset + length;
+    float max_val = x[offset];
+    for (int i = offset + 1; i < size; i++)
+        if (x[i] > max_val) max_val = x[i];
+    float sum = 0.0f;
+    for (int i = offset; i < size; i++) {
+        x[i] = (float)exp((double)(x[i] - max_val));
+        sum += x[i];
+    }
+    for (int i = 0; i < size; i++) x[i] = x[i] / sum;
+}
+
+/* SiLU -- core/math/ActivationFunction.java:31: (float)(x * (1.0f / (1.0f + exp(-x)))), all in double */
+float jo_silu(float x) { return (float)((double)x * (1.0 / (1.0 + exp((double)(-x))))); }
+
+/* KV page geometry -- core/tensor/KvBufferCache.java:224-280 (computePageSize).
+ * s = 2 * sizeof(working dtype) * kvSegmentLength; returns layersPerPage, ctxPerPage. */
+void jo_kv_page_geometry(int64_t maxPageBytes, int nLayers, int contextLength, int kvLength, int dtypeSize,
+                         int* layersPerPage, int* ctxPerPage) {
+    int64_t s = 2LL * dtypeSize * kvLength;
+    int optL = 1, optC = 1;
+    int64_t maxProduct = 0;
+    for (int x = nLayers; x >= 1; x--) {
+        int64_t y = maxPageBytes / (x * s);
+        if (y >= 1 && y <= contextLength) {
+            int64_t product = x * y;
+            if (product > maxProduct) { optL = x; optC = (int)y; maxProduct = product; }
+            if (product < maxProduct) break;
+        }
+    }
+    *layersPerPage = optL;
+    *ctxPerPage = optC;
+}
+
+/* ------------------------------------------------------------------------------------
+ * a13/a14. whole-model forward in the reference's op order.
+ *   AbstractModel.forward core/model/AbstractModel.java:314-329
+ *   TransformerBlock.forward core/model/TransformerBlock.java:158-215
+ *   CausalSelfAttention.forward core/model/CausalSelfAttention.java:145-385 (GQA branch)
+ *   MLPBlock.forward core/model/MLPBlock.java:105-166
+ *   LlamaModel core/model/llama/LlamaModel.java:67-184 (embedding, maybeQuantize, lm head)
+ *   AbstractModel.sample core/model/AbstractModel.java:443-491
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t embedding_length, hidden_length, n_heads, n_kv_heads, head_size;
+    int32_t n_layers, vocab_size, context_length;
+    int32_t weight_dtype;     /* JO_DT_Q4 (JQ4: I8 activations) | JO_DT_BF16 (BF16 activations) | JO_DT_F32 */
+    int32_t layer_start, layer_end; /* DistributedContext.layerStart/End (core/model/DistributedContext.java:75-77) */
+    float rms_eps;
+    float rope_theta;
+    float rope_scaling;
+} jo_config;
+
+enum { JO_W_Q = 0, JO_W_K, JO_W_V, JO_W_O, JO_W_GATE, JO_W_UP, JO_W_DOWN, JO_W_NORM1, JO_W_NORM2,
+       JO_W_EMBED, JO_W_LMHEAD, JO_W_FINALNORM, JO_W_COUNT };
+
+typedef struct { int dtype; const void* data; const float* scales; int rows, cols; } jo_weight;
+
+/* optional reference GEMM entry points (oracle/_ref/libjlama_ref.so = nc/simd/vector_simd.c
+ * compiled as-is; signatures nc/simd/vector_simd.h:22,30) */
+typedef void (*jo_ref_q8q4_fn)(int, const float*, const char*, int, const float*, const char*, int, float*, int,
+                               int, int, int, int, int, int, int, int, int);
+typedef void (*jo_ref_f32q4_fn)(int, const float*, int, const float*, const char*, int, float*, int, int, int,
+                                int, int, int, int, int, int);
+
+typedef struct jo_model {
+    jo_config c;
+    jo_weight* layer_w; /* [n_layers][JO_W_COUNT] */
+    jo_weight global_w[JO_W_COUNT];
+    float* rope;        /* [context_length * head_size/2][2] */
+    float attention_scale;
+    jo_ref_q8q4_fn ref_q8q4;
+    jo_ref_f32q4_fn ref_f32q4;
+    int ref_flags;
+    int nthreads;       /* pchunk split for ref GEMMs (core/math/VectorMath.java:38-67) */
+} jo_model;
+
+typedef struct jo_session {
+    jo_model* m;
+    int layers_per_page, ctx_per_page, n_layer_pages, n_ctx_pages;
+    float** pages; /* [n_layer_pages * n_ctx_pages] lazily allocated, each [layersPerPage,2,ctxPerPage,kvLength] */
+    /* taps (DebugSupport names, core/model/TransformerBlock.java:165-205) */
+    int tap_layer;
+    float* taps[16];
+    int tap_len[16];
+} jo_session;
+
+jo_model* jo_model_create(const jo_config* cfg) {
+    jo_model* m = (jo_model*)calloc(1, sizeof(jo_model));
+    m->c = *cfg;
+    m->layer_w = (jo_weight*)calloc((size_t)cfg->n_layers * JO_W_COUNT, sizeof(jo_weight));
+    int half = cfg->head_size / 2;
+    m->rope = (float*)malloc(sizeof(float) * 2 * (size_t)cfg->context_length * half);
+    /* Config ctor core/safetensors/Config.java:270-274 */
+    jo_rope_table(cfg->head_size, cfg->context_length, (double)cfg->rope_theta, (double)cfg->rope_scaling, m->rope);
+    /* CausalSelfAttention.java:134 */
+    m->attention_scale = (float)(1.0 / sqrt((double)cfg->head_size));
+    m->nthreads = 1;
+    return m;
+}
+void jo_model_destroy(jo_model* m) {
+    if (!m) return;
+    free(m->layer_w);
+    free(m->rope);
+    free(m);
+}
+/* pointers are borrowed (caller keeps the arrays alive) */
+int jo_model_set_weight(jo_model* m, int layer, int which, int dtype, const void* data, const float* scales,
+                        int rows, int cols) {
+    if (which < 0 || which >= JO_W_COUNT) return -1;
+    jo_weight* w = layer < 0 ? &m->global_w[which] : &m->layer_w[(size_t)layer * JO_W_COUNT + which];
+    w->dtype = dtype; w->data = data; w->scales = scales; w->rows = rows; w->cols = cols;
+    return 0;
+}
+void jo_model_set_ref_gemm(jo_model* m, void* q8q4, void* f32q4, int flags, int nthreads) {
+    m->ref_q8q4 = (jo_ref_q8q4_fn)q8q4;
+    m->ref_f32q4 = (jo_ref_f32q4_fn)f32q4;
+    m->ref_flags = flags;
+    m->nthreads = nthreads > 0 ? nthreads : 1;
+}
+
+jo_session* jo_session_create(jo_model* m, int64_t max_page_bytes) {
+    jo_session* s = (jo_session*)calloc(1, sizeof(jo_session));
+    s->m = m;
+    int kvLength = m->c.n_kv_heads * m->c.head_size;
+    int nl = m->c.layer_end - m->c.layer_start;
+    jo_kv_page_geometry(max_page_bytes > 0 ? max_page_bytes : (1 << 23), nl, m->c.context_length, kvLength, 4,
+                        &s->layers_per_page, &s->ctx_per_page);
+    s->n_layer_pages = (nl + s->layers_per_page - 1) / s->layers_per_page;
+    s->n_ctx_pages = (m->c.context_length + s->ctx_per_page - 1) / s->ctx_per_page;
+    s->pages = (float**)calloc((size_t)s->n_layer_pages * s->n_ctx_pages, sizeof(float*));
+    s->tap_layer = -1;
+    return s;
+}
+void jo_session_destroy(jo_session* s) {
+    if (!s) return;
+    for (int i = 0; i < s->n_layer_pages * s->n_ctx_pages; i++) free(s->pages[i]);
+    free(s->pages);
+    for (int i = 0; i < 16; i++) free(s->taps[i]);
+    free(s);
+}
+void jo_session_page_info(jo_session* s, int* out4) {
+    out4[0] = s->layers_per_page; out4[1] = s->ctx_per_page; out4[2] = s->n_layer_pages; out4[3] = s->n_ctx_pages;
+}
+
+/* KvBuffer.getTensorForPosition core/tensor/KvBufferCache.java:307-321: row (layer, idx, pos) */
+static float* jo_kv_row(jo_session* s, int rel_layer, int idx, int pos) {
+    int kvLength = s->m->c.n_kv_heads * s->m->c.head_size;
+    int lp = rel_layer / s->layers_per_page, cp = pos / s->ctx_per_page;
+    int rl = rel_layer % s->layers_per_page, rc = pos % s->ctx_per_page;
+    float** slot = &s->pages[(size_t)lp * s->n_ctx_pages + cp];
+    if (!*slot) *slot = (float*)calloc((size_t)s->layers_per_page * 2 * s->ctx_per_page * kvLength, sizeof(float));
+    return *slot + (((size_t)rl * 2 + idx) * s->ctx_per_page + rc) * kvLength;
+}
+
+enum { JO_TAP_INPUT_EMB = 0, JO_TAP_LN_EMB, JO_TAP_QUERY, JO_TAP_KEY, JO_TAP_VALUE, JO_TAP_QUERY_ROPE,
+       JO_TAP_KEY_ROPE, JO_TAP_AFTER_ATTENTION, JO_TAP_POST_ATTN, JO_TAP_PRE_FF_NORM, JO_TAP_POST_FF,
+       JO_TAP_POST_FF_RES, JO_TAP_COUNT };
+
+static void jo_tap(jo_session* s, int layer, int which, const float* v, int n) {
+    if (layer != s->tap_layer) return;
+    s->taps[which] = (float*)realloc(s->taps[which], sizeof(float) * (size_t)n);
+    memcpy(s->taps[which], v, sizeof(float) * (size_t)n);
+    s->tap_len[which] = n;
+}
+void jo_session_set_tap_layer(jo_session* s, int layer) { s->tap_layer = layer; }
+int jo_session_get_tap(jo_session* s, int which, float* out, int n) {
+    if (which < 0 || which >= JO_TAP_COUNT || !s->taps[which]) return -1;
+    int m = s->tap_len[which] < n ? s->tap_len[which] : n;
+    memcpy(out, s->taps[which], sizeof(float) * (size_t)m);
+    return m;
+}
+
+/* working buffer of a quantized activation batch */
+typedef struct { int8_t* q; float* d; uint16_t* h; const float* f; int K; } jo_act;
+
+/* LlamaModel.maybeQuantize core/model/llama/LlamaModel.java:176-184 + dtype policy
+ * core/model/AbstractModel.java:119-169: Q4 model => I8, BF16 model => BF16, F32 => copy. */
+static void jo_maybe_quantize(jo_model* m, const float* x, int B, int K, jo_act* out) {
+    out->K = K; out->f = x; out->q = NULL; out->d = NULL; out->h = NULL;
+    if (m->c.weight_dtype == JO_DT_Q4) {
+        out->q = (int8_t*)malloc((size_t)B * K);
+        out->d = (float*)malloc(sizeof(float) * (size_t)B * (K / JO_BLOCK));
+        jo_q8_quantize(x, B, K, 0, K, out->q, K, out->d, K / JO_BLOCK);
+    } else if (m->c.weight_dtype == JO_DT_BF16) {
+        out->h = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)B * K);
+        jo_bf16_quantize(x, (int64_t)B * K, out->h);
+    }
+}
+static void jo_act_free(jo_act* a) { free(a->q); free(a->d); free(a->h); }
+
+/* dotProductChunk over the full N range of weight w, A columns [aColOff, aColOff+K) */
+static void jo_weight_gemm(jo_model* m, const jo_act* a, int B, const jo_weight* w, int colOff, int K,
+                           float* r, int ldc) {
+    int N = w->rows;
+    if (w->dtype == JO_DT_Q4 && a->q) {
+        if (m->ref_q8q4) {
+            /* CPU-baseline leg: reference C SIMD GEMM, N split into nthreads chunks like
+             * VectorMath.pchunk (core/math/VectorMath.java:38-67); marshaling as
+             * jlama-native/.../NativeSimdTensorOperations.java:96-107,204-223 */
+            int T = m->nthreads, chunk = N / T, rem = N % T;
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int t = 0; t < T; t++) {
+                int n0 = t * chunk, n = (t == T - 1) ? chunk + rem : chunk;
+                m->ref_q8q4(m->ref_flags, a->d, (const char*)a->q, colOff, w->scales, (const char*)w->data,
+                            colOff / 2, r, 0, B, n0, n, K, a->K, a->K / JO_BLOCK, w->cols / 2,
+                            w->cols / JO_BLOCK, ldc);
+            }
+        } else {
+            jo_gemm_i8q4(a->q, a->d, a->K, a->K / JO_BLOCK, (const uint8_t*)w->data, w->scales, w->cols / 2,
+                         w->cols / JO_BLOCK, r, ldc, B, colOff, colOff, K, 0, 0, N);
+        }
+    } else if (w->dtype == JO_DT_Q4) {
+        if (m->ref_f32q4) {
+            int T = m->nthreads, chunk = N / T, rem = N % T;
+#pragma omp parallel for schedule(static) num_threads(T)
+            for (int t = 0; t < T; t++) {
+                int n0 = t * chunk, n = (t == T - 1) ? chunk + rem : chunk;
+                m->ref_f32q4(m->ref_flags, a->f, colOff, w->scales, (const char*)w->data, colOff / 2, r, 0, B,
+                             n0, n, K, a->K, w->cols / 2, w->cols / JO_BLOCK, ldc);
+            }
+        } else {
+            jo_gemm_f32q4(a->f, a->K, (const uint8_t*)w->data, w->scales, w->cols / 2, w->cols / JO_BLOCK, r,
+                          ldc, B, colOff, colOff, K, 0, 0, N);
+        }
+    } else if (w->dtype == JO_DT_BF16 && a->h) {
+        jo_gemm_bf16(a->h, a->K, (const uint16_t*)w->data, w->cols, r, ldc, B, colOff, colOff, K, 0, 0, N);
+    } else if (w->dtype == JO_DT_BF16) {
+        jo_gemm_f32bf16(a->f, a->K, (const uint16_t*)w->data, w->cols, r, ldc, B, colOff, colOff, K, 0, 0, N);
+    } else {
+        jo_gemm_f32(a->f, a->K, (const float*)w->data, w->cols, r, ldc, B, colOff, colOff, K, 0, 0, N);
+    }
+}
+
+/* read a 1-D norm weight (BF16 or F32; never quantized: AbstractTensor.java:284) */
+static void jo_load_norm(const jo_weight* w, int E, float* out) {
+    for (int j = 0; j < E; j++)
+        out[j] = w->dtype == JO_DT_BF16 ? jo_bf16_to_f32(((const uint16_t*)w->data)[j]) : ((const float*)w->data)[j];
+}
+
+/* EmbedInput: LlamaModel.loadInputWeights core/model/llama/LlamaModel.java:67-98.  For a Q4
+ * table the row stays Q4 and every consumer reads (nib-8)*scale; BF16 widens by <<16. */
+static void jo_embed(jo_model* m, int token, float* out) {
+    const jo_weight* w = &m->global_w[JO_W_EMBED];
+    int E = m->c.embedding_length;
+    if (w->dtype == JO_DT_Q4) {
+        const uint8_t* nr = (const uint8_t*)w->data + (size_t)token * (E / 2);
+        const float* sr = w->scales + (size_t)token * (E / JO_BLOCK);
+        for (int j = 0; j < E; j++) out[j] = jo_q4_get(nr, sr, j);
+    } else if (w->dtype == JO_DT_BF16) {
+        for (int j = 0; j < E; j++) out[j] = jo_bf16_to_f32(((const uint16_t*)w->data)[(size_t)token * E + j]);
+    } else {
+        memcpy(out, (const float*)w->data + (size_t)token * E, sizeof(float) * E);
+    }
+}
+
+/* forward a batch of B rows through layers [layer_start, layer_end).  x: [B,E] in/out.
+ * If tokens != NULL the rows are first filled from the embedding table. */
+int jo_forward(jo_session* s, const int32_t* tokens, float* x, int B, int start_pos) {
+    jo_model* m = s->m;
+    const jo_config* c = &m->c;
+    int E = c->embedding_length, H = c->hidden_length, hs = c->head_size;
+    int A = c->n_heads * hs, KV = c->n_kv_heads * hs, half = hs / 2;
+    int group = c->n_heads / c->n_kv_heads;
+    if (tokens)
+        for (int b = 0; b < B; b++) jo_embed(m, tokens[b], x + (size_t)b * E);
+
+    float* ln = (float*)malloc(sizeof(float) * (size_t)B * E);
+    float* q = (float*)malloc(sizeof(float) * (size_t)B * A);
+    float* k = (float*)malloc(sizeof(float) * (size_t)B * KV);
+    float* v = (float*)malloc(sizeof(float) * (size_t)B * KV);
+    float* val = (float*)malloc(sizeof(float) * (size_t)B * A);
+    float* att_out = (float*)malloc(sizeof(float) * (size_t)B * E);
+    float* g = (float*)malloc(sizeof(float) * (size_t)B * H);
+    float* u = (float*)malloc(sizeof(float) * (size_t)B * H);
+    float* ff = (float*)malloc(sizeof(float) * (size_t)B * E);
+    float* nw = (float*)malloc(sizeof(float) * (size_t)E);
+    int max_ctx_alloc = ((start_pos + B) / s->ctx_per_page + 1) * s->ctx_per_page;
+    float* attn_all = (float*)malloc(sizeof(float) * (size_t)max_ctx_alloc * (size_t)jo_num_threads());
+
+    for (int li = c->layer_start; li < c->layer_end; li++) {
+        int rel = li - c->layer_start;
+        const jo_weight* W = &m->layer_w[(size_t)li * JO_W_COUNT];
+        jo_tap(s, li, JO_TAP_INPUT_EMB, x, B * E);
+        /* preAttentionNorm TransformerBlock.java:167 */
+        jo_load_norm(&W[JO_W_NORM1], E, nw);
+        for (int b = 0; b < B; b++) jo_rmsnorm(x + (size_t)b * E, nw, 0.0f, E, c->rms_eps, ln + (size_t)b * E);
+        jo_tap(s, li, JO_TAP_LN_EMB, ln, B * E);
+        jo_act qa;
+        jo_maybe_quantize(m, ln, B, E, &qa); /* :172 */
+        /* Q,K,V GEMMs CausalSelfAttention.java:161-171 */
+        jo_weight_gemm(m, &qa, B, &W[JO_W_Q], 0, E, q, A);
+        jo_weight_gemm(m, &qa, B, &W[JO_W_K], 0, E, k, KV);
+        jo_weight_gemm(m, &qa, B, &W[JO_W_V], 0, E, v, KV);
+        jo_act_free(&qa);
+        jo_tap(s, li, JO_TAP_QUERY, q, B * A);
+        jo_tap(s, li, JO_TAP_KEY, k, B * KV);
+        jo_tap(s, li, JO_TAP_VALUE, v, B * KV);
+        memset(val, 0, sizeof(float) * (size_t)B * A); /* TensorCache buffers are zeroed on release (TensorCache.java:104-111) */
+
+        for (int bi = 0, position = start_pos; bi < B; bi++, position++) {
+            float* key = jo_kv_row(s, rel, 0, position);
+            float* vrow = jo_kv_row(s, rel, 1, position);
+            memcpy(key, k + (size_t)bi * KV, sizeof(float) * KV);  /* :226-241 copyFrom (KV dtype == working dtype F32) */
+            memcpy(vrow, v + (size_t)bi * KV, sizeof(float) * KV);
+            float* query = q + (size_t)bi * A;
+            float* value = val + (size_t)bi * A;
+            /* RoPE :247-286 (GQA branch). table index poffset + g, g over kvHead*hs + [0,half)
+             * => effective position pos + 2*kvHead (quirk kept). */
+            int poffset = position * half;
+            for (int h = 0; h < c->n_heads; h++) {
+                int offset = h * hs, goffset = (h / group) * hs; /* Config.maybeMapToGroupHead */
+                for (int i = offset, gg = goffset; i < offset + half; i++, gg++) {
+                    float q0 = query[i], q1 = query[i + half];
+                    float fcr = m->rope[(size_t)(poffset + gg) * 2], fci = m->rope[(size_t)(poffset + gg) * 2 + 1];
+                    query[i] = q0 * fcr - q1 * fci;
+                    query[i + half] = q0 * fci + q1 * fcr;
+                }
+            }
+            for (int h = 0; h < c->n_kv_heads; h++) {
+                int offset = h * hs;
+                for (int i = offset; i < offset + half; i++) {
+                    float k0 = key[i], k1 = key[i + half];
+                    float fcr = m->rope[(size_t)(poffset + i) * 2], fci = m->rope[(size_t)(poffset + i) * 2 + 1];
+                    key[i] = k0 * fcr - k1 * fci;
+                    key[i + half] = k0 * fci + k1 * fcr;
+                }
+            }
+            if (bi == B - 1) {
+                jo_tap(s, li, JO_TAP_QUERY_ROPE, query, A);
+                jo_tap(s, li, JO_TAP_KEY_ROPE, key, KV);
+            }
+            /* attention per head :314-356 */
+            int npages = position / s->ctx_per_page + 1;
+            for (int pg = 0; pg < npages; pg++) { (void)jo_kv_row(s, rel, 0, pg * s->ctx_per_page); } /* materialise pages before the parallel loop */
+            /* VectorMath.pfor(headStart, headEnd, ...) core/math/VectorMath.java:34-36 */
+#pragma omp parallel for schedule(static) if (c->n_heads >= 8 && position >= 64)
+            for (int h = 0; h < c->n_heads; h++) {
+                float* attn = attn_all + (size_t)max_ctx_alloc * (size_t)jo_thread_id();
+                int xoffset = (h / group) * hs, yoffset = h * hs;
+                for (int pg = 0; pg < npages; pg++) {
+                    int len = s->ctx_per_page, off = pg * len;
+                    int size = pg == npages - 1 ? (position + 1) - off : len;
+                    float* kpage = jo_kv_row(s, rel, 0, off);
+                    /* batchDotProduct(attn, query, kvp[i], yoffset, xoffset, headSize, offset, 0, size) :328-329 */
+                    jo_gemm_f32(query, A, kpage, KV, attn, 0, 1, yoffset, xoffset, hs, off, 0, size);
+                }
+                jo_scale_f32(m->attention_scale, attn, 0, position + 1); /* :332 */
+                jo_softmax(attn, 0, position + 1);                      /* :345 */
+                for (int pg = 0; pg < npages; pg++) {
+                    int len = s->ctx_per_page, off = pg * len;
+                    int size = pg == npages - 1 ? (position + 1) - off : len;
+                    float* vpage = jo_kv_row(s, rel, 1, off);
+                    /* saxpy(attn, vvp[i], value, xoffset, yoffset, headSize, offset, 0, size) :349-354 */
+                    jo_saxpy_batch_f32(attn, vpage, KV, value, xoffset, yoffset, hs, off, 0, size);
+                }
+            }
+        }
+        jo_tap(s, li, JO_TAP_AFTER_ATTENTION, val, B * A);
+        /* O projection :363-376 */
+        jo_act va;
+        jo_maybe_quantize(m, val, B, A, &va);
+        jo_weight_gemm(m, &va, B, &W[JO_W_O], 0, A, att_out, E);
+        jo_act_free(&va);
+        jo_tap(s, li, JO_TAP_POST_ATTN, att_out, B * E);
+        /* residual TransformerBlock.java:185: lnattn += embedding */
+        for (int b = 0; b < B; b++) jo_accumulate_f32(att_out + (size_t)b * E, x + (size_t)b * E, 0, E);
+        /* preFFNorm :187 */
+        jo_load_norm(&W[JO_W_NORM2], E, nw);
+        for (int b = 0; b < B; b++) jo_rmsnorm(att_out + (size_t)b * E, nw, 0.0f, E, c->rms_eps, ln + (size_t)b * E);
+        jo_tap(s, li, JO_TAP_PRE_FF_NORM, ln, B * E);
+        jo_act fa;
+        jo_maybe_quantize(m, ln, B, E, &fa); /* :192 */
+        /* MLPBlock.forward MLPBlock.java:117-142 */
+        jo_weight_gemm(m, &fa, B, &W[JO_W_GATE], 0, E, g, H);
+        jo_weight_gemm(m, &fa, B, &W[JO_W_UP], 0, E, u, H);
+        jo_act_free(&fa);
+        for (size_t t = 0; t < (size_t)B * H; t++) g[t] = jo_silu(g[t]);
+        jo_maccumulate_f32(g, u, 0, B * H);
+        jo_act ha;
+        jo_maybe_quantize(m, g, B, H, &ha); /* :144 */
+        jo_weight_gemm(m, &ha, B, &W[JO_W_DOWN], 0, H, ff, E);
+        jo_act_free(&ha);
+        jo_tap(s, li, JO_TAP_POST_FF, ff, B * E);
+        /* residual TransformerBlock.java:203: lnpostFF += lnattn */
+        for (int b = 0; b < B; b++) jo_accumulate_f32(ff + (size_t)b * E, att_out + (size_t)b * E, 0, E);
+        jo_tap(s, li, JO_TAP_POST_FF_RES, ff, B * E);
+        memcpy(x, ff, sizeof(float) * (size_t)B * E);
+    }
+    free(ln); free(q); free(k); free(v); free(val); free(att_out); free(g); free(u); free(ff); free(nw); free(attn_all);
+    return 0;
+}
+
+/* AbstractModel.sample core/model/AbstractModel.java:443-491.  last_row: [E].  logits: [V] out. */
+int jo_sample(jo_model* m, const float* last_row, float temperature, float uniform, float* logits) {
+    const jo_config* c = &m->c;
+    int E = c->embedding_length, V = c->vocab_size;
+    float* nw = (float*)malloc(sizeof(float) * E);
+    float* emb = (float*)malloc(sizeof(float) * E);
+    jo_load_norm(&m->global_w[JO_W_FINALNORM], E, nw);
+    jo_rmsnorm(last_row, nw, 0.0f, E, c->rms_eps, emb);
+    /* LM head: the F32 normed row is NOT re-quantized (:443-449) => F32xQ4 / F32xBF16 / F32xF32 */
+    jo_act a = { NULL, NULL, NULL, emb, E };
+    const jo_weight* w = m->global_w[JO_W_LMHEAD].data ? &m->global_w[JO_W_LMHEAD] : &m->global_w[JO_W_EMBED];
+    jo_weight_gemm(m, &a, 1, w, 0, E, logits, V);
+    free(nw); free(emb);
+    int maxi = INT32_MIN;
+    double maxv = -INFINITY;
+    for (int i = 0; i < V; i++) {
+        float v = logits[i];
+        if (v > maxv) { maxi = i; maxv = v; }
+    }
+    if (temperature == 0.0f) return maxi;
+    float sum = 0;
+    for (int i = 0; i < V; i++) {
+        float v = (float)exp(((double)logits[i] - maxv) / (double)temperature);
+        sum += v;
+        logits[i] = v;
+    }
+    float acc = 0;
+    for (int i = 0; i < V; i++) {
+        float v = logits[i] / sum;
+        acc += v;
+        if (acc >= uniform) return i;
+    }
+    return V - 1;
+}
+
+/* AbstractModel.generate core/model/AbstractModel.java:515-646 at the token-id level:
+ * batchForward(prompt) in chunks of max_batch (jlama.max_batch_size=256, :57,:304) -> sample ->
+ * decode loop.  Writes n_gen token ids; returns number generated.  times_ms[0]=prompt,
+ * times_ms[1]=decode (clock starts after the first sampled token, :589). */
+int jo_generate(jo_session* s, const int32_t* prompt, int n_prompt, int n_gen, float temperature,
+                int32_t* out_tokens, float* logits_last, double* times_ms) {
+    jo_model* m = s->m;
+    int E = m->c.embedding_length, V = m->c.vocab_size;
+    const int MAXB = 256;
+    float* x = (float*)malloc(sizeof(float) * (size_t)MAXB * E);
+    float* logits = (float*)malloc(sizeof(float) * (size_t)V);
+    double t0 = 0, t1 = 0, t2 = 0;
+#ifdef _OPENMP
+    t0 = omp_get_wtime();
+#endif
+    int lastB = 0;
+    for (int i = 0; i < n_prompt; i += MAXB) {
+        int B = n_prompt - i < MAXB ? n_prompt - i : MAXB;
+        jo_forward(s, prompt + i, x, B, i);
+        lastB = B;
+    }
+    int next = jo_sample(m, x + (size_t)(lastB - 1) * E, temperature, 0.5f, logits);
+#ifdef _OPENMP
+    t1 = omp_get_wtime();
+#endif
+    int n = 0;
+    out_tokens[n++] = next;
+    for (int pos = n_prompt; n < n_gen; pos++) {
+        int32_t tok = next;
+        jo_forward(s, &tok, x, 1, pos);
+        next = jo_sample(m, x, temperature, 0.5f, logits);
+        out_tokens[n++] = next;
+    }
+#ifdef _OPENMP
+    t2 = omp_get_wtime();
+#endif
+    if (logits_last) memcpy(logits_last, logits, sizeof(float) * (size_t)V);
+    if (times_ms) { times_ms[0] = (t1 - t0) * 1e3; times_ms[1] = (t2 - t1) * 1e3; }
+    free(x); free(logits);
+    return n;
+}
+
