@@ -1,0 +1,247 @@
+/*
+ * jlama_hip.h -- C ABI of libjlamahip.so, the MI355X (gfx950) tensor backend for Jlama.
+ *
+ * Plain `extern "C"`: only int32/int64/float/pointer parameters, no structs by value, no
+ * callbacks -- bindable from Panama FFM (jextract), a JNI shim, cgo or ctypes alike.  The
+ * reference's own native providers are bound the same way
+ * (jlama-native/src/main/c/simd/jextract_vector_simd.sh:6-28,
+ *  jlama-native/src/main/java22/.../cnative/NativeSimd.java:117-189).
+ *
+ * Two tiers:
+ *   Tier 1 -- drop-in for the Java interface `TensorOperations`
+ *             (jlama-core/.../tensor/operations/TensorOperations.java:25-161).  Same offset /
+ *             stride conventions as the reference's C SIMD library
+ *             (jlama-native/src/main/c/simd/vector_simd.h:22-38) so a Java
+ *             `HipTensorOperations` can copy the marshaling of
+ *             jlama-native/.../NativeSimdTensorOperations.java:84-232.  Host pointers in, host
+ *             pointers out; weights may be pre-registered in HBM
+ *             (cf. NativeGPUTensorOperations.registerModelTensor :104-151, vector_gpu.h:11).
+ *   Tier 2 -- device-resident model/session: activations, paged KV and the decode loop stay
+ *             in HBM (what the metric is measured on).  Call order = TransformerBlock.forward
+ *             (jlama-core/.../model/TransformerBlock.java:158-215).
+ *
+ * Errors: every function returns 0 on success or a negative JH_ERR_* code; jh_last_error()
+ * gives the message for the calling thread.  Nothing aborts.  JH_ERR_UNSUPPORTED lets the
+ * Java wrapper throw UnsupportedOperationException exactly where Panama does
+ * (PanamaTensorOperations.java:125-142).
+ */
+#ifndef JLAMA_HIP_H
+#define JLAMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JH_OK 0
+#define JH_ERR_NO_DEVICE (-1)   /* constructor of the provider must throw => fallback (TensorOperationsProvider.java:50-87) */
+#define JH_ERR_OOM (-2)         /* registration failed => caller keeps the tensor on CPU (NativeGPUTensorOperations.java:111-150) */
+#define JH_ERR_UNSUPPORTED (-3) /* dtype pair / shape not supported */
+#define JH_ERR_INVALID (-4)     /* bad argument */
+#define JH_ERR_HIP (-5)         /* HIP runtime error; see jh_last_error() */
+
+/* DType tags (jlama-core/.../safetensors/DType.java:18-61 subset on the hot path) */
+#define JH_DT_F32 0
+#define JH_DT_BF16 1
+#define JH_DT_I8 2
+#define JH_DT_Q4 3
+
+/* ------------------------------------------------------------------ runtime / provider facts */
+
+/* Select `device` (HIP ordinal) for the calling thread's later calls and initialise the runtime.
+ * out_info (may be NULL): [0]=free HBM bytes, [1]=CU count, [2]=device count, [3]=LDS bytes/CU.
+ * Replaces init_gpu (jlama-native/src/main/c/gpu/vector_gpu.h:9). */
+int jh_init(int device, int64_t* out_info);
+/* TensorOperations.name() :28 */
+const char* jh_name(void);
+/* TensorOperations.parallelSplitSize() :30 -- 1: every GEMM arrives whole
+ * (NativeGPUTensorOperations.java:98-101). */
+int jh_parallel_split_size(void);
+/* TensorOperations.preferredWorkingQuantizedType() :32-34 -> JH_DT_I8 */
+int jh_preferred_working_qtype(void);
+const char* jh_last_error(void);
+/* Block until all work queued by this thread's stream has finished. */
+int jh_synchronize(void);
+
+/* ------------------------------------------------------------------ Tier 1: TensorOperations */
+
+/* registerModelTensor (TensorOperations.java:39; vector_gpu.h:11 register_tensor): copy a weight
+ * buffer (nibbles, scales, bf16 or f32 data -- raw bytes) to HBM once.  Returns id >= 0 or
+ * JH_ERR_OOM / JH_ERR_HIP.  The host buffer is not retained. */
+int64_t jh_register_tensor(const void* host, int64_t bytes);
+int jh_unregister_tensor(int64_t id);
+
+/* batchDotProduct, I8 activations x Q4 weights -> F32.  Replaces gemm_q8_q4
+ * (vector_simd.h:22).  Identical argument meaning:
+ *   r[ldc*i + j - roffset] = sum_blk af[ldaf*i + aoffset/32 + blk] * bf[ldbf*j + (boffset*2)/32 + blk]
+ *                            * sum_t a[lda*i + aoffset + 32*blk + t] * (nib(b[ldb*j + boffset + 16*blk], t) - 8)
+ *   for i in [0,m), j in [n0, n0+n).  aoffset in elements, boffset in BYTES of the nibble
+ *   buffer, ldb in bytes, ldaf/ldbf in floats (vector_simd.c:300-305,344).
+ * b_id/bf_id: ids from jh_register_tensor, or -1 to use the host pointers b/bf. */
+int jh_gemm_q8_q4(int64_t b_id, int64_t bf_id, const float* af, const int8_t* a, int aoffset, const float* bf,
+                  const uint8_t* b, int boffset, float* r, int roffset, int m, int n0, int n, int k, int lda,
+                  int ldaf, int ldb, int ldbf, int ldc);
+/* F32 x Q4 -> F32.  Replaces gemm_f32_q4 (vector_simd.h:30). */
+int jh_gemm_f32_q4(int64_t b_id, int64_t bf_id, const float* a, int aoffset, const float* bf, const uint8_t* b,
+                   int boffset, float* r, int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldbf,
+                   int ldc);
+/* F32 x F32 -> F32.  Replaces gemm_f32 (vector_simd.h:26). */
+int jh_gemm_f32(int64_t b_id, const float* a, int aoffset, const float* b, int boffset, float* r, int roffset,
+                int m, int n0, int n, int k, int lda, int ldb, int ldc);
+/* BF16 x BF16 -> F32 (r) -- replaces gemm_bf16 (vector_simd.h:34) with cr == NULL. */
+int jh_gemm_bf16(int64_t b_id, const uint16_t* a, int aoffset, const uint16_t* b, int boffset, float* r,
+                 int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldc);
+/* F32 x BF16 -> F32 -- replaces gemm_f32_bf16 (vector_simd.h:38) with cr == NULL. */
+int jh_gemm_f32_bf16(int64_t b_id, const float* a, int aoffset, const uint16_t* b, int boffset, float* r,
+                     int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldc);
+/* `_batch` forms (dotProductBatchChunk, TensorOperations.java:86-99; vector_simd.h:23,31): the same A against
+ * batch_num weight tensors, results into batch_num result buffers. */
+int jh_gemm_q8_q4_batch(int batch_num, const int64_t* b_ids, const int64_t* bf_ids, const float* af,
+                        const int8_t* a, int aoffset, const float* const* bf, const uint8_t* const* b, int boffset,
+                        float* const* r, int roffset, int m, int n0, int n, int k, int lda, int ldaf, int ldb,
+                        int ldbf, int ldc);
+int jh_gemm_f32_q4_batch(int batch_num, const int64_t* b_ids, const int64_t* bf_ids, const float* a, int aoffset,
+                         const float* const* bf, const uint8_t* const* b, int boffset, float* const* r, int roffset,
+                         int m, int n0, int n, int k, int lda, int ldb, int ldbf, int ldc);
+
+/* accumulate (TensorOperations.java:104): a[i] += b[i], i in [offset, offset+length).  F32 += F32
+ * (PanamaTensorOperations.java:2281-2295). */
+int jh_accumulate_f32(float* a, const float* b, int offset, int length);
+/* F32 += Q4 row (PanamaTensorOperations.java:2297-2325): a[i] += (nib-8)*scale.  nib/scales point at the row. */
+int jh_accumulate_f32_q4(float* a, const uint8_t* nib_row, const float* scale_row, int offset, int length);
+/* maccumulate (:109): a[i] *= b[i] */
+int jh_maccumulate_f32(float* a, const float* b, int offset, int length);
+/* scale (:140): a[i] *= factor */
+int jh_scale_f32(float factor, float* a, int offset, int length);
+/* saxpy (:114): y[yoffset+t] = fma(x[xoffset+t], alpha, y[yoffset+t]) */
+int jh_saxpy_f32(float alpha, const float* x, float* y, int xoffset, int yoffset, int limit);
+/* batched saxpy (:119-135, Panama :2648-2698): y += sum_n alpha[aoffset+n] * x[(xrowoffset+n)*ldx + xoffset ..],
+ * one fma chain per element over rows in ascending order. */
+int jh_saxpy_batch_f32(const float* alpha, const float* x, int ldx, float* y, int xoffset, int yoffset, int limit,
+                       int aoffset, int xrowoffset, int batch_size);
+/* quantize (:145-149) F32 -> I8 with the Panama-512 semantics (PanamaTensorOperations.java:1684-1723):
+ * d = max|x|/127, q = (int8) trunc(x*(127/max|x|) + 0.5f).  x: [rows, ldx]; columns [offset, offset+length). */
+int jh_quantize_q8(const float* x, int rows, int ldx, int offset, int length, int8_t* q, int ldq, float* d,
+                   int ldd);
+/* quantize F32 -> BF16, round-to-nearest-even (FloatConversions.java:35-60). */
+int jh_quantize_bf16(const float* x, int64_t n, uint16_t* out);
+
+/* Ops the reference keeps in scalar Java OUTSIDE TensorOperations; exported so a Java caller can stop
+ * bouncing activations (last bullet) and so each device kernel has a host-buffer parity hook. */
+/* RMSNorm.forward (jlama-core/.../model/RMSNorm.java:33-56).  w: F32 norm weights. */
+int jh_rmsnorm_f32(const float* x, const float* w, float weight_adj, int n, float eps, float* out);
+/* VectorMath.softMax (jlama-core/.../math/VectorMath.java:69-90) in place on x[offset, offset+length). */
+int jh_softmax_f32(float* x, int offset, int length);
+/* SiLU(x)*up (ActivationFunction.java:31 + MLPBlock.java:132-142): g[i] = silu(g[i]) * u[i]. */
+int jh_silu_mul_f32(float* g, const float* u, int n);
+/* VectorMath.precomputeFreqsCis (VectorMath.java:148-165): out [end*dim/2][2] = (cos, sin). Host-side. */
+int jh_rope_table(int dim, int end, double theta, double scaling, float* out);
+/* RoPE rotation of one q row [n_heads*head_size] and one k row [n_kv_heads*head_size] at `position`
+ * (CausalSelfAttention.java:247-286, GQA branch incl. the per-kv-head table offset). rope = jh_rope_table output. */
+int jh_rope_apply_f32(float* q, float* k, const float* rope, int position, int n_heads, int n_kv_heads,
+                      int head_size);
+/* KvBufferCache.computePageSize (jlama-core/.../tensor/KvBufferCache.java:224-280). out2 = {layersPerPage, ctxPerPage}. */
+int jh_kv_page_geometry(int64_t max_page_bytes, int n_layers, int context_length, int kv_length, int dtype_size,
+                        int32_t* out2);
+
+/* ------------------------------------------------------------------ Tier 2: resident model */
+
+typedef struct jh_model jh_model;
+typedef struct jh_session jh_session;
+
+/* Config fields the path needs (jlama-core/.../safetensors/Config.java:253-274, LlamaConfig.java:29-41,
+ * DistributedContext.java:75-77).  Passed by pointer. */
+typedef struct jh_config {
+    int32_t embedding_length; /* E */
+    int32_t hidden_length;    /* H */
+    int32_t n_heads, n_kv_heads, head_size;
+    int32_t n_layers;         /* total layers of the model */
+    int32_t vocab_size;
+    int32_t context_length;
+    int32_t weight_dtype;     /* JH_DT_Q4 => I8 activations; JH_DT_BF16 => BF16 activations (AbstractModel.java:119-169) */
+    int32_t layer_start, layer_end; /* this shard's layers [start,end) */
+    float rms_eps;
+    float rope_theta;
+    float rope_scaling;
+} jh_config;
+
+/* weight slots (LlamaModel.java:102-147,152-173) */
+#define JH_W_Q 0
+#define JH_W_K 1
+#define JH_W_V 2
+#define JH_W_O 3
+#define JH_W_GATE 4
+#define JH_W_UP 5
+#define JH_W_DOWN 6
+#define JH_W_NORM1 7      /* input_layernorm */
+#define JH_W_NORM2 8      /* post_attention_layernorm */
+#define JH_W_EMBED 9      /* model.embed_tokens (layer = -1) */
+#define JH_W_LMHEAD 10    /* lm_head (layer = -1); absent => tied to EMBED (LlamaModel.java:155-158) */
+#define JH_W_FINALNORM 11 /* model.norm (layer = -1) */
+#define JH_W_COUNT 12
+
+/* tap ids = DebugSupport.debug names (TransformerBlock.java:165-205, CausalSelfAttention.java:194-196,309-310,359) */
+#define JH_TAP_INPUT_EMB 0
+#define JH_TAP_QUERY 2
+#define JH_TAP_KEY 3
+#define JH_TAP_VALUE 4
+#define JH_TAP_QUERY_ROPE 5
+#define JH_TAP_KEY_ROPE 6
+#define JH_TAP_AFTER_ATTENTION 7
+#define JH_TAP_ATTN_RES 8        /* post_attn + residual (TransformerBlock.java:185) */
+#define JH_TAP_FF_H 10           /* silu(gate)*up (MLPBlock.java:132-142) */
+#define JH_TAP_POST_FF_RES 11
+
+int jh_model_create(const jh_config* cfg, jh_model** out);
+int jh_model_destroy(jh_model* m);
+/* Upload one weight.  data/scales are HOST pointers unless from_device != 0 (then device pointers, copied
+ * device-to-device).  Q4: data = nibbles [rows, cols/2] bytes, scales = F32 [rows, cols/32] (the JQ4 layout:
+ * `<name>` + `<name>.qb`, Weights.java:159-171).  Norm weights: F32 or BF16 [1, cols], scales NULL. */
+int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void* data, const float* scales,
+                        int rows, int cols, int from_device);
+/* Bytes of weights resident in HBM (for the roofline's algorithmic-bytes accounting). */
+int64_t jh_model_weight_bytes(jh_model* m);
+
+/* One KV buffer (KvBufferCache.getKvBuffer, KvBufferCache.java:58-60): pages of max_page_bytes (0 => 8 MiB)
+ * shaped [layersPerPage, 2, ctxPerPage, kvLength] F32, enough pages for positions [0, max_ctx). */
+int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_session** out);
+int jh_session_destroy(jh_session* s);
+/* out4 = {layersPerPage, ctxPerPage, nLayerPages, nCtxPages} */
+int jh_session_page_info(jh_session* s, int32_t* out4);
+
+/* batchForward (AbstractModel.java:295-312): run rows through this shard's layers at positions
+ * [start_pos, start_pos+n).  tokens != NULL: rows come from the embedding table (first shard);
+ * else x_in (HOST, [n,E] F32) is the previous shard's output.  x_out (HOST [n,E], may be NULL) receives the
+ * shard output ("PassRecord.tensor", jlama-net/.../Worker.java:193-196). */
+int jh_forward(jh_session* s, const int32_t* tokens, const float* x_in, int n, int start_pos, float* x_out);
+/* Same with DEVICE activations (layer-sharded pipelines hand HBM buffers to RCCL send/recv directly). */
+int jh_forward_device(jh_session* s, const int32_t* tokens, const float* x_in_dev, int n, int start_pos,
+                      float* x_out_dev);
+/* AbstractModel.sample (AbstractModel.java:443-491) on the last forwarded row: final norm -> LM head -> argmax
+ * (temperature 0) or softmax-sample with the caller's uniform u.  logits_out (HOST [V]) may be NULL. */
+int jh_sample(jh_session* s, float temperature, float u, int32_t* next_token, float* logits_out);
+/* One decode iteration of AbstractModel.generate (:590-621): forward(token,pos) + sample at T=0. */
+int jh_decode_step(jh_session* s, int32_t token, int pos, int32_t* next_token);
+/* n greedy decode iterations chained on the device (argmax feeds the next embedding lookup without a host
+ * round trip; one hipGraph replay per token).  out_tokens: HOST [n].  Timing region of the metric. */
+int jh_decode_n(jh_session* s, int32_t first_token, int start_pos, int n, int32_t* out_tokens);
+/* Same, but returns after queueing; jh_decode_wait() fetches the tokens.  Lets a caller bracket the loop with
+ * its own device events. */
+int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n);
+int jh_decode_wait(jh_session* s, int32_t* out_tokens, int n);
+/* Logits of the last jh_sample/jh_decode_step, HOST [V]. */
+int jh_get_logits(jh_session* s, float* out_v);
+/* Stage taps: record the named intermediate of `layer` during the next jh_forward of ONE row. */
+int jh_set_tap_layer(jh_session* s, int layer);
+int jh_get_tap(jh_session* s, int which, float* out, int n);
+/* The HIP stream the session launches on (hipStream_t as void*), so callers can record their own events. */
+void* jh_session_stream(jh_session* s);
+/* Average duration (ms) of the decode graph replays timed with hipEvents inside the last jh_decode_n, and the
+ * number of kernels per replay. */
+int jh_decode_stats(jh_session* s, double* ms_per_token, int32_t* kernels_per_token);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JLAMA_HIP_H */

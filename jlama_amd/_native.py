@@ -1,0 +1,140 @@
+"""Loader / builder of libjlamahip.so and its ctypes prototypes (include/jlama_hip.h)."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "lib", "libjlamahip.so")
+SRC = os.path.join(HERE, "csrc", "jlama_hip.hip")
+HDRS = [os.path.join(HERE, "csrc", "jh_kernels.h"), os.path.join(ROOT, "include", "jlama_hip.h")]
+
+JH_OK, JH_ERR_NO_DEVICE, JH_ERR_OOM, JH_ERR_UNSUPPORTED, JH_ERR_INVALID, JH_ERR_HIP = 0, -1, -2, -3, -4, -5
+DT_F32, DT_BF16, DT_I8, DT_Q4 = 0, 1, 2, 3
+(W_Q, W_K, W_V, W_O, W_GATE, W_UP, W_DOWN, W_NORM1, W_NORM2, W_EMBED, W_LMHEAD, W_FINALNORM) = range(12)
+TAP = {"input_emb": 0, "query": 2, "key": 3, "value": 4, "query+rope": 5, "key+rope": 6, "after_attention": 7,
+       "attn_res": 8, "ff_h": 10, "post_ff_res": 11}
+
+
+class JhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"jlama-hip error {code}: {msg}")
+        self.code = code
+
+
+class UnsupportedOperation(JhError):
+    """Mirror of Java's UnsupportedOperationException for unsupported dtype pairs."""
+
+
+class Config(C.Structure):
+    _fields_ = [("embedding_length", C.c_int32), ("hidden_length", C.c_int32), ("n_heads", C.c_int32),
+                ("n_kv_heads", C.c_int32), ("head_size", C.c_int32), ("n_layers", C.c_int32),
+                ("vocab_size", C.c_int32), ("context_length", C.c_int32), ("weight_dtype", C.c_int32),
+                ("layer_start", C.c_int32), ("layer_end", C.c_int32), ("rms_eps", C.c_float),
+                ("rope_theta", C.c_float), ("rope_scaling", C.c_float)]
+
+
+def build(force=False, verbose=False):
+    """Compile libjlamahip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    newest = max(os.path.getmtime(p) for p in [SRC] + HDRS)
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-Wno-unused-value", SRC, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+_i, _l, _f, _d, _p = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p
+_PROTOS = {
+    "jh_init": (_i, [_i, _p]),
+    "jh_name": (C.c_char_p, []),
+    "jh_parallel_split_size": (_i, []),
+    "jh_preferred_working_qtype": (_i, []),
+    "jh_last_error": (C.c_char_p, []),
+    "jh_synchronize": (_i, []),
+    "jh_register_tensor": (_l, [_p, _l]),
+    "jh_unregister_tensor": (_i, [_l]),
+    "jh_gemm_q8_q4": (_i, [_l, _l, _p, _p, _i, _p, _p, _i, _p, _i] + [_i] * 9),
+    "jh_gemm_f32_q4": (_i, [_l, _l, _p, _i, _p, _p, _i, _p, _i] + [_i] * 8),
+    "jh_gemm_f32": (_i, [_l, _p, _i, _p, _i, _p, _i] + [_i] * 7),
+    "jh_gemm_bf16": (_i, [_l, _p, _i, _p, _i, _p, _i] + [_i] * 7),
+    "jh_gemm_f32_bf16": (_i, [_l, _p, _i, _p, _i, _p, _i] + [_i] * 7),
+    "jh_gemm_q8_q4_batch": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i] + [_i] * 9),
+    "jh_gemm_f32_q4_batch": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _p, _i] + [_i] * 8),
+    "jh_accumulate_f32": (_i, [_p, _p, _i, _i]),
+    "jh_accumulate_f32_q4": (_i, [_p, _p, _p, _i, _i]),
+    "jh_maccumulate_f32": (_i, [_p, _p, _i, _i]),
+    "jh_scale_f32": (_i, [_f, _p, _i, _i]),
+    "jh_saxpy_f32": (_i, [_f, _p, _p, _i, _i, _i]),
+    "jh_saxpy_batch_f32": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
+    "jh_quantize_q8": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i]),
+    "jh_quantize_bf16": (_i, [_p, _l, _p]),
+    "jh_rmsnorm_f32": (_i, [_p, _p, _f, _i, _f, _p]),
+    "jh_softmax_f32": (_i, [_p, _i, _i]),
+    "jh_silu_mul_f32": (_i, [_p, _p, _i]),
+    "jh_rope_table": (_i, [_i, _i, _d, _d, _p]),
+    "jh_rope_apply_f32": (_i, [_p, _p, _p, _i, _i, _i, _i]),
+    "jh_kv_page_geometry": (_i, [_l, _i, _i, _i, _i, _p]),
+    "jh_model_create": (_i, [_p, _p]),
+    "jh_model_destroy": (_i, [_p]),
+    "jh_model_set_weight": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _i]),
+    "jh_model_weight_bytes": (_l, [_p]),
+    "jh_session_create": (_i, [_p, _i, _l, _p]),
+    "jh_session_destroy": (_i, [_p]),
+    "jh_session_page_info": (_i, [_p, _p]),
+    "jh_forward": (_i, [_p, _p, _p, _i, _i, _p]),
+    "jh_forward_device": (_i, [_p, _p, _p, _i, _i, _p]),
+    "jh_sample": (_i, [_p, _f, _f, _p, _p]),
+    "jh_decode_step": (_i, [_p, _i, _i, _p]),
+    "jh_decode_n": (_i, [_p, _i, _i, _i, _p]),
+    "jh_decode_n_async": (_i, [_p, _i, _i, _i]),
+    "jh_decode_wait": (_i, [_p, _p, _i]),
+    "jh_get_logits": (_i, [_p, _p]),
+    "jh_set_tap_layer": (_i, [_p, _i]),
+    "jh_get_tap": (_i, [_p, _i, _p, _i]),
+    "jh_session_stream": (_p, [_p]),
+    "jh_decode_stats": (_i, [_p, _p, _p]),
+}
+EXPORTS = sorted(_PROTOS)
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) if it is missing or cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc is not None and rc < 0:
+        msg = lib().jh_last_error().decode(errors="replace")
+        if rc == JH_ERR_UNSUPPORTED:
+            raise UnsupportedOperation(rc, msg)
+        raise JhError(rc, msg)
+    return rc
+
+
+def ptr(a):
+    """void* of a numpy array (or None)."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def init(device=0):
+    info = (C.c_int64 * 4)()
+    check(lib().jh_init(device, info))
+    return {"free_bytes": info[0], "cu_count": info[1], "device_count": info[2], "lds_bytes": info[3]}

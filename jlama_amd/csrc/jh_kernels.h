@@ -1,0 +1,1055 @@
+// jh_kernels.h -- hand-written CDNA4 (gfx950, wave64) kernels for the Jlama decode hot path.
+//
+// What each kernel computes is fixed by the reference (file:line cited per kernel; abbreviations as in
+// core/ = jlama-core/src/main/java/com/github/tjake/jlama/, PTO =
+// core/tensor/operations/PanamaTensorOperations.java).  HOW it is computed is MI355X-first:
+//   * Q4 weights are streamed exactly once per token with 16-byte-per-lane coalesced loads (one Q4 block of 32
+//     weights per lane, 1 KiB per wave instruction), never staged through LDS (GEMV: LDS round trip is pure
+//     overhead, cdna_hip_programming.md "glds vs register staging" table);
+//   * the I8 activation row is quantized ONCE per workgroup into LDS (fused RMSNorm+Q8 prologue) and then
+//     held in registers by the lane that owns the matching K blocks;
+//   * block sums are exact integers (v_dot4_i32_i8), the -8 nibble bias is folded in as -8*sum(a_block);
+//   * the K reduction is a wave64 butterfly (__shfl_xor), epilogues (residual add, SiLU*up+Q8) are fused.
+// Compiled with -ffp-contract=off: every FMA is explicit (fmaf) where the reference calls FloatVector.fma().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jh {
+
+constexpr int QB = 32;  // Q4/Q8 block size (Q4ByteBufferTensor.java:36, Q8ByteBufferTensor.java:39)
+using i32x4 = int __attribute__((ext_vector_type(4)));
+using i32x2 = int __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// FloatConversions.float32ToBFloat16 (core/math/FloatConversions.java:35-60): RNE incl. carry into exponent
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t nbits = __float_as_uint(f);
+    uint32_t s = (nbits >> 16) & 0x8000u, e = (nbits >> 16) & 0x7f80u, m = nbits & 0x7fffffu;
+    if (e != 0x7f80u) {
+        uint32_t mshift = m >> 16, masked = m & 0xffffu, m1;
+        if (masked > 0x8000u) m1 = mshift + 1;
+        else if (masked < 0x8000u) m1 = mshift;
+        else m1 = (mshift & 1u) ? mshift + 1 : mshift;
+        return (uint16_t)(s | (e + m1));
+    }
+    return m != 0 ? (uint16_t)0x7fc0 : (uint16_t)(nbits >> 16);
+}
+
+// Java (byte)(float) on the quantizer's value range: truncate toward zero, keep low 8 bits (PTO:1705-1710 F2B)
+__device__ __forceinline__ int f2b(float v) { return ((int)v) & 0xff; }
+
+// SiLU exactly as ActivationFunction.java:31: (float)(x * (1.0f / (1.0f + exp(-x)))) evaluated in double
+__device__ __forceinline__ float silu_ref(float x) {
+    double dx = (double)x;
+    return (float)(dx * (1.0 / (1.0 + exp(-dx))));
+}
+
+__device__ __forceinline__ int sdot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+
+// exact integer dot of one Q4 block (16 bytes: low nibble = elem j, high = elem j+16,
+// Q4ByteBufferTensor.java:88-106) with 32 int8 activations held as alo (elems 0..15) / ahi (16..31).
+// Returns sum_t a[t]*nib[t]  (bias -8*sum(a) is applied by the caller).
+__device__ __forceinline__ int q4_block_dot(const i32x4& w, const i32x4& alo, const i32x4& ahi) {
+    int s = 0;
+    s = sdot4(alo.x, w.x & 0x0F0F0F0F, s);
+    s = sdot4(alo.y, w.y & 0x0F0F0F0F, s);
+    s = sdot4(alo.z, w.z & 0x0F0F0F0F, s);
+    s = sdot4(alo.w, w.w & 0x0F0F0F0F, s);
+    s = sdot4(ahi.x, (w.x >> 4) & 0x0F0F0F0F, s);
+    s = sdot4(ahi.y, (w.y >> 4) & 0x0F0F0F0F, s);
+    s = sdot4(ahi.z, (w.z >> 4) & 0x0F0F0F0F, s);
+    s = sdot4(ahi.w, (w.w >> 4) & 0x0F0F0F0F, s);
+    return s;
+}
+
+__device__ __forceinline__ i32x4 ldg_nt(const i32x4* p) {
+    // streamed-once weights: non-temporal hint (MI355X_MICROARCH.md row "nt-weights")
+    return __builtin_nontemporal_load(p);
+}
+
+// ------------------------------------------------------------------------------------------------ GEMV params
+enum { PRO_Q8 = 0, PRO_RMS_Q8 = 1, PRO_F32 = 2, PRO_RMS_F32 = 3 };
+enum { EPI_STORE = 0, EPI_RESID = 1 };
+
+struct GemvParams {
+    const uint8_t* w[3];   // Q4 nibbles of up to 3 weight tensors stacked along N (q,k,v | gate,up)
+    const float* ws[3];    // their F32 block scales
+    float* out[3];         // F32 outputs (row index local to the tensor)
+    int nrows[3];
+    int ntens;
+    int K;                 // columns (multiple of 32)
+    int ldb;               // bytes per nibble row
+    int ldbf;              // floats per scale row
+    const float* x;        // F32 activation row (PRO_RMS_*, PRO_F32)
+    const void* nw;        // norm weights (F32 or BF16)
+    int nw_bf16;
+    float eps;
+    const int8_t* aq;      // PRO_Q8: pre-quantized activation
+    const float* ad;
+    const float* resid;    // EPI_RESID
+    int8_t* hq;            // gate/up epilogue: Q8 of silu(g)*u
+    float* hd;
+    float* hf;             // optional F32 copy of silu(g)*u (taps)
+    float* amax_part;      // LM head: per-workgroup (max logit, index) partials
+    int* amax_idx;
+};
+
+// LDS carve for an I8 activation row of nblk blocks
+struct ActI8 {
+    i32x4* lo;     // [nblk] elements 0..15 of each block
+    i32x4* hi;     // [nblk] elements 16..31
+    float* d;     // [nblk] block scales
+    int* asum;    // [nblk] sum of the block's int8 values
+    double* red;  // [32] reduction scratch
+    float* tile;  // [64] epilogue tile (2 x 32)
+};
+__device__ __forceinline__ ActI8 carve_i8(char* smem, int nblk) {
+    ActI8 a;
+    a.lo = (i32x4*)smem;
+    a.hi = a.lo + nblk;
+    a.d = (float*)(a.hi + nblk);
+    a.asum = (int*)(a.d + nblk);
+    a.red = (double*)(((uintptr_t)(a.asum + nblk) + 15) & ~(uintptr_t)15);
+    a.tile = (float*)(a.red + 32);
+    return a;
+}
+static inline size_t lds_bytes_i8(int K) { return (size_t)(K / QB) * (16 + 16 + 4 + 4) + 16 + 32 * 8 + 64 * 4; }
+
+// block-wide double sum, result broadcast to every thread.  red: >= 32 doubles of LDS.
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum_d(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; i++) t += red[i];  // fixed order => deterministic
+    __syncthreads();
+    return t;
+}
+
+// RMSNorm scale factor (core/model/RMSNorm.java:41-49): float squares, double sum, /E, +eps, 1/sqrt in double.
+__device__ __forceinline__ float rms_factor(const float* __restrict__ x, int K, float eps, double* red) {
+    double ss = 0.0;
+    const float4* x4 = (const float4*)x;
+    for (int j = threadIdx.x; j < K / 4; j += blockDim.x) {
+        float4 v = x4[j];
+        ss += (double)(v.x * v.x);
+        ss += (double)(v.y * v.y);
+        ss += (double)(v.z * v.z);
+        ss += (double)(v.w * v.w);
+    }
+    ss = block_sum_d(ss, red);
+    ss /= (double)K;
+    ss += (double)eps;
+    ss = 1.0 / sqrt(ss);
+    return (float)ss;
+}
+
+__device__ __forceinline__ void load8_norm(const void* nw, int bf16, int e0, float (&w)[8]) {
+    if (bf16) {
+        uint4 r = *(const uint4*)((const uint16_t*)nw + e0);
+        w[0] = bf16_to_f32(r.x & 0xffff); w[1] = bf16_to_f32(r.x >> 16);
+        w[2] = bf16_to_f32(r.y & 0xffff); w[3] = bf16_to_f32(r.y >> 16);
+        w[4] = bf16_to_f32(r.z & 0xffff); w[5] = bf16_to_f32(r.z >> 16);
+        w[6] = bf16_to_f32(r.w & 0xffff); w[7] = bf16_to_f32(r.w >> 16);
+    } else {
+        float4 a = *(const float4*)((const float*)nw + e0), b = *(const float4*)((const float*)nw + e0 + 4);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    }
+}
+
+// Quantize 8 consecutive values held by one lane; the 4 lanes of a quad cover one block of 32.
+// Panama quantizeQ8_512 (PTO:1684-1723): d = max/127, id = 127/max (0 if max==0), q = (byte)(x*id + 0.5f).
+__device__ __forceinline__ void quad_quantize_store(const float (&y)[8], int unit, const ActI8& a) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(y[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const float d = amax / 127.0f;
+    const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
+    int q[8];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float v = y[i] * id;
+        v = v + 0.5f;
+        q[i] = f2b(v);
+        s += (int)(int8_t)q[i];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const int blk = unit >> 2, sub = unit & 3;
+    i32x2 packed;
+    packed.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+    packed.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+    i32x2* dst = (i32x2*)((sub < 2) ? (a.lo + blk) : (a.hi + blk)) + (sub & 1);
+    *dst = packed;
+    if (sub == 0) {
+        a.d[blk] = d;
+        a.asum[blk] = s;
+    }
+}
+
+// Prologue: build the I8 activation row in LDS.
+template <int PRO>
+__device__ __forceinline__ void stage_act_i8(const GemvParams& p, const ActI8& a) {
+    const int K = p.K, nblk = K / QB;
+    if (PRO == PRO_Q8) {
+        // activation already quantized by the producer kernel (attention / gate-up epilogues)
+        for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
+            const i32x4* src = (const i32x4*)(p.aq + (size_t)blk * QB);
+            i32x4 l = src[0], h = src[1];
+            a.lo[blk] = l;
+            a.hi[blk] = h;
+            a.d[blk] = p.ad[blk];
+            int s = 0;
+            s = sdot4(l.x, 0x01010101, s); s = sdot4(l.y, 0x01010101, s);
+            s = sdot4(l.z, 0x01010101, s); s = sdot4(l.w, 0x01010101, s);
+            s = sdot4(h.x, 0x01010101, s); s = sdot4(h.y, 0x01010101, s);
+            s = sdot4(h.z, 0x01010101, s); s = sdot4(h.w, 0x01010101, s);
+            a.asum[blk] = s;
+        }
+    } else {
+        // RMSNorm.forward (core/model/RMSNorm.java:33-56) fused with LlamaModel.maybeQuantize
+        // (core/model/llama/LlamaModel.java:176-184 -> PTO:1684-1723)
+        const float fs = rms_factor(p.x, K, p.eps, a.red);
+        for (int unit = threadIdx.x; unit < K / 8; unit += blockDim.x) {
+            const int e0 = unit * 8;
+            float4 xa = *(const float4*)(p.x + e0), xb = *(const float4*)(p.x + e0 + 4);
+            float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            float w[8], y[8];
+            load8_norm(p.nw, p.nw_bf16, e0, w);
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = w[i] * (fs * xv[i]);  // (0 + w) * ((float)ss * x)
+            quad_quantize_store(y, unit, a);
+        }
+    }
+    __syncthreads();
+}
+
+// locate the tensor a stacked row belongs to (wave-uniform)
+__device__ __forceinline__ void locate(const GemvParams& p, int row, int& t, int& local) {
+    t = 0;
+    local = row;
+    if (p.ntens > 1 && local >= p.nrows[0]) { local -= p.nrows[0]; t = 1; }
+    if (p.ntens > 2 && t == 1 && local >= p.nrows[1]) { local -= p.nrows[1]; t = 2; }
+}
+
+// ------------------------------------------------------------------------------------------------ K1: GEMV I8 x Q4
+// batchDotProduct I8xQ4 at M=1 (GemmerI8Q4_512, PTO:768-1044; C twin nc/simd/vector_simd.c:261-437):
+//   C[j] = sum_blk (da[blk]*sb[j,blk]) * (float) sum_t a[blk,t]*(nib[j,blk,t]-8)
+// One wave computes R rows at a time; lane l owns K blocks l, l+64, ... (NB per lane, 0 = runtime loop).
+template <int PRO, int EPI, int R, int NB>
+__global__ __launch_bounds__(512) void gemv_i8q4_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nblk = p.K / QB;
+    const ActI8 a = carve_i8(smem, nblk);
+    stage_act_i8<PRO>(p, a);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    int total = p.nrows[0] + (p.ntens > 1 ? p.nrows[1] : 0) + (p.ntens > 2 ? p.nrows[2] : 0);
+    const int ngroups = total / R;
+
+    // activation blocks owned by this lane, kept in registers for every row group (NB > 0)
+    i32x4 alo[NB > 0 ? NB : 1], ahi[NB > 0 ? NB : 1];
+    float adv[NB > 0 ? NB : 1];
+    int asv[NB > 0 ? NB : 1];
+    if (NB > 0) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int blk = lane + 64 * i;
+            alo[i] = a.lo[blk]; ahi[i] = a.hi[blk]; adv[i] = a.d[blk]; asv[i] = a.asum[blk];
+        }
+    }
+
+    for (int g = blockIdx.x * nwaves + wave; g < ngroups; g += gridDim.x * nwaves) {
+        int t, local;
+        locate(p, g * R, t, local);
+        const uint8_t* wbase = p.w[t] + (size_t)local * p.ldb;
+        const float* sbase = p.ws[t] + (size_t)local * p.ldbf;
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = 0.0f;
+
+        if (NB > 0) {
+            i32x4 wv[R][NB > 0 ? NB : 1];
+            float sv[R][NB > 0 ? NB : 1];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    const int blk = lane + 64 * i;
+                    wv[r][i] = ldg_nt((const i32x4*)(wbase + (size_t)r * p.ldb) + blk);
+                    sv[r][i] = __builtin_nontemporal_load(sbase + (size_t)r * p.ldbf + blk);
+                }
+#pragma unroll
+            for (int i = 0; i < NB; i++)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int isum = q4_block_dot(wv[r][i], alo[i], ahi[i]) - 8 * asv[i];
+                    acc[r] = fmaf(adv[i] * sv[r][i], (float)isum, acc[r]);
+                }
+        } else {
+            for (int blk = lane; blk < nblk; blk += 64) {
+                const i32x4 l = a.lo[blk], h = a.hi[blk];
+                const float da = a.d[blk];
+                const int as8 = 8 * a.asum[blk];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const i32x4 wv = ldg_nt((const i32x4*)(wbase + (size_t)r * p.ldb) + blk);
+                    const float sb = sbase[(size_t)r * p.ldbf + blk];
+                    const int isum = q4_block_dot(wv, l, h) - as8;
+                    acc[r] = fmaf(da * sb, (float)isum, acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                float v = acc[r];
+                if (EPI == EPI_RESID) v = v + p.resid[local + r];  // accumulate(lnattn, embedding) TransformerBlock.java:185,203
+                p.out[t][local + r] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K1b: gate/up GEMV
+// MLPBlock.forward (core/model/MLPBlock.java:117-144): gate & up GEMVs, SiLU (ActivationFunction.java:31) on gate,
+// maccumulate (gate *= up), then maybeQuantize -> Q8.  A workgroup (8 waves) owns tiles of 32 consecutive hidden
+// units j, so the Q8 block of the down-projection's activation is produced right here (fused epilogue).
+template <int PRO, int NB>
+__global__ __launch_bounds__(512) void gemv_gateup_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nblk = p.K / QB;
+    const ActI8 a = carve_i8(smem, nblk);
+    stage_act_i8<PRO>(p, a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // 8 waves
+    const int ntiles = p.nrows[0] / 32;
+
+    i32x4 alo[NB > 0 ? NB : 1], ahi[NB > 0 ? NB : 1];
+    float adv[NB > 0 ? NB : 1];
+    int asv[NB > 0 ? NB : 1];
+    if (NB > 0) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int blk = lane + 64 * i;
+            alo[i] = a.lo[blk]; ahi[i] = a.hi[blk]; adv[i] = a.d[blk]; asv[i] = a.asum[blk];
+        }
+    }
+    int par = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
+        const int j0 = tile * 32 + wave * 4;
+        const uint8_t* gb = p.w[0] + (size_t)j0 * p.ldb;
+        const uint8_t* ub = p.w[1] + (size_t)j0 * p.ldb;
+        const float* gs = p.ws[0] + (size_t)j0 * p.ldbf;
+        const float* us = p.ws[1] + (size_t)j0 * p.ldbf;
+        float ag[4] = {0, 0, 0, 0}, au[4] = {0, 0, 0, 0};
+        if (NB > 0) {
+            i32x4 wg[4][NB > 0 ? NB : 1], wu[4][NB > 0 ? NB : 1];
+            float sg[4][NB > 0 ? NB : 1], su[4][NB > 0 ? NB : 1];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    const int blk = lane + 64 * i;
+                    wg[r][i] = ldg_nt((const i32x4*)(gb + (size_t)r * p.ldb) + blk);
+                    wu[r][i] = ldg_nt((const i32x4*)(ub + (size_t)r * p.ldb) + blk);
+                    sg[r][i] = __builtin_nontemporal_load(gs + (size_t)r * p.ldbf + blk);
+                    su[r][i] = __builtin_nontemporal_load(us + (size_t)r * p.ldbf + blk);
+                }
+#pragma unroll
+            for (int i = 0; i < NB; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ig = q4_block_dot(wg[r][i], alo[i], ahi[i]) - 8 * asv[i];
+                    const int iu = q4_block_dot(wu[r][i], alo[i], ahi[i]) - 8 * asv[i];
+                    ag[r] = fmaf(adv[i] * sg[r][i], (float)ig, ag[r]);
+                    au[r] = fmaf(adv[i] * su[r][i], (float)iu, au[r]);
+                }
+        } else {
+            for (int blk = lane; blk < nblk; blk += 64) {
+                const i32x4 l = a.lo[blk], h = a.hi[blk];
+                const float da = a.d[blk];
+                const int as8 = 8 * a.asum[blk];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const i32x4 wgv = ldg_nt((const i32x4*)(gb + (size_t)r * p.ldb) + blk);
+                    const i32x4 wuv = ldg_nt((const i32x4*)(ub + (size_t)r * p.ldb) + blk);
+                    const int ig = q4_block_dot(wgv, l, h) - as8;
+                    const int iu = q4_block_dot(wuv, l, h) - as8;
+                    ag[r] = fmaf(da * gs[(size_t)r * p.ldbf + blk], (float)ig, ag[r]);
+                    au[r] = fmaf(da * us[(size_t)r * p.ldbf + blk], (float)iu, au[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { ag[r] = wave_sum(ag[r]); au[r] = wave_sum(au[r]); }
+        float* tl = a.tile + par * 32;
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) tl[wave * 4 + r] = silu_ref(ag[r]) * au[r];
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 32) {
+            // Q8 block of 32 (PTO:1684-1723)
+            const float y = tl[lane];
+            float amax = fabsf(y);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+            const float d = amax / 127.0f;
+            const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
+            float v = y * id;
+            v = v + 0.5f;
+            p.hq[tile * 32 + lane] = (int8_t)f2b(v);
+            if (lane == 0) p.hd[tile] = d;
+            if (p.hf) p.hf[tile * 32 + lane] = y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K1c: GEMV F32 x Q4
+// batchDotProduct F32xQ4 at M=1 (GemmerF32Q4_512 PTO:336-374; C twin vector_simd.c:880-965): dequantize first
+// w = float(nib-8)*scale, then acc = fma(a, w, acc).  fma(scale, float(nib), -8*scale) == round(scale*(nib-8))
+// exactly, so the per-weight cost is cvt + fma + fma.  Used by the LM head (AbstractModel.java:443-449): the
+// normed hidden row is NOT re-quantized.  The epilogue keeps a per-workgroup running argmax
+// (strict >, lowest index wins: AbstractModel.java:455-469).
+struct ActF32 {
+    float4* y;    // [8][nblk] chunk-major: chunk c (4 floats) of block blk at y[c*nblk + blk]
+    double* red;  // [32]
+    float* bestv; // [16]
+    int* besti;   // [16]
+};
+__device__ __forceinline__ ActF32 carve_f32(char* smem, int nblk) {
+    ActF32 a;
+    a.y = (float4*)smem;
+    a.red = (double*)(a.y + 8 * (size_t)nblk);
+    a.bestv = (float*)(a.red + 32);
+    a.besti = (int*)(a.bestv + 16);
+    return a;
+}
+static inline size_t lds_bytes_f32(int K) { return (size_t)K * 4 + 32 * 8 + 16 * 4 + 16 * 4; }
+
+__device__ __forceinline__ float q4_block_dot_f32(const i32x4& w, float scale, const float4 (&y)[8], float acc) {
+    const float m8 = -8.0f * scale;
+    const int wl[4] = {w.x & 0x0F0F0F0F, w.y & 0x0F0F0F0F, w.z & 0x0F0F0F0F, w.w & 0x0F0F0F0F};
+    const int wh[4] = {(w.x >> 4) & 0x0F0F0F0F, (w.y >> 4) & 0x0F0F0F0F, (w.z >> 4) & 0x0F0F0F0F,
+                       (w.w >> 4) & 0x0F0F0F0F};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        acc = fmaf(y[c].x, fmaf(scale, (float)(wl[c] & 0xff), m8), acc);
+        acc = fmaf(y[c].y, fmaf(scale, (float)((wl[c] >> 8) & 0xff), m8), acc);
+        acc = fmaf(y[c].z, fmaf(scale, (float)((wl[c] >> 16) & 0xff), m8), acc);
+        acc = fmaf(y[c].w, fmaf(scale, (float)((wl[c] >> 24) & 0xff), m8), acc);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        acc = fmaf(y[4 + c].x, fmaf(scale, (float)(wh[c] & 0xff), m8), acc);
+        acc = fmaf(y[4 + c].y, fmaf(scale, (float)((wh[c] >> 8) & 0xff), m8), acc);
+        acc = fmaf(y[4 + c].z, fmaf(scale, (float)((wh[c] >> 16) & 0xff), m8), acc);
+        acc = fmaf(y[4 + c].w, fmaf(scale, (float)((wh[c] >> 24) & 0xff), m8), acc);
+    }
+    return acc;
+}
+
+template <int PRO, int R, int NB>
+__global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = p.K, nblk = K / QB;
+    const ActF32 a = carve_f32(smem, nblk);
+    float fs = 1.0f;
+    if (PRO == PRO_RMS_F32) fs = rms_factor(p.x, K, p.eps, a.red);
+    for (int unit = threadIdx.x; unit < K / 8; unit += blockDim.x) {
+        const int e0 = unit * 8;
+        float4 xa = *(const float4*)(p.x + e0), xb = *(const float4*)(p.x + e0 + 4);
+        if (PRO == PRO_RMS_F32) {
+            float w[8];
+            load8_norm(p.nw, p.nw_bf16, e0, w);
+            xa.x = w[0] * (fs * xa.x); xa.y = w[1] * (fs * xa.y); xa.z = w[2] * (fs * xa.z); xa.w = w[3] * (fs * xa.w);
+            xb.x = w[4] * (fs * xb.x); xb.y = w[5] * (fs * xb.y); xb.z = w[6] * (fs * xb.z); xb.w = w[7] * (fs * xb.w);
+        }
+        const int blk = unit >> 2, c = (unit & 3) * 2;
+        a.y[(size_t)c * nblk + blk] = xa;
+        a.y[(size_t)(c + 1) * nblk + blk] = xb;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int ngroups = p.nrows[0] / R;
+    float4 yr[NB > 0 ? NB : 1][8];
+    if (NB > 0) {
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) yr[i][c] = a.y[(size_t)c * nblk + lane + 64 * i];
+    }
+    float bestv = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int g = blockIdx.x * nwaves + wave; g < ngroups; g += gridDim.x * nwaves) {
+        const int row0 = g * R;
+        const uint8_t* wbase = p.w[0] + (size_t)row0 * p.ldb;
+        const float* sbase = p.ws[0] + (size_t)row0 * p.ldbf;
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = 0.0f;
+        if (NB > 0) {
+            i32x4 wv[R][NB > 0 ? NB : 1];
+            float sv[R][NB > 0 ? NB : 1];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    wv[r][i] = ldg_nt((const i32x4*)(wbase + (size_t)r * p.ldb) + lane + 64 * i);
+                    sv[r][i] = __builtin_nontemporal_load(sbase + (size_t)r * p.ldbf + lane + 64 * i);
+                }
+#pragma unroll
+            for (int i = 0; i < NB; i++)
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = q4_block_dot_f32(wv[r][i], sv[r][i], yr[i], acc[r]);
+        } else {
+            for (int blk = lane; blk < nblk; blk += 64) {
+                float4 yb[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) yb[c] = a.y[(size_t)c * nblk + blk];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const i32x4 wv = ldg_nt((const i32x4*)(wbase + (size_t)r * p.ldb) + blk);
+                    acc[r] = q4_block_dot_f32(wv, sbase[(size_t)r * p.ldbf + blk], yb, acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            acc[r] = wave_sum(acc[r]);
+            if (acc[r] > bestv) { bestv = acc[r]; besti = row0 + r; }  // rows ascend within a wave: strict > keeps the first
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) p.out[0][row0 + r] = acc[r];
+        }
+    }
+    if (p.amax_part) {
+        if (lane == 0) { a.bestv[wave] = bestv; a.besti[wave] = besti; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int w = 0; w < nwaves; w++) {
+                const float v = a.bestv[w];
+                const int i = a.besti[w];
+                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+            }
+            p.amax_part[blockIdx.x] = bv;
+            p.amax_idx[blockIdx.x] = bi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ decode state
+struct DecodeState {
+    int pos;     // position of the row being forwarded
+    int token;   // its token id
+    int step;    // index into out_tokens
+    int pad;
+};
+
+__global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
+    st->pos = pos; st->token = token; st->step = step;
+}
+
+// EmbedInput for a Q4 / BF16 / F32 table (core/model/llama/LlamaModel.java:67-98): x[j] = (nib-8)*scale
+__device__ __forceinline__ void embed_row(const void* table, const float* scales, int dtype, int token, int E,
+                                          float* x) {
+    if (dtype == 3) {
+        const uint8_t* nr = (const uint8_t*)table + (size_t)token * (E / 2);
+        const float* sr = scales + (size_t)token * (E / QB);
+        for (int j = threadIdx.x; j < E / 2; j += blockDim.x) {
+            const int blk = j / 16, in = j % 16;
+            const uint8_t b = nr[j];
+            const float s = sr[blk];
+            x[blk * 32 + in] = (float)((int)(b & 0x0F) - 8) * s;
+            x[blk * 32 + in + 16] = (float)((int)((b >> 4) & 0x0F) - 8) * s;
+        }
+    } else if (dtype == 1) {
+        const uint16_t* r = (const uint16_t*)table + (size_t)token * E;
+        for (int j = threadIdx.x; j < E; j += blockDim.x) x[j] = bf16_to_f32(r[j]);
+    } else {
+        const float* r = (const float*)table + (size_t)token * E;
+        for (int j = threadIdx.x; j < E; j += blockDim.x) x[j] = r[j];
+    }
+}
+
+__global__ void embed_kernel(const void* table, const float* scales, int dtype, const DecodeState* st, int E,
+                             float* x) {
+    embed_row(table, scales, dtype, st->token, E, x);
+}
+
+// argmax over the LM head's per-workgroup partials -> next token; advance the decode state and look up the
+// next embedding row, so a greedy decode step needs no host round trip (AbstractModel.java:590-599).
+__global__ void finish_token_kernel(const float* partv, const int* parti, int nparts, DecodeState* st,
+                                    int* out_tokens, const void* table, const float* scales, int dtype, int E,
+                                    float* x, int do_embed) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int tok;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+        const float v = partv[i];
+        const int id = parti[i];
+        if (v > bv || (v == bv && id < bi)) { bv = v; bi = id; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < nw; w++)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        tok = bi;
+        out_tokens[st->step] = bi;
+        st->token = bi;
+        st->pos = st->pos + 1;
+        st->step = st->step + 1;
+    }
+    __syncthreads();
+    if (do_embed) embed_row(table, scales, dtype, tok, E, x);
+}
+
+// ------------------------------------------------------------------------------------------------ K4: decode attention
+// CausalSelfAttention.forward for ONE new position (core/model/CausalSelfAttention.java:199-357), fused:
+//   copy K,V row into the KV page (:226-241) -> RoPE on q (all heads) and on the stored k row (:247-286, incl. the
+//   per-kv-head table offset g = kvHead*headSize+i => effective position pos+2*kvHead) -> per head:
+//   scores = q.K^T (:324-330) * attentionScale (:332) -> softMax (VectorMath.java:69-90) -> saxpy over V (:349-354)
+//   -> maybeQuantize(valueBatch) to Q8 for the O projection (:364).
+// Grid (max_splits, n_kv_heads): a workgroup serves the `group` q-heads of one kv head for one slice of the
+// context, so K/V are read once per group (GQA).  Slices are combined by the last-arriving workgroup of the kv
+// head (agent-scope release/acquire, cdna_hip_programming.md Guideline 16).
+struct AttnParams {
+    const float* qkv;      // [A + 2*KV]: q | k | v of the new row (F32, pre-RoPE)
+    const float* rope;     // [ctx*hs/2][2]
+    float* const* pages;   // this layer-page's context pages: pages[cp] -> [layersPerPage,2,ctxPerPage,KV]
+    int rel_layer_in_page, ctx_per_page;
+    int n_heads, n_kv_heads, head_size;
+    const DecodeState* st;
+    float scale;
+    float* part;           // [n_heads][max_splits][hs+2]
+    unsigned* counters;    // [n_kv_heads], zero between launches
+    int max_splits;
+    int8_t* outq;          // [A]
+    float* outd;           // [A/32]
+    float* outf;           // [A] F32 copy ("after_attention" tap), may be null
+    float* tap_q;          // roped q [A] (tap), may be null
+};
+
+__device__ __forceinline__ const float* kv_row(const AttnParams& p, int which, int t, int kvlen) {
+    const int cp = t / p.ctx_per_page, rc = t - cp * p.ctx_per_page;
+    return p.pages[cp] + ((size_t)(p.rel_layer_in_page * 2 + which) * p.ctx_per_page + rc) * kvlen;
+}
+
+template <int HS, int GROUP>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
+    // LDS: q[GROUP][HS], knew[HS], vnew[HS], sc[GROUP][chunk], red[8][GROUP][HS], misc
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pos = p.st->pos;
+    const int kvh = blockIdx.y, split = blockIdx.x;
+    const int n = pos + 1;
+    int S = (n + 31) / 32;
+    if (S > p.max_splits) S = p.max_splits;
+    if (split >= S) return;
+    const int chunk = (n + S - 1) / S;
+    const int t0 = split * chunk;
+    int t1 = t0 + chunk;
+    if (t1 > n) t1 = n;
+    const int cnt = t1 - t0;  // may be <= 0 for trailing splits when chunk rounding overshoots
+    const int KV = p.n_kv_heads * HS, A = p.n_heads * HS, half = HS / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    float* qs = (float*)smem;                // GROUP*HS
+    float* knew = qs + GROUP * HS;           // HS
+    float* vnew = knew + HS;                 // HS
+    float* red = vnew + HS;                  // (256/(HS/4))*GROUP*HS = 1024*GROUP floats
+    float* ml = red + (256 / (HS / 4)) * GROUP * HS;  // 2*GROUP (m, l)
+    int* flag = (int*)(ml + 2 * GROUP);      // 4 ints
+    float* sc = (float*)(flag + 4);          // GROUP*chunk_cap
+
+    // ---- RoPE (q for the group's heads, k for this kv head) ------------------------------------------------
+    const float* rf = p.rope + ((size_t)pos * half + (size_t)kvh * HS) * 2;  // rf[poffset + g], g = kvh*HS + i
+    for (int i = tid; i < GROUP * half; i += blockDim.x) {
+        const int gi = i / half, d = i - gi * half;
+        const float* qh = p.qkv + (size_t)(kvh * GROUP + gi) * HS;
+        const float q0 = qh[d], q1 = qh[d + half];
+        const float fcr = rf[2 * d], fci = rf[2 * d + 1];
+        const float r0 = q0 * fcr - q1 * fci;   // contraction is off: mul, mul, sub as in Java
+        const float r1 = q0 * fci + q1 * fcr;
+        qs[gi * HS + d] = r0;
+        qs[gi * HS + d + half] = r1;
+        if (p.tap_q && split == 0) {
+            p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d] = r0;
+            p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d + half] = r1;
+        }
+    }
+    const bool owns_new = (pos >= t0 && pos < t1);
+    if (owns_new) {
+        const float* kh = p.qkv + A + (size_t)kvh * HS;
+        const float* vh = p.qkv + A + KV + (size_t)kvh * HS;
+        float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
+        float* vdst = (float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS;
+        for (int d = tid; d < half; d += blockDim.x) {
+            const float k0 = kh[d], k1 = kh[d + half];
+            const float fcr = rf[2 * d], fci = rf[2 * d + 1];
+            const float r0 = k0 * fcr - k1 * fci;
+            const float r1 = k0 * fci + k1 * fcr;
+            knew[d] = r0; knew[d + half] = r1;
+            kdst[d] = r0; kdst[d + half] = r1;   // K is stored post-RoPE (:273-286 rotates the page row in place)
+        }
+        for (int d = tid; d < HS; d += blockDim.x) {
+            const float v = vh[d];
+            vnew[d] = v;
+            vdst[d] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- scores: 32 lanes x float4 cover one K row; a wave does 2 rows per step ---------------------------
+    constexpr int LPR = HS / 4;          // lanes per K/V row (float4 each): 32 for HS=128, 16 for HS=64
+    constexpr int RPW = 64 / LPR;        // rows per wave step
+    const int sub = lane / LPR, l32 = lane % LPR;
+    float4 qv[GROUP];
+#pragma unroll
+    for (int gi = 0; gi < GROUP; gi++) qv[gi] = ((const float4*)(qs + gi * HS))[l32];
+    for (int tt = wave * RPW + sub; tt < cnt; tt += 4 * RPW) {
+        const int t = t0 + tt;
+        float4 kv4;
+        if (t == pos) kv4 = ((const float4*)knew)[l32];
+        else kv4 = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[l32];
+#pragma unroll
+        for (int gi = 0; gi < GROUP; gi++) {
+            float s = qv[gi].x * kv4.x;
+            s = fmaf(qv[gi].y, kv4.y, s);
+            s = fmaf(qv[gi].z, kv4.z, s);
+            s = fmaf(qv[gi].w, kv4.w, s);
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (l32 == 0) sc[gi * chunk + tt] = s * p.scale;   // ops.scale after the dot (:332): separate rounding
+        }
+    }
+    __syncthreads();
+
+    // ---- local softmax per head (one wave per head, round-robin) ------------------------------------------
+    for (int gi = wave; gi < GROUP; gi += 4) {
+        float m = -INFINITY;
+        for (int tt = lane; tt < cnt; tt += 64) m = fmaxf(m, sc[gi * chunk + tt]);
+        m = wave_max(m);
+        float l = 0.0f;
+        for (int tt = lane; tt < cnt; tt += 64) {
+            const float e = (float)exp((double)(sc[gi * chunk + tt] - m));  // (float)FastMath.exp(x - max)
+            sc[gi * chunk + tt] = e;
+            l += e;
+        }
+        l = wave_sum(l);
+        for (int tt = lane; tt < cnt; tt += 64) sc[gi * chunk + tt] = sc[gi * chunk + tt] / l;  // normalise by division
+        if (lane == 0) { ml[2 * gi] = m; ml[2 * gi + 1] = l; }
+    }
+    __syncthreads();
+
+    // ---- o = sum_t w[t] * V[t]: thread = (t-group of 8, float4 column); fma chain per element -------------
+    {
+        constexpr int NTG = 256 / LPR;
+        const int c4 = tid % LPR, tg = tid / LPR;
+        float4 acc[GROUP];
+#pragma unroll
+        for (int gi = 0; gi < GROUP; gi++) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int tt = tg; tt < cnt; tt += NTG) {
+            const int t = t0 + tt;
+            float4 v4;
+            if (t == pos) v4 = ((const float4*)vnew)[c4];
+            else v4 = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++) {
+                const float w = sc[gi * chunk + tt];
+                acc[gi].x = fmaf(v4.x, w, acc[gi].x);
+                acc[gi].y = fmaf(v4.y, w, acc[gi].y);
+                acc[gi].z = fmaf(v4.z, w, acc[gi].z);
+                acc[gi].w = fmaf(v4.w, w, acc[gi].w);
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < GROUP; gi++) ((float4*)(red + ((size_t)tg * GROUP + gi) * HS))[c4] = acc[gi];
+    }
+    __syncthreads();
+    // reduce the 8 t-groups: thread -> (gi, d)
+    float* oloc = qs;  // reuse q storage for the slice's output [GROUP][HS]
+    for (int i = tid; i < GROUP * HS; i += blockDim.x) {
+        float s = 0.0f;
+#pragma unroll
+        for (int tg = 0; tg < 256 / (HS / 4); tg++) s += red[(size_t)tg * GROUP * HS + i];
+        oloc[i] = s;
+    }
+    __syncthreads();
+
+    if (S > 1) {
+        // publish this slice's (o, m, l); the last arriver of the kv head combines
+        for (int i = tid; i < GROUP * HS; i += blockDim.x) {
+            const int gi = i / HS, d = i - gi * HS;
+            p.part[((size_t)(kvh * GROUP + gi) * p.max_splits + split) * (HS + 2) + d] = oloc[i];
+        }
+        if (tid < GROUP) {
+            float* pr = p.part + ((size_t)(kvh * GROUP + tid) * p.max_splits + split) * (HS + 2) + HS;
+            pr[0] = ml[2 * tid];
+            pr[1] = ml[2 * tid + 1];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tk = __hip_atomic_fetch_add(&p.counters[kvh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (tk == (unsigned)(S - 1));
+            if (last) {
+                __hip_atomic_store(&p.counters[kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            flag[0] = last;
+        }
+        __syncthreads();
+        if (!flag[0]) return;
+        // combine: w_s = l_s * exp(m_s - M) / sum_s(l_s * exp(m_s - M)); o = sum_s w_s * o_s
+        for (int i = tid; i < GROUP * HS; i += blockDim.x) {
+            const int gi = i / HS, d = i - gi * HS;
+            const float* pb = p.part + (size_t)(kvh * GROUP + gi) * p.max_splits * (HS + 2);
+            float M = -INFINITY;
+            for (int s = 0; s < S; s++) M = fmaxf(M, pb[(size_t)s * (HS + 2) + HS]);
+            float L = 0.0f;
+            for (int s = 0; s < S; s++) {
+                const float ls = pb[(size_t)s * (HS + 2) + HS + 1];
+                L += ls * (float)exp((double)(pb[(size_t)s * (HS + 2) + HS] - M));
+            }
+            float o = 0.0f;
+            for (int s = 0; s < S; s++) {
+                const float ls = pb[(size_t)s * (HS + 2) + HS + 1];
+                const float ws = (ls * (float)exp((double)(pb[(size_t)s * (HS + 2) + HS] - M))) / L;
+                o = fmaf(pb[(size_t)s * (HS + 2) + d], ws, o);
+            }
+            oloc[i] = o;
+        }
+        __syncthreads();
+    }
+
+    // ---- Q8 quantize the group's output (maybeQuantize(valueBatch), :364 -> PTO:1684-1723): 32 lanes per block
+    for (int i = tid; i < GROUP * HS; i += blockDim.x) {
+        const float y = oloc[i];
+        float amax = fabsf(y);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const float d = amax / 127.0f;
+        const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
+        float v = y * id;
+        v = v + 0.5f;
+        const size_t e = (size_t)kvh * GROUP * HS + i;
+        p.outq[e] = (int8_t)f2b(v);
+        if ((i & 31) == 0) p.outd[e >> 5] = d;
+        if (p.outf) p.outf[e] = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Tier-1 generic kernels
+// One wave per output element C[i, j]; lanes stride over K.  Correct for every offset/stride combination the
+// reference's C entry points accept (nc/simd/vector_simd.h:22-38); used for M>1, windows, F32/BF16 operands.
+enum { G_Q8Q4 = 0, G_F32Q4 = 1, G_F32 = 2, G_BF16 = 3, G_F32BF16 = 4 };
+struct GemmParams {
+    const void* a; const float* af; const void* b; const float* bf; float* r;
+    int aoffset, boffset, roffset, m, n0, n, k, lda, ldaf, ldb, ldbf, ldc;
+};
+template <int KIND>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long widx = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (widx >= (long long)p.m * p.n) return;
+    const int i = (int)(widx / p.n), j = p.n0 + (int)(widx % p.n);
+    float acc = 0.0f;
+    if (KIND == G_Q8Q4) {
+        const int8_t* ar = (const int8_t*)p.a + (size_t)p.lda * i + p.aoffset;
+        const float* afr = p.af + (size_t)p.ldaf * i + p.aoffset / QB;
+        const uint8_t* br = (const uint8_t*)p.b + (size_t)p.ldb * j + p.boffset;
+        const float* bfr = p.bf + (size_t)p.ldbf * j + (p.boffset * 2) / QB;
+        for (int blk = lane; blk < p.k / QB; blk += 64) {
+            int isum = 0;
+            for (int t = 0; t < 16; t++) {
+                const int bb = br[blk * 16 + t];
+                isum += (int)ar[blk * 32 + t] * ((bb & 0x0F) - 8) + (int)ar[blk * 32 + t + 16] * (((bb >> 4) & 0x0F) - 8);
+            }
+            acc = fmaf(afr[blk] * bfr[blk], (float)isum, acc);
+        }
+    } else if (KIND == G_F32Q4) {
+        const float* ar = (const float*)p.a + (size_t)p.lda * i + p.aoffset;
+        const uint8_t* br = (const uint8_t*)p.b + (size_t)p.ldb * j + p.boffset;
+        const float* bfr = p.bf + (size_t)p.ldbf * j + (p.boffset * 2) / QB;
+        for (int blk = lane; blk < p.k / QB; blk += 64) {
+            const float s = bfr[blk];
+            for (int t = 0; t < 16; t++) {
+                const int bb = br[blk * 16 + t];
+                acc = fmaf(ar[blk * 32 + t], (float)((bb & 0x0F) - 8) * s, acc);
+            }
+            for (int t = 0; t < 16; t++) {
+                const int bb = br[blk * 16 + t];
+                acc = fmaf(ar[blk * 32 + t + 16], (float)(((bb >> 4) & 0x0F) - 8) * s, acc);
+            }
+        }
+    } else if (KIND == G_F32) {
+        const float* ar = (const float*)p.a + (size_t)p.lda * i + p.aoffset;
+        const float* br = (const float*)p.b + (size_t)p.ldb * j + p.boffset;
+        for (int kk = lane; kk < p.k; kk += 64) acc = fmaf(ar[kk], br[kk], acc);
+    } else if (KIND == G_BF16) {
+        const uint16_t* ar = (const uint16_t*)p.a + (size_t)p.lda * i + p.aoffset;
+        const uint16_t* br = (const uint16_t*)p.b + (size_t)p.ldb * j + p.boffset;
+        for (int kk = lane; kk < p.k; kk += 64) acc = fmaf(bf16_to_f32(ar[kk]), bf16_to_f32(br[kk]), acc);
+    } else {
+        const float* ar = (const float*)p.a + (size_t)p.lda * i + p.aoffset;
+        const uint16_t* br = (const uint16_t*)p.b + (size_t)p.ldb * j + p.boffset;
+        for (int kk = lane; kk < p.k; kk += 64) acc = fmaf(ar[kk], bf16_to_f32(br[kk]), acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) p.r[(size_t)p.ldc * i + j - p.roffset] = acc;
+}
+
+// element-wise (PTO:2281-2295, 2297-2325, 2083-2097, 2499-2514, 2593-2611)
+enum { EW_ACC = 0, EW_MACC = 1, EW_SCALE = 2, EW_SAXPY = 3, EW_SILU_MUL = 4 };
+template <int OP>
+__global__ void ew_kernel(float* a, const float* b, float f, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (OP == EW_ACC) a[i] = a[i] + b[i];
+    else if (OP == EW_MACC) a[i] = a[i] * b[i];
+    else if (OP == EW_SCALE) a[i] = a[i] * f;
+    else if (OP == EW_SAXPY) a[i] = fmaf(b[i], f, a[i]);
+    else a[i] = silu_ref(a[i]) * b[i];
+}
+__global__ void acc_q4_kernel(float* a, const uint8_t* nib, const float* sc, int offset, int n) {
+    const int i = offset + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= offset + n) return;
+    const int blk = i / 32, in = i % 32;
+    const uint8_t b = nib[blk * 16 + (in & 15)];
+    const int x = (in < 16) ? (b & 0x0F) - 8 : ((b >> 4) & 0x0F) - 8;
+    a[i] = a[i] + (float)x * sc[blk];
+}
+// batched saxpy: thread per element, fma chain over rows in ascending order (PTO:2648-2698)
+__global__ void saxpy_batch_kernel(const float* alpha, const float* x, int ldx, float* y, int limit, int rows) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= limit) return;
+    float acc = y[t];
+    for (int n = 0; n < rows; n++) acc = fmaf(x[(size_t)n * ldx + t], alpha[n], acc);
+    y[t] = acc;
+}
+// quantize F32 -> I8 (PTO:1684-1723): one 32-lane half-wave per block
+__global__ void quantize_q8_kernel(const float* x, int rows, int ldx, int offset, int length, int8_t* q, int ldq,
+                                   float* d, int ldd) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int hw = gid >> 5, l = gid & 31;
+    const int bpr = length / QB;
+    if (hw >= rows * bpr) return;
+    const int r = hw / bpr, blk = hw % bpr;
+    const int e = offset + blk * QB + l;
+    const float y = x[(size_t)r * ldx + e];
+    float amax = fabsf(y);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float dd = amax / 127.0f;
+    const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
+    float v = y * id;
+    v = v + 0.5f;
+    q[(size_t)r * ldq + e] = (int8_t)f2b(v);
+    if (l == 0) d[(size_t)r * ldd + e / QB] = dd;
+}
+__global__ void quantize_bf16_kernel(const float* x, long long n, uint16_t* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f32_to_bf16(x[i]);
+}
+// RMSNorm.forward (core/model/RMSNorm.java:33-56), single workgroup per row
+__global__ __launch_bounds__(1024) void rmsnorm_kernel(const float* x, const float* w, float adj, int n, float eps,
+                                                       float* out) {
+    __shared__ double red[32];
+    double ss = 0.0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) { const float v = x[j]; ss += (double)(v * v); }
+    ss = block_sum_d(ss, red);
+    ss /= (double)n;
+    ss += (double)eps;
+    ss = 1.0 / sqrt(ss);
+    const float fs = (float)ss;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) out[j] = (adj + w[j]) * (fs * x[j]);
+}
+// VectorMath.softMax (core/math/VectorMath.java:69-90), single workgroup
+__global__ __launch_bounds__(1024) void softmax_kernel(float* x, int offset, int length) {
+    __shared__ float redf[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float m = -INFINITY;
+    for (int i = offset + threadIdx.x; i < offset + length; i += blockDim.x) m = fmaxf(m, x[i]);
+    m = wave_max(m);
+    if (lane == 0) redf[wave] = m;
+    __syncthreads();
+    m = redf[0];
+    for (int i = 1; i < nw; i++) m = fmaxf(m, redf[i]);
+    __syncthreads();
+    float s = 0.0f;
+    for (int i = offset + threadIdx.x; i < offset + length; i += blockDim.x) {
+        const float e = (float)exp((double)(x[i] - m));
+        x[i] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) redf[wave] = s;
+    __syncthreads();
+    s = 0.0f;
+    for (int i = 0; i < nw; i++) s += redf[i];
+    for (int i = threadIdx.x; i < offset + length; i += blockDim.x) x[i] = x[i] / s;  // reference divides from index 0
+}
+// RoPE rotation, GQA branch (core/model/CausalSelfAttention.java:247-286)
+__global__ void rope_kernel(float* q, float* k, const float* rope, int position, int n_heads, int n_kv_heads, int hs) {
+    const int half = hs / 2, group = n_heads / n_kv_heads;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int poffset = position * half;
+    if (i < n_heads * half) {
+        const int h = i / half, d = i % half;
+        const int g = (h / group) * hs + d;
+        const float fcr = rope[(size_t)(poffset + g) * 2], fci = rope[(size_t)(poffset + g) * 2 + 1];
+        const float q0 = q[h * hs + d], q1 = q[h * hs + d + half];
+        q[h * hs + d] = q0 * fcr - q1 * fci;
+        q[h * hs + d + half] = q0 * fci + q1 * fcr;
+    } else if (i < (n_heads + n_kv_heads) * half) {
+        const int ii = i - n_heads * half;
+        const int h = ii / half, d = ii % half;
+        const int g = h * hs + d;
+        const float fcr = rope[(size_t)(poffset + g) * 2], fci = rope[(size_t)(poffset + g) * 2 + 1];
+        const float k0 = k[h * hs + d], k1 = k[h * hs + d + half];
+        k[h * hs + d] = k0 * fcr - k1 * fci;
+        k[h * hs + d + half] = k0 * fci + k1 * fcr;
+    }
+}
+
+}  // namespace jh

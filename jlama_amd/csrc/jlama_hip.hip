@@ -1,0 +1,1223 @@
+// jlama_hip.hip -- C ABI of libjlamahip.so (see include/jlama_hip.h for the contract and the reference
+// interfaces each entry point replaces).  HIP runtime only: no torch, no oracle, no CPU fallback -- every
+// compute entry point fails with JH_ERR_NO_DEVICE / JH_ERR_HIP when no MI355X is usable.
+#include "../../include/jlama_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "jh_kernels.h"
+
+using namespace jh;
+
+// ------------------------------------------------------------------------------------------------ errors / context
+static thread_local std::string g_err;
+static int set_err(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return set_err(JH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + \
+                                           std::to_string(__LINE__));                                    \
+    } while (0)
+#define JHCHK(expr)            \
+    do {                       \
+        int _r = (expr);       \
+        if (_r != JH_OK) return _r; \
+    } while (0)
+
+namespace {
+
+constexpr int NSCRATCH = 8;
+struct ThreadCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void* scratch[NSCRATCH] = {nullptr};
+    size_t cap[NSCRATCH] = {0};
+};
+thread_local ThreadCtx tctx;
+int g_default_device = 0;
+int g_cu_count = 256;
+
+int ensure_ctx() {
+    if (tctx.device >= 0) {
+        HIPCHK(hipSetDevice(tctx.device));
+        return JH_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return set_err(JH_ERR_NO_DEVICE, "no HIP device (hipGetDeviceCount)");
+    int dev = g_default_device < n ? g_default_device : 0;
+    HIPCHK(hipSetDevice(dev));
+    HIPCHK(hipStreamCreateWithFlags(&tctx.stream, hipStreamNonBlocking));
+    tctx.device = dev;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cu_count = prop.multiProcessorCount;
+    return JH_OK;
+}
+
+int dev_buf(int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (tctx.cap[slot] < bytes) {
+        if (tctx.scratch[slot]) HIPCHK(hipFree(tctx.scratch[slot]));
+        tctx.scratch[slot] = nullptr;
+        tctx.cap[slot] = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&tctx.scratch[slot], want);
+        if (e != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc scratch: ") + hipGetErrorString(e));
+        tctx.cap[slot] = want;
+    }
+    *out = tctx.scratch[slot];
+    return JH_OK;
+}
+
+struct RegTensor {
+    void* ptr;
+    int64_t bytes;
+    int device;
+};
+std::mutex g_reg_mu;
+std::unordered_map<int64_t, RegTensor> g_reg;
+int64_t g_next_id = 1;
+
+const void* reg_ptr(int64_t id) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_reg.find(id);
+    return it == g_reg.end() ? nullptr : it->second.ptr;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return JH_OK;
+}
+
+int nb_for(int K) {
+    const int nblk = K / QB;
+    if (nblk % 64) return 0;
+    const int nb = nblk / 64;
+    return (nb == 1 || nb == 2 || nb == 4 || nb == 7) ? nb : 0;
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------
+template <int PRO, int EPI, int R>
+int launch_gemv_i8q4_r(const GemvParams& p, int grid, int threads, hipStream_t st) {
+    const size_t lds = lds_bytes_i8(p.K);
+    switch (nb_for(p.K)) {
+#define JH_CASE(NBV)                                                                      \
+    case NBV:                                                                             \
+        JHCHK(allow_lds(gemv_i8q4_kernel<PRO, EPI, R, NBV>, lds));                        \
+        hipLaunchKernelGGL((gemv_i8q4_kernel<PRO, EPI, R, NBV>), dim3(grid), dim3(threads), lds, st, p); \
+        break;
+        JH_CASE(1) JH_CASE(2) JH_CASE(4) JH_CASE(7)
+        default:
+            JHCHK(allow_lds(gemv_i8q4_kernel<PRO, EPI, R, 0>, lds));
+            hipLaunchKernelGGL((gemv_i8q4_kernel<PRO, EPI, R, 0>), dim3(grid), dim3(threads), lds, st, p);
+#undef JH_CASE
+    }
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+
+struct LaunchCfg { int R, waves, grid_cap; };
+
+template <int PRO, int EPI>
+int launch_gemv_i8q4(const GemvParams& p, LaunchCfg cfg, hipStream_t st) {
+    int total = p.nrows[0] + (p.ntens > 1 ? p.nrows[1] : 0) + (p.ntens > 2 ? p.nrows[2] : 0);
+    int R = cfg.R;
+    for (int t = 0; t < p.ntens; t++)
+        while (R > 1 && p.nrows[t] % R) R >>= 1;
+    const int ngroups = total / R;
+    int grid = (ngroups + cfg.waves - 1) / cfg.waves;
+    if (grid > cfg.grid_cap) grid = cfg.grid_cap;
+    if (grid < 1) grid = 1;
+    const int threads = cfg.waves * 64;
+    if (R >= 4) return launch_gemv_i8q4_r<PRO, EPI, 4>(p, grid, threads, st);
+    if (R >= 2) return launch_gemv_i8q4_r<PRO, EPI, 2>(p, grid, threads, st);
+    return launch_gemv_i8q4_r<PRO, EPI, 1>(p, grid, threads, st);
+}
+
+template <int PRO>
+int launch_gateup(const GemvParams& p, int grid_cap, hipStream_t st) {
+    const size_t lds = lds_bytes_i8(p.K);
+    const int ntiles = p.nrows[0] / 32;
+    int grid = ntiles < grid_cap ? ntiles : grid_cap;
+    switch (nb_for(p.K)) {
+#define JH_CASE(NBV)                                                                \
+    case NBV:                                                                       \
+        JHCHK(allow_lds(gemv_gateup_kernel<PRO, NBV>, lds));                        \
+        hipLaunchKernelGGL((gemv_gateup_kernel<PRO, NBV>), dim3(grid), dim3(512), lds, st, p); \
+        break;
+        JH_CASE(1) JH_CASE(2) JH_CASE(4)
+        default:
+            JHCHK(allow_lds(gemv_gateup_kernel<PRO, 0>, lds));
+            hipLaunchKernelGGL((gemv_gateup_kernel<PRO, 0>), dim3(grid), dim3(512), lds, st, p);
+#undef JH_CASE
+    }
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+
+template <int PRO, int R>
+int launch_gemv_f32q4_r(const GemvParams& p, int grid, int threads, hipStream_t st) {
+    const size_t lds = lds_bytes_f32(p.K);
+    const int nb = nb_for(p.K);
+    if (nb == 1) {
+        JHCHK(allow_lds(gemv_f32q4_kernel<PRO, R, 1>, lds));
+        hipLaunchKernelGGL((gemv_f32q4_kernel<PRO, R, 1>), dim3(grid), dim3(threads), lds, st, p);
+    } else if (nb == 2) {
+        JHCHK(allow_lds(gemv_f32q4_kernel<PRO, R, 2>, lds));
+        hipLaunchKernelGGL((gemv_f32q4_kernel<PRO, R, 2>), dim3(grid), dim3(threads), lds, st, p);
+    } else {
+        JHCHK(allow_lds(gemv_f32q4_kernel<PRO, R, 0>, lds));
+        hipLaunchKernelGGL((gemv_f32q4_kernel<PRO, R, 0>), dim3(grid), dim3(threads), lds, st, p);
+    }
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+template <int PRO>
+int launch_gemv_f32q4(const GemvParams& p, LaunchCfg cfg, int* grid_out, hipStream_t st) {
+    int R = cfg.R > 2 ? 2 : cfg.R;
+    while (R > 1 && p.nrows[0] % R) R >>= 1;
+    const int ngroups = p.nrows[0] / R;
+    int grid = (ngroups + cfg.waves - 1) / cfg.waves;
+    if (grid > cfg.grid_cap) grid = cfg.grid_cap;
+    if (grid < 1) grid = 1;
+    if (grid_out) *grid_out = grid;
+    if (R == 2) return launch_gemv_f32q4_r<PRO, 2>(p, grid, cfg.waves * 64, st);
+    return launch_gemv_f32q4_r<PRO, 1>(p, grid, cfg.waves * 64, st);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ runtime facts
+extern "C" {
+
+int jh_init(int device, int64_t* out_info) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return set_err(JH_ERR_NO_DEVICE, "no HIP device (hipGetDeviceCount)");
+    if (device < 0 || device >= n) return set_err(JH_ERR_INVALID, "device ordinal out of range");
+    g_default_device = device;
+    if (tctx.device != device) {
+        tctx.device = -1;  // re-create the per-thread stream on the new device
+        tctx.stream = nullptr;
+        for (int i = 0; i < NSCRATCH; i++) { tctx.scratch[i] = nullptr; tctx.cap[i] = 0; }
+    }
+    JHCHK(ensure_ctx());
+    if (out_info) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        out_info[0] = (int64_t)fr;
+        out_info[1] = prop.multiProcessorCount;
+        out_info[2] = n;
+        out_info[3] = (int64_t)prop.maxSharedMemoryPerMultiProcessor;
+    }
+    return JH_OK;
+}
+const char* jh_name(void) { return "HIP CDNA4 (gfx950) Operations"; }
+int jh_parallel_split_size(void) { return 1; }
+int jh_preferred_working_qtype(void) { return JH_DT_I8; }
+const char* jh_last_error(void) { return g_err.c_str(); }
+int jh_synchronize(void) {
+    JHCHK(ensure_ctx());
+    HIPCHK(hipStreamSynchronize(tctx.stream));
+    return JH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Tier 1
+int64_t jh_register_tensor(const void* host, int64_t bytes) {
+    if (!host || bytes <= 0) return set_err(JH_ERR_INVALID, "jh_register_tensor: null/empty");
+    int rc = ensure_ctx();
+    if (rc != JH_OK) return rc;
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, (size_t)bytes + 64);
+    if (e != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc weight: ") + hipGetErrorString(e));
+    e = hipMemcpy(d, host, (size_t)bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(d);
+        return set_err(JH_ERR_HIP, std::string("hipMemcpy weight: ") + hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    int64_t id = g_next_id++;
+    g_reg[id] = RegTensor{d, bytes, tctx.device};
+    return id;
+}
+int jh_unregister_tensor(int64_t id) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_reg.find(id);
+    if (it == g_reg.end()) return set_err(JH_ERR_INVALID, "unknown tensor id");
+    hipFree(it->second.ptr);
+    g_reg.erase(it);
+    return JH_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// Shared Tier-1 GEMM driver.  a_es/b_es: element size in bytes of A / B storage rows (Q4: ldb already in bytes).
+int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float* af, int aoffset, const void* b,
+               const float* bf, int boffset, float* r, int roffset, int m, int n0, int n, int k, int lda, int ldaf,
+               int ldb, int ldbf, int ldc) {
+    if (m < 0 || n < 0 || k < 0 || !r || !a) return set_err(JH_ERR_INVALID, "gemm: bad argument");
+    const bool q4 = (kind == G_Q8Q4 || kind == G_F32Q4);
+    if (q4 && (k % QB)) return set_err(JH_ERR_INVALID, "gemm: K must be a multiple of 32 for Q4/Q8 blocks");
+    if (m == 0 || n == 0) return JH_OK;
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    const size_t a_es = (kind == G_Q8Q4) ? 1 : (kind == G_BF16 ? 2 : 4);
+    const size_t b_es = q4 ? 1 : ((kind == G_BF16 || kind == G_F32BF16) ? 2 : 4);
+    // ---- A (+ scales)
+    const size_t a_elems = (size_t)lda * (m - 1) + aoffset + k;
+    void *dA = nullptr, *dAf = nullptr;
+    JHCHK(dev_buf(0, a_elems * a_es, &dA));
+    HIPCHK(hipMemcpyAsync(dA, a, a_elems * a_es, hipMemcpyHostToDevice, st));
+    if (kind == G_Q8Q4) {
+        if (!af) return set_err(JH_ERR_INVALID, "gemm_q8_q4: af is null");
+        const size_t af_elems = (size_t)ldaf * (m - 1) + aoffset / QB + k / QB;
+        JHCHK(dev_buf(1, af_elems * 4, &dAf));
+        HIPCHK(hipMemcpyAsync(dAf, af, af_elems * 4, hipMemcpyHostToDevice, st));
+    }
+    // ---- B (+ scales): registered (whole tensor resident) or copied rows [n0, n0+n)
+    const uint8_t* dB = nullptr;
+    const float* dBf = nullptr;
+    if (b_id >= 0) {
+        dB = (const uint8_t*)reg_ptr(b_id);
+        if (!dB) return set_err(JH_ERR_INVALID, "gemm: unknown b_id");
+    } else {
+        if (!b) return set_err(JH_ERR_INVALID, "gemm: b is null and not registered");
+        const size_t row0 = (size_t)ldb * n0 * b_es;
+        const size_t bytes = ((size_t)ldb * (n - 1) + boffset + (q4 ? k / 2 : k)) * b_es;
+        void* t = nullptr;
+        JHCHK(dev_buf(2, bytes, &t));
+        HIPCHK(hipMemcpyAsync(t, (const uint8_t*)b + row0, bytes, hipMemcpyHostToDevice, st));
+        dB = (const uint8_t*)t - row0;  // so that kernel-side ldb*j indexing lands in the copied window
+    }
+    if (q4) {
+        if (bf_id >= 0) {
+            dBf = (const float*)reg_ptr(bf_id);
+            if (!dBf) return set_err(JH_ERR_INVALID, "gemm: unknown bf_id");
+        } else {
+            if (!bf) return set_err(JH_ERR_INVALID, "gemm: bf is null and not registered");
+            const size_t row0 = (size_t)ldbf * n0;
+            const size_t elems = (size_t)ldbf * (n - 1) + (boffset * 2) / QB + k / QB;
+            void* t = nullptr;
+            JHCHK(dev_buf(3, elems * 4, &t));
+            HIPCHK(hipMemcpyAsync(t, bf + row0, elems * 4, hipMemcpyHostToDevice, st));
+            dBf = (const float*)t - row0;
+        }
+    }
+    // ---- R
+    const long long cmin = (long long)n0 - roffset;
+    if (cmin < 0) return set_err(JH_ERR_INVALID, "gemm: n0 - roffset < 0");
+    const size_t r_elems = (size_t)ldc * (m - 1) + (size_t)cmin + n;
+    void* dR = nullptr;
+    JHCHK(dev_buf(4, r_elems * 4, &dR));
+
+    bool fast = (m == 1) && q4 && (aoffset % QB == 0) && (boffset % 16 == 0) && (ldb % 16 == 0) &&
+                !env_int("JH_TIER1_GENERIC", 0);
+    if (fast) {
+        GemvParams p;
+        memset(&p, 0, sizeof(p));
+        p.ntens = 1;
+        p.nrows[0] = n;
+        p.K = k;
+        p.ldb = ldb;
+        p.ldbf = ldbf;
+        p.w[0] = dB + (size_t)ldb * n0 + boffset;
+        p.ws[0] = dBf + (size_t)ldbf * n0 + (boffset * 2) / QB;
+        p.out[0] = (float*)dR + cmin;
+        LaunchCfg cfg{env_int("JH_GEMV_R", 2), env_int("JH_GEMV_WAVES", 8), g_cu_count * 4};
+        if (kind == G_Q8Q4) {
+            p.aq = (const int8_t*)dA + aoffset;
+            p.ad = (const float*)dAf + aoffset / QB;
+            JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_STORE>(p, cfg, st)));
+        } else {
+            p.x = (const float*)dA + aoffset;
+            if (aoffset % 4) fast = false;
+            else JHCHK((launch_gemv_f32q4<PRO_F32>(p, cfg, nullptr, st)));
+        }
+    }
+    if (!fast) {
+        GemmParams g{dA, (const float*)dAf, dB, dBf, (float*)dR, aoffset, boffset, roffset, m, n0, n, k,
+                     lda, ldaf, ldb, ldbf, ldc};
+        if (!q4) { g.ldb = ldb; }
+        const long long waves = (long long)m * n;
+        const int grid = (int)((waves + 3) / 4);
+        switch (kind) {
+            case G_Q8Q4: hipLaunchKernelGGL((gemm_generic_kernel<G_Q8Q4>), dim3(grid), dim3(256), 0, st, g); break;
+            case G_F32Q4: hipLaunchKernelGGL((gemm_generic_kernel<G_F32Q4>), dim3(grid), dim3(256), 0, st, g); break;
+            case G_F32: hipLaunchKernelGGL((gemm_generic_kernel<G_F32>), dim3(grid), dim3(256), 0, st, g); break;
+            case G_BF16: hipLaunchKernelGGL((gemm_generic_kernel<G_BF16>), dim3(grid), dim3(256), 0, st, g); break;
+            default: hipLaunchKernelGGL((gemm_generic_kernel<G_F32BF16>), dim3(grid), dim3(256), 0, st, g); break;
+        }
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpy2DAsync(r + cmin, (size_t)ldc * 4, (float*)dR + cmin, (size_t)ldc * 4, (size_t)n * 4, m,
+                            hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+
+// element-wise Tier-1 helper: a (in/out) and b windows copied, op applied, a copied back
+template <int OP>
+int tier1_ew(float* a, const float* b, float f, int offset, int length) {
+    if (length < 0 || !a) return set_err(JH_ERR_INVALID, "elementwise: bad argument");
+    if (length == 0) return JH_OK;
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    void *dA = nullptr, *dB = nullptr;
+    JHCHK(dev_buf(0, (size_t)length * 4, &dA));
+    HIPCHK(hipMemcpyAsync(dA, a + offset, (size_t)length * 4, hipMemcpyHostToDevice, st));
+    if (b) {
+        JHCHK(dev_buf(1, (size_t)length * 4, &dB));
+        HIPCHK(hipMemcpyAsync(dB, b + offset, (size_t)length * 4, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL((ew_kernel<OP>), dim3((length + 255) / 256), dim3(256), 0, st, (float*)dA, (const float*)dB, f, length);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(a + offset, dA, (size_t)length * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int jh_gemm_q8_q4(int64_t b_id, int64_t bf_id, const float* af, const int8_t* a, int aoffset, const float* bf,
+                  const uint8_t* b, int boffset, float* r, int roffset, int m, int n0, int n, int k, int lda,
+                  int ldaf, int ldb, int ldbf, int ldc) {
+    return tier1_gemm(G_Q8Q4, b_id, bf_id, a, af, aoffset, b, bf, boffset, r, roffset, m, n0, n, k, lda, ldaf, ldb,
+                      ldbf, ldc);
+}
+int jh_gemm_f32_q4(int64_t b_id, int64_t bf_id, const float* a, int aoffset, const float* bf, const uint8_t* b,
+                   int boffset, float* r, int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldbf,
+                   int ldc) {
+    return tier1_gemm(G_F32Q4, b_id, bf_id, a, nullptr, aoffset, b, bf, boffset, r, roffset, m, n0, n, k, lda, 0,
+                      ldb, ldbf, ldc);
+}
+int jh_gemm_f32(int64_t b_id, const float* a, int aoffset, const float* b, int boffset, float* r, int roffset, int m,
+                int n0, int n, int k, int lda, int ldb, int ldc) {
+    return tier1_gemm(G_F32, b_id, -1, a, nullptr, aoffset, b, nullptr, boffset, r, roffset, m, n0, n, k, lda, 0, ldb,
+                      0, ldc);
+}
+int jh_gemm_bf16(int64_t b_id, const uint16_t* a, int aoffset, const uint16_t* b, int boffset, float* r, int roffset,
+                 int m, int n0, int n, int k, int lda, int ldb, int ldc) {
+    return tier1_gemm(G_BF16, b_id, -1, a, nullptr, aoffset, b, nullptr, boffset, r, roffset, m, n0, n, k, lda, 0, ldb,
+                      0, ldc);
+}
+int jh_gemm_f32_bf16(int64_t b_id, const float* a, int aoffset, const uint16_t* b, int boffset, float* r, int roffset,
+                     int m, int n0, int n, int k, int lda, int ldb, int ldc) {
+    return tier1_gemm(G_F32BF16, b_id, -1, a, nullptr, aoffset, b, nullptr, boffset, r, roffset, m, n0, n, k, lda, 0,
+                      ldb, 0, ldc);
+}
+int jh_gemm_q8_q4_batch(int batch_num, const int64_t* b_ids, const int64_t* bf_ids, const float* af, const int8_t* a,
+                        int aoffset, const float* const* bf, const uint8_t* const* b, int boffset, float* const* r,
+                        int roffset, int m, int n0, int n, int k, int lda, int ldaf, int ldb, int ldbf, int ldc) {
+    for (int i = 0; i < batch_num; i++)
+        JHCHK(jh_gemm_q8_q4(b_ids ? b_ids[i] : -1, bf_ids ? bf_ids[i] : -1, af, a, aoffset, bf ? bf[i] : nullptr,
+                            b ? b[i] : nullptr, boffset, r[i], roffset, m, n0, n, k, lda, ldaf, ldb, ldbf, ldc));
+    return JH_OK;
+}
+int jh_gemm_f32_q4_batch(int batch_num, const int64_t* b_ids, const int64_t* bf_ids, const float* a, int aoffset,
+                         const float* const* bf, const uint8_t* const* b, int boffset, float* const* r, int roffset,
+                         int m, int n0, int n, int k, int lda, int ldb, int ldbf, int ldc) {
+    for (int i = 0; i < batch_num; i++)
+        JHCHK(jh_gemm_f32_q4(b_ids ? b_ids[i] : -1, bf_ids ? bf_ids[i] : -1, a, aoffset, bf ? bf[i] : nullptr,
+                             b ? b[i] : nullptr, boffset, r[i], roffset, m, n0, n, k, lda, ldb, ldbf, ldc));
+    return JH_OK;
+}
+
+int jh_accumulate_f32(float* a, const float* b, int offset, int length) {
+    if (!b) return set_err(JH_ERR_INVALID, "accumulate: b is null");
+    return tier1_ew<EW_ACC>(a, b, 0.f, offset, length);
+}
+int jh_maccumulate_f32(float* a, const float* b, int offset, int length) {
+    if (!b) return set_err(JH_ERR_INVALID, "maccumulate: b is null");
+    return tier1_ew<EW_MACC>(a, b, 0.f, offset, length);
+}
+int jh_scale_f32(float factor, float* a, int offset, int length) { return tier1_ew<EW_SCALE>(a, nullptr, factor, offset, length); }
+int jh_silu_mul_f32(float* g, const float* u, int n) {
+    if (!u) return set_err(JH_ERR_INVALID, "silu_mul: u is null");
+    return tier1_ew<EW_SILU_MUL>(g, u, 0.f, 0, n);
+}
+int jh_saxpy_f32(float alpha, const float* x, float* y, int xoffset, int yoffset, int limit) {
+    if (!x || !y || limit < 0) return set_err(JH_ERR_INVALID, "saxpy: bad argument");
+    if (limit == 0) return JH_OK;
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    void *dY = nullptr, *dX = nullptr;
+    JHCHK(dev_buf(0, (size_t)limit * 4, &dY));
+    JHCHK(dev_buf(1, (size_t)limit * 4, &dX));
+    HIPCHK(hipMemcpyAsync(dY, y + yoffset, (size_t)limit * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dX, x + xoffset, (size_t)limit * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((ew_kernel<EW_SAXPY>), dim3((limit + 255) / 256), dim3(256), 0, st, (float*)dY, (const float*)dX, alpha, limit);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(y + yoffset, dY, (size_t)limit * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+int jh_saxpy_batch_f32(const float* alpha, const float* x, int ldx, float* y, int xoffset, int yoffset, int limit,
+                       int aoffset, int xrowoffset, int batch_size) {
+    if (!alpha || !x || !y || limit < 0 || batch_size < 0) return set_err(JH_ERR_INVALID, "saxpy_batch: bad argument");
+    if (limit == 0 || batch_size == 0) return JH_OK;
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    void *dY = nullptr, *dX = nullptr, *dAl = nullptr;
+    const size_t xelems = (size_t)ldx * (batch_size - 1) + limit;
+    JHCHK(dev_buf(0, (size_t)limit * 4, &dY));
+    JHCHK(dev_buf(1, xelems * 4, &dX));
+    JHCHK(dev_buf(2, (size_t)batch_size * 4, &dAl));
+    HIPCHK(hipMemcpyAsync(dY, y + yoffset, (size_t)limit * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dX, x + (size_t)xrowoffset * ldx + xoffset, xelems * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dAl, alpha + aoffset, (size_t)batch_size * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(saxpy_batch_kernel, dim3((limit + 127) / 128), dim3(128), 0, st, (const float*)dAl, (const float*)dX, ldx,
+                       (float*)dY, limit, batch_size);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(y + yoffset, dY, (size_t)limit * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+int jh_accumulate_f32_q4(float* a, const uint8_t* nib_row, const float* scale_row, int offset, int length) {
+    if (!a || !nib_row || !scale_row || length < 0) return set_err(JH_ERR_INVALID, "accumulate_q4: bad argument");
+    if (length == 0) return JH_OK;
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    const int end = offset + length;
+    void *dA = nullptr, *dN = nullptr, *dS = nullptr;
+    JHCHK(dev_buf(0, (size_t)end * 4, &dA));
+    JHCHK(dev_buf(1, (size_t)(end + 31) / 32 * 16, &dN));
+    JHCHK(dev_buf(2, (size_t)(end + 31) / 32 * 4, &dS));
+    HIPCHK(hipMemcpyAsync((float*)dA + offset, a + offset, (size_t)length * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dN, nib_row, (size_t)(end + 31) / 32 * 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dS, scale_row, (size_t)(end + 31) / 32 * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(acc_q4_kernel, dim3((length + 255) / 256), dim3(256), 0, st, (float*)dA, (const uint8_t*)dN, (const float*)dS,
+                       offset, length);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(a + offset, (float*)dA + offset, (size_t)length * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+int jh_quantize_q8(const float* x, int rows, int ldx, int offset, int length, int8_t* q, int ldq, float* d, int ldd) {
+    if (!x || !q || !d || rows < 0 || length < 0 || (length % QB) || (offset % QB))
+        return set_err(JH_ERR_INVALID, "quantize_q8: length/offset must be multiples of 32");
+    if (rows == 0 || length == 0) return JH_OK;
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    void *dX = nullptr, *dQ = nullptr, *dD = nullptr;
+    const size_t xe = (size_t)ldx * (rows - 1) + offset + length;
+    const size_t qe = (size_t)ldq * (rows - 1) + offset + length;
+    const size_t de = (size_t)ldd * (rows - 1) + (offset + length) / QB;
+    JHCHK(dev_buf(0, xe * 4, &dX));
+    JHCHK(dev_buf(1, qe, &dQ));
+    JHCHK(dev_buf(2, de * 4, &dD));
+    HIPCHK(hipMemcpyAsync(dX, x, xe * 4, hipMemcpyHostToDevice, st));
+    const long long threads = (long long)rows * (length / QB) * 32;
+    hipLaunchKernelGGL(quantize_q8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const float*)dX, rows, ldx,
+                       offset, length, (int8_t*)dQ, ldq, (float*)dD, ldd);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy2DAsync(q + offset, (size_t)ldq, (int8_t*)dQ + offset, (size_t)ldq, (size_t)length, rows, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpy2DAsync(d + offset / QB, (size_t)ldd * 4, (float*)dD + offset / QB, (size_t)ldd * 4, (size_t)(length / QB) * 4, rows,
+                            hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+int jh_quantize_bf16(const float* x, int64_t n, uint16_t* out) {
+    if (!x || !out || n < 0) return set_err(JH_ERR_INVALID, "quantize_bf16: bad argument");
+    if (n == 0) return JH_OK;
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    void *dX = nullptr, *dO = nullptr;
+    JHCHK(dev_buf(0, (size_t)n * 4, &dX));
+    JHCHK(dev_buf(1, (size_t)n * 2, &dO));
+    HIPCHK(hipMemcpyAsync(dX, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(quantize_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)dX, (long long)n, (uint16_t*)dO);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dO, (size_t)n * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+int jh_rmsnorm_f32(const float* x, const float* w, float weight_adj, int n, float eps, float* out) {
+    if (!x || !w || !out || n <= 0) return set_err(JH_ERR_INVALID, "rmsnorm: bad argument");
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    void *dX = nullptr, *dW = nullptr, *dO = nullptr;
+    JHCHK(dev_buf(0, (size_t)n * 4, &dX));
+    JHCHK(dev_buf(1, (size_t)n * 4, &dW));
+    JHCHK(dev_buf(2, (size_t)n * 4, &dO));
+    HIPCHK(hipMemcpyAsync(dX, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dW, w, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(1024), 0, st, (const float*)dX, (const float*)dW, weight_adj, n, eps, (float*)dO);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dO, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+int jh_softmax_f32(float* x, int offset, int length) {
+    if (!x || length <= 0 || offset < 0) return set_err(JH_ERR_INVALID, "softmax: bad argument");
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    void* dX = nullptr;
+    const size_t n = (size_t)offset + length;
+    JHCHK(dev_buf(0, n * 4, &dX));
+    HIPCHK(hipMemcpyAsync(dX, x, n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(1024), 0, st, (float*)dX, offset, length);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(x, dX, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+
+// VectorMath.precomputeFreqsCis (core/math/VectorMath.java:148-165) -- host side, double cos/sin of the float angle.
+int jh_rope_table(int dim, int end, double theta, double scaling, float* out) {
+    if (!out || dim <= 0 || (dim & 1) || end <= 0) return set_err(JH_ERR_INVALID, "rope_table: bad argument");
+    const int half = dim / 2;
+    std::vector<float> freqs((size_t)half);
+    float step = 0.0f;
+    for (int i = 0; i < half; i++, step = (float)(step + 2.0))
+        freqs[(size_t)i] = (float)((1.0 / pow(theta, (double)(step / (float)dim))) / scaling);
+    for (int p = 0; p < end; p++) {
+        const float t = (float)p;
+        for (int i = 0; i < half; i++) {
+            const float ang = t * freqs[(size_t)i];
+            out[((size_t)p * half + i) * 2 + 0] = (float)cos((double)ang);
+            out[((size_t)p * half + i) * 2 + 1] = (float)sin((double)ang);
+        }
+    }
+    return JH_OK;
+}
+int jh_rope_apply_f32(float* q, float* k, const float* rope, int position, int n_heads, int n_kv_heads, int head_size) {
+    if (!q || !k || !rope || position < 0 || n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads || (head_size & 1))
+        return set_err(JH_ERR_INVALID, "rope_apply: bad argument");
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    const int half = head_size / 2;
+    // rows of the table this call touches: [position*half, position*half + n_kv_heads*head_size)
+    const size_t r0 = (size_t)position * half, rn = (size_t)n_kv_heads * head_size;
+    void *dQ = nullptr, *dK = nullptr, *dR = nullptr;
+    JHCHK(dev_buf(0, (size_t)n_heads * head_size * 4, &dQ));
+    JHCHK(dev_buf(1, (size_t)n_kv_heads * head_size * 4, &dK));
+    JHCHK(dev_buf(2, rn * 8, &dR));
+    HIPCHK(hipMemcpyAsync(dQ, q, (size_t)n_heads * head_size * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dK, k, (size_t)n_kv_heads * head_size * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dR, rope + r0 * 2, rn * 8, hipMemcpyHostToDevice, st));
+    const int threads = (n_heads + n_kv_heads) * half;
+    hipLaunchKernelGGL(rope_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, (float*)dQ, (float*)dK,
+                       (const float*)dR - r0 * 2, position, n_heads, n_kv_heads, head_size);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(q, dQ, (size_t)n_heads * head_size * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(k, dK, (size_t)n_kv_heads * head_size * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+// KvBufferCache.computePageSize (core/tensor/KvBufferCache.java:224-280)
+int jh_kv_page_geometry(int64_t max_page_bytes, int n_layers, int context_length, int kv_length, int dtype_size,
+                        int32_t* out2) {
+    if (!out2 || n_layers <= 0 || context_length <= 0 || kv_length <= 0) return set_err(JH_ERR_INVALID, "kv geometry: bad argument");
+    const int64_t s = 2LL * dtype_size * kv_length;
+    if (max_page_bytes <= s) return set_err(JH_ERR_INVALID, "maxPageSizeInBytes must be greater than the size of a single layer");
+    int optL = 1, optC = 1;
+    int64_t maxProduct = 0;
+    for (int x = n_layers; x >= 1; x--) {
+        const int64_t y = max_page_bytes / (x * s);
+        if (y >= 1 && y <= context_length) {
+            const int64_t product = x * y;
+            if (product > maxProduct) { optL = x; optC = (int)y; maxProduct = product; }
+            if (product < maxProduct) break;
+        }
+    }
+    out2[0] = optL;
+    out2[1] = optC;
+    return JH_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ Tier 2
+struct JWeight {
+    int dtype = -1;
+    void* data = nullptr;
+    float* scales = nullptr;
+    int rows = 0, cols = 0;
+};
+struct jh_model {
+    jh_config c;
+    int device;
+    std::vector<JWeight> layer_w;  // [n_layers][JH_W_COUNT]
+    JWeight global_w[JH_W_COUNT];
+    float* rope = nullptr;
+    float attention_scale;
+    int64_t weight_bytes = 0;
+};
+enum { TAP_SLOTS = 12 };
+struct jh_session {
+    jh_model* m;
+    hipStream_t stream = nullptr;
+    int layers_per_page = 0, ctx_per_page = 0, n_layer_pages = 0, n_ctx_pages = 0, n_ctx_alloc = 0;
+    std::vector<float*> pages_host;
+    float** pages_dev = nullptr;
+    int max_ctx = 0, max_splits = 32, chunk_cap = 32;
+    // activations
+    float *x = nullptr, *x1 = nullptr, *qkv = nullptr, *attd = nullptr, *attf = nullptr, *hd = nullptr, *hf = nullptr;
+    int8_t *attq = nullptr, *hq = nullptr;
+    float *logits = nullptr, *amax_v = nullptr, *part = nullptr, *tapq = nullptr;
+    int* amax_i = nullptr;
+    unsigned* counters = nullptr;
+    DecodeState* st = nullptr;
+    int* out_tokens = nullptr;
+    int out_cap = 0;
+    int lm_grid = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int pending_n = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double ms_per_token = 0;
+    int kernels_per_token = 0;
+    int tap_layer = -1;
+    float* taps[TAP_SLOTS] = {nullptr};
+    int tap_len[TAP_SLOTS] = {0};
+    LaunchCfg cfg_qkv, cfg_o, cfg_down, cfg_lm;
+    int gateup_grid_cap;
+};
+
+namespace {
+
+bool is_global_slot(int which) { return which == JH_W_EMBED || which == JH_W_LMHEAD || which == JH_W_FINALNORM; }
+
+int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    const int lp = rel / s->layers_per_page;
+    p.qkv = s->qkv;
+    p.rope = m->rope;
+    p.pages = s->pages_dev + (size_t)lp * s->n_ctx_pages;
+    p.rel_layer_in_page = rel % s->layers_per_page;
+    p.ctx_per_page = s->ctx_per_page;
+    p.n_heads = c.n_heads;
+    p.n_kv_heads = c.n_kv_heads;
+    p.head_size = c.head_size;
+    p.st = s->st;
+    p.scale = m->attention_scale;
+    p.part = s->part;
+    p.counters = s->counters;
+    p.max_splits = s->max_splits;
+    p.outq = s->attq;
+    p.outd = s->attd;
+    p.outf = s->attf;
+    p.tap_q = tap ? s->tapq : nullptr;
+    const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
+    const size_t lds = ((size_t)group * hs + 2 * hs + 1024 * (size_t)group + 2 * group + 4 + (size_t)group * s->chunk_cap) * 4;
+    dim3 grid(s->max_splits, c.n_kv_heads), block(256);
+#define JH_ATTN(HSV, GV)                                                                   \
+    if (hs == HSV && group == GV) {                                                        \
+        JHCHK(allow_lds(attn_decode_kernel<HSV, GV>, lds));                                \
+        hipLaunchKernelGGL((attn_decode_kernel<HSV, GV>), grid, block, lds, st, p);        \
+        HIPCHK(hipGetLastError());                                                         \
+        return JH_OK;                                                                      \
+    }
+    JH_ATTN(128, 4) JH_ATTN(128, 8) JH_ATTN(64, 4) JH_ATTN(128, 1) JH_ATTN(128, 2) JH_ATTN(64, 1) JH_ATTN(64, 2) JH_ATTN(64, 8)
+#undef JH_ATTN
+    return set_err(JH_ERR_UNSUPPORTED, "attention: head_size must be 64 or 128 and heads/kv_heads in {1,2,4,8}");
+}
+
+int tap_copy(jh_session* s, int which, const float* src, int n, hipStream_t st) {
+    if (!s->taps[which] || s->tap_len[which] < n) {
+        if (s->taps[which]) HIPCHK(hipFree(s->taps[which]));
+        HIPCHK(hipMalloc(&s->taps[which], (size_t)n * 4));
+    }
+    s->tap_len[which] = n;
+    HIPCHK(hipMemcpyAsync(s->taps[which], src, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    return JH_OK;
+}
+
+// One TransformerBlock.forward (core/model/TransformerBlock.java:158-215) for the row described by s->st:
+// 5 launches -- qkv(+rmsnorm+q8) | attention(+rope+kv write+q8) | o-proj(+residual) | gate/up(+rmsnorm+q8,+silu*up+q8) | down(+residual)
+int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_tap) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int rel = li - c.layer_start;
+    const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
+    const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    if (tap) JHCHK(tap_copy(s, JH_TAP_INPUT_EMB, s->x, E, st));
+    {   // q,k,v projections (CausalSelfAttention.java:161-171) with fused preAttentionNorm + maybeQuantize
+        GemvParams p;
+        memset(&p, 0, sizeof(p));
+        p.ntens = 3;
+        p.w[0] = (const uint8_t*)W[JH_W_Q].data; p.ws[0] = W[JH_W_Q].scales; p.nrows[0] = A; p.out[0] = s->qkv;
+        p.w[1] = (const uint8_t*)W[JH_W_K].data; p.ws[1] = W[JH_W_K].scales; p.nrows[1] = KV; p.out[1] = s->qkv + A;
+        p.w[2] = (const uint8_t*)W[JH_W_V].data; p.ws[2] = W[JH_W_V].scales; p.nrows[2] = KV; p.out[2] = s->qkv + A + KV;
+        p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
+        p.x = s->x; p.nw = W[JH_W_NORM1].data; p.nw_bf16 = W[JH_W_NORM1].dtype == JH_DT_BF16; p.eps = c.rms_eps;
+        JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
+    }
+    if (tap) {
+        JHCHK(tap_copy(s, JH_TAP_QUERY, s->qkv, A, st));
+        JHCHK(tap_copy(s, JH_TAP_KEY, s->qkv + A, KV, st));
+        JHCHK(tap_copy(s, JH_TAP_VALUE, s->qkv + A + KV, KV, st));
+    }
+    JHCHK(attn_launch(s, rel, st, tap));
+    if (tap) {
+        JHCHK(tap_copy(s, JH_TAP_QUERY_ROPE, s->tapq, A, st));
+        const int lp = rel / s->layers_per_page, cp = pos_for_tap / s->ctx_per_page, rc = pos_for_tap % s->ctx_per_page;
+        const float* krow = s->pages_host[(size_t)lp * s->n_ctx_pages + cp] +
+                            ((size_t)((rel % s->layers_per_page) * 2 + 0) * s->ctx_per_page + rc) * KV;
+        JHCHK(tap_copy(s, JH_TAP_KEY_ROPE, krow, KV, st));
+        JHCHK(tap_copy(s, JH_TAP_AFTER_ATTENTION, s->attf, A, st));
+    }
+    {   // output projection (:365-376) + residual (TransformerBlock.java:185)
+        GemvParams p;
+        memset(&p, 0, sizeof(p));
+        p.ntens = 1;
+        p.w[0] = (const uint8_t*)W[JH_W_O].data; p.ws[0] = W[JH_W_O].scales; p.nrows[0] = E; p.out[0] = s->x1;
+        p.K = A; p.ldb = A / 2; p.ldbf = A / QB;
+        p.aq = s->attq; p.ad = s->attd; p.resid = s->x;
+        JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_o, st)));
+    }
+    if (tap) JHCHK(tap_copy(s, 8, s->x1, E, st));
+    {   // gate/up (MLPBlock.java:117-142) with fused preFFNorm + maybeQuantize, SiLU*up + maybeQuantize
+        GemvParams p;
+        memset(&p, 0, sizeof(p));
+        p.ntens = 2;
+        p.w[0] = (const uint8_t*)W[JH_W_GATE].data; p.ws[0] = W[JH_W_GATE].scales; p.nrows[0] = H;
+        p.w[1] = (const uint8_t*)W[JH_W_UP].data; p.ws[1] = W[JH_W_UP].scales; p.nrows[1] = H;
+        p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
+        p.x = s->x1; p.nw = W[JH_W_NORM2].data; p.nw_bf16 = W[JH_W_NORM2].dtype == JH_DT_BF16; p.eps = c.rms_eps;
+        p.hq = s->hq; p.hd = s->hd; p.hf = tap ? s->hf : nullptr;
+        JHCHK((launch_gateup<PRO_RMS_Q8>(p, s->gateup_grid_cap, st)));
+    }
+    if (tap) JHCHK(tap_copy(s, 10, s->hf, H, st));
+    {   // down projection (:147-158) + residual (TransformerBlock.java:203)
+        GemvParams p;
+        memset(&p, 0, sizeof(p));
+        p.ntens = 1;
+        p.w[0] = (const uint8_t*)W[JH_W_DOWN].data; p.ws[0] = W[JH_W_DOWN].scales; p.nrows[0] = E; p.out[0] = s->x;
+        p.K = H; p.ldb = H / 2; p.ldbf = H / QB;
+        p.aq = s->hq; p.ad = s->hd; p.resid = s->x1;
+        JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_down, st)));
+    }
+    if (tap) JHCHK(tap_copy(s, JH_TAP_POST_FF_RES, s->x, E, st));
+    return JH_OK;
+}
+
+int layers_launch(jh_session* s, hipStream_t st, int pos_for_tap) {
+    const jh_config& c = s->m->c;
+    for (int li = c.layer_start; li < c.layer_end; li++)
+        JHCHK(layer_launch(s, li, st, s->tap_layer == li, pos_for_tap));
+    return JH_OK;
+}
+
+const JWeight* lm_head_weight(jh_model* m) {
+    return m->global_w[JH_W_LMHEAD].data ? &m->global_w[JH_W_LMHEAD] : &m->global_w[JH_W_EMBED];
+}
+
+// AbstractModel.sample's device part (core/model/AbstractModel.java:443-469): final RMSNorm -> F32xQ4 LM head -> argmax partials
+int lmhead_launch(jh_session* s, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const JWeight* w = lm_head_weight(m);
+    if (!w->data || !m->global_w[JH_W_FINALNORM].data) return set_err(JH_ERR_INVALID, "sample: this shard has no output weights");
+    GemvParams p;
+    memset(&p, 0, sizeof(p));
+    p.ntens = 1;
+    p.w[0] = (const uint8_t*)w->data; p.ws[0] = w->scales; p.nrows[0] = c.vocab_size; p.out[0] = s->logits;
+    p.K = c.embedding_length; p.ldb = p.K / 2; p.ldbf = p.K / QB;
+    p.x = s->x; p.nw = m->global_w[JH_W_FINALNORM].data; p.nw_bf16 = m->global_w[JH_W_FINALNORM].dtype == JH_DT_BF16;
+    p.eps = c.rms_eps;
+    p.amax_part = s->amax_v; p.amax_idx = s->amax_i;
+    int grid = 0;
+    JHCHK((launch_gemv_f32q4<PRO_RMS_F32>(p, s->cfg_lm, &grid, st)));
+    s->lm_grid = grid;
+    return JH_OK;
+}
+
+int finish_launch(jh_session* s, hipStream_t st, int do_embed) {
+    jh_model* m = s->m;
+    const JWeight& e = m->global_w[JH_W_EMBED];
+    hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(256), 0, st, (const float*)s->amax_v, (const int*)s->amax_i, s->lm_grid,
+                       s->st, s->out_tokens, (const void*)e.data, (const float*)e.scales, e.dtype, m->c.embedding_length, s->x,
+                       (do_embed && e.data) ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+
+int ensure_out_tokens(jh_session* s, int n) {
+    if (s->out_cap >= n) return JH_OK;
+    if (s->out_tokens) HIPCHK(hipFree(s->out_tokens));
+    HIPCHK(hipMalloc(&s->out_tokens, (size_t)n * sizeof(int)));
+    s->out_cap = n;
+    if (s->exec) {  // out_tokens pointer is baked into the captured graph
+        hipGraphExecDestroy(s->exec); s->exec = nullptr;
+        hipGraphDestroy(s->graph); s->graph = nullptr;
+    }
+    return JH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jh_model_create(const jh_config* cfg, jh_model** out) {
+    if (!cfg || !out) return set_err(JH_ERR_INVALID, "model_create: null");
+    if (cfg->weight_dtype != JH_DT_Q4)
+        return set_err(JH_ERR_UNSUPPORTED, "model_create: only JQ4 (Q4 weights, I8 activations) resident models are built so far");
+    if (cfg->embedding_length % 256 || cfg->hidden_length % 32 || cfg->n_heads % cfg->n_kv_heads ||
+        (cfg->head_size != 64 && cfg->head_size != 128) || cfg->layer_start < 0 || cfg->layer_end > cfg->n_layers ||
+        cfg->layer_start >= cfg->layer_end)
+        return set_err(JH_ERR_INVALID, "model_create: unsupported shape (E%256, H%32, head_size in {64,128})");
+    JHCHK(ensure_ctx());
+    jh_model* m = new jh_model();
+    m->c = *cfg;
+    m->device = tctx.device;
+    m->layer_w.resize((size_t)cfg->n_layers * JH_W_COUNT);
+    // Config ctor (core/safetensors/Config.java:270-274): table over the whole context
+    const int half = cfg->head_size / 2;
+    std::vector<float> table((size_t)cfg->context_length * half * 2);
+    jh_rope_table(cfg->head_size, cfg->context_length, (double)cfg->rope_theta, (double)cfg->rope_scaling, table.data());
+    hipError_t e = hipMalloc(&m->rope, table.size() * 4);
+    if (e != hipSuccess) { delete m; return set_err(JH_ERR_OOM, "hipMalloc rope table"); }
+    HIPCHK(hipMemcpy(m->rope, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    m->attention_scale = (float)(1.0 / sqrt((double)cfg->head_size));  // CausalSelfAttention.java:134
+    *out = m;
+    return JH_OK;
+}
+int jh_model_destroy(jh_model* m) {
+    if (!m) return JH_OK;
+    hipSetDevice(m->device);
+    for (auto& w : m->layer_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
+    for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
+    if (m->rope) hipFree(m->rope);
+    delete m;
+    return JH_OK;
+}
+int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void* data, const float* scales, int rows,
+                        int cols, int from_device) {
+    if (!m || !data || which < 0 || which >= JH_W_COUNT) return set_err(JH_ERR_INVALID, "set_weight: bad argument");
+    HIPCHK(hipSetDevice(m->device));
+    JWeight* w;
+    if (layer < 0) {
+        if (!is_global_slot(which)) return set_err(JH_ERR_INVALID, "set_weight: slot needs a layer index");
+        w = &m->global_w[which];
+    } else {
+        if (layer >= m->c.n_layers || is_global_slot(which)) return set_err(JH_ERR_INVALID, "set_weight: bad layer/slot");
+        w = &m->layer_w[(size_t)layer * JH_W_COUNT + which];
+    }
+    size_t bytes, sbytes = 0;
+    if (dtype == JH_DT_Q4) {
+        if (!scales || cols % QB) return set_err(JH_ERR_INVALID, "set_weight: Q4 needs scales and cols%32==0");
+        bytes = (size_t)rows * cols / 2;
+        sbytes = (size_t)rows * (cols / QB) * 4;
+    } else if (dtype == JH_DT_BF16) bytes = (size_t)rows * cols * 2;
+    else if (dtype == JH_DT_F32) bytes = (size_t)rows * cols * 4;
+    else return set_err(JH_ERR_UNSUPPORTED, "set_weight: dtype");
+    const bool is_norm = (which == JH_W_NORM1 || which == JH_W_NORM2 || which == JH_W_FINALNORM);
+    if (!is_norm && dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "set_weight: matmul weights must be Q4 in this build");
+    if (w->data) { hipFree(w->data); m->weight_bytes -= 0; }
+    if (w->scales) hipFree(w->scales);
+    w->data = nullptr; w->scales = nullptr;
+    hipError_t e = hipMalloc(&w->data, bytes + 64);
+    if (e != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc weight: ") + hipGetErrorString(e));
+    const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIPCHK(hipMemcpy(w->data, data, bytes, kind));
+    if (sbytes) {
+        e = hipMalloc((void**)&w->scales, sbytes + 64);
+        if (e != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc scales: ") + hipGetErrorString(e));
+        HIPCHK(hipMemcpy(w->scales, scales, sbytes, kind));
+    }
+    w->dtype = dtype; w->rows = rows; w->cols = cols;
+    if (!is_norm && which != JH_W_EMBED) m->weight_bytes += (int64_t)(bytes + sbytes);
+    return JH_OK;
+}
+int64_t jh_model_weight_bytes(jh_model* m) { return m ? m->weight_bytes : 0; }
+
+int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_session** out) {
+    if (!m || !out || max_ctx <= 0) return set_err(JH_ERR_INVALID, "session_create: bad argument");
+    HIPCHK(hipSetDevice(m->device));
+    const jh_config& c = m->c;
+    if (max_ctx > c.context_length) max_ctx = c.context_length;
+    jh_session* s = new jh_session();
+    s->m = m;
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const int nl = c.layer_end - c.layer_start;
+    const int KV = c.n_kv_heads * c.head_size, A = c.n_heads * c.head_size, E = c.embedding_length, H = c.hidden_length;
+    int32_t geo[2];
+    JHCHK(jh_kv_page_geometry(max_page_bytes > 0 ? max_page_bytes : (1 << 23), nl, c.context_length, KV, 4, geo));
+    s->layers_per_page = geo[0];
+    s->ctx_per_page = geo[1];
+    s->n_layer_pages = (nl + geo[0] - 1) / geo[0];
+    s->n_ctx_pages = (c.context_length + geo[1] - 1) / geo[1];
+    s->n_ctx_alloc = (max_ctx + geo[1] - 1) / geo[1];
+    s->max_ctx = max_ctx;
+    s->pages_host.assign((size_t)s->n_layer_pages * s->n_ctx_pages, nullptr);
+    const size_t page_bytes = (size_t)geo[0] * 2 * geo[1] * KV * 4;
+    for (int lp = 0; lp < s->n_layer_pages; lp++)
+        for (int cp = 0; cp < s->n_ctx_alloc; cp++) {
+            float* pg = nullptr;
+            hipError_t e = hipMalloc(&pg, page_bytes);
+            if (e != hipSuccess) { jh_session_destroy(s); return set_err(JH_ERR_OOM, "hipMalloc KV page"); }
+            HIPCHK(hipMemset(pg, 0, page_bytes));
+            s->pages_host[(size_t)lp * s->n_ctx_pages + cp] = pg;
+        }
+    HIPCHK(hipMalloc(&s->pages_dev, s->pages_host.size() * sizeof(float*)));
+    HIPCHK(hipMemcpy(s->pages_dev, s->pages_host.data(), s->pages_host.size() * sizeof(float*), hipMemcpyHostToDevice));
+    s->max_splits = env_int("JH_ATTN_SPLITS", 32);
+    if (s->max_splits < 1) s->max_splits = 1;
+    s->chunk_cap = (max_ctx + s->max_splits - 1) / s->max_splits;
+    if (s->chunk_cap < 32) s->chunk_cap = 32;
+    HIPCHK(hipMalloc(&s->x, (size_t)E * 4));
+    HIPCHK(hipMalloc(&s->x1, (size_t)E * 4));
+    HIPCHK(hipMalloc(&s->qkv, (size_t)(A + 2 * KV) * 4));
+    HIPCHK(hipMalloc(&s->attq, (size_t)A));
+    HIPCHK(hipMalloc(&s->attd, (size_t)(A / QB) * 4));
+    HIPCHK(hipMalloc(&s->attf, (size_t)A * 4));
+    HIPCHK(hipMalloc(&s->tapq, (size_t)A * 4));
+    HIPCHK(hipMalloc(&s->hq, (size_t)H));
+    HIPCHK(hipMalloc(&s->hd, (size_t)(H / QB) * 4));
+    HIPCHK(hipMalloc(&s->hf, (size_t)H * 4));
+    HIPCHK(hipMalloc(&s->logits, (size_t)c.vocab_size * 4));
+    HIPCHK(hipMalloc(&s->amax_v, 4096 * 4));
+    HIPCHK(hipMalloc(&s->amax_i, 4096 * 4));
+    HIPCHK(hipMalloc(&s->part, (size_t)c.n_heads * s->max_splits * (c.head_size + 2) * 4));
+    HIPCHK(hipMalloc(&s->counters, (size_t)c.n_kv_heads * 4));
+    HIPCHK(hipMemset(s->counters, 0, (size_t)c.n_kv_heads * 4));
+    HIPCHK(hipMalloc(&s->st, sizeof(DecodeState)));
+    HIPCHK(hipMemset(s->st, 0, sizeof(DecodeState)));
+    HIPCHK(hipEventCreate(&s->ev0));
+    HIPCHK(hipEventCreate(&s->ev1));
+    JHCHK(ensure_out_tokens(s, 1024));
+    const int cu = g_cu_count;
+    s->cfg_qkv = LaunchCfg{env_int("JH_QKV_R", 2), env_int("JH_QKV_WAVES", 8), env_int("JH_QKV_GRID", cu * 2)};
+    s->cfg_o = LaunchCfg{env_int("JH_O_R", 2), env_int("JH_O_WAVES", 8), env_int("JH_O_GRID", cu * 2)};
+    s->cfg_down = LaunchCfg{env_int("JH_DOWN_R", 2), env_int("JH_DOWN_WAVES", 8), env_int("JH_DOWN_GRID", cu * 2)};
+    s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 2), env_int("JH_LM_WAVES", 8), env_int("JH_LM_GRID", cu * 4)};
+    if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
+    s->gateup_grid_cap = env_int("JH_GATEUP_GRID", cu * 2);
+    *out = s;
+    return JH_OK;
+}
+int jh_session_destroy(jh_session* s) {
+    if (!s) return JH_OK;
+    hipSetDevice(s->m->device);
+    if (s->stream) hipStreamSynchronize(s->stream);
+    if (s->exec) hipGraphExecDestroy(s->exec);
+    if (s->graph) hipGraphDestroy(s->graph);
+    for (float* p : s->pages_host) if (p) hipFree(p);
+    void* bufs[] = {s->pages_dev, s->x, s->x1, s->qkv, s->attq, s->attd, s->attf, s->tapq, s->hq, s->hd, s->hf, s->logits,
+                    s->amax_v, s->amax_i, s->part, s->counters, s->st, s->out_tokens};
+    for (void* b : bufs) if (b) hipFree(b);
+    for (float* t : s->taps) if (t) hipFree(t);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return JH_OK;
+}
+int jh_session_page_info(jh_session* s, int32_t* out4) {
+    if (!s || !out4) return set_err(JH_ERR_INVALID, "page_info: null");
+    out4[0] = s->layers_per_page; out4[1] = s->ctx_per_page; out4[2] = s->n_layer_pages; out4[3] = s->n_ctx_pages;
+    return JH_OK;
+}
+void* jh_session_stream(jh_session* s) { return s ? (void*)s->stream : nullptr; }
+
+static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in, bool x_in_dev, int n, int start_pos,
+                        float* x_out, bool x_out_dev) {
+    if (!s || n <= 0 || start_pos < 0 || (!tokens && !x_in)) return set_err(JH_ERR_INVALID, "forward: bad argument");
+    if (start_pos + n > s->max_ctx) return set_err(JH_ERR_INVALID, "forward: position beyond the session's max_ctx");
+    jh_model* m = s->m;
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = s->stream;
+    const int E = m->c.embedding_length;
+    const JWeight& emb = m->global_w[JH_W_EMBED];
+    if (tokens && !emb.data) return set_err(JH_ERR_INVALID, "forward: this shard has no embedding table");
+    // batchForwardSlow order (core/model/AbstractModel.java:282-290): rows one position at a time -- per-row
+    // arithmetic is identical to the batched path (attention is per position there too, CausalSelfAttention.java:199).
+    for (int i = 0; i < n; i++) {
+        hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, start_pos + i, tokens ? tokens[i] : 0, 0);
+        if (tokens) {
+            hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                               (const DecodeState*)s->st, E, s->x);
+        } else {
+            HIPCHK(hipMemcpyAsync(s->x, x_in + (size_t)i * E, (size_t)E * 4, x_in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(hipGetLastError());
+        JHCHK(layers_launch(s, st, start_pos + i));
+        if (x_out)
+            HIPCHK(hipMemcpyAsync(x_out + (size_t)i * E, s->x, (size_t)E * 4, x_out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    }
+    if (!x_out_dev) HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+int jh_forward(jh_session* s, const int32_t* tokens, const float* x_in, int n, int start_pos, float* x_out) {
+    return forward_impl(s, tokens, x_in, false, n, start_pos, x_out, false);
+}
+int jh_forward_device(jh_session* s, const int32_t* tokens, const float* x_in_dev, int n, int start_pos, float* x_out_dev) {
+    return forward_impl(s, tokens, x_in_dev, true, n, start_pos, x_out_dev, true);
+}
+
+int jh_get_logits(jh_session* s, float* out_v) {
+    if (!s || !out_v) return set_err(JH_ERR_INVALID, "get_logits: null");
+    HIPCHK(hipSetDevice(s->m->device));
+    HIPCHK(hipMemcpyAsync(out_v, s->logits, (size_t)s->m->c.vocab_size * 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return JH_OK;
+}
+
+int jh_sample(jh_session* s, float temperature, float u, int32_t* next_token, float* logits_out) {
+    if (!s || !next_token) return set_err(JH_ERR_INVALID, "sample: null");
+    HIPCHK(hipSetDevice(s->m->device));
+    hipStream_t st = s->stream;
+    JHCHK(lmhead_launch(s, st));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, 0, 0, 0);
+    JHCHK(finish_launch(s, st, 0));
+    int tok = 0;
+    HIPCHK(hipMemcpyAsync(&tok, s->out_tokens, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int V = s->m->c.vocab_size;
+    if (logits_out || temperature != 0.0f) {
+        std::vector<float> tmp;
+        float* lg = logits_out;
+        if (!lg) { tmp.resize((size_t)V); lg = tmp.data(); }
+        JHCHK(jh_get_logits(s, lg));
+        if (temperature != 0.0f) {
+            // AbstractModel.java:475-489 (host side: the uniform comes from the caller; sequential float sums)
+            std::vector<float> pr((size_t)V);
+            const double maxv = (double)lg[tok];
+            float sum = 0;
+            for (int i = 0; i < V; i++) {
+                const float v = (float)exp(((double)lg[i] - maxv) / (double)temperature);
+                sum += v;
+                pr[(size_t)i] = v;
+            }
+            float acc = 0;
+            int pick = V - 1;
+            for (int i = 0; i < V; i++) {
+                acc += pr[(size_t)i] / sum;
+                if (acc >= u) { pick = i; break; }
+            }
+            tok = pick;
+        }
+    }
+    *next_token = tok;
+    return JH_OK;
+}
+
+int jh_decode_step(jh_session* s, int32_t token, int pos, int32_t* next_token) {
+    if (!s || !next_token) return set_err(JH_ERR_INVALID, "decode_step: null");
+    JHCHK(jh_forward(s, &token, nullptr, 1, pos, nullptr));
+    return jh_sample(s, 0.0f, 0.5f, next_token, nullptr);
+}
+
+static int build_graph(jh_session* s) {
+    if (s->exec) return JH_OK;
+    hipStream_t st = s->stream;
+    const jh_config& c = s->m->c;
+    const int saved_tap = s->tap_layer;
+    s->tap_layer = -1;
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = layers_launch(s, st, 0);
+    const bool has_out = lm_head_weight(s->m)->data && s->m->global_w[JH_W_FINALNORM].data;
+    if (rc == JH_OK && has_out) rc = lmhead_launch(s, st);
+    if (rc == JH_OK && has_out) rc = finish_launch(s, st, 1);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(st, &g);
+    s->tap_layer = saved_tap;
+    if (rc != JH_OK) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    s->graph = g;
+    HIPCHK(hipGraphInstantiate(&s->exec, g, nullptr, nullptr, 0));
+    s->kernels_per_token = (c.layer_end - c.layer_start) * 5 + (has_out ? 2 : 0);
+    return JH_OK;
+}
+
+int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) {
+    if (!s || n <= 0 || start_pos < 0) return set_err(JH_ERR_INVALID, "decode_n: bad argument");
+    if (start_pos + n > s->max_ctx) return set_err(JH_ERR_INVALID, "decode_n: positions beyond the session's max_ctx");
+    jh_model* m = s->m;
+    HIPCHK(hipSetDevice(m->device));
+    const JWeight& emb = m->global_w[JH_W_EMBED];
+    if (!emb.data || !lm_head_weight(m)->data) return set_err(JH_ERR_INVALID, "decode_n: needs embedding and output weights on this shard");
+    JHCHK(ensure_out_tokens(s, n));
+    hipStream_t st = s->stream;
+    const bool use_graph = !env_int("JH_NO_GRAPH", 0);
+    if (use_graph) JHCHK(build_graph(s));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, start_pos, first_token, 0);
+    hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                       (const DecodeState*)s->st, m->c.embedding_length, s->x);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev0, st));
+    for (int i = 0; i < n; i++) {
+        if (use_graph) HIPCHK(hipGraphLaunch(s->exec, st));
+        else {
+            const int saved = s->tap_layer;
+            s->tap_layer = -1;
+            int rc = layers_launch(s, st, 0);
+            if (rc == JH_OK) rc = lmhead_launch(s, st);
+            if (rc == JH_OK) rc = finish_launch(s, st, 1);
+            s->tap_layer = saved;
+            JHCHK(rc);
+        }
+    }
+    HIPCHK(hipEventRecord(s->ev1, st));
+    s->pending_n = n;
+    return JH_OK;
+}
+int jh_decode_wait(jh_session* s, int32_t* out_tokens, int n) {
+    if (!s) return set_err(JH_ERR_INVALID, "decode_wait: null");
+    HIPCHK(hipSetDevice(s->m->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->pending_n > 0) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        s->ms_per_token = (double)ms / s->pending_n;
+    }
+    if (out_tokens && n > 0) {
+        if (n > s->pending_n) n = s->pending_n;
+        HIPCHK(hipMemcpy(out_tokens, s->out_tokens, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    s->pending_n = 0;
+    return JH_OK;
+}
+int jh_decode_n(jh_session* s, int32_t first_token, int start_pos, int n, int32_t* out_tokens) {
+    JHCHK(jh_decode_n_async(s, first_token, start_pos, n));
+    return jh_decode_wait(s, out_tokens, n);
+}
+int jh_decode_stats(jh_session* s, double* ms_per_token, int32_t* kernels_per_token) {
+    if (!s) return set_err(JH_ERR_INVALID, "decode_stats: null");
+    if (ms_per_token) *ms_per_token = s->ms_per_token;
+    if (kernels_per_token) *kernels_per_token = s->kernels_per_token;
+    return JH_OK;
+}
+int jh_set_tap_layer(jh_session* s, int layer) {
+    if (!s) return set_err(JH_ERR_INVALID, "set_tap_layer: null");
+    s->tap_layer = layer;
+    return JH_OK;
+}
+int jh_get_tap(jh_session* s, int which, float* out, int n) {
+    if (!s || !out || which < 0 || which >= TAP_SLOTS || !s->taps[which]) return set_err(JH_ERR_INVALID, "get_tap: not recorded");
+    HIPCHK(hipSetDevice(s->m->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const int m = s->tap_len[which] < n ? s->tap_len[which] : n;
+    HIPCHK(hipMemcpy(out, s->taps[which], (size_t)m * 4, hipMemcpyDeviceToHost));
+    return m;
+}
+
+}  // extern "C"

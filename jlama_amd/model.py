@@ -1,0 +1,197 @@
+"""Host mirror of AbstractModel on the device-resident (Tier-2) C ABI.
+
+Mirrors, at the token-id level, jlama-core/.../model/AbstractModel.java: ``forward`` (:267-279),
+``batchForward`` (:295-312), ``sample`` (:443-491) and ``generate`` (:515-646).  Tokenisation is out of scope
+(prompts are token ids).  All arithmetic runs in libjlamahip.so on the GPU; this file only marshals.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _native as N
+
+MAX_BATCH_SIZE = 256  # jlama.max_batch_size (AbstractModel.java:57)
+
+
+class HipLlamaModel:
+    def __init__(self, cfg: dict, weights: dict, layer_range=None, device=0):
+        """weights: {(layer|-1, slot): {dtype, data, scales, shape}} with numpy arrays (host) or
+        objects exposing ``data_ptr()`` (device tensors); layer_range = this shard's [start, end)."""
+        N.init(device)
+        L = cfg["n_layers"]
+        ls, le = layer_range if layer_range else (0, L)
+        self.cfg = dict(cfg)
+        self.layer_range = (ls, le)
+        self.c = N.Config(cfg["embedding_length"], cfg["hidden_length"], cfg["n_heads"], cfg["n_kv_heads"],
+                          cfg["head_size"], L, cfg["vocab_size"], cfg["context_length"], cfg["weight_dtype"], ls, le,
+                          cfg["rms_eps"], cfg["rope_theta"], cfg.get("rope_scaling", 1.0))
+        self.h = C.c_void_p()
+        N.check(N.lib().jh_model_create(C.byref(self.c), C.byref(self.h)))
+        for (layer, slot), w in weights.items():
+            if layer >= 0 and not (ls <= layer < le):
+                continue
+            self.set_weight(layer, slot, w)
+
+    @staticmethod
+    def _addr(a):
+        if a is None:
+            return None, False
+        if hasattr(a, "data_ptr"):  # torch tensor
+            return C.c_void_p(a.data_ptr()), bool(getattr(a, "is_cuda", False))
+        return N.ptr(np.ascontiguousarray(a)), False
+
+    def set_weight(self, layer, slot, w):
+        rows, cols = w["shape"]
+        d, dev = self._addr(w["data"])
+        s, _ = self._addr(w.get("scales"))
+        N.check(N.lib().jh_model_set_weight(self.h, layer, slot, w["dtype"], d, s, rows, cols, 1 if dev else 0))
+
+    def weight_bytes(self):
+        return N.lib().jh_model_weight_bytes(self.h)
+
+    def session(self, max_ctx, max_page_bytes=0):
+        return HipSession(self, max_ctx, max_page_bytes)
+
+    def close(self):
+        if self.h:
+            N.lib().jh_model_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipSession:
+    """One KV buffer + activation workspace (KvBufferCache.getKvBuffer, KvBufferCache.java:58-60)."""
+
+    def __init__(self, model, max_ctx, max_page_bytes=0):
+        self.model = model
+        self.max_ctx = max_ctx
+        self.h = C.c_void_p()
+        N.check(N.lib().jh_session_create(model.h, max_ctx, max_page_bytes, C.byref(self.h)))
+
+    def page_info(self):
+        out = (C.c_int32 * 4)()
+        N.check(N.lib().jh_session_page_info(self.h, out))
+        return tuple(out)
+
+    # -- AbstractModel.batchForward / forward ---------------------------------------------------------
+    def forward(self, tokens=None, start_pos=0, x=None, want_output=True):
+        E = self.model.cfg["embedding_length"]
+        if tokens is not None:
+            tokens = np.ascontiguousarray(tokens, dtype=np.int32).reshape(-1)
+            n = tokens.size
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, E)
+            n = x.shape[0]
+        out = np.empty((n, E), dtype=np.float32) if want_output else None
+        N.check(N.lib().jh_forward(self.h, N.ptr(tokens) if tokens is not None else None,
+                                   N.ptr(x) if tokens is None else None, n, start_pos, N.ptr(out)))
+        return out
+
+    def forward_device(self, tokens, x_in_ptr, n, start_pos, x_out_ptr):
+        """Device-pointer variant for layer-sharded pipelines (activations handed to RCCL send/recv)."""
+        tk = np.ascontiguousarray(tokens, dtype=np.int32) if tokens is not None else None
+        N.check(N.lib().jh_forward_device(self.h, N.ptr(tk) if tk is not None else None,
+                                          C.c_void_p(x_in_ptr) if x_in_ptr else None, n, start_pos,
+                                          C.c_void_p(x_out_ptr) if x_out_ptr else None))
+
+    def batch_forward(self, tokens, start_pos=0):
+        """Chunks of jlama.max_batch_size rows (AbstractModel.java:304); returns the last chunk's output."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        last = None
+        for i in range(0, tokens.size, MAX_BATCH_SIZE):
+            last = self.forward(tokens[i:i + MAX_BATCH_SIZE], start_pos + i)
+        return last
+
+    # -- AbstractModel.sample ---------------------------------------------------------------------------
+    def sample(self, temperature=0.0, u=0.5, want_logits=False):
+        tok = C.c_int32()
+        logits = np.empty(self.model.cfg["vocab_size"], dtype=np.float32) if want_logits else None
+        N.check(N.lib().jh_sample(self.h, temperature, u, C.byref(tok), N.ptr(logits)))
+        return (tok.value, logits) if want_logits else tok.value
+
+    def logits(self):
+        out = np.empty(self.model.cfg["vocab_size"], dtype=np.float32)
+        N.check(N.lib().jh_get_logits(self.h, N.ptr(out)))
+        return out
+
+    def decode_step(self, token, pos):
+        tok = C.c_int32()
+        N.check(N.lib().jh_decode_step(self.h, int(token), int(pos), C.byref(tok)))
+        return tok.value
+
+    def decode_n(self, first_token, start_pos, n):
+        out = np.empty(n, dtype=np.int32)
+        N.check(N.lib().jh_decode_n(self.h, int(first_token), int(start_pos), int(n), N.ptr(out)))
+        return out
+
+    def decode_n_async(self, first_token, start_pos, n):
+        N.check(N.lib().jh_decode_n_async(self.h, int(first_token), int(start_pos), int(n)))
+
+    def decode_wait(self, n):
+        out = np.empty(n, dtype=np.int32)
+        N.check(N.lib().jh_decode_wait(self.h, N.ptr(out), n))
+        return out
+
+    def decode_stats(self):
+        ms, k = C.c_double(), C.c_int32()
+        N.check(N.lib().jh_decode_stats(self.h, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
+    def stream(self):
+        return N.lib().jh_session_stream(self.h)
+
+    # -- taps --------------------------------------------------------------------------------------------
+    def set_tap_layer(self, layer):
+        N.check(N.lib().jh_set_tap_layer(self.h, layer))
+
+    def tap(self, name, n):
+        out = np.empty(n, dtype=np.float32)
+        got = N.check(N.lib().jh_get_tap(self.h, N.TAP[name], N.ptr(out), n))
+        assert got == n, (name, got, n)
+        return out
+
+    # -- AbstractModel.generate at the token-id level ---------------------------------------------------
+    def generate(self, prompt_tokens, ntokens, temperature=0.0, rng=None, eos_tokens=(), on_device_loop=True):
+        """prompt_tokens already contain BOS.  Returns dict(tokens, prompt_ms, generate_ms, tokens_generated);
+        decode clock starts after the first sampled token (AbstractModel.java:589), like the reference."""
+        prompt_tokens = np.ascontiguousarray(prompt_tokens, dtype=np.int32)
+        t0 = time.perf_counter()
+        self.batch_forward(prompt_tokens, 0)
+        u = float(rng.random()) if (rng is not None and temperature > 0) else 0.5
+        nxt = self.sample(temperature, u)
+        t1 = time.perf_counter()
+        out = [nxt]
+        start = prompt_tokens.size
+        n_more = ntokens - start
+        if temperature == 0.0 and on_device_loop and n_more > 0 and not eos_tokens:
+            out.extend(int(t) for t in self.decode_n(nxt, start, n_more))
+        else:
+            for i in range(start, ntokens):
+                if temperature == 0.0:
+                    nxt = self.decode_step(nxt, i)
+                else:
+                    self.forward([nxt], i, want_output=False)
+                    nxt = self.sample(temperature, float(rng.random()) if rng is not None else 0.5)
+                out.append(nxt)
+                if nxt in eos_tokens:
+                    break
+        t2 = time.perf_counter()
+        return {"tokens": np.array(out, dtype=np.int32), "prompt_ms": (t1 - t0) * 1e3, "generate_ms": (t2 - t1) * 1e3,
+                "tokens_generated": len(out) - 1}
+
+    def close(self):
+        if self.h:
+            N.lib().jh_session_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

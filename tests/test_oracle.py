@@ -1,0 +1,201 @@
+"""CPU tests that PIN the oracle (oracle/jlama_oracle.c) before anything trusts it:
+
+* the reference's own known-answer vectors (RoPE table, TestCorrectness.java:92-115),
+* the reference's own C SIMD GEMM library compiled as-is (oracle/_ref), bit-exact for F32xQ4 / F32xF32,
+* the reference tests' control implementation (NaiveTensorOperations) within the reference's own 1% bound
+  (TestOperations.java:128-139) -- in practice ~1e-6,
+* BF16 round-trip bound (TestCorrectness.java:137-145), KV page geometries quoted in SURVEY.md 8(a7).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_rope_table_known_answers(oracle):
+    kat = json.load(open(os.path.join(HERE, "golden", "rope_kat.json")))
+    t = oracle.rope_table(kat["head_dim"], kat["context"], kat["theta"], kat["scaling"])
+    half = kat["head_dim"] // 2
+    np.testing.assert_allclose(t[1 * half:(1 + 1) * half, 1], kat["sin_pos1"], atol=kat["tolerance"])
+    np.testing.assert_allclose(t[64 * half:65 * half, 1], kat["sin_pos64"], atol=kat["tolerance"])
+    # cos^2 + sin^2 == 1 everywhere (size-independent property)
+    np.testing.assert_allclose((t.astype(np.float64) ** 2).sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_bf16_round_trip(oracle):
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, 4096).astype(np.float32)
+    h = oracle.bf16_quantize(x)
+    back = oracle.bf16_to_f32(h)
+    assert np.abs(back - x).max() < 0.01  # TestCorrectness.java:137-145
+    # RNE ties: 1.0 + 2^-8 is exactly half way between two bf16 values -> even mantissa
+    tie = np.array([1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8], dtype=np.float32)
+    hh = oracle.bf16_quantize(tie)
+    assert hh[0] == 0x3F80 and hh[1] == 0x3F82
+
+
+def test_kv_page_geometry(oracle):
+    # Llama-3-8B 32x32, Llama-3.2-1B 16x128, Llama-3-70B 80x12, 10-layer shard 10x102, GPT-2 11x124
+    assert oracle.kv_page_geometry(1 << 23, 32, 8192, 1024) == (32, 32)
+    assert oracle.kv_page_geometry(1 << 23, 16, 131072, 512) == (16, 128)
+    assert oracle.kv_page_geometry(1 << 23, 80, 8192, 1024) == (80, 12)
+    assert oracle.kv_page_geometry(1 << 23, 10, 8192, 1024) == (10, 102)
+    assert oracle.kv_page_geometry(1 << 23, 12, 1024, 768) == (11, 124)
+
+
+def test_q4_layout_and_quantizer(oracle):
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((8, 256)).astype(np.float32)
+    x[0, :32] = 0.0                      # all-zero block: scale -0.0, every nibble 8
+    x[1, 5] = -7.5                       # negative max => positive scale
+    nib, sc = oracle.q4_quantize(x)
+    assert nib.shape == (8, 128) and sc.shape == (8, 8)
+    assert (nib[0, :16] == 0x88).all() and sc[0, 0] == 0.0
+    deq = oracle.q4_dequantize(nib, sc)
+    # value = (nibble-8)*scale, byte j: low nibble = elem j, high = elem j+16 (Q4ByteBufferTensor.java:88-106)
+    b = nib[2, :16]
+    manual = np.concatenate([(b & 15).astype(np.int32) - 8, (b >> 4).astype(np.int32) - 8]) * sc[2, 0]
+    np.testing.assert_array_equal(deq[2, :32], manual.astype(np.float32))
+    # quantization error bounded by one step; the max-abs element maps to nibble 0 exactly
+    step = np.abs(np.repeat(sc, 32, axis=1))
+    assert (np.abs(deq - x) <= step * 1.0001 + 1e-12).all()
+
+
+def test_numpy_q4_quantizer_matches_oracle(oracle):
+    from jlama_amd import jq4
+    rng = np.random.default_rng(1)
+    for scale in (1.0, 0.02, 1e-30, 100.0):
+        x = (rng.standard_normal((16, 512)) * scale).astype(np.float32)
+        x[3, 64:96] = 0
+        n1, s1 = oracle.q4_quantize(x)
+        n2, s2 = jq4.quantize_q4(x)
+        np.testing.assert_array_equal(n1, n2)
+        np.testing.assert_array_equal(s1.view(np.uint32), s2.view(np.uint32))
+        np.testing.assert_array_equal(oracle.q4_dequantize(n1, s1), jq4.dequantize_q4(n2, s2))
+    h1 = oracle.bf16_quantize(x)
+    np.testing.assert_array_equal(h1, jq4.f32_to_bf16(x))
+
+
+def test_q8_quantizer_truncation_semantics(oracle):
+    # q = (byte)(x*id + 0.5f): truncation toward zero AFTER adding 0.5 => -0.7*... rounds toward zero for negatives
+    x = np.zeros((1, 32), dtype=np.float32)
+    x[0, 0] = 127.0
+    x[0, 1] = -1.4      # -1.4 + 0.5 = -0.9 -> 0   (round-to-nearest would give -1)
+    x[0, 2] = -1.6      # -1.6 + 0.5 = -1.1 -> -1  (round-to-nearest would give -2)
+    x[0, 3] = 1.5       # 2.0 -> 2
+    x[0, 4] = -127.0    # -126.5 -> -126
+    q, d = oracle.q8_quantize(x)
+    assert d[0, 0] == np.float32(1.0)
+    assert list(q[0, :5]) == [127, 0, -1, 2, -126]
+    z, dz = oracle.q8_quantize(np.zeros((1, 32), dtype=np.float32))
+    assert (z == 0).all() and dz[0, 0] == 0.0
+
+
+def _operands(rng, M, N, K):
+    # value ranges of TestOperations.java:94-109: activations U(-1,100), weights U(0,1)
+    a = rng.uniform(-1, 100, (M, K)).astype(np.float32)
+    w = rng.uniform(0, 1, (N, K)).astype(np.float32)
+    return a, w
+
+
+@pytest.mark.parametrize("M", [1, 2, 5])
+def test_gemm_against_reference_library(oracle, M):
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    rng = np.random.default_rng(10 + M)
+    K, N = 1024, 128  # SIZE / ROWS of TestOperations.java:46-48
+    a, w = _operands(rng, M, N, K)
+    bn, bs = oracle.q4_quantize(w)
+    aq, ad = oracle.q8_quantize(a)
+    # F32xQ4 and F32xF32: same 16-lane fma structure as the C twins => bit-exact
+    np.testing.assert_array_equal(oracle.gemm_f32q4(a, bn, bs), oracle.ref_gemm_f32_q4(a, bn, bs))
+    np.testing.assert_array_equal(oracle.gemm_f32(a, w), oracle.ref_gemm_f32(a, w))
+    # I8xQ4: identical integers, 16 (Panama) vs 8 (C) float lanes => rounding-level difference only
+    r1, r2 = oracle.gemm_i8q4(aq, ad, bn, bs), oracle.ref_gemm_q8_q4(aq, ad, bn, bs)
+    assert np.abs(r1 - r2).max() <= 2e-6 * np.abs(r1).max()
+    # windows: column offsets 512 (TestOperations.java:151-187) and result offsets
+    r1 = oracle.gemm_i8q4(aq, ad, bn, bs, aColOff=512, bColOff=512, K=512, rRowOff=0, bRowOff=32, N=64)
+    r2 = oracle.ref_gemm_q8_q4(aq, ad, bn, bs, aColOff=512, bColOff=512, K=512, rRowOff=0, bRowOff=32, N=64)
+    assert np.abs(r1 - r2).max() <= 2e-6 * np.abs(r1).max()
+
+
+def test_reference_library_tiler_leaves_corner_uncomputed(oracle):
+    """Documented reference quirk: nc/simd/vector_simd.c:65-184 `gemm()` recursion never visits
+    [mp,m) x [np,n) -- with M=8, N=128 the 3x3 corner stays zero.  This is why the compiled reference is used
+    as an oracle for M <= 5 only, and why decode (M=1) is the pinned case."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(5)
+    a, w = _operands(rng, 8, 128, 1024)
+    bn, bs = oracle.q4_quantize(w)
+    ref = oracle.ref_gemm_f32_q4(a, bn, bs)
+    ours = oracle.gemm_f32q4(a, bn, bs)
+    assert (ref[5:, 125:] == 0).all()
+    np.testing.assert_array_equal(ref[:5], ours[:5])
+    np.testing.assert_array_equal(ref[5:, :125], ours[5:, :125])
+
+
+@pytest.mark.parametrize("M", [1, 32])
+def test_gemm_against_naive_control(oracle, M):
+    """The reference's own test contract: every provider within 1% of NaiveTensorOperations
+    (TestOperations.java:128-139, sums compared).  We hold 1e-5 per element."""
+    O = oracle
+    rng = np.random.default_rng(20 + M)
+    K, N = 1024, 128
+    a, w = _operands(rng, M, N, K)
+    bn, bs = O.q4_quantize(w)
+    aq, ad = O.q8_quantize(a)
+    ah, wh = O.bf16_quantize(a), O.bf16_quantize(w)
+    cases = [
+        (O.gemm_i8q4(aq, ad, bn, bs), O.gemm_naive(O.DT_I8, aq, ad, O.DT_Q4, bn, bs, M, 0, 0, K, 0, 0, N)),
+        (O.gemm_f32q4(a, bn, bs), O.gemm_naive(O.DT_F32, a, None, O.DT_Q4, bn, bs, M, 0, 0, K, 0, 0, N)),
+        (O.gemm_f32(a, w), O.gemm_naive(O.DT_F32, a, None, O.DT_F32, w, None, M, 0, 0, K, 0, 0, N)),
+        (O.gemm_bf16(ah, wh), O.gemm_naive(O.DT_BF16, ah, None, O.DT_BF16, wh, None, M, 0, 0, K, 0, 0, N)),
+        (O.gemm_f32bf16(a, wh), O.gemm_naive(O.DT_F32, a, None, O.DT_BF16, wh, None, M, 0, 0, K, 0, 0, N)),
+    ]
+    for got, ctl in cases:
+        assert abs(got.sum() - ctl.sum()) <= 0.01 * abs(ctl.sum())          # the reference's bound
+        assert np.abs(got - ctl).max() <= 1e-5 * np.abs(ctl).max()          # ours
+
+
+def test_small_ops(oracle):
+    O = oracle
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(512).astype(np.float32)
+    w = (1 + 0.01 * rng.standard_normal(512)).astype(np.float32)
+    y = O.rmsnorm(x, w, 1e-5)
+    ref = w.astype(np.float64) * x / np.sqrt((x.astype(np.float64) ** 2).mean() + 1e-5)
+    np.testing.assert_allclose(y, ref, rtol=3e-7)
+    s = O.softmax(rng.standard_normal(300).astype(np.float32) * 4, 0, 300)
+    assert abs(s.sum() - 1) < 1e-5 and (s >= 0).all()
+    v = np.array([-20, -1, 0, 1, 20], dtype=np.float32)
+    np.testing.assert_allclose(O.silu(v), v / (1 + np.exp(-v.astype(np.float64))), rtol=1e-7)
+    # batched saxpy == fma chain over rows
+    alpha = rng.random(10).astype(np.float32)
+    xs = rng.standard_normal((10, 64)).astype(np.float32)
+    out = O.saxpy_batch(alpha, xs, np.zeros(64, np.float32), 0, 0, 64, 0, 0, 10)
+    np.testing.assert_allclose(out, (alpha[:, None].astype(np.float64) * xs).sum(0), rtol=1e-5, atol=1e-6)
+
+
+def test_model_forward_is_causal_and_batch_equals_sequential(oracle):
+    """Whole-model restatement: prefill as one batch == token-by-token (batchForwardSlow, AbstractModel.java:282-290),
+    logits finite, greedy generation deterministic."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.TINY)
+    w = S.make_weights(cfg, seed=0)
+    m = oracle.OracleModel(cfg, w)
+    prompt = S.prompt_tokens(cfg, n=12, seed=3)
+    s1 = m.session()
+    full = s1.forward(prompt, 0)
+    s2 = m.session()
+    rows = [s2.forward(prompt[i:i + 1], i)[0] for i in range(prompt.size)]
+    np.testing.assert_array_equal(full, np.stack(rows))
+    tok, logits = m.sample(full[-1])
+    assert np.isfinite(logits).all() and 0 <= tok < cfg["vocab_size"]
+    g1, _, _ = m.session().generate(prompt, 8)
+    g2, _, _ = m.session().generate(prompt, 8)
+    np.testing.assert_array_equal(g1, g2)
+    assert g1[0] == tok
