@@ -108,6 +108,18 @@ int allow_lds(K kernel, size_t bytes) {
     return JH_OK;
 }
 
+int g_trace = -1;
+int trace_sync(const char* what, hipStream_t st) {
+    if (g_trace < 0) g_trace = env_int("JH_TRACE", 0);
+    if (!g_trace) return JH_OK;
+    fprintf(stderr, "[jh] %s ...", what);
+    fflush(stderr);
+    hipError_t e = hipStreamSynchronize(st);
+    fprintf(stderr, " %s\n", hipGetErrorString(e));
+    fflush(stderr);
+    return e == hipSuccess ? JH_OK : set_err(JH_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
 int nb_for(int K) {
     const int nblk = K / QB;
     if (nblk % 64) return 0;
@@ -769,6 +781,7 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
         p.x = s->x; p.nw = W[JH_W_NORM1].data; p.nw_bf16 = W[JH_W_NORM1].dtype == JH_DT_BF16; p.eps = c.rms_eps;
         JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
+        JHCHK(trace_sync("qkv", st));
     }
     if (tap) {
         JHCHK(tap_copy(s, JH_TAP_QUERY, s->qkv, A, st));
@@ -776,6 +789,7 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         JHCHK(tap_copy(s, JH_TAP_VALUE, s->qkv + A + KV, KV, st));
     }
     JHCHK(attn_launch(s, rel, st, tap));
+    JHCHK(trace_sync("attn", st));
     if (tap) {
         JHCHK(tap_copy(s, JH_TAP_QUERY_ROPE, s->tapq, A, st));
         const int lp = rel / s->layers_per_page, cp = pos_for_tap / s->ctx_per_page, rc = pos_for_tap % s->ctx_per_page;
@@ -792,6 +806,7 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         p.K = A; p.ldb = A / 2; p.ldbf = A / QB;
         p.aq = s->attq; p.ad = s->attd; p.resid = s->x;
         JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_o, st)));
+        JHCHK(trace_sync("oproj", st));
     }
     if (tap) JHCHK(tap_copy(s, 8, s->x1, E, st));
     {   // gate/up (MLPBlock.java:117-142) with fused preFFNorm + maybeQuantize, SiLU*up + maybeQuantize
@@ -804,6 +819,7 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         p.x = s->x1; p.nw = W[JH_W_NORM2].data; p.nw_bf16 = W[JH_W_NORM2].dtype == JH_DT_BF16; p.eps = c.rms_eps;
         p.hq = s->hq; p.hd = s->hd; p.hf = tap ? s->hf : nullptr;
         JHCHK((launch_gateup<PRO_RMS_Q8>(p, s->gateup_grid_cap, st)));
+        JHCHK(trace_sync("gateup", st));
     }
     if (tap) JHCHK(tap_copy(s, 10, s->hf, H, st));
     {   // down projection (:147-158) + residual (TransformerBlock.java:203)
@@ -814,6 +830,7 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         p.K = H; p.ldb = H / 2; p.ldbf = H / QB;
         p.aq = s->hq; p.ad = s->hd; p.resid = s->x1;
         JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_down, st)));
+        JHCHK(trace_sync("down", st));
     }
     if (tap) JHCHK(tap_copy(s, JH_TAP_POST_FF_RES, s->x, E, st));
     return JH_OK;
@@ -1048,6 +1065,9 @@ static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in,
     const int E = m->c.embedding_length;
     const JWeight& emb = m->global_w[JH_W_EMBED];
     if (tokens && !emb.data) return set_err(JH_ERR_INVALID, "forward: this shard has no embedding table");
+    if (tokens)
+        for (int i = 0; i < n; i++)
+            if (tokens[i] < 0 || tokens[i] >= m->c.vocab_size) return set_err(JH_ERR_INVALID, "forward: token id out of range");
     // batchForwardSlow order (core/model/AbstractModel.java:282-290): rows one position at a time -- per-row
     // arithmetic is identical to the batched path (attention is per position there too, CausalSelfAttention.java:199).
     for (int i = 0; i < n; i++) {
@@ -1155,6 +1175,7 @@ int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) 
     HIPCHK(hipSetDevice(m->device));
     const JWeight& emb = m->global_w[JH_W_EMBED];
     if (!emb.data || !lm_head_weight(m)->data) return set_err(JH_ERR_INVALID, "decode_n: needs embedding and output weights on this shard");
+    if (first_token < 0 || first_token >= m->c.vocab_size) return set_err(JH_ERR_INVALID, "decode_n: token id out of range");
     JHCHK(ensure_out_tokens(s, n));
     hipStream_t st = s->stream;
     const bool use_graph = !env_int("JH_NO_GRAPH", 0);

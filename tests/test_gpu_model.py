@@ -127,6 +127,17 @@ def test_attention_split_combine_long_context(gpu, oracle):
     assert _rel(outs[0], outs[2]) <= 1e-3
 
 
+def test_out_of_range_token_is_rejected(gpu):
+    from jlama_amd import _native as N, synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    cfg = dict(S.TINY)
+    hs = HipLlamaModel(cfg, S.make_weights(cfg, seed=0)).session(16)
+    with pytest.raises(N.JhError):
+        hs.forward([cfg["vocab_size"]], 0)
+    with pytest.raises(N.JhError):
+        hs.forward([3], 16)  # beyond the session's max_ctx
+
+
 def test_sampling_with_temperature_uses_callers_uniform(gpu, oracle):
     from jlama_amd import synthetic as S
     cfg = dict(S.TINY)
@@ -168,7 +179,7 @@ def test_real_shapes_one_layer(gpu, oracle, name):
     exercises the exact kernel instantiations the bench uses (NB=1/2/7 blocks per lane, head size 64/128)."""
     from jlama_amd import synthetic as S
     cfg = dict(getattr(S, name))
-    cfg.update(n_layers=1, vocab_size=2048, context_length=512)
+    cfg.update(n_layers=1, vocab_size=2048, context_length=512, bos_token=1)
     cfg.pop("tied", None)
     hm, om, _ = _pair(cfg, 7, oracle)
     prompt = S.prompt_tokens(cfg, n=40, seed=8)
