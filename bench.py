@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s of Llama-3-8B JQ4 on MI355X (BASELINE.json metric), with roofline + CPU baseline.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched under torch.distributed.run,
+one rank per GPU.  A "step" = one decoded token (one pass of the hot path): W untimed warm-up decode steps on a
+throw-away session, then a fresh session is prefilled with the 129-row prompt (128 synthetic ids + BOS,
+AbstractModel.java:549-555) and EXACTLY K greedy decode steps are timed (clock starts after the first sampled
+token, AbstractModel.java:589), bracketed by barrier + device synchronize; rank 0 prints ONE JSON line.
+
+N=1: the whole model on one GPU.  N>1: DistributedContext layer split (DistributedContext.java:75-77) -- rank r owns
+layers [r*L/N,(r+1)*L/N) and its KV pages; [1,E] F32 activations hop rank->rank with RCCL send/recv and the sampled
+token returns to rank 0; N sessions are kept in flight (one per pipeline stage) so every GPU streams its weights on
+every tick; value = tokens completed by all sessions / time.  Total work (K tokens) is fixed => "strong" scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--config", default="LLAMA3_8B")
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--probe-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, host_w, n_prompt, n_decode):
+    """Reference native-SIMD GEMM (oracle/_ref = vector_simd.c compiled as-is) + restated Java ops, threaded like the
+    reference: T = max(2, nproc/2) (PhysicalCoreExecutor.java:27).  Bounded sample of the same workload."""
+    from oracle import oracle as O
+    nproc = os.cpu_count() or 2
+    T = max(2, nproc // 2)
+    os.environ["OMP_NUM_THREADS"] = str(T)
+    m = O.OracleModel(cfg, host_w)
+    kind = "port"
+    if O.ref_lib() is not None:
+        m.use_reference_gemm(T)
+        kind = "reference"
+    from jlama_amd import synthetic as S
+    prompt = S.prompt_tokens(cfg, n=n_prompt - 1, seed=1234)
+    toks, _, (t_prompt, t_dec) = m.session().generate(prompt, n_decode + 1)
+    tps = n_decode / (t_dec / 1e3)
+    return {"value": round(tps, 3), "unit": "tokens/s", "cores": T, "kind": kind,
+            "sample": f"{n_decode} greedy decode steps after a {n_prompt}-row prompt, full {cfg['n_layers']}-layer model; "
+                      f"{'reference C SIMD GEMM (vector_simd.c) + ' if kind == 'reference' else ''}restated Java ops; "
+                      f"{T} threads of {nproc} host CPUs; prompt {t_prompt / 1e3:.1f}s"}, toks, prompt
+
+
+def run_single(args, cfg):
+    import torch
+    from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
+    from jlama_amd.model import HipLlamaModel
+    torch.cuda.set_device(0)
+    N.init(0)
+    t0 = time.time()
+    w = ST.make_weights(cfg, seed=0, device="cuda")
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    model = HipLlamaModel(cfg, w)
+    prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
+    max_ctx = prompt.size + max(args.steps, args.warmup) + 8
+    # warm-up on a throw-away session (builds the hipGraph, faults the weights in)
+    ws = model.session(max_ctx)
+    ws.batch_forward(prompt[:8], 0)
+    first = ws.sample()
+    if args.warmup > 0:
+        ws.decode_n(first, 8, args.warmup)
+    ws.close()
+    # measured run
+    s = model.session(max_ctx)
+    tp0 = time.perf_counter()
+    s.batch_forward(prompt, 0)
+    first = s.sample()
+    prompt_ms = (time.perf_counter() - tp0) * 1e3
+    torch.cuda.synchronize(); s.synchronize()
+    t0 = time.perf_counter()
+    s.decode_n_async(first, prompt.size, args.steps)
+    toks = s.decode_wait(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev_ms, kernels = s.decode_stats()
+    tps = args.steps / dt
+    # roofline of the dominant kernel (gate/up GEMV: 54% of the weight bytes), HIP events on the session's stream
+    probe = {}
+    names = ["qkv", "attention", "o_proj", "gate_up", "down"]
+    for i, nm in enumerate(names):
+        ms, b = s.kernel_bench(i, args.probe_iters)
+        probe[nm] = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
+    dom = probe["gate_up"]
+    wbytes = S.weight_bytes(cfg)
+    kvb = S.kv_bytes_per_position(cfg)
+    mean_pos = prompt.size + (args.steps - 1) / 2.0
+    bytes_per_token = wbytes + kvb * (mean_pos + 1) + kvb
+    out = {
+        "metric": "decode tokens/sec Llama-3-8B JQ4, 128-tok prompt" if args.config == "LLAMA3_8B" else f"decode tokens/sec {args.config} JQ4",
+        "value": round(tps, 2), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "i8xq4->f32", "data": "synthetic",
+        "config": {"workload": f"{args.config} JQ4 (Q4 weights, I8 activations, F32 paged KV), {prompt.size}-row prefill + "
+                               f"{args.steps} greedy decode steps, batch 1", "parallelism": "1 GPU",
+                   "kernels_per_token": kernels, "prefill_ms": round(prompt_ms, 1)},
+        "roofline": {"bound": "hbm", "kernel": "gemv_gateup_kernel (gate+up GEMV, fused RMSNorm+Q8 / SiLU*up+Q8)",
+                     "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                     "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]},
+        "token_roofline": {"bytes_per_token": int(bytes_per_token), "achieved_GBps": round(bytes_per_token * tps / 1e9, 1),
+                           "frac_of_8TBps": round(bytes_per_token * tps / 1e9 / HBM_PEAK_GBS, 4),
+                           "event_ms_per_token": round(ev_ms, 4)},
+        "kernels": probe,
+        "weights_gen_s": round(gen_s, 1),
+    }
+    if not args.no_cpu_baseline:
+        host_w = ST.to_host(w)
+        cb, cpu_toks, cpu_prompt = cpu_baseline(cfg, host_w, 8, args.cpu_steps)
+        out["cpu_baseline"] = cb
+        # end-to-end parity at FULL size on the same weights: GPU vs CPU greedy ids for the sample prompt
+        ps = model.session(64)
+        res = ps.generate(cpu_prompt, cpu_prompt.size + args.cpu_steps)
+        out["parity_full_size"] = {"tokens_equal": bool(np.array_equal(res["tokens"], cpu_toks)), "n": int(cpu_toks.size)}
+    return out, toks
+
+
+def main():
+    args = parse()
+    from jlama_amd import synthetic as S
+    cfg = dict(getattr(S, args.config))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from jlama_amd import distributed as D
+        out = D.bench_pipeline(args, cfg)
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        return
+    out, _ = run_single(args, cfg)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -237,6 +237,12 @@ int jh_set_tap_layer(jh_session* s, int layer);
 int jh_get_tap(jh_session* s, int which, float* out, int n);
 /* The HIP stream the session launches on (hipStream_t as void*), so callers can record their own events. */
 void* jh_session_stream(jh_session* s);
+/* Wait for everything queued on the session's stream. */
+int jh_session_synchronize(jh_session* s);
+/* Roofline probe: average duration (ms) of ONE launch of decode kernel `which` (0 qkv, 1 attention, 2 o-proj,
+ * 3 gate/up, 4 down), launched back-to-back over all of the shard's layers for `iters` sweeps so the weights stream
+ * from HBM, timed with hipEvents on the session's stream; bytes_per_launch = that launch's algorithmic bytes. */
+int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t* out_bytes_per_launch);
 /* Average duration (ms) of the decode graph replays timed with hipEvents inside the last jh_decode_n, and the
  * number of kernels per replay. */
 int jh_decode_stats(jh_session* s, double* ms_per_token, int32_t* kernels_per_token);

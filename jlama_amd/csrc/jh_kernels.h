@@ -22,19 +22,45 @@ using i32x4 = int __attribute__((ext_vector_type(4)));
 using i32x2 = int __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------ helpers
+// 64-lane butterfly reductions on the VALU's DPP path (quad_perm / row_half_mirror / row_mirror stay inside a
+// 16-lane row; the two cross-row steps use ds_swizzle-free v_permlane/bpermute via __shfl_xor).  Every lane ends up
+// with the full result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
+    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
+    v += dpp_f<0x141>(v);   // row_half_mirror      (pairs lanes across 4)
+    v += dpp_f<0x140>(v);   // row_mirror           (pairs lanes across 8)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
     return v;
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0, (unsigned)u, CTRL, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0, (unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     return v;
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
@@ -86,28 +112,34 @@ __device__ __forceinline__ i32x4 ldg_nt(const i32x4* p) {
 }
 
 // ------------------------------------------------------------------------------------------------ GEMV params
-enum { PRO_Q8 = 0, PRO_RMS_Q8 = 1, PRO_F32 = 2, PRO_RMS_F32 = 3 };
-enum { EPI_STORE = 0, EPI_RESID = 1 };
+// Prologues: how the activation row reaches LDS.  Epilogues: what happens to the dot products.
+enum { PRO_Q8 = 0,       // already I8 + scales in global memory (Tier-1 jh_gemm_q8_q4)
+       PRO_RMS_Q8 = 1,   // RMSNorm (core/model/RMSNorm.java:33-56) then Q8 quantize (PTO:1684-1723)
+       PRO_QUANT_Q8 = 2, // Q8 quantize an F32 row (LlamaModel.maybeQuantize, core/model/llama/LlamaModel.java:176-184)
+       PRO_F32 = 3,      // F32 row as is (F32xQ4)
+       PRO_RMS_F32 = 4 };// RMSNorm, keep F32 (LM head: AbstractModel.java:443-449)
+enum { EPI_STORE = 0,    // out[j] = dot
+       EPI_RESID = 1,    // out[j] = dot + resid[j]            (TransformerBlock.java:185,203)
+       EPI_SILU_MUL = 2 };// out[j] = silu(dot_gate[j]) * dot_up[j] (MLPBlock.java:132-142)
 
 struct GemvParams {
-    const uint8_t* w[3];   // Q4 nibbles of up to 3 weight tensors stacked along N (q,k,v | gate,up)
-    const float* ws[3];    // their F32 block scales
-    float* out[3];         // F32 outputs (row index local to the tensor)
-    int nrows[3];
-    int ntens;
+    // No arrays in here on purpose: a kernarg array indexed by a runtime value makes hipcc spill the whole struct to
+    // scratch (or fetch the pointer with a dependent vector load) before the first weight load can issue.
+    const uint8_t* w;      // Q4 nibbles [nrows, K/2]  (q|k|v are stored stacked in one allocation)
+    const float* ws;       // F32 block scales [nrows, K/32]
+    const uint8_t* w2;     // EPI_SILU_MUL: the up-projection (w = gate)
+    const float* ws2;
+    float* out;            // F32 output [nrows]
+    int nrows;
     int K;                 // columns (multiple of 32)
     int ldb;               // bytes per nibble row
     int ldbf;              // floats per scale row
-    const float* x;        // F32 activation row (PRO_RMS_*, PRO_F32)
-    const void* nw;        // norm weights (F32 or BF16)
-    int nw_bf16;
+    const float* x;        // F32 activation row (PRO_RMS_*, PRO_QUANT_Q8, PRO_F32)
+    const float* nw;       // norm weights, F32 (BF16 on disk is widened at upload)
     float eps;
     const int8_t* aq;      // PRO_Q8: pre-quantized activation
     const float* ad;
     const float* resid;    // EPI_RESID
-    int8_t* hq;            // gate/up epilogue: Q8 of silu(g)*u
-    float* hd;
-    float* hf;             // optional F32 copy of silu(g)*u (taps)
     float* amax_part;      // LM head: per-workgroup (max logit, index) partials
     int* amax_idx;
 };
@@ -116,10 +148,9 @@ struct GemvParams {
 struct ActI8 {
     i32x4* lo;     // [nblk] elements 0..15 of each block
     i32x4* hi;     // [nblk] elements 16..31
-    float* d;     // [nblk] block scales
-    int* asum;    // [nblk] sum of the block's int8 values
-    double* red;  // [32] reduction scratch
-    float* tile;  // [64] epilogue tile (2 x 32)
+    float* d;      // [nblk] block scales
+    int* asum;     // [nblk] sum of the block's int8 values
+    double* red;   // [32] reduction scratch
 };
 __device__ __forceinline__ ActI8 carve_i8(char* smem, int nblk) {
     ActI8 a;
@@ -127,11 +158,10 @@ __device__ __forceinline__ ActI8 carve_i8(char* smem, int nblk) {
     a.hi = a.lo + nblk;
     a.d = (float*)(a.hi + nblk);
     a.asum = (int*)(a.d + nblk);
-    a.red = (double*)(((uintptr_t)(a.asum + nblk) + 15) & ~(uintptr_t)15);
-    a.tile = (float*)(a.red + 32);
+    a.red = (double*)(a.asum + nblk);   // 40*nblk bytes in: 8-byte aligned (no integer cast: keeps the LDS address space)
     return a;
 }
-static inline size_t lds_bytes_i8(int K) { return (size_t)(K / QB) * (16 + 16 + 4 + 4) + 16 + 32 * 8 + 64 * 4; }
+static inline size_t lds_bytes_i8(int K) { return (size_t)(K / QB) * (16 + 16 + 4 + 4) + 16 + 32 * 8; }
 
 // block-wide double sum, result broadcast to every thread.  red: >= 32 doubles of LDS.
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
@@ -163,17 +193,10 @@ __device__ __forceinline__ float rms_factor(const float* __restrict__ x, int K, 
     return (float)ss;
 }
 
-__device__ __forceinline__ void load8_norm(const void* nw, int bf16, int e0, float (&w)[8]) {
-    if (bf16) {
-        uint4 r = *(const uint4*)((const uint16_t*)nw + e0);
-        w[0] = bf16_to_f32(r.x & 0xffff); w[1] = bf16_to_f32(r.x >> 16);
-        w[2] = bf16_to_f32(r.y & 0xffff); w[3] = bf16_to_f32(r.y >> 16);
-        w[4] = bf16_to_f32(r.z & 0xffff); w[5] = bf16_to_f32(r.z >> 16);
-        w[6] = bf16_to_f32(r.w & 0xffff); w[7] = bf16_to_f32(r.w >> 16);
-    } else {
-        float4 a = *(const float4*)((const float*)nw + e0), b = *(const float4*)((const float*)nw + e0 + 4);
-        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-    }
+// norm weights are widened to F32 once at upload (bf16 -> f32 is exact), so the prologue's loads are branch-free
+__device__ __forceinline__ void load8_norm(const float* nw, int e0, float (&w)[8]) {
+    float4 a = *(const float4*)(nw + e0), b = *(const float4*)(nw + e0 + 4);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
 }
 
 // Quantize 8 consecutive values held by one lane; the 4 lanes of a quad cover one block of 32.
@@ -209,12 +232,36 @@ __device__ __forceinline__ void quad_quantize_store(const float (&y)[8], int uni
     }
 }
 
-// Prologue: build the I8 activation row in LDS.
+// Prologue: build the I8 activation row in LDS (once per workgroup), in two halves so the caller can put its
+// weight loads BETWEEN them:  stage_issue() only issues the loads of x / norm weights (one round trip, up to UMAX
+// 8-element units per thread kept in registers);  stage_finish() reduces, quantizes and fills LDS.
+// Order matters: s_waitcnt vmcnt retires loads oldest-first, so x must be requested BEFORE the (much larger) weight
+// stream or the prologue would wait for every weight byte.
+constexpr int UMAX = 2;
+struct ActRegs {
+    float xv[UMAX][8];
+    float wv[UMAX][8];
+};
 template <int PRO>
-__device__ __forceinline__ void stage_act_i8(const GemvParams& p, const ActI8& a) {
+__device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegs& r) {
+    if (PRO == PRO_Q8) return;
+    const int units = p.K / 8, T = blockDim.x;
+    // branch-free (clamped) addresses: a guarded load would make hipcc wait for it at the end of its basic block,
+    // serialising this round trip with the weight stream that is issued next
+#pragma unroll
+    for (int u = 0; u < UMAX; u++) {
+        int unit = threadIdx.x + u * T;
+        unit = unit < units ? unit : units - 1;
+        const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
+        r.xv[u][0] = xa.x; r.xv[u][1] = xa.y; r.xv[u][2] = xa.z; r.xv[u][3] = xa.w;
+        r.xv[u][4] = xb.x; r.xv[u][5] = xb.y; r.xv[u][6] = xb.z; r.xv[u][7] = xb.w;
+        if (PRO == PRO_RMS_Q8) load8_norm(p.nw, unit * 8, r.wv[u]);
+    }
+}
+template <int PRO>
+__device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a, ActRegs& r) {
     const int K = p.K, nblk = K / QB;
     if (PRO == PRO_Q8) {
-        // activation already quantized by the producer kernel (attention / gate-up epilogues)
         for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
             const i32x4* src = (const i32x4*)(p.aq + (size_t)blk * QB);
             i32x4 l = src[0], h = src[1];
@@ -229,207 +276,231 @@ __device__ __forceinline__ void stage_act_i8(const GemvParams& p, const ActI8& a
             a.asum[blk] = s;
         }
     } else {
-        // RMSNorm.forward (core/model/RMSNorm.java:33-56) fused with LlamaModel.maybeQuantize
-        // (core/model/llama/LlamaModel.java:176-184 -> PTO:1684-1723)
-        const float fs = rms_factor(p.x, K, p.eps, a.red);
-        for (int unit = threadIdx.x; unit < K / 8; unit += blockDim.x) {
-            const int e0 = unit * 8;
-            float4 xa = *(const float4*)(p.x + e0), xb = *(const float4*)(p.x + e0 + 4);
-            float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-            float w[8], y[8];
-            load8_norm(p.nw, p.nw_bf16, e0, w);
+        const int units = K / 8, T = blockDim.x;
+        float fs = 1.0f;
+        if (PRO == PRO_RMS_Q8) {
+            // RMSNorm (core/model/RMSNorm.java:41-49): float squares, double sum, /E, +eps, 1/sqrt in double
+            double ss = 0.0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) y[i] = w[i] * (fs * xv[i]);  // (0 + w) * ((float)ss * x)
+            for (int u = 0; u < UMAX; u++)
+                if (threadIdx.x + u * T < units)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) ss += (double)(r.xv[u][i] * r.xv[u][i]);
+            for (int unit = threadIdx.x + UMAX * T; unit < units; unit += T) {   // rows longer than UMAX*T*8
+                const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
+                ss += (double)(xa.x * xa.x); ss += (double)(xa.y * xa.y); ss += (double)(xa.z * xa.z); ss += (double)(xa.w * xa.w);
+                ss += (double)(xb.x * xb.x); ss += (double)(xb.y * xb.y); ss += (double)(xb.z * xb.z); ss += (double)(xb.w * xb.w);
+            }
+            ss = block_sum_d(ss, a.red);
+            ss /= (double)K;
+            ss += (double)p.eps;
+            ss = 1.0 / sqrt(ss);
+            fs = (float)ss;
+        }
+#pragma unroll
+        for (int u = 0; u < UMAX; u++) {
+            const int unit = threadIdx.x + u * T;
+            if (unit < units) {
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[i] = (PRO == PRO_RMS_Q8) ? r.wv[u][i] * (fs * r.xv[u][i]) : r.xv[u][i];  // (0 + w) * ((float)ss * x)
+                quad_quantize_store(y, unit, a);
+            }
+        }
+        for (int unit = threadIdx.x + UMAX * T; unit < units; unit += T) {
+            const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
+            float y[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            if (PRO == PRO_RMS_Q8) {
+                float w[8];
+                load8_norm(p.nw, unit * 8, w);
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[i] = w[i] * (fs * y[i]);
+            }
             quad_quantize_store(y, unit, a);
         }
     }
     __syncthreads();
 }
 
-// locate the tensor a stacked row belongs to (wave-uniform)
-__device__ __forceinline__ void locate(const GemvParams& p, int row, int& t, int& local) {
-    t = 0;
-    local = row;
-    if (p.ntens > 1 && local >= p.nrows[0]) { local -= p.nrows[0]; t = 1; }
-    if (p.ntens > 2 && t == 1 && local >= p.nrows[1]) { local -= p.nrows[1]; t = 2; }
-}
-
-// ------------------------------------------------------------------------------------------------ K1: GEMV I8 x Q4
+// ------------------------------------------------------------------------------------------------ K1: streaming GEMV I8 x Q4
 // batchDotProduct I8xQ4 at M=1 (GemmerI8Q4_512, PTO:768-1044; C twin nc/simd/vector_simd.c:261-437):
 //   C[j] = sum_blk (da[blk]*sb[j,blk]) * (float) sum_t a[blk,t]*(nib[j,blk,t]-8)
-// One wave computes R rows at a time; lane l owns K blocks l, l+64, ... (NB per lane, 0 = runtime loop).
-template <int PRO, int EPI, int R, int NB>
-__global__ __launch_bounds__(512) void gemv_i8q4_kernel(GemvParams p) {
+// Shape of the kernel = the streaming-read microbenchmark that reaches 7.1 TB/s on this chip (tools/membw.hip):
+// one 256-thread workgroup per CU, every lane keeps >= 8 independent 16-byte non-temporal loads in flight.
+// A wave owns a contiguous range of rows and walks it in groups of R rows; lane l owns K blocks l, l+64, ...
+// (NB per lane).  The next group's weights are loaded into a second register set BEFORE the current group is
+// reduced, and the first group is requested before the activation prologue runs, so the HBM stream never drains.
+template <int R, int NB>
+struct WBuf {
+    i32x4 w[R][NB];
+    float s[R][NB];
+};
+
+template <int EPI, int R, int NB>
+__device__ __forceinline__ void load_group(const GemvParams& p, int g, int lane, WBuf<R, NB>& b) {
+    if (EPI == EPI_SILU_MUL) {
+        // group g = hidden units j0..j0+R/2-1: rows [0,R/2) are gate rows, [R/2,R) the matching up rows
+        const int j0 = g * (R / 2);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int j = j0 + r % (R / 2);
+            const i32x4* wp = (const i32x4*)((r < R / 2 ? p.w : p.w2) + (size_t)j * p.ldb);
+            const float* sp = (r < R / 2 ? p.ws : p.ws2) + (size_t)j * p.ldbf;
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                b.w[r][i] = __builtin_nontemporal_load(wp + lane + 64 * i);
+                b.s[r][i] = __builtin_nontemporal_load(sp + lane + 64 * i);
+            }
+        }
+    } else {
+        const uint8_t* wbase = p.w + (size_t)g * R * p.ldb;
+        const float* sbase = p.ws + (size_t)g * R * p.ldbf;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                b.w[r][i] = __builtin_nontemporal_load((const i32x4*)(wbase + (size_t)r * p.ldb) + lane + 64 * i);
+                b.s[r][i] = __builtin_nontemporal_load(sbase + (size_t)r * p.ldbf + lane + 64 * i);
+            }
+    }
+}
+
+template <int EPI, int R>
+__device__ __forceinline__ void store_group(const GemvParams& p, int g, int lane, const float (&acc)[R]) {
+    // acc[] holds full sums in every lane (butterfly).  Lane r stores row r of the group: one coalesced store.
+    if (EPI == EPI_SILU_MUL) {
+        float gsel = 0.0f, usel = 0.0f;   // select first, then ONE double-precision SiLU per lane (not R/2 serial ones)
+#pragma unroll
+        for (int r = 0; r < R / 2; r++)
+            if (lane == r) { gsel = acc[r]; usel = acc[r + R / 2]; }
+        const float h = silu_ref(gsel) * usel;
+        if (lane < R / 2) p.out[g * (R / 2) + lane] = h;
+    } else {
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (lane == r) v = acc[r];
+        if (lane < R) {
+            if (EPI == EPI_RESID) v = v + p.resid[g * R + lane];   // accumulate(...) TransformerBlock.java:185,203
+            p.out[g * R + lane] = v;
+        }
+    }
+}
+
+// PIPE = 0: one group per wave, every weight load issued before the activation prologue ("single shot": the whole
+//           GEMV is requested from HBM at t=0 and the prologue hides under the first-byte latency);
+// PIPE = 1: a wave walks several groups, loading group g+1 into a second register set while it reduces group g.
+template <int PRO, int EPI, int R, int NB, int PIPE>
+__global__ __launch_bounds__((PIPE || R * NB > 8) ? 512 : 1024) void gemv_i8q4_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblk = p.K / QB;
     const ActI8 a = carve_i8(smem, nblk);
-    stage_act_i8<PRO>(p, a);
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    int total = p.nrows[0] + (p.ntens > 1 ? p.nrows[1] : 0) + (p.ntens > 2 ? p.nrows[2] : 0);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    // rows -> groups -> contiguous group range per wave
+    const int total = (EPI == EPI_SILU_MUL) ? 2 * p.nrows : p.nrows;
     const int ngroups = total / R;
+    const int tw = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
+    const int per = (ngroups + tw - 1) / tw;
+    const int g0 = gw * per;
+    int g1 = g0 + per;
+    if (g1 > ngroups) g1 = ngroups;
 
-    // activation blocks owned by this lane, kept in registers for every row group (NB > 0)
-    i32x4 alo[NB > 0 ? NB : 1], ahi[NB > 0 ? NB : 1];
-    float adv[NB > 0 ? NB : 1];
-    int asv[NB > 0 ? NB : 1];
-    if (NB > 0) {
+    if constexpr (NB > 0 && PIPE == 0) {
+        WBuf<R, NB> cur;
+        ActRegs ar;
+        const int g = gw;   // host launches >= ngroups waves
+        stage_issue<PRO>(p, ar);                                    // activation loads first (retire first) ...
+        load_group<EPI, R, NB>(p, g < ngroups ? g : ngroups - 1, lane, cur);   // ... then this wave's whole weight stream
+        stage_finish<PRO>(p, a, ar);                                // prologue runs under the weights' flight time
+        if (g < ngroups) {
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                const int blk = lane + 64 * i;
+                const i32x4 alo = a.lo[blk], ahi = a.hi[blk];
+                const float adv = a.d[blk];
+                const int as8 = 8 * a.asum[blk];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int isum = q4_block_dot(cur.w[r][i], alo, ahi) - as8;
+                    acc[r] = fmaf(adv * cur.s[r][i], (float)isum, acc[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+            store_group<EPI, R>(p, g, lane, acc);
+        }
+    } else if constexpr (NB > 0) {
+        WBuf<R, NB> cur, nxt;
+        ActRegs ar;
+        stage_issue<PRO>(p, ar);
+        load_group<EPI, R, NB>(p, g0 < ngroups ? g0 : ngroups - 1, lane, cur);   // first group in flight across the prologue
+        stage_finish<PRO>(p, a, ar);
+        i32x4 alo[NB], ahi[NB];
+        float adv[NB];
+        int as8[NB];
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             const int blk = lane + 64 * i;
-            alo[i] = a.lo[blk]; ahi[i] = a.hi[blk]; adv[i] = a.d[blk]; asv[i] = a.asum[blk];
+            alo[i] = a.lo[blk]; ahi[i] = a.hi[blk]; adv[i] = a.d[blk]; as8[i] = 8 * a.asum[blk];
         }
-    }
-
-    for (int g = blockIdx.x * nwaves + wave; g < ngroups; g += gridDim.x * nwaves) {
-        int t, local;
-        locate(p, g * R, t, local);
-        const uint8_t* wbase = p.w[t] + (size_t)local * p.ldb;
-        const float* sbase = p.ws[t] + (size_t)local * p.ldbf;
-        float acc[R];
+        for (int g = g0; g < g1; g++) {
+            if (g + 1 < g1) load_group<EPI, R, NB>(p, g + 1, lane, nxt);
+            float acc[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = 0.0f;
-
-        if (NB > 0) {
-            i32x4 wv[R][NB > 0 ? NB : 1];
-            float sv[R][NB > 0 ? NB : 1];
-#pragma unroll
-            for (int r = 0; r < R; r++)
-#pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    const int blk = lane + 64 * i;
-                    wv[r][i] = ldg_nt((const i32x4*)(wbase + (size_t)r * p.ldb) + blk);
-                    sv[r][i] = __builtin_nontemporal_load(sbase + (size_t)r * p.ldbf + blk);
-                }
+            for (int r = 0; r < R; r++) acc[r] = 0.0f;
 #pragma unroll
             for (int i = 0; i < NB; i++)
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const int isum = q4_block_dot(wv[r][i], alo[i], ahi[i]) - 8 * asv[i];
-                    acc[r] = fmaf(adv[i] * sv[r][i], (float)isum, acc[r]);
+                    const int isum = q4_block_dot(cur.w[r][i], alo[i], ahi[i]) - as8[i];
+                    acc[r] = fmaf(adv[i] * cur.s[r][i], (float)isum, acc[r]);
                 }
-        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+            store_group<EPI, R>(p, g, lane, acc);
+            cur = nxt;
+        }
+    } else {
+        // generic K (any multiple of 32): activation re-read from LDS per block, no register double buffering
+        ActRegs ar;
+        stage_issue<PRO>(p, ar);
+        stage_finish<PRO>(p, a, ar);
+        for (int g = g0; g < g1; g++) {
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = 0.0f;
             for (int blk = lane; blk < nblk; blk += 64) {
                 const i32x4 l = a.lo[blk], h = a.hi[blk];
                 const float da = a.d[blk];
                 const int as8 = 8 * a.asum[blk];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const i32x4 wv = ldg_nt((const i32x4*)(wbase + (size_t)r * p.ldb) + blk);
-                    const float sb = sbase[(size_t)r * p.ldbf + blk];
+                    const uint8_t* wr;
+                    const float* sr;
+                    if (EPI == EPI_SILU_MUL) {
+                        const int j = g * (R / 2) + r % (R / 2);
+                        wr = (r < R / 2 ? p.w : p.w2) + (size_t)j * p.ldb;
+                        sr = (r < R / 2 ? p.ws : p.ws2) + (size_t)j * p.ldbf;
+                    } else {
+                        wr = p.w + (size_t)(g * R + r) * p.ldb;
+                        sr = p.ws + (size_t)(g * R + r) * p.ldbf;
+                    }
+                    const i32x4 wv = __builtin_nontemporal_load((const i32x4*)wr + blk);
                     const int isum = q4_block_dot(wv, l, h) - as8;
-                    acc[r] = fmaf(da * sb, (float)isum, acc[r]);
+                    acc[r] = fmaf(da * sr[blk], (float)isum, acc[r]);
                 }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                float v = acc[r];
-                if (EPI == EPI_RESID) v = v + p.resid[local + r];  // accumulate(lnattn, embedding) TransformerBlock.java:185,203
-                p.out[t][local + r] = v;
-            }
+            for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+            store_group<EPI, R>(p, g, lane, acc);
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------ K1b: gate/up GEMV
-// MLPBlock.forward (core/model/MLPBlock.java:117-144): gate & up GEMVs, SiLU (ActivationFunction.java:31) on gate,
-// maccumulate (gate *= up), then maybeQuantize -> Q8.  A workgroup (8 waves) owns tiles of 32 consecutive hidden
-// units j, so the Q8 block of the down-projection's activation is produced right here (fused epilogue).
-template <int PRO, int NB>
-__global__ __launch_bounds__(512) void gemv_gateup_kernel(GemvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nblk = p.K / QB;
-    const ActI8 a = carve_i8(smem, nblk);
-    stage_act_i8<PRO>(p, a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // 8 waves
-    const int ntiles = p.nrows[0] / 32;
-
-    i32x4 alo[NB > 0 ? NB : 1], ahi[NB > 0 ? NB : 1];
-    float adv[NB > 0 ? NB : 1];
-    int asv[NB > 0 ? NB : 1];
-    if (NB > 0) {
-#pragma unroll
-        for (int i = 0; i < NB; i++) {
-            const int blk = lane + 64 * i;
-            alo[i] = a.lo[blk]; ahi[i] = a.hi[blk]; adv[i] = a.d[blk]; asv[i] = a.asum[blk];
-        }
-    }
-    int par = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
-        const int j0 = tile * 32 + wave * 4;
-        const uint8_t* gb = p.w[0] + (size_t)j0 * p.ldb;
-        const uint8_t* ub = p.w[1] + (size_t)j0 * p.ldb;
-        const float* gs = p.ws[0] + (size_t)j0 * p.ldbf;
-        const float* us = p.ws[1] + (size_t)j0 * p.ldbf;
-        float ag[4] = {0, 0, 0, 0}, au[4] = {0, 0, 0, 0};
-        if (NB > 0) {
-            i32x4 wg[4][NB > 0 ? NB : 1], wu[4][NB > 0 ? NB : 1];
-            float sg[4][NB > 0 ? NB : 1], su[4][NB > 0 ? NB : 1];
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    const int blk = lane + 64 * i;
-                    wg[r][i] = ldg_nt((const i32x4*)(gb + (size_t)r * p.ldb) + blk);
-                    wu[r][i] = ldg_nt((const i32x4*)(ub + (size_t)r * p.ldb) + blk);
-                    sg[r][i] = __builtin_nontemporal_load(gs + (size_t)r * p.ldbf + blk);
-                    su[r][i] = __builtin_nontemporal_load(us + (size_t)r * p.ldbf + blk);
-                }
-#pragma unroll
-            for (int i = 0; i < NB; i++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int ig = q4_block_dot(wg[r][i], alo[i], ahi[i]) - 8 * asv[i];
-                    const int iu = q4_block_dot(wu[r][i], alo[i], ahi[i]) - 8 * asv[i];
-                    ag[r] = fmaf(adv[i] * sg[r][i], (float)ig, ag[r]);
-                    au[r] = fmaf(adv[i] * su[r][i], (float)iu, au[r]);
-                }
-        } else {
-            for (int blk = lane; blk < nblk; blk += 64) {
-                const i32x4 l = a.lo[blk], h = a.hi[blk];
-                const float da = a.d[blk];
-                const int as8 = 8 * a.asum[blk];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const i32x4 wgv = ldg_nt((const i32x4*)(gb + (size_t)r * p.ldb) + blk);
-                    const i32x4 wuv = ldg_nt((const i32x4*)(ub + (size_t)r * p.ldb) + blk);
-                    const int ig = q4_block_dot(wgv, l, h) - as8;
-                    const int iu = q4_block_dot(wuv, l, h) - as8;
-                    ag[r] = fmaf(da * gs[(size_t)r * p.ldbf + blk], (float)ig, ag[r]);
-                    au[r] = fmaf(da * us[(size_t)r * p.ldbf + blk], (float)iu, au[r]);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) { ag[r] = wave_sum(ag[r]); au[r] = wave_sum(au[r]); }
-        float* tl = a.tile + par * 32;
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) tl[wave * 4 + r] = silu_ref(ag[r]) * au[r];
-        }
-        __syncthreads();
-        if (wave == 0 && lane < 32) {
-            // Q8 block of 32 (PTO:1684-1723)
-            const float y = tl[lane];
-            float amax = fabsf(y);
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-            const float d = amax / 127.0f;
-            const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
-            float v = y * id;
-            v = v + 0.5f;
-            p.hq[tile * 32 + lane] = (int8_t)f2b(v);
-            if (lane == 0) p.hd[tile] = d;
-            if (p.hf) p.hf[tile * 32 + lane] = y;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ K1c: GEMV F32 x Q4
+// ------------------------------------------------------------------------------------------------ K1c: streaming GEMV F32 x Q4
 // batchDotProduct F32xQ4 at M=1 (GemmerF32Q4_512 PTO:336-374; C twin vector_simd.c:880-965): dequantize first
 // w = float(nib-8)*scale, then acc = fma(a, w, acc).  fma(scale, float(nib), -8*scale) == round(scale*(nib-8))
 // exactly, so the per-weight cost is cvt + fma + fma.  Used by the LM head (AbstractModel.java:443-449): the
@@ -478,6 +549,19 @@ __global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = p.K, nblk = K / QB;
     const ActF32 a = carve_f32(smem, nblk);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int ngroups = p.nrows / R;
+    const int tw = gridDim.x * nwaves, gw = blockIdx.x * nwaves + wave;
+    const int per = (ngroups + tw - 1) / tw;
+    const int g0 = gw * per;
+    int g1 = g0 + per;
+    if (g1 > ngroups) g1 = ngroups;
+
+    WBuf<R, (NB > 0 ? NB : 1)> cur, nxt;
+    if constexpr (NB > 0) {
+        if (g0 < g1) load_group<EPI_STORE, R, NB>(p, g0, lane, cur);
+    }
+
     float fs = 1.0f;
     if (PRO == PRO_RMS_F32) fs = rms_factor(p.x, K, p.eps, a.red);
     for (int unit = threadIdx.x; unit < K / 8; unit += blockDim.x) {
@@ -485,7 +569,7 @@ __global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
         float4 xa = *(const float4*)(p.x + e0), xb = *(const float4*)(p.x + e0 + 4);
         if (PRO == PRO_RMS_F32) {
             float w[8];
-            load8_norm(p.nw, p.nw_bf16, e0, w);
+            load8_norm(p.nw, e0, w);
             xa.x = w[0] * (fs * xa.x); xa.y = w[1] * (fs * xa.y); xa.z = w[2] * (fs * xa.z); xa.w = w[3] * (fs * xa.w);
             xb.x = w[4] * (fs * xb.x); xb.y = w[5] * (fs * xb.y); xb.z = w[6] * (fs * xb.z); xb.w = w[7] * (fs * xb.w);
         }
@@ -495,58 +579,54 @@ __global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int ngroups = p.nrows[0] / R;
-    float4 yr[NB > 0 ? NB : 1][8];
-    if (NB > 0) {
+    float bestv = -INFINITY;
+    int besti = 0x7fffffff;
+    if constexpr (NB > 0) {
+        float4 yr[NB][8];
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
             for (int c = 0; c < 8; c++) yr[i][c] = a.y[(size_t)c * nblk + lane + 64 * i];
-    }
-    float bestv = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int g = blockIdx.x * nwaves + wave; g < ngroups; g += gridDim.x * nwaves) {
-        const int row0 = g * R;
-        const uint8_t* wbase = p.w[0] + (size_t)row0 * p.ldb;
-        const float* sbase = p.ws[0] + (size_t)row0 * p.ldbf;
-        float acc[R];
+        for (int g = g0; g < g1; g++) {
+            if (g + 1 < g1) load_group<EPI_STORE, R, NB>(p, g + 1, lane, nxt);
+            float acc[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = 0.0f;
-        if (NB > 0) {
-            i32x4 wv[R][NB > 0 ? NB : 1];
-            float sv[R][NB > 0 ? NB : 1];
-#pragma unroll
-            for (int r = 0; r < R; r++)
-#pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    wv[r][i] = ldg_nt((const i32x4*)(wbase + (size_t)r * p.ldb) + lane + 64 * i);
-                    sv[r][i] = __builtin_nontemporal_load(sbase + (size_t)r * p.ldbf + lane + 64 * i);
-                }
+            for (int r = 0; r < R; r++) acc[r] = 0.0f;
 #pragma unroll
             for (int i = 0; i < NB; i++)
 #pragma unroll
-                for (int r = 0; r < R; r++) acc[r] = q4_block_dot_f32(wv[r][i], sv[r][i], yr[i], acc[r]);
-        } else {
+                for (int r = 0; r < R; r++) acc[r] = q4_block_dot_f32(cur.w[r][i], cur.s[r][i], yr[i], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                acc[r] = wave_sum(acc[r]);
+                if (acc[r] > bestv) { bestv = acc[r]; besti = g * R + r; }  // rows ascend: strict > keeps the first
+            }
+            store_group<EPI_STORE, R>(p, g, lane, acc);
+            cur = nxt;
+        }
+    } else {
+        for (int g = g0; g < g1; g++) {
+            const uint8_t* wbase = p.w + (size_t)g * R * p.ldb;
+            const float* sbase = p.ws + (size_t)g * R * p.ldbf;
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = 0.0f;
             for (int blk = lane; blk < nblk; blk += 64) {
                 float4 yb[8];
 #pragma unroll
                 for (int c = 0; c < 8; c++) yb[c] = a.y[(size_t)c * nblk + blk];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const i32x4 wv = ldg_nt((const i32x4*)(wbase + (size_t)r * p.ldb) + blk);
+                    const i32x4 wv = __builtin_nontemporal_load((const i32x4*)(wbase + (size_t)r * p.ldb) + blk);
                     acc[r] = q4_block_dot_f32(wv, sbase[(size_t)r * p.ldbf + blk], yb, acc[r]);
                 }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            acc[r] = wave_sum(acc[r]);
-            if (acc[r] > bestv) { bestv = acc[r]; besti = row0 + r; }  // rows ascend within a wave: strict > keeps the first
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < R; r++) p.out[0][row0 + r] = acc[r];
+            for (int r = 0; r < R; r++) {
+                acc[r] = wave_sum(acc[r]);
+                if (acc[r] > bestv) { bestv = acc[r]; besti = g * R + r; }
+            }
+            store_group<EPI_STORE, R>(p, g, lane, acc);
         }
     }
     if (p.amax_part) {
@@ -646,11 +726,12 @@ __global__ void finish_token_kernel(const float* partv, const int* parti, int np
 // CausalSelfAttention.forward for ONE new position (core/model/CausalSelfAttention.java:199-357), fused:
 //   copy K,V row into the KV page (:226-241) -> RoPE on q (all heads) and on the stored k row (:247-286, incl. the
 //   per-kv-head table offset g = kvHead*headSize+i => effective position pos+2*kvHead) -> per head:
-//   scores = q.K^T (:324-330) * attentionScale (:332) -> softMax (VectorMath.java:69-90) -> saxpy over V (:349-354)
-//   -> maybeQuantize(valueBatch) to Q8 for the O projection (:364).
+//   scores = q.K^T (:324-330) * attentionScale (:332) -> softMax (VectorMath.java:69-90) -> saxpy over V (:349-354).
 // Grid (max_splits, n_kv_heads): a workgroup serves the `group` q-heads of one kv head for one slice of the
-// context, so K/V are read once per group (GQA).  Slices are combined by the last-arriving workgroup of the kv
-// head (agent-scope release/acquire, cdna_hip_programming.md Guideline 16).
+// context, so K/V are read once per group (GQA).  Every global load a thread will need (q, rope entry, its K rows,
+// its V rows) is issued up front so the kernel pays ONE memory round trip, not five.  Slices publish (o, m, l)
+// with write-through (sc1) stores + a relaxed agent-scope ticket; the last-arriving workgroup of the kv head
+// combines them reading with sc1 loads -- no release/acquire fences (cdna_hip_programming.md Guideline 16, R1).
 struct AttnParams {
     const float* qkv;      // [A + 2*KV]: q | k | v of the new row (F32, pre-RoPE)
     const float* rope;     // [ctx*hs/2][2]
@@ -662,9 +743,7 @@ struct AttnParams {
     float* part;           // [n_heads][max_splits][hs+2]
     unsigned* counters;    // [n_kv_heads], zero between launches
     int max_splits;
-    int8_t* outq;          // [A]
-    float* outd;           // [A/32]
-    float* outf;           // [A] F32 copy ("after_attention" tap), may be null
+    float* outf;           // [A] attention output ("after_attention" tap; the O projection quantizes it)
     float* tap_q;          // roped q [A] (tap), may be null
 };
 
@@ -672,11 +751,22 @@ __device__ __forceinline__ const float* kv_row(const AttnParams& p, int which, i
     const int cp = t / p.ctx_per_page, rc = t - cp * p.ctx_per_page;
     return p.pages[cp] + ((size_t)(p.rel_layer_in_page * 2 + which) * p.ctx_per_page + rc) * kvlen;
 }
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 
 template <int HS, int GROUP>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
-    // LDS: q[GROUP][HS], knew[HS], vnew[HS], sc[GROUP][chunk], red[8][GROUP][HS], misc
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LPR = HS / 4;          // lanes per K/V row (float4 each): 32 for HS=128, 16 for HS=64
+    constexpr int RPS = 256 / LPR;       // rows per workgroup step (scores and PV use the same row->thread map)
+    constexpr int PRE = 4;               // row steps prefetched into registers (covers chunk <= PRE*RPS)
+    constexpr int half = HS / 2;
+    constexpr int NQ = (GROUP * half + 255) / 256;   // q-rotation pairs per thread
+    constexpr int CS = 16;               // slices combined per batch of in-flight loads
     const int pos = p.st->pos;
     const int kvh = blockIdx.y, split = blockIdx.x;
     const int n = pos + 1;
@@ -687,68 +777,87 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
     const int t0 = split * chunk;
     int t1 = t0 + chunk;
     if (t1 > n) t1 = n;
-    const int cnt = t1 - t0;  // may be <= 0 for trailing splits when chunk rounding overshoots
-    const int KV = p.n_kv_heads * HS, A = p.n_heads * HS, half = HS / 2;
+    const int cnt = t1 - t0;  // may be <= 0 for a trailing slice when chunk rounding overshoots
+    const int KV = p.n_kv_heads * HS, A = p.n_heads * HS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rsub = tid / LPR, c4 = tid % LPR;   // thread -> (row within step, float4 column)
 
-    float* qs = (float*)smem;                // GROUP*HS
+    float* qs = (float*)smem;                // GROUP*HS roped q, later the slice output
     float* knew = qs + GROUP * HS;           // HS
     float* vnew = knew + HS;                 // HS
-    float* red = vnew + HS;                  // (256/(HS/4))*GROUP*HS = 1024*GROUP floats
-    float* ml = red + (256 / (HS / 4)) * GROUP * HS;  // 2*GROUP (m, l)
+    float* red = vnew + HS;                  // RPS*GROUP*HS = 1024*GROUP floats
+    float* ml = red + RPS * GROUP * HS;      // 2*GROUP (m, l)
     int* flag = (int*)(ml + 2 * GROUP);      // 4 ints
-    float* sc = (float*)(flag + 4);          // GROUP*chunk_cap
+    float* sc = (float*)(flag + 4);          // GROUP*max(chunk_cap, 2*max_splits): scores / weights; combine scratch
 
-    // ---- RoPE (q for the group's heads, k for this kv head) ------------------------------------------------
+    // ---- ONE round trip: every global load of the main phase is issued here, branch-free (clamped addresses), in
+    // the order the results are consumed (vmcnt retires oldest-first): q + rope, new k/v, then K rows, then V rows.
     const float* rf = p.rope + ((size_t)pos * half + (size_t)kvh * HS) * 2;  // rf[poffset + g], g = kvh*HS + i
-    for (int i = tid; i < GROUP * half; i += blockDim.x) {
+    float q0[NQ], q1[NQ], qc[NQ], qsn[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; u++) {
+        int i = tid + u * 256;
+        i = i < GROUP * half ? i : GROUP * half - 1;
         const int gi = i / half, d = i - gi * half;
         const float* qh = p.qkv + (size_t)(kvh * GROUP + gi) * HS;
-        const float q0 = qh[d], q1 = qh[d + half];
-        const float fcr = rf[2 * d], fci = rf[2 * d + 1];
-        const float r0 = q0 * fcr - q1 * fci;   // contraction is off: mul, mul, sub as in Java
-        const float r1 = q0 * fci + q1 * fcr;
-        qs[gi * HS + d] = r0;
-        qs[gi * HS + d + half] = r1;
-        if (p.tap_q && split == 0) {
-            p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d] = r0;
-            p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d + half] = r1;
+        q0[u] = qh[d]; q1[u] = qh[d + half];
+        qc[u] = rf[2 * d]; qsn[u] = rf[2 * d + 1];
+    }
+    const int dk = tid < half ? tid : half - 1;
+    const float k0n = p.qkv[A + (size_t)kvh * HS + dk], k1n = p.qkv[A + (size_t)kvh * HS + dk + half];
+    const float kc = rf[2 * dk], ksn = rf[2 * dk + 1];
+    const float vn = p.qkv[A + KV + (size_t)kvh * HS + (tid < HS ? tid : HS - 1)];
+    float4 kreg[PRE], vreg[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; k++) {
+        int t = t0 + rsub + k * RPS;
+        t = t < 0 ? 0 : (t > pos ? pos : t);   // any valid row; out-of-slice rows are never used
+        kreg[k] = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4];
+    }
+#pragma unroll
+    for (int k = 0; k < PRE; k++) {
+        int t = t0 + rsub + k * RPS;
+        t = t < 0 ? 0 : (t > pos ? pos : t);
+        vreg[k] = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
+    }
+
+    // ---- RoPE (q for the group's heads, k for this kv head) ------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < NQ; u++) {
+        const int i = tid + u * 256;
+        if (i < GROUP * half) {
+            const int gi = i / half, d = i - gi * half;
+            const float r0 = q0[u] * qc[u] - q1[u] * qsn[u];   // contraction is off: mul, mul, sub as in Java
+            const float r1 = q0[u] * qsn[u] + q1[u] * qc[u];
+            qs[gi * HS + d] = r0;
+            qs[gi * HS + d + half] = r1;
+            if (p.tap_q && split == 0) {
+                p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d] = r0;
+                p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d + half] = r1;
+            }
         }
     }
     const bool owns_new = (pos >= t0 && pos < t1);
     if (owns_new) {
-        const float* kh = p.qkv + A + (size_t)kvh * HS;
-        const float* vh = p.qkv + A + KV + (size_t)kvh * HS;
-        float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
-        float* vdst = (float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS;
-        for (int d = tid; d < half; d += blockDim.x) {
-            const float k0 = kh[d], k1 = kh[d + half];
-            const float fcr = rf[2 * d], fci = rf[2 * d + 1];
-            const float r0 = k0 * fcr - k1 * fci;
-            const float r1 = k0 * fci + k1 * fcr;
-            knew[d] = r0; knew[d + half] = r1;
-            kdst[d] = r0; kdst[d + half] = r1;   // K is stored post-RoPE (:273-286 rotates the page row in place)
+        if (tid < half) {
+            const float r0 = k0n * kc - k1n * ksn;
+            const float r1 = k0n * ksn + k1n * kc;
+            knew[tid] = r0; knew[tid + half] = r1;
+            float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
+            kdst[tid] = r0; kdst[tid + half] = r1;   // K is stored post-RoPE (:273-286 rotates the page row in place)
         }
-        for (int d = tid; d < HS; d += blockDim.x) {
-            const float v = vh[d];
-            vnew[d] = v;
-            vdst[d] = v;
+        if (tid < HS) {
+            vnew[tid] = vn;
+            ((float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS)[tid] = vn;
         }
     }
     __syncthreads();
 
-    // ---- scores: 32 lanes x float4 cover one K row; a wave does 2 rows per step ---------------------------
-    constexpr int LPR = HS / 4;          // lanes per K/V row (float4 each): 32 for HS=128, 16 for HS=64
-    constexpr int RPW = 64 / LPR;        // rows per wave step
-    const int sub = lane / LPR, l32 = lane % LPR;
+    // ---- scores: LPR lanes x float4 cover one K row ---------------------------------------------------------
     float4 qv[GROUP];
 #pragma unroll
-    for (int gi = 0; gi < GROUP; gi++) qv[gi] = ((const float4*)(qs + gi * HS))[l32];
-    for (int tt = wave * RPW + sub; tt < cnt; tt += 4 * RPW) {
-        const int t = t0 + tt;
-        float4 kv4;
-        if (t == pos) kv4 = ((const float4*)knew)[l32];
-        else kv4 = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[l32];
+    for (int gi = 0; gi < GROUP; gi++) qv[gi] = ((const float4*)(qs + gi * HS))[c4];
+    auto score_row = [&](int tt, const float4& kv4) {
 #pragma unroll
         for (int gi = 0; gi < GROUP; gi++) {
             float s = qv[gi].x * kv4.x;
@@ -757,8 +866,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
             s = fmaf(qv[gi].w, kv4.w, s);
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (l32 == 0) sc[gi * chunk + tt] = s * p.scale;   // ops.scale after the dot (:332): separate rounding
+            if (c4 == 0) sc[gi * chunk + tt] = s * p.scale;   // ops.scale after the dot (:332): separate rounding
         }
+    };
+#pragma unroll
+    for (int k = 0; k < PRE; k++) {
+        const int tt = rsub + k * RPS;
+        if (tt < cnt) score_row(tt, (t0 + tt == pos) ? ((const float4*)knew)[c4] : kreg[k]);
+    }
+    for (int k = PRE; rsub + k * RPS < cnt; k++) {
+        const int tt = rsub + k * RPS, t = t0 + tt;
+        score_row(tt, (t == pos) ? ((const float4*)knew)[c4]
+                                 : ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4]);
     }
     __syncthreads();
 
@@ -779,18 +898,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
     }
     __syncthreads();
 
-    // ---- o = sum_t w[t] * V[t]: thread = (t-group of 8, float4 column); fma chain per element -------------
+    // ---- o = sum_t w[t] * V[t]: thread = (row-in-step, float4 column); fma chain per element ----------------
     {
-        constexpr int NTG = 256 / LPR;
-        const int c4 = tid % LPR, tg = tid / LPR;
         float4 acc[GROUP];
 #pragma unroll
         for (int gi = 0; gi < GROUP; gi++) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int tt = tg; tt < cnt; tt += NTG) {
-            const int t = t0 + tt;
-            float4 v4;
-            if (t == pos) v4 = ((const float4*)vnew)[c4];
-            else v4 = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
+        auto pv_row = [&](int tt, const float4& v4) {
 #pragma unroll
             for (int gi = 0; gi < GROUP; gi++) {
                 const float w = sc[gi * chunk + tt];
@@ -799,84 +912,112 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
                 acc[gi].z = fmaf(v4.z, w, acc[gi].z);
                 acc[gi].w = fmaf(v4.w, w, acc[gi].w);
             }
+        };
+#pragma unroll
+        for (int k = 0; k < PRE; k++) {
+            const int tt = rsub + k * RPS;
+            if (tt < cnt) pv_row(tt, (t0 + tt == pos) ? ((const float4*)vnew)[c4] : vreg[k]);
+        }
+        for (int k = PRE; rsub + k * RPS < cnt; k++) {
+            const int tt = rsub + k * RPS, t = t0 + tt;
+            pv_row(tt, (t == pos) ? ((const float4*)vnew)[c4]
+                                  : ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4]);
         }
 #pragma unroll
-        for (int gi = 0; gi < GROUP; gi++) ((float4*)(red + ((size_t)tg * GROUP + gi) * HS))[c4] = acc[gi];
+        for (int gi = 0; gi < GROUP; gi++) ((float4*)(red + ((size_t)rsub * GROUP + gi) * HS))[c4] = acc[gi];
     }
     __syncthreads();
-    // reduce the 8 t-groups: thread -> (gi, d)
     float* oloc = qs;  // reuse q storage for the slice's output [GROUP][HS]
     for (int i = tid; i < GROUP * HS; i += blockDim.x) {
         float s = 0.0f;
 #pragma unroll
-        for (int tg = 0; tg < 256 / (HS / 4); tg++) s += red[(size_t)tg * GROUP * HS + i];
+        for (int rg = 0; rg < RPS; rg++) s += red[(size_t)rg * GROUP * HS + i];
         oloc[i] = s;
     }
     __syncthreads();
 
     if (S > 1) {
-        // publish this slice's (o, m, l); the last arriver of the kv head combines
+        // publish this slice's (o, m, l) write-through; the last arriver of the kv head combines
         for (int i = tid; i < GROUP * HS; i += blockDim.x) {
             const int gi = i / HS, d = i - gi * HS;
-            p.part[((size_t)(kvh * GROUP + gi) * p.max_splits + split) * (HS + 2) + d] = oloc[i];
+            st_sc1(p.part + ((size_t)(kvh * GROUP + gi) * p.max_splits + split) * (HS + 2) + d, oloc[i]);
         }
         if (tid < GROUP) {
             float* pr = p.part + ((size_t)(kvh * GROUP + tid) * p.max_splits + split) * (HS + 2) + HS;
-            pr[0] = ml[2 * tid];
-            pr[1] = ml[2 * tid + 1];
+            st_sc1(pr, ml[2 * tid]);
+            st_sc1(pr + 1, ml[2 * tid + 1]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned tk = __hip_atomic_fetch_add(&p.counters[kvh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (tk == (unsigned)(S - 1));
-            if (last) {
-                __hip_atomic_store(&p.counters[kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
+            if (last) __hip_atomic_store(&p.counters[kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             flag[0] = last;
         }
         __syncthreads();
         if (!flag[0]) return;
-        // combine: w_s = l_s * exp(m_s - M) / sum_s(l_s * exp(m_s - M)); o = sum_s w_s * o_s
-        for (int i = tid; i < GROUP * HS; i += blockDim.x) {
+        // combine: w_s = l_s * exp(m_s - M) / sum_s(l_s * exp(m_s - M)); o = sum_s w_s * o_s.
+        // (m, l) of every slice and the first CS partial outputs of this thread's elements are requested together.
+        float* cm = sc;               // [GROUP][S] m_s, then w_s
+        float* cl = sc + GROUP * S;   // [GROUP][S] l_s
+        constexpr int EPT = (GROUP * HS + 255) / 256;   // output elements per thread
+        float mreg = 0.f, lreg = 0.f;
+        {
+            int i = tid < GROUP * S ? tid : GROUP * S - 1;
+            const int gi = i / S, s = i - gi * S;
+            const float* pr = p.part + ((size_t)(kvh * GROUP + gi) * p.max_splits + s) * (HS + 2) + HS;
+            mreg = ld_sc1(pr);
+            lreg = ld_sc1(pr + 1);
+        }
+        float pv[EPT][CS];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            int i = tid + e * 256;
+            i = i < GROUP * HS ? i : GROUP * HS - 1;
             const int gi = i / HS, d = i - gi * HS;
-            const float* pb = p.part + (size_t)(kvh * GROUP + gi) * p.max_splits * (HS + 2);
-            float M = -INFINITY;
-            for (int s = 0; s < S; s++) M = fmaxf(M, pb[(size_t)s * (HS + 2) + HS]);
+            const float* pb = p.part + (size_t)(kvh * GROUP + gi) * p.max_splits * (HS + 2) + d;
+#pragma unroll
+            for (int s = 0; s < CS; s++) pv[e][s] = ld_sc1(pb + (size_t)(s < S ? s : S - 1) * (HS + 2));
+        }
+        if (tid < GROUP * S) { cm[tid] = mreg; cl[tid] = lreg; }
+        for (int i = tid + 256; i < GROUP * S; i += 256) {   // GROUP*S > 256 only for GROUP=8 with > 32 slices
+            const int gi = i / S, s = i - gi * S;
+            const float* pr = p.part + ((size_t)(kvh * GROUP + gi) * p.max_splits + s) * (HS + 2) + HS;
+            cm[i] = ld_sc1(pr);
+            cl[i] = ld_sc1(pr + 1);
+        }
+        __syncthreads();
+        for (int gi = wave; gi < GROUP; gi += 4) {
+            float m = -INFINITY;
+            for (int s = lane; s < S; s += 64) m = fmaxf(m, cm[gi * S + s]);
+            m = wave_max(m);
             float L = 0.0f;
-            for (int s = 0; s < S; s++) {
-                const float ls = pb[(size_t)s * (HS + 2) + HS + 1];
-                L += ls * (float)exp((double)(pb[(size_t)s * (HS + 2) + HS] - M));
+            for (int s = lane; s < S; s += 64) {
+                const float w = cl[gi * S + s] * (float)exp((double)(cm[gi * S + s] - m));
+                cm[gi * S + s] = w;
+                L += w;
             }
+            L = wave_sum(L);
+            for (int s = lane; s < S; s += 64) cm[gi * S + s] = cm[gi * S + s] / L;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = tid + e * 256;
+            if (i >= GROUP * HS) break;
+            const int gi = i / HS, d = i - gi * HS;
+            const float* pb = p.part + (size_t)(kvh * GROUP + gi) * p.max_splits * (HS + 2) + d;
             float o = 0.0f;
-            for (int s = 0; s < S; s++) {
-                const float ls = pb[(size_t)s * (HS + 2) + HS + 1];
-                const float ws = (ls * (float)exp((double)(pb[(size_t)s * (HS + 2) + HS] - M))) / L;
-                o = fmaf(pb[(size_t)s * (HS + 2) + d], ws, o);
-            }
+#pragma unroll
+            for (int s = 0; s < CS; s++)
+                if (s < S) o = fmaf(pv[e][s], cm[gi * S + s], o);
+            for (int s = CS; s < S; s++) o = fmaf(ld_sc1(pb + (size_t)s * (HS + 2)), cm[gi * S + s], o);
             oloc[i] = o;
         }
         __syncthreads();
     }
-
-    // ---- Q8 quantize the group's output (maybeQuantize(valueBatch), :364 -> PTO:1684-1723): 32 lanes per block
-    for (int i = tid; i < GROUP * HS; i += blockDim.x) {
-        const float y = oloc[i];
-        float amax = fabsf(y);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-        const float d = amax / 127.0f;
-        const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
-        float v = y * id;
-        v = v + 0.5f;
-        const size_t e = (size_t)kvh * GROUP * HS + i;
-        p.outq[e] = (int8_t)f2b(v);
-        if ((i & 31) == 0) p.outd[e >> 5] = d;
-        if (p.outf) p.outf[e] = y;
-    }
+    for (int i = tid; i < GROUP * HS; i += blockDim.x) p.outf[(size_t)kvh * GROUP * HS + i] = oloc[i];
 }
 
 // ------------------------------------------------------------------------------------------------ Tier-1 generic kernels
@@ -986,6 +1127,10 @@ __global__ void quantize_q8_kernel(const float* x, int rows, int ldx, int offset
     v = v + 0.5f;
     q[(size_t)r * ldq + e] = (int8_t)f2b(v);
     if (l == 0) d[(size_t)r * ldd + e / QB] = dd;
+}
+__global__ void widen_bf16_kernel(const uint16_t* in, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bf16_to_f32(in[i]);
 }
 __global__ void quantize_bf16_kernel(const float* x, long long n, uint16_t* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -128,62 +128,90 @@ int nb_for(int K) {
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------
-template <int PRO, int EPI, int R>
-int launch_gemv_i8q4_r(const GemvParams& p, int grid, int threads, hipStream_t st) {
-    const size_t lds = lds_bytes_i8(p.K);
-    switch (nb_for(p.K)) {
-#define JH_CASE(NBV)                                                                      \
-    case NBV:                                                                             \
-        JHCHK(allow_lds(gemv_i8q4_kernel<PRO, EPI, R, NBV>, lds));                        \
-        hipLaunchKernelGGL((gemv_i8q4_kernel<PRO, EPI, R, NBV>), dim3(grid), dim3(threads), lds, st, p); \
-        break;
-        JH_CASE(1) JH_CASE(2) JH_CASE(4) JH_CASE(7)
-        default:
-            JHCHK(allow_lds(gemv_i8q4_kernel<PRO, EPI, R, 0>, lds));
-            hipLaunchKernelGGL((gemv_i8q4_kernel<PRO, EPI, R, 0>), dim3(grid), dim3(threads), lds, st, p);
-#undef JH_CASE
-    }
-    HIPCHK(hipGetLastError());
-    return JH_OK;
-}
+struct LaunchCfg { int R, waves, grid_cap, pipe; };   // 0 / -1 = let the planner decide
 
-struct LaunchCfg { int R, waves, grid_cap; };
+// (R, NB, PIPE) instantiations of gemv_i8q4_kernel
+#define JH_GEMV_COMBOS(X)                                                                                         \
+    X(1, 1, 0) X(1, 2, 0) X(1, 4, 0) X(1, 7, 0) X(2, 1, 0) X(2, 2, 0) X(2, 4, 0) X(2, 7, 0) X(4, 1, 0) X(4, 2, 0)  \
+    X(4, 4, 0) X(8, 1, 0) X(8, 2, 0) X(14, 2, 0)                                                                  \
+    X(2, 2, 1) X(4, 2, 1) X(2, 4, 1) X(4, 1, 1) X(8, 1, 1) X(2, 7, 1) X(1, 0, 1) X(2, 0, 1) X(4, 0, 1)
 
 template <int PRO, int EPI>
-int launch_gemv_i8q4(const GemvParams& p, LaunchCfg cfg, hipStream_t st) {
-    int total = p.nrows[0] + (p.ntens > 1 ? p.nrows[1] : 0) + (p.ntens > 2 ? p.nrows[2] : 0);
-    int R = cfg.R;
-    for (int t = 0; t < p.ntens; t++)
-        while (R > 1 && p.nrows[t] % R) R >>= 1;
-    const int ngroups = total / R;
-    int grid = (ngroups + cfg.waves - 1) / cfg.waves;
-    if (grid > cfg.grid_cap) grid = cfg.grid_cap;
-    if (grid < 1) grid = 1;
-    const int threads = cfg.waves * 64;
-    if (R >= 4) return launch_gemv_i8q4_r<PRO, EPI, 4>(p, grid, threads, st);
-    if (R >= 2) return launch_gemv_i8q4_r<PRO, EPI, 2>(p, grid, threads, st);
-    return launch_gemv_i8q4_r<PRO, EPI, 1>(p, grid, threads, st);
+int launch_gemv_i8q4_combo(const GemvParams& p, int R, int NB, int PIPE, int grid, int threads, hipStream_t st) {
+    const size_t lds = lds_bytes_i8(p.K);
+#define X(RV, NBV, PV)                                                                                          \
+    if (R == RV && NB == NBV && PIPE == PV) {                                                                   \
+        if constexpr (!(EPI == EPI_SILU_MUL && ((RV) & 1))) {                                                   \
+            JHCHK(allow_lds(gemv_i8q4_kernel<PRO, EPI, RV, NBV, PV>, lds));                                     \
+            hipLaunchKernelGGL((gemv_i8q4_kernel<PRO, EPI, RV, NBV, PV>), dim3(grid), dim3(threads), lds, st, p); \
+            HIPCHK(hipGetLastError());                                                                          \
+            return JH_OK;                                                                                       \
+        }                                                                                                       \
+    }
+    JH_GEMV_COMBOS(X)
+#undef X
+    return set_err(JH_ERR_INVALID, "gemv: no kernel instantiation for R=" + std::to_string(R) + " NB=" + std::to_string(NB) +
+                                       " PIPE=" + std::to_string(PIPE));
 }
 
-template <int PRO>
-int launch_gateup(const GemvParams& p, int grid_cap, hipStream_t st) {
-    const size_t lds = lds_bytes_i8(p.K);
-    const int ntiles = p.nrows[0] / 32;
-    int grid = ntiles < grid_cap ? ntiles : grid_cap;
-    switch (nb_for(p.K)) {
-#define JH_CASE(NBV)                                                                \
-    case NBV:                                                                       \
-        JHCHK(allow_lds(gemv_gateup_kernel<PRO, NBV>, lds));                        \
-        hipLaunchKernelGGL((gemv_gateup_kernel<PRO, NBV>), dim3(grid), dim3(512), lds, st, p); \
-        break;
-        JH_CASE(1) JH_CASE(2) JH_CASE(4)
-        default:
-            JHCHK(allow_lds(gemv_gateup_kernel<PRO, 0>, lds));
-            hipLaunchKernelGGL((gemv_gateup_kernel<PRO, 0>), dim3(grid), dim3(512), lds, st, p);
-#undef JH_CASE
+// Plan a GEMV launch.  Goal (tools/membw.hip calibration): every CU gets one workgroup whose waves each hold
+// R*NB >= ~8 independent 16-byte loads, ALL issued before the activation prologue (PIPE=0).  When a wave's share of
+// rows does not fit in registers, fall back to the software-pipelined loop (PIPE=1).
+template <int PRO, int EPI>
+int launch_gemv_i8q4(const GemvParams& p, LaunchCfg cfg, hipStream_t st) {
+    const int total = (EPI == EPI_SILU_MUL) ? 2 * p.nrows : p.nrows;
+    const int nb = nb_for(p.K);
+    const int cu = g_cu_count;
+    auto divides = [&](int R) {
+        if (EPI == EPI_SILU_MUL) return (R % 2 == 0) && (p.nrows % (R / 2) == 0);
+        return p.nrows % R == 0;
+    };
+    int R = cfg.R, pipe = cfg.pipe, waves = cfg.waves;
+    if (nb == 0) {
+        pipe = 1;
+        if (R <= 0) R = 2;
+        while (R > 1 && !divides(R)) R >>= 1;
+        if (EPI == EPI_SILU_MUL && R < 2) return set_err(JH_ERR_INVALID, "gate/up GEMV needs an even hidden length");
+        if (waves <= 0) waves = 8;
+    } else if (R <= 0 || pipe < 0) {
+        // rows per wave if every CU ran 16 waves
+        const int need = (total + cu * 16 - 1) / (cu * 16);
+        static const int oneshot[] = {1, 2, 4, 8, 14};
+        int pick = 0;
+        for (int r : oneshot) {
+            const bool inst = (r == 1 || r == 2) || (r == 4 && nb <= 4) || (r == 8 && nb <= 2) || (r == 14 && nb == 2);
+            if (inst && r >= need && r * nb <= 28 && divides(r)) { pick = r; break; }
+        }
+        if (pick && (pipe < 0 || pipe == 0)) {
+            R = pick;
+            pipe = 0;
+        } else {
+            pipe = 1;
+            R = (nb == 1) ? 8 : (nb == 2 ? 4 : 2);
+            while (R > 2 && !divides(R)) R >>= 1;
+        }
     }
-    HIPCHK(hipGetLastError());
-    return JH_OK;
+    const int ngroups = total / R;
+    int grid, threads;
+    if (pipe == 0) {
+        // VGPR budget: 1024-thread blocks are capped at 128 registers
+        int wmax = (R * nb <= 8) ? 16 : 8;   // must match gemv_i8q4_kernel's __launch_bounds__
+        if (waves <= 0) {
+            waves = (ngroups + cu - 1) / cu;
+            if (waves < 4) waves = 4;
+            if (waves > wmax) waves = wmax;
+        }
+        if (waves > wmax) waves = wmax;
+        grid = (ngroups + waves - 1) / waves;
+    } else {
+        if (waves <= 0 || waves > 8) waves = 8;
+        grid = (ngroups + waves - 1) / waves;
+        const int cap = cfg.grid_cap > 0 ? cfg.grid_cap : cu * 2;
+        if (grid > cap) grid = cap;
+    }
+    if (grid < 1) grid = 1;
+    threads = waves * 64;
+    return launch_gemv_i8q4_combo<PRO, EPI>(p, R, nb, pipe, grid, threads, st);
 }
 
 template <int PRO, int R>
@@ -205,13 +233,15 @@ int launch_gemv_f32q4_r(const GemvParams& p, int grid, int threads, hipStream_t 
 }
 template <int PRO>
 int launch_gemv_f32q4(const GemvParams& p, LaunchCfg cfg, int* grid_out, hipStream_t st) {
-    int R = cfg.R > 2 ? 2 : cfg.R;
-    while (R > 1 && p.nrows[0] % R) R >>= 1;
-    const int ngroups = p.nrows[0] / R;
+    int R = cfg.R <= 0 ? 4 : cfg.R;
+    if (R > 4) R = 4;
+    while (R > 1 && p.nrows % R) R >>= 1;
+    const int ngroups = p.nrows / R;
     int grid = (ngroups + cfg.waves - 1) / cfg.waves;
     if (grid > cfg.grid_cap) grid = cfg.grid_cap;
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = grid;
+    if (R == 4) return launch_gemv_f32q4_r<PRO, 4>(p, grid, cfg.waves * 64, st);
     if (R == 2) return launch_gemv_f32q4_r<PRO, 2>(p, grid, cfg.waves * 64, st);
     return launch_gemv_f32q4_r<PRO, 1>(p, grid, cfg.waves * 64, st);
 }
@@ -349,15 +379,15 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
     if (fast) {
         GemvParams p;
         memset(&p, 0, sizeof(p));
-        p.ntens = 1;
-        p.nrows[0] = n;
+        p.nrows = n;
         p.K = k;
         p.ldb = ldb;
         p.ldbf = ldbf;
-        p.w[0] = dB + (size_t)ldb * n0 + boffset;
-        p.ws[0] = dBf + (size_t)ldbf * n0 + (boffset * 2) / QB;
-        p.out[0] = (float*)dR + cmin;
-        LaunchCfg cfg{env_int("JH_GEMV_R", 2), env_int("JH_GEMV_WAVES", 8), g_cu_count * 4};
+        p.w = dB + (size_t)ldb * n0 + boffset;
+        p.ws = dBf + (size_t)ldbf * n0 + (boffset * 2) / QB;
+        p.out = (float*)dR + cmin;
+        LaunchCfg cfg{env_int("JH_GEMV_R", 0), env_int("JH_GEMV_WAVES", 0), 0, env_int("JH_GEMV_PIPE", -1)};
+        LaunchCfg cfgf{env_int("JH_GEMV_R", 0), 8, g_cu_count * 2, 1};
         if (kind == G_Q8Q4) {
             p.aq = (const int8_t*)dA + aoffset;
             p.ad = (const float*)dAf + aoffset / QB;
@@ -365,7 +395,7 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         } else {
             p.x = (const float*)dA + aoffset;
             if (aoffset % 4) fast = false;
-            else JHCHK((launch_gemv_f32q4<PRO_F32>(p, cfg, nullptr, st)));
+            else JHCHK((launch_gemv_f32q4<PRO_F32>(p, cfgf, nullptr, st)));
         }
     }
     if (!fast) {
@@ -672,7 +702,8 @@ struct JWeight {
 struct jh_model {
     jh_config c;
     int device;
-    std::vector<JWeight> layer_w;  // [n_layers][JH_W_COUNT]
+    std::vector<JWeight> layer_w;  // [n_layers][JH_W_COUNT]; Q/K/V entries alias slices of qkv[layer]
+    std::vector<JWeight> qkv;      // [n_layers] q|k|v stacked along N in ONE allocation => one GEMV, no tensor switch
     JWeight global_w[JH_W_COUNT];
     float* rope = nullptr;
     float attention_scale;
@@ -687,8 +718,7 @@ struct jh_session {
     float** pages_dev = nullptr;
     int max_ctx = 0, max_splits = 32, chunk_cap = 32;
     // activations
-    float *x = nullptr, *x1 = nullptr, *qkv = nullptr, *attd = nullptr, *attf = nullptr, *hd = nullptr, *hf = nullptr;
-    int8_t *attq = nullptr, *hq = nullptr;
+    float *x = nullptr, *x1 = nullptr, *qkv = nullptr, *attf = nullptr, *hf = nullptr;
     float *logits = nullptr, *amax_v = nullptr, *part = nullptr, *tapq = nullptr;
     int* amax_i = nullptr;
     unsigned* counters = nullptr;
@@ -705,8 +735,7 @@ struct jh_session {
     int tap_layer = -1;
     float* taps[TAP_SLOTS] = {nullptr};
     int tap_len[TAP_SLOTS] = {0};
-    LaunchCfg cfg_qkv, cfg_o, cfg_down, cfg_lm;
-    int gateup_grid_cap;
+    LaunchCfg cfg_qkv, cfg_o, cfg_gateup, cfg_down, cfg_lm;
 };
 
 namespace {
@@ -732,12 +761,11 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap) {
     p.part = s->part;
     p.counters = s->counters;
     p.max_splits = s->max_splits;
-    p.outq = s->attq;
-    p.outd = s->attd;
     p.outf = s->attf;
     p.tap_q = tap ? s->tapq : nullptr;
     const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
-    const size_t lds = ((size_t)group * hs + 2 * hs + 1024 * (size_t)group + 2 * group + 4 + (size_t)group * s->chunk_cap) * 4;
+    const int sc_cap = s->chunk_cap > 2 * s->max_splits ? s->chunk_cap : 2 * s->max_splits;
+    const size_t lds = ((size_t)group * hs + 2 * hs + 1024 * (size_t)group + 2 * group + 4 + (size_t)group * sc_cap) * 4;
     dim3 grid(s->max_splits, c.n_kv_heads), block(256);
 #define JH_ATTN(HSV, GV)                                                                   \
     if (hs == HSV && group == GV) {                                                        \
@@ -774,12 +802,11 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
     {   // q,k,v projections (CausalSelfAttention.java:161-171) with fused preAttentionNorm + maybeQuantize
         GemvParams p;
         memset(&p, 0, sizeof(p));
-        p.ntens = 3;
-        p.w[0] = (const uint8_t*)W[JH_W_Q].data; p.ws[0] = W[JH_W_Q].scales; p.nrows[0] = A; p.out[0] = s->qkv;
-        p.w[1] = (const uint8_t*)W[JH_W_K].data; p.ws[1] = W[JH_W_K].scales; p.nrows[1] = KV; p.out[1] = s->qkv + A;
-        p.w[2] = (const uint8_t*)W[JH_W_V].data; p.ws[2] = W[JH_W_V].scales; p.nrows[2] = KV; p.out[2] = s->qkv + A + KV;
+        const JWeight& F = m->qkv[(size_t)li];
+        if (!F.data || !W[JH_W_Q].data || !W[JH_W_K].data || !W[JH_W_V].data) return set_err(JH_ERR_INVALID, "layer: q/k/v weights not set");
+        p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
-        p.x = s->x; p.nw = W[JH_W_NORM1].data; p.nw_bf16 = W[JH_W_NORM1].dtype == JH_DT_BF16; p.eps = c.rms_eps;
+        p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
         JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
         JHCHK(trace_sync("qkv", st));
     }
@@ -801,35 +828,32 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
     {   // output projection (:365-376) + residual (TransformerBlock.java:185)
         GemvParams p;
         memset(&p, 0, sizeof(p));
-        p.ntens = 1;
-        p.w[0] = (const uint8_t*)W[JH_W_O].data; p.ws[0] = W[JH_W_O].scales; p.nrows[0] = E; p.out[0] = s->x1;
+        p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = s->x1;
         p.K = A; p.ldb = A / 2; p.ldbf = A / QB;
-        p.aq = s->attq; p.ad = s->attd; p.resid = s->x;
-        JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_o, st)));
+        p.x = s->attf; p.resid = s->x;   // maybeQuantize(valueBatch) (:364) happens in the prologue
+        JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_o, st)));
         JHCHK(trace_sync("oproj", st));
     }
     if (tap) JHCHK(tap_copy(s, 8, s->x1, E, st));
     {   // gate/up (MLPBlock.java:117-142) with fused preFFNorm + maybeQuantize, SiLU*up + maybeQuantize
         GemvParams p;
         memset(&p, 0, sizeof(p));
-        p.ntens = 2;
-        p.w[0] = (const uint8_t*)W[JH_W_GATE].data; p.ws[0] = W[JH_W_GATE].scales; p.nrows[0] = H;
-        p.w[1] = (const uint8_t*)W[JH_W_UP].data; p.ws[1] = W[JH_W_UP].scales; p.nrows[1] = H;
+        p.w = (const uint8_t*)W[JH_W_GATE].data; p.ws = W[JH_W_GATE].scales; p.nrows = H;
+        p.w2 = (const uint8_t*)W[JH_W_UP].data; p.ws2 = W[JH_W_UP].scales;
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
-        p.x = s->x1; p.nw = W[JH_W_NORM2].data; p.nw_bf16 = W[JH_W_NORM2].dtype == JH_DT_BF16; p.eps = c.rms_eps;
-        p.hq = s->hq; p.hd = s->hd; p.hf = tap ? s->hf : nullptr;
-        JHCHK((launch_gateup<PRO_RMS_Q8>(p, s->gateup_grid_cap, st)));
+        p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
+        p.out = s->hf;   // silu(gate)*up, F32; the down projection's prologue quantizes it (MLPBlock.java:144)
+        JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
         JHCHK(trace_sync("gateup", st));
     }
     if (tap) JHCHK(tap_copy(s, 10, s->hf, H, st));
     {   // down projection (:147-158) + residual (TransformerBlock.java:203)
         GemvParams p;
         memset(&p, 0, sizeof(p));
-        p.ntens = 1;
-        p.w[0] = (const uint8_t*)W[JH_W_DOWN].data; p.ws[0] = W[JH_W_DOWN].scales; p.nrows[0] = E; p.out[0] = s->x;
+        p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x;
         p.K = H; p.ldb = H / 2; p.ldbf = H / QB;
-        p.aq = s->hq; p.ad = s->hd; p.resid = s->x1;
-        JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_down, st)));
+        p.x = s->hf; p.resid = s->x1;
+        JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
         JHCHK(trace_sync("down", st));
     }
     if (tap) JHCHK(tap_copy(s, JH_TAP_POST_FF_RES, s->x, E, st));
@@ -855,10 +879,9 @@ int lmhead_launch(jh_session* s, hipStream_t st) {
     if (!w->data || !m->global_w[JH_W_FINALNORM].data) return set_err(JH_ERR_INVALID, "sample: this shard has no output weights");
     GemvParams p;
     memset(&p, 0, sizeof(p));
-    p.ntens = 1;
-    p.w[0] = (const uint8_t*)w->data; p.ws[0] = w->scales; p.nrows[0] = c.vocab_size; p.out[0] = s->logits;
+    p.w = (const uint8_t*)w->data; p.ws = w->scales; p.nrows = c.vocab_size; p.out = s->logits;
     p.K = c.embedding_length; p.ldb = p.K / 2; p.ldbf = p.K / QB;
-    p.x = s->x; p.nw = m->global_w[JH_W_FINALNORM].data; p.nw_bf16 = m->global_w[JH_W_FINALNORM].dtype == JH_DT_BF16;
+    p.x = s->x; p.nw = (const float*)m->global_w[JH_W_FINALNORM].data;
     p.eps = c.rms_eps;
     p.amax_part = s->amax_v; p.amax_idx = s->amax_i;
     int grid = 0;
@@ -906,6 +929,7 @@ int jh_model_create(const jh_config* cfg, jh_model** out) {
     m->c = *cfg;
     m->device = tctx.device;
     m->layer_w.resize((size_t)cfg->n_layers * JH_W_COUNT);
+    m->qkv.resize((size_t)cfg->n_layers);
     // Config ctor (core/safetensors/Config.java:270-274): table over the whole context
     const int half = cfg->head_size / 2;
     std::vector<float> table((size_t)cfg->context_length * half * 2);
@@ -920,7 +944,14 @@ int jh_model_create(const jh_config* cfg, jh_model** out) {
 int jh_model_destroy(jh_model* m) {
     if (!m) return JH_OK;
     hipSetDevice(m->device);
-    for (auto& w : m->layer_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
+    for (size_t i = 0; i < m->layer_w.size(); i++) {
+        const int which = (int)(i % JH_W_COUNT);
+        if (which == JH_W_Q || which == JH_W_K || which == JH_W_V) continue;  // slices of the fused allocation
+        auto& w = m->layer_w[i];
+        if (w.data) hipFree(w.data);
+        if (w.scales) hipFree(w.scales);
+    }
+    for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
     for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
     if (m->rope) hipFree(m->rope);
     delete m;
@@ -948,18 +979,67 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     else return set_err(JH_ERR_UNSUPPORTED, "set_weight: dtype");
     const bool is_norm = (which == JH_W_NORM1 || which == JH_W_NORM2 || which == JH_W_FINALNORM);
     if (!is_norm && dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "set_weight: matmul weights must be Q4 in this build");
-    if (w->data) { hipFree(w->data); m->weight_bytes -= 0; }
+    std::vector<float> widened;
+    void* widened_dev = nullptr;
+    if (is_norm && dtype == JH_DT_BF16) {
+        // 1-D norm weights (BF16 on disk, never quantized: AbstractTensor.java:284) are widened to F32 once; exact.
+        const size_t n = (size_t)rows * cols;
+        if (from_device) {
+            HIPCHK(hipMalloc(&widened_dev, n * 4));
+            hipLaunchKernelGGL(widen_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const uint16_t*)data, (long long)n,
+                               (float*)widened_dev);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipDeviceSynchronize());
+            data = widened_dev;
+        } else {
+            widened.resize(n);
+            const uint16_t* h = (const uint16_t*)data;
+            for (size_t i = 0; i < n; i++) {
+                const uint32_t u = ((uint32_t)h[i]) << 16;
+                memcpy(&widened[i], &u, 4);
+            }
+            data = widened.data();
+        }
+        dtype = JH_DT_F32;
+        bytes = n * 4;
+    }
+    const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (layer >= 0 && (which == JH_W_Q || which == JH_W_K || which == JH_W_V)) {
+        // q|k|v live stacked in one [A+2KV, E] allocation (CausalSelfAttention.java:161-171 issues three GEMVs over the
+        // same activation; here they become one)
+        const int A = m->c.n_heads * m->c.head_size, KV = m->c.n_kv_heads * m->c.head_size, E = m->c.embedding_length;
+        const int want_rows = which == JH_W_Q ? A : KV;
+        if (rows != want_rows || cols != E || dtype != JH_DT_Q4) return set_err(JH_ERR_INVALID, "set_weight: q/k/v shape");
+        JWeight& f = m->qkv[(size_t)layer];
+        if (!f.data) {
+            const size_t tot = (size_t)(A + 2 * KV);
+            hipError_t e2 = hipMalloc(&f.data, tot * E / 2 + 64);
+            if (e2 != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc qkv: ") + hipGetErrorString(e2));
+            e2 = hipMalloc((void**)&f.scales, tot * (E / QB) * 4 + 64);
+            if (e2 != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc qkv scales: ") + hipGetErrorString(e2));
+            f.dtype = JH_DT_Q4; f.rows = (int)tot; f.cols = E;
+        }
+        const size_t row0 = which == JH_W_Q ? 0 : (which == JH_W_K ? (size_t)A : (size_t)(A + KV));
+        uint8_t* dd = (uint8_t*)f.data + row0 * (E / 2);
+        float* ds = f.scales + row0 * (E / QB);
+        HIPCHK(hipMemcpy(dd, data, bytes, kind));
+        HIPCHK(hipMemcpy(ds, scales, sbytes, kind));
+        if (!w->data) m->weight_bytes += (int64_t)(bytes + sbytes);
+        w->data = dd; w->scales = ds; w->dtype = dtype; w->rows = rows; w->cols = cols;
+        return JH_OK;
+    }
+    if (w->data) hipFree(w->data);
     if (w->scales) hipFree(w->scales);
     w->data = nullptr; w->scales = nullptr;
     hipError_t e = hipMalloc(&w->data, bytes + 64);
     if (e != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc weight: ") + hipGetErrorString(e));
-    const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     HIPCHK(hipMemcpy(w->data, data, bytes, kind));
     if (sbytes) {
         e = hipMalloc((void**)&w->scales, sbytes + 64);
         if (e != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc scales: ") + hipGetErrorString(e));
         HIPCHK(hipMemcpy(w->scales, scales, sbytes, kind));
     }
+    if (widened_dev) hipFree(widened_dev);
     w->dtype = dtype; w->rows = rows; w->cols = cols;
     if (!is_norm && which != JH_W_EMBED) m->weight_bytes += (int64_t)(bytes + sbytes);
     return JH_OK;
@@ -996,19 +1076,15 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
         }
     HIPCHK(hipMalloc(&s->pages_dev, s->pages_host.size() * sizeof(float*)));
     HIPCHK(hipMemcpy(s->pages_dev, s->pages_host.data(), s->pages_host.size() * sizeof(float*), hipMemcpyHostToDevice));
-    s->max_splits = env_int("JH_ATTN_SPLITS", 32);
+    s->max_splits = env_int("JH_ATTN_SPLITS", 16);
     if (s->max_splits < 1) s->max_splits = 1;
     s->chunk_cap = (max_ctx + s->max_splits - 1) / s->max_splits;
     if (s->chunk_cap < 32) s->chunk_cap = 32;
     HIPCHK(hipMalloc(&s->x, (size_t)E * 4));
     HIPCHK(hipMalloc(&s->x1, (size_t)E * 4));
     HIPCHK(hipMalloc(&s->qkv, (size_t)(A + 2 * KV) * 4));
-    HIPCHK(hipMalloc(&s->attq, (size_t)A));
-    HIPCHK(hipMalloc(&s->attd, (size_t)(A / QB) * 4));
     HIPCHK(hipMalloc(&s->attf, (size_t)A * 4));
     HIPCHK(hipMalloc(&s->tapq, (size_t)A * 4));
-    HIPCHK(hipMalloc(&s->hq, (size_t)H));
-    HIPCHK(hipMalloc(&s->hd, (size_t)(H / QB) * 4));
     HIPCHK(hipMalloc(&s->hf, (size_t)H * 4));
     HIPCHK(hipMalloc(&s->logits, (size_t)c.vocab_size * 4));
     HIPCHK(hipMalloc(&s->amax_v, 4096 * 4));
@@ -1022,12 +1098,13 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     HIPCHK(hipEventCreate(&s->ev1));
     JHCHK(ensure_out_tokens(s, 1024));
     const int cu = g_cu_count;
-    s->cfg_qkv = LaunchCfg{env_int("JH_QKV_R", 2), env_int("JH_QKV_WAVES", 8), env_int("JH_QKV_GRID", cu * 2)};
-    s->cfg_o = LaunchCfg{env_int("JH_O_R", 2), env_int("JH_O_WAVES", 8), env_int("JH_O_GRID", cu * 2)};
-    s->cfg_down = LaunchCfg{env_int("JH_DOWN_R", 2), env_int("JH_DOWN_WAVES", 8), env_int("JH_DOWN_GRID", cu * 2)};
-    s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 2), env_int("JH_LM_WAVES", 8), env_int("JH_LM_GRID", cu * 4)};
+    // launch plans: see launch_gemv_i8q4 (env overrides are for tuning sweeps only)
+    s->cfg_qkv = LaunchCfg{env_int("JH_QKV_R", 0), env_int("JH_QKV_WAVES", 0), cu * env_int("JH_QKV_GRIDX", 2), env_int("JH_QKV_PIPE", -1)};
+    s->cfg_o = LaunchCfg{env_int("JH_O_R", 0), env_int("JH_O_WAVES", 0), cu * env_int("JH_O_GRIDX", 2), env_int("JH_O_PIPE", -1)};
+    s->cfg_gateup = LaunchCfg{env_int("JH_GATEUP_R", 0), env_int("JH_GATEUP_WAVES", 0), cu * env_int("JH_GATEUP_GRIDX", 2), env_int("JH_GATEUP_PIPE", -1)};
+    s->cfg_down = LaunchCfg{env_int("JH_DOWN_R", 0), env_int("JH_DOWN_WAVES", 0), cu * env_int("JH_DOWN_GRIDX", 2), env_int("JH_DOWN_PIPE", -1)};
+    s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 0), env_int("JH_LM_WAVES", 8), cu * env_int("JH_LM_GRIDX", 2), 1};
     if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
-    s->gateup_grid_cap = env_int("JH_GATEUP_GRID", cu * 2);
     *out = s;
     return JH_OK;
 }
@@ -1038,7 +1115,7 @@ int jh_session_destroy(jh_session* s) {
     if (s->exec) hipGraphExecDestroy(s->exec);
     if (s->graph) hipGraphDestroy(s->graph);
     for (float* p : s->pages_host) if (p) hipFree(p);
-    void* bufs[] = {s->pages_dev, s->x, s->x1, s->qkv, s->attq, s->attd, s->attf, s->tapq, s->hq, s->hd, s->hf, s->logits,
+    void* bufs[] = {s->pages_dev, s->x, s->x1, s->qkv, s->attf, s->tapq, s->hf, s->logits,
                     s->amax_v, s->amax_i, s->part, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
@@ -1054,6 +1131,80 @@ int jh_session_page_info(jh_session* s, int32_t* out4) {
     return JH_OK;
 }
 void* jh_session_stream(jh_session* s) { return s ? (void*)s->stream : nullptr; }
+int jh_session_synchronize(jh_session* s) {
+    if (!s) return set_err(JH_ERR_INVALID, "session_synchronize: null");
+    HIPCHK(hipSetDevice(s->m->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return JH_OK;
+}
+
+// Roofline probe: launch ONE kernel kind of the decode step back-to-back over all of this shard's layers (so the
+// weights stream from HBM, not from the 256 MiB Infinity Cache), `iters` sweeps, bracketed by hipEvents on the
+// session's stream.  out_ms = average duration of one launch.
+int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t* out_bytes_per_launch) {
+    if (!s || !out_ms || iters <= 0) return set_err(JH_ERR_INVALID, "kernel_bench: bad argument");
+    jh_model* m = s->m;
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = s->stream;
+    const jh_config& c = m->c;
+    const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
+    const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    const int nl = c.layer_end - c.layer_start;
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, s->max_ctx / 2, 0, 0);
+    int launches = 0;
+    for (int it = -1; it < iters; it++) {
+        if (it == 0) HIPCHK(hipEventRecord(s->ev0, st));
+        for (int li = c.layer_start; li < c.layer_end; li++) {
+            const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+            GemvParams p;
+            memset(&p, 0, sizeof(p));
+            if (which == 0) {
+                const JWeight& F = m->qkv[(size_t)li];
+                p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
+                p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
+                p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
+                JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
+            } else if (which == 1) {
+                JHCHK(attn_launch(s, li - c.layer_start, st, false));
+            } else if (which == 2) {
+                p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = s->x1;
+                p.K = A; p.ldb = A / 2; p.ldbf = A / QB; p.x = s->attf; p.resid = s->x;
+                JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_o, st)));
+            } else if (which == 3) {
+                p.w = (const uint8_t*)W[JH_W_GATE].data; p.ws = W[JH_W_GATE].scales; p.nrows = H;
+                p.w2 = (const uint8_t*)W[JH_W_UP].data; p.ws2 = W[JH_W_UP].scales;
+                p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
+                p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
+                p.out = s->hf;
+                JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
+            } else if (which == 4) {
+                p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x1;
+                p.K = H; p.ldb = H / 2; p.ldbf = H / QB; p.x = s->hf; p.resid = s->x;
+                JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
+            } else {
+                return set_err(JH_ERR_INVALID, "kernel_bench: which in 0..4 (qkv, attn, oproj, gateup, down)");
+            }
+            if (it >= 0) launches++;
+        }
+    }
+    HIPCHK(hipEventRecord(s->ev1, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    *out_ms = (double)ms / launches;
+    if (out_bytes_per_launch) {
+        const double bpw = 0.625;  // 0.5 B nibble + 4 B scale / 32 weights
+        int64_t b = 0;
+        if (which == 0) b = (int64_t)((double)(A + 2 * KV) * E * bpw);
+        else if (which == 1) b = (int64_t)2 * (s->max_ctx / 2 + 1) * KV * 4 + (int64_t)2 * KV * 4;
+        else if (which == 2) b = (int64_t)((double)E * A * bpw);
+        else if (which == 3) b = (int64_t)((double)2 * H * E * bpw);
+        else b = (int64_t)((double)E * H * bpw);
+        *out_bytes_per_launch = b;
+    }
+    (void)nl;
+    return JH_OK;
+}
 
 static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in, bool x_in_dev, int n, int start_pos,
                         float* x_out, bool x_out_dev) {

@@ -143,6 +143,15 @@ class HipSession:
         N.check(N.lib().jh_decode_stats(self.h, C.byref(ms), C.byref(k)))
         return ms.value, k.value
 
+    def synchronize(self):
+        N.check(N.lib().jh_session_synchronize(self.h))
+
+    def kernel_bench(self, which, iters=3):
+        """(ms per launch, algorithmic bytes per launch) of decode kernel `which` (0 qkv,1 attn,2 o,3 gate/up,4 down)."""
+        ms, b = C.c_double(), C.c_int64()
+        N.check(N.lib().jh_kernel_bench(self.h, which, iters, C.byref(ms), C.byref(b)))
+        return ms.value, b.value
+
     def stream(self):
         return N.lib().jh_session_stream(self.h)
 

@@ -45,6 +45,27 @@ _lib = None
 _ref = None
 
 
+def available_cpus():
+    """CPUs this process may actually use: affinity mask AND cgroup quota (what Java's availableProcessors() reports;
+    the reference sizes its pool from it, PhysicalCoreExecutor.java:27)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+if "OMP_NUM_THREADS" not in os.environ:
+    os.environ["OMP_NUM_THREADS"] = str(available_cpus())  # before libgomp loads: never oversubscribe a cgroup quota
+
+
 def lib():
     global _lib
     if _lib is None:
