@@ -63,6 +63,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     v += __shfl_xor(v, 32);
     return v;
 }
+// Workgroup barrier for LDS hand-offs ONLY.  __syncthreads() carries a workgroup-scope fence, for which hipcc emits
+// s_waitcnt vmcnt(0): every global load in flight (our whole prefetched weight stream) would have to land before the
+// barrier.  This one drains just the LDS queue (lgkmcnt), so weights keep streaming across prologue barriers
+// (cdna_hip_programming.md §5 "Pipelining across barriers").  Never use it to order GLOBAL memory between waves.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // FloatConversions.float32ToBFloat16 (core/math/FloatConversions.java:35-60): RNE incl. carry into exponent
@@ -168,10 +178,10 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     v = wave_sum_d(v);
     if (lane == 0) red[wave] = v;
-    __syncthreads();
+    lds_barrier();
     double t = 0.0;
     for (int i = 0; i < nw; i++) t += red[i];  // fixed order => deterministic
-    __syncthreads();
+    lds_barrier();
     return t;
 }
 
@@ -205,8 +215,8 @@ __device__ __forceinline__ void quad_quantize_store(const float (&y)[8], int uni
     float amax = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(y[i]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1));
-    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    amax = fmaxf(amax, dpp_f<0xB1>(amax));   // quad butterfly on the DPP path (no LDS round trip)
+    amax = fmaxf(amax, dpp_f<0x4E>(amax));
     const float d = amax / 127.0f;
     const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
     int q[8];
@@ -218,8 +228,8 @@ __device__ __forceinline__ void quad_quantize_store(const float (&y)[8], int uni
         q[i] = f2b(v);
         s += (int)(int8_t)q[i];
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
+    s += __builtin_amdgcn_update_dpp(0, s, 0xB1, 0xf, 0xf, false);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x4E, 0xf, 0xf, false);
     const int blk = unit >> 2, sub = unit & 3;
     i32x2 packed;
     packed.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
@@ -319,7 +329,7 @@ __device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a
             quad_quantize_store(y, unit, a);
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------ K1: streaming GEMV I8 x Q4
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
         a.y[(size_t)c * nblk + blk] = xa;
         a.y[(size_t)(c + 1) * nblk + blk] = xb;
     }
-    __syncthreads();
+    lds_barrier();
 
     float bestv = -INFINITY;
     int besti = 0x7fffffff;
@@ -631,7 +641,7 @@ __global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
     }
     if (p.amax_part) {
         if (lane == 0) { a.bestv[wave] = bestv; a.besti[wave] = besti; }
-        __syncthreads();
+        lds_barrier();
         if (threadIdx.x == 0) {
             float bv = -INFINITY;
             int bi = 0x7fffffff;
@@ -735,7 +745,8 @@ __global__ void finish_token_kernel(const float* partv, const int* parti, int np
 struct AttnParams {
     const float* qkv;      // [A + 2*KV]: q | k | v of the new row (F32, pre-RoPE)
     const float* rope;     // [ctx*hs/2][2]
-    float* const* pages;   // this layer-page's context pages: pages[cp] -> [layersPerPage,2,ctxPerPage,KV]
+    float* kv_base;        // context page 0 of this layer page; page cp lives at kv_base + cp*page_elems,
+    long long page_elems;  //   each page = [layersPerPage, 2, ctxPerPage, KV] F32 (KvBufferCache.java:99-112)
     int rel_layer_in_page, ctx_per_page;
     int n_heads, n_kv_heads, head_size;
     const DecodeState* st;
@@ -749,7 +760,7 @@ struct AttnParams {
 
 __device__ __forceinline__ const float* kv_row(const AttnParams& p, int which, int t, int kvlen) {
     const int cp = t / p.ctx_per_page, rc = t - cp * p.ctx_per_page;
-    return p.pages[cp] + ((size_t)(p.rel_layer_in_page * 2 + which) * p.ctx_per_page + rc) * kvlen;
+    return p.kv_base + (size_t)cp * p.page_elems + ((size_t)(p.rel_layer_in_page * 2 + which) * p.ctx_per_page + rc) * kvlen;
 }
 __device__ __forceinline__ void st_sc1(float* p, float v) {
     __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -851,7 +862,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
             ((float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS)[tid] = vn;
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- scores: LPR lanes x float4 cover one K row ---------------------------------------------------------
     float4 qv[GROUP];
@@ -879,7 +890,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
         score_row(tt, (t == pos) ? ((const float4*)knew)[c4]
                                  : ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4]);
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- local softmax per head (one wave per head, round-robin) ------------------------------------------
     for (int gi = wave; gi < GROUP; gi += 4) {
@@ -896,7 +907,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
         for (int tt = lane; tt < cnt; tt += 64) sc[gi * chunk + tt] = sc[gi * chunk + tt] / l;  // normalise by division
         if (lane == 0) { ml[2 * gi] = m; ml[2 * gi + 1] = l; }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- o = sum_t w[t] * V[t]: thread = (row-in-step, float4 column); fma chain per element ----------------
     {
@@ -926,7 +937,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
 #pragma unroll
         for (int gi = 0; gi < GROUP; gi++) ((float4*)(red + ((size_t)rsub * GROUP + gi) * HS))[c4] = acc[gi];
     }
-    __syncthreads();
+    lds_barrier();
     float* oloc = qs;  // reuse q storage for the slice's output [GROUP][HS]
     for (int i = tid; i < GROUP * HS; i += blockDim.x) {
         float s = 0.0f;
@@ -934,7 +945,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
         for (int rg = 0; rg < RPS; rg++) s += red[(size_t)rg * GROUP * HS + i];
         oloc[i] = s;
     }
-    __syncthreads();
+    lds_barrier();
 
     if (S > 1) {
         // publish this slice's (o, m, l) write-through; the last arriver of the kv head combines

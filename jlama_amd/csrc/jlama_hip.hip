@@ -174,22 +174,28 @@ int launch_gemv_i8q4(const GemvParams& p, LaunchCfg cfg, hipStream_t st) {
         if (EPI == EPI_SILU_MUL && R < 2) return set_err(JH_ERR_INVALID, "gate/up GEMV needs an even hidden length");
         if (waves <= 0) waves = 8;
     } else if (R <= 0 || pipe < 0) {
-        // rows per wave if every CU ran 16 waves
-        const int need = (total + cu * 16 - 1) / (cu * 16);
-        static const int oneshot[] = {1, 2, 4, 8, 14};
-        int pick = 0;
-        for (int r : oneshot) {
-            const bool inst = (r == 1 || r == 2) || (r == 4 && nb <= 4) || (r == 8 && nb <= 2) || (r == 14 && nb == 2);
-            if (inst && r >= need && r * nb <= 28 && divides(r)) { pick = r; break; }
+        // Measured on MI355X (tools/gemv_lab2.hip, gate/up-sized matrix): issuing a wave's whole weight stream before the
+        // prologue ("single shot", PIPE=0) only helps when the prologue is trivial -- a CU keeps ~32-64 KB of loads in
+        // flight, so a wave that queues more than that is still ISSUING loads when its prologue should already run.
+        // The software-pipelined loop with ~8 KB per wave prefetched (R*NB = 4..8) is the better default.
+        if (pipe < 0) {
+            // small/medium GEMVs (<= ~200 KB of weights per CU) run best single-shot, the big gate/up one pipelined
+            const double bytes_per_cu = (double)total * p.K * 0.625 / cu;
+            pipe = bytes_per_cu <= 200e3 ? 0 : 1;
         }
-        if (pick && (pipe < 0 || pipe == 0)) {
-            R = pick;
-            pipe = 0;
-        } else {
-            pipe = 1;
-            R = (nb == 1) ? 8 : (nb == 2 ? 4 : 2);
-            while (R > 2 && !divides(R)) R >>= 1;
+        if (R <= 0) {
+            if (pipe == 1) R = (nb == 1) ? 4 : 2;
+            else {
+                const int need = (total + cu * 16 - 1) / (cu * 16);
+                static const int oneshot[] = {1, 2, 4, 8, 14};
+                R = 1;
+                for (int r : oneshot) {
+                    const bool inst = (r == 1 || r == 2) || (r == 4 && nb <= 4) || (r == 8 && nb <= 2) || (r == 14 && nb == 2);
+                    if (inst && r >= need && r * nb <= 28 && divides(r)) { R = r; break; }
+                }
+            }
         }
+        while (R > 2 && !divides(R)) R >>= 1;
     }
     const int ngroups = total / R;
     int grid, threads;
@@ -206,7 +212,7 @@ int launch_gemv_i8q4(const GemvParams& p, LaunchCfg cfg, hipStream_t st) {
     } else {
         if (waves <= 0 || waves > 8) waves = 8;
         grid = (ngroups + waves - 1) / waves;
-        const int cap = cfg.grid_cap > 0 ? cfg.grid_cap : cu * 2;
+        const int cap = cfg.grid_cap > 0 ? cfg.grid_cap : cu;
         if (grid > cap) grid = cap;
     }
     if (grid < 1) grid = 1;
@@ -716,6 +722,8 @@ struct jh_session {
     int layers_per_page = 0, ctx_per_page = 0, n_layer_pages = 0, n_ctx_pages = 0, n_ctx_alloc = 0;
     std::vector<float*> pages_host;
     float** pages_dev = nullptr;
+    float* kv_slab = nullptr;
+    size_t page_elems = 0;
     int max_ctx = 0, max_splits = 32, chunk_cap = 32;
     // activations
     float *x = nullptr, *x1 = nullptr, *qkv = nullptr, *attf = nullptr, *hf = nullptr;
@@ -750,7 +758,8 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap) {
     const int lp = rel / s->layers_per_page;
     p.qkv = s->qkv;
     p.rope = m->rope;
-    p.pages = s->pages_dev + (size_t)lp * s->n_ctx_pages;
+    p.kv_base = s->kv_slab + (size_t)lp * s->n_ctx_alloc * s->page_elems;   // first context page of this layer page
+    p.page_elems = (long long)s->page_elems;
     p.rel_layer_in_page = rel % s->layers_per_page;
     p.ctx_per_page = s->ctx_per_page;
     p.n_heads = c.n_heads;
@@ -1065,15 +1074,21 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     s->n_ctx_alloc = (max_ctx + geo[1] - 1) / geo[1];
     s->max_ctx = max_ctx;
     s->pages_host.assign((size_t)s->n_layer_pages * s->n_ctx_pages, nullptr);
-    const size_t page_bytes = (size_t)geo[0] * 2 * geo[1] * KV * 4;
+    // KvBufferCache pages (KvBufferCache.java:99-112: [layersPerPage, 2, ctxPerPage, kvLength] F32 each) carved out of
+    // ONE slab: the attention kernel computes a row's address arithmetically instead of chasing a page pointer (a
+    // dependent global load on its critical path).  The page table is still materialised for hosts / taps.
+    const size_t page_elems = (size_t)geo[0] * 2 * geo[1] * KV;
+    const size_t page_bytes = page_elems * 4;
+    const size_t slab_bytes = page_bytes * s->n_layer_pages * s->n_ctx_alloc;
+    {
+        hipError_t e = hipMalloc(&s->kv_slab, slab_bytes);
+        if (e != hipSuccess) { jh_session_destroy(s); return set_err(JH_ERR_OOM, "hipMalloc KV pages"); }
+        HIPCHK(hipMemset(s->kv_slab, 0, slab_bytes));
+    }
     for (int lp = 0; lp < s->n_layer_pages; lp++)
-        for (int cp = 0; cp < s->n_ctx_alloc; cp++) {
-            float* pg = nullptr;
-            hipError_t e = hipMalloc(&pg, page_bytes);
-            if (e != hipSuccess) { jh_session_destroy(s); return set_err(JH_ERR_OOM, "hipMalloc KV page"); }
-            HIPCHK(hipMemset(pg, 0, page_bytes));
-            s->pages_host[(size_t)lp * s->n_ctx_pages + cp] = pg;
-        }
+        for (int cp = 0; cp < s->n_ctx_alloc; cp++)
+            s->pages_host[(size_t)lp * s->n_ctx_pages + cp] = s->kv_slab + ((size_t)lp * s->n_ctx_alloc + cp) * page_elems;
+    s->page_elems = page_elems;
     HIPCHK(hipMalloc(&s->pages_dev, s->pages_host.size() * sizeof(float*)));
     HIPCHK(hipMemcpy(s->pages_dev, s->pages_host.data(), s->pages_host.size() * sizeof(float*), hipMemcpyHostToDevice));
     s->max_splits = env_int("JH_ATTN_SPLITS", 16);
@@ -1099,10 +1114,10 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     JHCHK(ensure_out_tokens(s, 1024));
     const int cu = g_cu_count;
     // launch plans: see launch_gemv_i8q4 (env overrides are for tuning sweeps only)
-    s->cfg_qkv = LaunchCfg{env_int("JH_QKV_R", 0), env_int("JH_QKV_WAVES", 0), cu * env_int("JH_QKV_GRIDX", 2), env_int("JH_QKV_PIPE", -1)};
-    s->cfg_o = LaunchCfg{env_int("JH_O_R", 0), env_int("JH_O_WAVES", 0), cu * env_int("JH_O_GRIDX", 2), env_int("JH_O_PIPE", -1)};
-    s->cfg_gateup = LaunchCfg{env_int("JH_GATEUP_R", 0), env_int("JH_GATEUP_WAVES", 0), cu * env_int("JH_GATEUP_GRIDX", 2), env_int("JH_GATEUP_PIPE", -1)};
-    s->cfg_down = LaunchCfg{env_int("JH_DOWN_R", 0), env_int("JH_DOWN_WAVES", 0), cu * env_int("JH_DOWN_GRIDX", 2), env_int("JH_DOWN_PIPE", -1)};
+    s->cfg_qkv = LaunchCfg{env_int("JH_QKV_R", 0), env_int("JH_QKV_WAVES", 0), cu * env_int("JH_QKV_GRIDX", 1), env_int("JH_QKV_PIPE", -1)};
+    s->cfg_o = LaunchCfg{env_int("JH_O_R", 0), env_int("JH_O_WAVES", 0), cu * env_int("JH_O_GRIDX", 1), env_int("JH_O_PIPE", -1)};
+    s->cfg_gateup = LaunchCfg{env_int("JH_GATEUP_R", 0), env_int("JH_GATEUP_WAVES", 0), cu * env_int("JH_GATEUP_GRIDX", 1), env_int("JH_GATEUP_PIPE", -1)};
+    s->cfg_down = LaunchCfg{env_int("JH_DOWN_R", 0), env_int("JH_DOWN_WAVES", 0), cu * env_int("JH_DOWN_GRIDX", 1), env_int("JH_DOWN_PIPE", -1)};
     s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 0), env_int("JH_LM_WAVES", 8), cu * env_int("JH_LM_GRIDX", 2), 1};
     if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
     *out = s;
@@ -1114,7 +1129,7 @@ int jh_session_destroy(jh_session* s) {
     if (s->stream) hipStreamSynchronize(s->stream);
     if (s->exec) hipGraphExecDestroy(s->exec);
     if (s->graph) hipGraphDestroy(s->graph);
-    for (float* p : s->pages_host) if (p) hipFree(p);
+    if (s->kv_slab) hipFree(s->kv_slab);
     void* bufs[] = {s->pages_dev, s->x, s->x1, s->qkv, s->attf, s->tapq, s->hf, s->logits,
                     s->amax_v, s->amax_i, s->part, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);

@@ -1,0 +1,189 @@
+"""Layer-sharded inference across the GPUs of one node -- Jlama's cluster layer split re-hosted on RCCL.
+
+Reference behaviour: ``DistributedContext.layerStart/layerEnd``
+(jlama-core/.../model/DistributedContext.java:75-77) gives every worker a contiguous layer range;
+``AbstractModel.forward`` runs only that range (AbstractModel.java:321-326); a worker hands its ``[batch, E]`` F32
+output to the next layer shard (``PassRecord.tensor``, jlama-net/.../Worker.java:193-196,226-248), the last shard's
+final row goes to the coordinator which samples (Coordinator.java:184) and feeds the token back to shard 0.
+
+Here: one process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests), rank r owns
+layers ``[r*L/N, (r+1)*L/N)`` and their KV pages; the hop between shards is a point-to-point send/recv of the F32
+activation (16 KiB per decode token at E=4096), the sampled token id (4 B) returns from the last rank to rank 0.
+No collective is needed on this path.  Because a single session is strictly sequential through the shards, N sessions
+are kept in flight (session j is on stage (t-j) mod N at tick t) so every GPU streams its weights on every tick.
+
+torch is plumbing only (process group + device buffers handed to RCCL); all arithmetic is in libjlamahip.so.
+"""
+import os
+import time
+
+import numpy as np
+
+
+def layer_range(rank, world, n_layers):
+    """DistributedContext layer split: contiguous, equal ranges (requires n_layers % world == 0)."""
+    if n_layers % world:
+        raise ValueError(f"{n_layers} layers do not split evenly over {world} shards")
+    per = n_layers // world
+    return rank * per, (rank + 1) * per
+
+
+class ShardEngine:
+    """What a pipeline stage must provide.  x buffers are torch tensors on the engine's device."""
+
+    def forward_tokens(self, session, tokens, start_pos, x_out):  # first shard: embedding rows -> x_out [n,E]
+        raise NotImplementedError
+
+    def forward_x(self, session, x_in, n, start_pos, x_out):      # later shards
+        raise NotImplementedError
+
+    def sample(self, session):                                    # last shard: argmax of the last forwarded row
+        raise NotImplementedError
+
+
+class HipShardEngine(ShardEngine):
+    """A layer shard resident on one MI355X (Tier-2 C ABI); activations never leave HBM between RCCL and the kernels."""
+
+    def __init__(self, cfg, weights, rank, world, device_index, n_sessions, max_ctx):
+        import torch
+        from .model import HipLlamaModel
+        self.torch = torch
+        ls, le = layer_range(rank, world, cfg["n_layers"])
+        self.model = HipLlamaModel(cfg, weights, layer_range=(ls, le), device=device_index)
+        self.sessions = [self.model.session(max_ctx) for _ in range(n_sessions)]
+
+    def _sync_torch(self):
+        self.torch.cuda.current_stream().synchronize()
+
+    def forward_tokens(self, session, tokens, start_pos, x_out):
+        s = self.sessions[session]
+        s.forward_device(np.ascontiguousarray(tokens, dtype=np.int32), 0, len(tokens), start_pos, x_out.data_ptr())
+        s.synchronize()
+
+    def forward_x(self, session, x_in, n, start_pos, x_out):
+        s = self.sessions[session]
+        self._sync_torch()  # the recv into x_in ran on torch's stream
+        s.forward_device(None, x_in.data_ptr(), n, start_pos, x_out.data_ptr())
+        s.synchronize()
+
+    def sample(self, session):
+        return self.sessions[session].sample(0.0, 0.5)
+
+
+def pipeline_prefill(dist, engine, rank, world, session, prompt, E, device, dtype):
+    """Prefill one session through all shards (batchForward, AbstractModel.java:295-312); returns the first sampled
+    token on every rank (broadcast from the last shard)."""
+    import torch
+    n = len(prompt)
+    x_in = torch.empty((n, E), dtype=dtype, device=device)
+    x_out = torch.empty((n, E), dtype=dtype, device=device)
+    if rank == 0:
+        engine.forward_tokens(session, prompt, 0, x_out)
+    else:
+        dist.recv(x_in, src=rank - 1)
+        engine.forward_x(session, x_in, n, 0, x_out)
+    tok = torch.zeros(1, dtype=torch.int32, device=device)
+    if rank < world - 1:
+        dist.send(x_out, dst=rank + 1)
+    else:
+        tok[0] = engine.sample(session)
+    dist.broadcast(tok, src=world - 1)
+    return int(tok.item())
+
+
+def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_per_session, E, device, dtype):
+    """Greedy-decode ``steps_per_session`` tokens for each of ``world`` sessions with the sessions staggered across the
+    pipeline.  Work item q = (session q % N, step q // N); rank r handles item q at tick q + r.
+    Returns the tokens the LAST rank sampled, as an int array [sessions, steps] (zeros on other ranks)."""
+    import torch
+    N = world
+    n_items = N * steps_per_session
+    out = np.zeros((N, steps_per_session), dtype=np.int32)
+    x_in = torch.empty((1, E), dtype=dtype, device=device)
+    x_out = [torch.empty((1, E), dtype=dtype, device=device) for _ in range(2)]
+    tok_in = torch.zeros(1, dtype=torch.int32, device=device)
+    tok_out = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(2)]
+    pending = None
+    for tick in range(n_items + N - 1):
+        q = tick - rank
+        if q < 0 or q >= n_items:
+            continue
+        j, k = q % N, q // N
+        buf = tick & 1
+        if rank == 0:
+            if k == 0:
+                token = int(first_tokens[j])
+            elif N == 1:
+                token = int(out[j, k - 1])
+            else:
+                dist.recv(tok_in, src=N - 1)      # sampled by the last shard one tick ago
+                token = int(tok_in.item())
+            engine.forward_tokens(j, [token], start_pos + k, x_out[buf])
+        else:
+            dist.recv(x_in, src=rank - 1)
+            engine.forward_x(j, x_in, 1, start_pos + k, x_out[buf])
+        if pending is not None:
+            pending.wait()
+            pending = None
+        if rank < N - 1:
+            pending = dist.isend(x_out[buf], dst=rank + 1)
+        else:
+            t = engine.sample(j)
+            out[j, k] = t
+            if N > 1 and k + 1 < steps_per_session:
+                tok_out[buf][0] = t
+                pending = dist.isend(tok_out[buf], dst=0)
+    if pending is not None:
+        pending.wait()
+    return out
+
+
+def bench_pipeline(args, cfg):
+    """bench.py's N>1 leg (one rank per GPU under torch.distributed.run).  Returns the JSON dict on rank 0."""
+    import torch
+    import torch.distributed as dist
+    from . import synthetic as S, synthetic_torch as ST
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist.init_process_group(backend="nccl", device_id=device)
+    L, E = cfg["n_layers"], cfg["embedding_length"]
+    ls, le = layer_range(rank, world, L)
+    w = ST.make_weights(cfg, seed=0, layers=(ls, le), device=device, need_embed=(rank == 0), need_head=(rank == world - 1))
+    prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
+    steps_per_session = max(1, args.steps // world)
+    max_ctx = prompt.size + max(steps_per_session, args.warmup) + 8
+    engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=world, max_ctx=max_ctx)
+    firsts = [pipeline_prefill(dist, engine, rank, world, j, prompt, E, device, torch.float32) for j in range(world)]
+    if args.warmup > 0:  # untimed decode ticks on the same sessions' KV tail (positions beyond the timed range are rewritten)
+        pipeline_decode(dist, engine, rank, world, firsts, prompt.size, max(1, args.warmup // world), E, device, torch.float32)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks = pipeline_decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    total = steps_per_session * world
+    out = None
+    if rank == 0:
+        tps = total / dt
+        wbytes, kvb = S.weight_bytes(cfg), S.kv_bytes_per_position(cfg)
+        bytes_per_token = wbytes + kvb * (prompt.size + (steps_per_session - 1) / 2.0 + 2)
+        out = {"metric": "decode tokens/sec Llama-3-8B JQ4, 128-tok prompt" if args.config == "LLAMA3_8B" else f"decode tokens/sec {args.config} JQ4",
+               "value": round(tps, 2), "unit": "tokens/s", "n_gpus": world, "steps": total, "warmup": args.warmup,
+               "ms_per_step": round(dt / total * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "i8xq4->f32", "data": "synthetic",
+               "config": {"workload": f"{args.config} JQ4, {prompt.size}-row prefill + {steps_per_session} greedy decode steps x {world} "
+                                      f"sessions in flight", "parallelism": f"layer-sharded pp{world} ({L // world} layers/GPU), RCCL send/recv of [1,E] F32"},
+               "roofline": {"bound": "hbm", "achieved": round(bytes_per_token * tps / 1e9 / world, 1), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(bytes_per_token * tps / 1e9 / world / 8000.0, 4), "traffic": None,
+                            "note": "per-GPU average: algorithmic bytes of all sessions / time / GPUs (kernel-level roofline is reported by the 1-GPU run)"}}
+    dist.destroy_process_group()
+    return out

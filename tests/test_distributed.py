@@ -1,0 +1,94 @@
+"""Layer-sharded pipeline (jlama_amd.distributed) on CPU: world_size 2 and 4 over gloo, with the ORACLE as the shard
+engine (tests may use the oracle; the product engine is HipShardEngine).  Checks the DistributedContext semantics the
+reference tests in-process (jlama-net/.../JlamaServiceTest.java:50-106, DistributedServiceTest.java:43-118): every
+session's tokens equal the un-sharded single-process generation, bit for bit (transfers are copies)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cfg, n_prompt, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      OMP_NUM_THREADS="2")
+    import torch
+    import torch.distributed as dist
+    from jlama_amd import distributed as D, synthetic as S
+    from oracle import oracle as O
+
+    class OracleShardEngine(D.ShardEngine):
+        def __init__(self):
+            ls, le = D.layer_range(rank, world, cfg["n_layers"])
+            self.w = S.make_weights(cfg, seed=3)
+            self.m = O.OracleModel(cfg, self.w, layer_range=(ls, le))
+            self.s = [self.m.session() for _ in range(world)]
+            self.last = [None] * world
+
+        def forward_tokens(self, session, tokens, start_pos, x_out):
+            x = self.s[session].forward(np.asarray(tokens, dtype=np.int32), start_pos)
+            x_out.copy_(torch.from_numpy(x))
+            self.last[session] = x[-1]
+
+        def forward_x(self, session, x_in, n, start_pos, x_out):
+            x = self.s[session].forward(None, start_pos, x=x_in.numpy()[:n])
+            x_out.copy_(torch.from_numpy(x))
+            self.last[session] = x[-1]
+
+        def sample(self, session):
+            return self.m.sample(self.last[session])[0]
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    eng = OracleShardEngine()
+    E = cfg["embedding_length"]
+    prompts = [S.prompt_tokens(cfg, n=n_prompt, seed=100 + j) for j in range(world)]
+    firsts = [D.pipeline_prefill(dist, eng, rank, world, j, prompts[j], E, "cpu", torch.float32) for j in range(world)]
+    toks = D.pipeline_decode(dist, eng, rank, world, firsts, prompts[0].size, steps, E, "cpu", torch.float32)
+    if rank == world - 1:
+        q.put((firsts, toks.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_layer_sharded_pipeline_matches_single_process(world):
+    import torch.multiprocessing as mp
+    from jlama_amd import distributed as D, synthetic as S
+    from oracle import oracle as O
+    cfg = dict(S.TINY)
+    cfg["n_layers"] = 4
+    n_prompt, steps = 6, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, n_prompt, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    firsts, toks = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: AbstractModel.generate per session
+    w = S.make_weights(cfg, seed=3)
+    om = O.OracleModel(cfg, w)
+    for j in range(world):
+        prompt = S.prompt_tokens(cfg, n=n_prompt, seed=100 + j)
+        want, _, _ = om.session().generate(prompt, steps + 1)
+        assert firsts[j] == want[0]
+        np.testing.assert_array_equal(np.array(toks[j]), want[1:])
+
+
+def test_layer_range_matches_distributed_context():
+    from jlama_amd import distributed as D
+    assert D.layer_range(0, 8, 80) == (0, 10) and D.layer_range(7, 8, 80) == (70, 80)   # Llama-3-70B on 8 GPUs
+    assert [D.layer_range(r, 4, 32) for r in range(4)] == [(0, 8), (8, 16), (16, 24), (24, 32)]
+    with pytest.raises(ValueError):
+        D.layer_range(0, 3, 32)

@@ -199,3 +199,22 @@ def test_model_forward_is_causal_and_batch_equals_sequential(oracle):
     g2, _, _ = m.session().generate(prompt, 8)
     np.testing.assert_array_equal(g1, g2)
     assert g1[0] == tok
+
+
+def test_reference_gemm_driven_model_matches_panama_order_at_m1(oracle):
+    """bench.py's cpu_baseline leg drives the reference's compiled C GEMM from the restated decode loop.  At M = 1
+    (decode, and prompts fed row by row) it must agree with the Panama-order restatement to rounding."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    from jlama_amd import synthetic as S
+    cfg = dict(S.SMALL)
+    w = S.make_weights(cfg, seed=1)
+    m1, m2 = oracle.OracleModel(cfg, w), oracle.OracleModel(cfg, w)
+    m2.use_reference_gemm(2)
+    p = S.prompt_tokens(cfg, n=7, seed=2)
+    s1, s2 = m1.session(), m2.session()
+    for i, t in enumerate(p):
+        x1, x2 = s1.forward([t], i), s2.forward([t], i)
+    assert np.abs(x1 - x2).max() <= 1e-5 * np.abs(x1).max()
+    (t1, l1), (t2, l2) = m1.sample(x1[-1]), m2.sample(x2[-1])
+    assert t1 == t2 and np.abs(l1 - l2).max() <= 1e-5
