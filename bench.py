@@ -168,7 +168,7 @@ def main():
     from jlama_amd import synthetic as S
     cfg = dict(getattr(S, args.config))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("JH_BENCH_FORCE_PIPELINE"):
         from jlama_amd import distributed as D
         out = D.bench_pipeline(args, cfg)
         if out is not None:
