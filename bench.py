@@ -122,26 +122,31 @@ def run_single(args, cfg):
     # roofline of the dominant kernel (gate/up GEMV: 54% of the weight bytes), HIP events on the session's stream
     probe = {}
     names = ["qkv", "attention", "o_proj", "gate_up", "down"]
-    for i, nm in enumerate(names):
-        ms, b = s.kernel_bench(i, args.probe_iters)
-        probe[nm] = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
-    dom = probe["gate_up"]
+    is_q4 = cfg["weight_dtype"] == N.DT_Q4
+    if is_q4:
+        for i, nm in enumerate(names):
+            ms, b = s.kernel_bench(i, args.probe_iters)
+            probe[nm] = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
+        dom = probe["gate_up"]
     wbytes = S.weight_bytes(cfg)
     kvb = S.kv_bytes_per_position(cfg)
     mean_pos = prompt.size + (args.steps - 1) / 2.0
     bytes_per_token = wbytes + kvb * (mean_pos + 1) + kvb
     out = {
-        "metric": "decode tokens/sec Llama-3-8B JQ4, 128-tok prompt" if args.config == "LLAMA3_8B" else f"decode tokens/sec {args.config} JQ4",
+        "metric": "decode tokens/sec Llama-3-8B JQ4, 128-tok prompt" if args.config == "LLAMA3_8B" else f"decode tokens/sec {args.config}",
         "value": round(tps, 2), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "i8xq4->f32", "data": "synthetic",
-        "config": {"workload": f"{args.config} JQ4 (Q4 weights, I8 activations, F32 paged KV), {prompt.size}-row prefill + "
+        "vs_baseline": None, "dtype": "i8xq4->f32" if is_q4 else "bf16xbf16->f32", "data": "synthetic",
+        "config": {"workload": f"{args.config} {'JQ4 (Q4 weights, I8 activations' if is_q4 else 'BF16 (BF16 weights and activations'}, F32 paged KV), {prompt.size}-row prefill + "
                                f"{args.steps} greedy decode steps, batch 1", "parallelism": "1 GPU",
                    "kernels_per_token": kernels, "prefill_ms": round(prompt_ms, 1)},
-        "roofline": {"bound": "hbm", "kernel": "gemv_i8q4_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV, fused RMSNorm+Q8 prologue, SiLU*up epilogue)",
-                     "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": _measured_traffic(args.config),
-                     "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]},
+        "roofline": ({"bound": "hbm", "kernel": "gemv_i8q4_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV, fused RMSNorm+Q8 prologue, SiLU*up epilogue)",
+                      "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": _measured_traffic(args.config),
+                      "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]} if is_q4 else
+                     {"bound": "hbm", "kernel": "whole decode step (per-kernel probe is JQ4-only)",
+                      "achieved": round(bytes_per_token * tps / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(bytes_per_token * tps / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}),
         "token_roofline": {"bytes_per_token": int(bytes_per_token), "achieved_GBps": round(bytes_per_token * tps / 1e9, 1),
                            "frac_of_8TBps": round(bytes_per_token * tps / 1e9 / HBM_PEAK_GBS, 4),
                            "event_ms_per_token": round(ev_ms, 4)},

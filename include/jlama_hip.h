@@ -237,6 +237,8 @@ int jh_set_tap_layer(jh_session* s, int layer);
 int jh_get_tap(jh_session* s, int which, float* out, int n);
 /* The HIP stream the session launches on (hipStream_t as void*), so callers can record their own events. */
 void* jh_session_stream(jh_session* s);
+/* Debug aid: wall-clock (100 MHz) phase stamps of one decode-attention launch at `pos`; out[split*16 + phase]. */
+int jh_debug_attn_timeline(jh_session* s, int pos, long long* out, int n);
 /* Wait for everything queued on the session's stream. */
 int jh_session_synchronize(jh_session* s);
 /* Roofline probe: average duration (ms) of ONE launch of decode kernel `which` (0 qkv, 1 attention, 2 o-proj,

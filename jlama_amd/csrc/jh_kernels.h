@@ -121,13 +121,22 @@ __device__ __forceinline__ i32x4 ldg_nt(const i32x4* p) {
     return __builtin_nontemporal_load(p);
 }
 
+// ------------------------------------------------------------------------------------------------ decode state
+struct DecodeState {
+    int pos;     // position of the row being forwarded
+    int token;   // its token id
+    int step;    // index into out_tokens
+    int pad;
+};
+
 // ------------------------------------------------------------------------------------------------ GEMV params
 // Prologues: how the activation row reaches LDS.  Epilogues: what happens to the dot products.
 enum { PRO_Q8 = 0,       // already I8 + scales in global memory (Tier-1 jh_gemm_q8_q4)
        PRO_RMS_Q8 = 1,   // RMSNorm (core/model/RMSNorm.java:33-56) then Q8 quantize (PTO:1684-1723)
        PRO_QUANT_Q8 = 2, // Q8 quantize an F32 row (LlamaModel.maybeQuantize, core/model/llama/LlamaModel.java:176-184)
        PRO_F32 = 3,      // F32 row as is (F32xQ4)
-       PRO_RMS_F32 = 4 };// RMSNorm, keep F32 (LM head: AbstractModel.java:443-449)
+       PRO_RMS_F32 = 4,  // RMSNorm, keep F32 (LM head: AbstractModel.java:443-449)
+       PRO_ATTN_Q8 = 5 };// combine the attention slices (softmax-weighted sum) then Q8 quantize: o-projection input
 enum { EPI_STORE = 0,    // out[j] = dot
        EPI_RESID = 1,    // out[j] = dot + resid[j]            (TransformerBlock.java:185,203)
        EPI_SILU_MUL = 2 };// out[j] = silu(dot_gate[j]) * dot_up[j] (MLPBlock.java:132-142)
@@ -152,6 +161,12 @@ struct GemvParams {
     const float* resid;    // EPI_RESID
     float* amax_part;      // LM head: per-workgroup (max logit, index) partials
     int* amax_idx;
+    // PRO_ATTN_Q8: attention slices published by attn_decode_kernel in "direct" mode (context <= direct_max)
+    const float* part_o;   // [n_heads][part_stride][head_size]
+    const float* part_ml;  // [n_heads][part_stride][2] = (max, sum) of each slice's local softmax
+    const DecodeState* st;
+    int direct_max, direct_chunk, part_stride, head_size, n_heads;
+    float* tap_att;        // optional: combined attention output [A] ("after_attention" tap), written by workgroup 0
 };
 
 // LDS carve for an I8 activation row of nblk blocks
@@ -161,6 +176,7 @@ struct ActI8 {
     float* d;      // [nblk] block scales
     int* asum;     // [nblk] sum of the block's int8 values
     double* red;   // [32] reduction scratch
+    float* wts;    // [256] PRO_ATTN_Q8: softmax-combine weight of (head, slice)
 };
 __device__ __forceinline__ ActI8 carve_i8(char* smem, int nblk) {
     ActI8 a;
@@ -169,9 +185,10 @@ __device__ __forceinline__ ActI8 carve_i8(char* smem, int nblk) {
     a.d = (float*)(a.hi + nblk);
     a.asum = (int*)(a.d + nblk);
     a.red = (double*)(a.asum + nblk);   // 40*nblk bytes in: 8-byte aligned (no integer cast: keeps the LDS address space)
+    a.wts = (float*)(a.red + 32);
     return a;
 }
-static inline size_t lds_bytes_i8(int K) { return (size_t)(K / QB) * (16 + 16 + 4 + 4) + 16 + 32 * 8; }
+static inline size_t lds_bytes_i8(int K) { return (size_t)(K / QB) * (16 + 16 + 4 + 4) + 16 + 32 * 8 + 256 * 4; }
 
 // block-wide double sum, result broadcast to every thread.  red: >= 32 doubles of LDS.
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
@@ -251,6 +268,9 @@ constexpr int UMAX = 2;
 struct ActRegs {
     float xv[UMAX][8];
     float wv[UMAX][8];
+    float po[UMAX][4][8];   // PRO_ATTN_Q8: this thread's 8 output elements of up to 4 slices
+    float m, l;             // PRO_ATTN_Q8: (max, sum) of slice (tid&3) of head (tid>>2)
+    int n;                  // context length pos+1
 };
 template <int PRO>
 __device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegs& r) {
@@ -258,6 +278,14 @@ __device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegs& r) {
     const int units = p.K / 8, T = blockDim.x;
     // branch-free (clamped) addresses: a guarded load would make hipcc wait for it at the end of its basic block,
     // serialising this round trip with the weight stream that is issued next
+    if (PRO == PRO_ATTN_Q8) {
+        r.n = p.st->pos + 1;
+        int t = threadIdx.x;
+        t = t < p.n_heads * 4 ? t : p.n_heads * 4 - 1;
+        const float* mlp = p.part_ml + ((size_t)(t >> 2) * p.part_stride + (t & 3)) * 2;
+        r.m = mlp[0];
+        r.l = mlp[1];
+    }
 #pragma unroll
     for (int u = 0; u < UMAX; u++) {
         int unit = threadIdx.x + u * T;
@@ -266,6 +294,16 @@ __device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegs& r) {
         r.xv[u][0] = xa.x; r.xv[u][1] = xa.y; r.xv[u][2] = xa.z; r.xv[u][3] = xa.w;
         r.xv[u][4] = xb.x; r.xv[u][5] = xb.y; r.xv[u][6] = xb.z; r.xv[u][7] = xb.w;
         if (PRO == PRO_RMS_Q8) load8_norm(p.nw, unit * 8, r.wv[u]);
+        if (PRO == PRO_ATTN_Q8) {
+            const int e0 = unit * 8, h = e0 / p.head_size, d0 = e0 - h * p.head_size;
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) {
+                const float* po = p.part_o + ((size_t)h * p.part_stride + sl) * p.head_size + d0;
+                const float4 a = *(const float4*)po, b = *(const float4*)(po + 4);
+                r.po[u][sl][0] = a.x; r.po[u][sl][1] = a.y; r.po[u][sl][2] = a.z; r.po[u][sl][3] = a.w;
+                r.po[u][sl][4] = b.x; r.po[u][sl][5] = b.y; r.po[u][sl][6] = b.z; r.po[u][sl][7] = b.w;
+            }
+        }
     }
 }
 template <int PRO>
@@ -288,6 +326,25 @@ __device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a
     } else {
         const int units = K / 8, T = blockDim.x;
         float fs = 1.0f;
+        bool direct = false;
+        int S = 1;
+        if (PRO == PRO_ATTN_Q8) {
+            // "direct" mode of attn_decode_kernel: <= 4 slices per head were published as (o_s, m_s, l_s); combine them
+            // here, under this GEMV's weight prefetch:  w_s = l_s*exp(m_s - M) / sum_s(l_s*exp(m_s - M)),  o = sum_s w_s*o_s
+            direct = r.n <= p.direct_max;
+            S = (r.n + p.direct_chunk - 1) / p.direct_chunk;
+            if (direct) {
+                const bool valid = (int)(threadIdx.x & 3) < S && (int)threadIdx.x < p.n_heads * 4;
+                const float m = valid ? r.m : -INFINITY;
+                float M = fmaxf(m, dpp_f<0xB1>(m));
+                M = fmaxf(M, dpp_f<0x4E>(M));
+                float e = valid ? r.l * (float)exp((double)(m - M)) : 0.0f;
+                float L = e + dpp_f<0xB1>(e);
+                L = L + dpp_f<0x4E>(L);
+                if ((int)threadIdx.x < p.n_heads * 4) a.wts[threadIdx.x] = e / L;
+            }
+            lds_barrier();
+        }
         if (PRO == PRO_RMS_Q8) {
             // RMSNorm (core/model/RMSNorm.java:41-49): float squares, double sum, /E, +eps, 1/sqrt in double
             double ss = 0.0;
@@ -314,6 +371,22 @@ __device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a
                 float y[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) y[i] = (PRO == PRO_RMS_Q8) ? r.wv[u][i] * (fs * r.xv[u][i]) : r.xv[u][i];  // (0 + w) * ((float)ss * x)
+                if (PRO == PRO_ATTN_Q8 && direct) {
+                    const int h = (unit * 8) / p.head_size;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) y[i] = 0.0f;
+#pragma unroll
+                    for (int sl = 0; sl < 4; sl++)
+                        if (sl < S) {
+                            const float w = a.wts[h * 4 + sl];
+#pragma unroll
+                            for (int i = 0; i < 8; i++) y[i] = fmaf(r.po[u][sl][i], w, y[i]);
+                        }
+                    if (p.tap_att && blockIdx.x == 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) p.tap_att[unit * 8 + i] = y[i];
+                    }
+                }
                 quad_quantize_store(y, unit, a);
             }
         }
@@ -401,7 +474,7 @@ __device__ __forceinline__ void store_group(const GemvParams& p, int g, int lane
 //           GEMV is requested from HBM at t=0 and the prologue hides under the first-byte latency);
 // PIPE = 1: a wave walks several groups, loading group g+1 into a second register set while it reduces group g.
 template <int PRO, int EPI, int R, int NB, int PIPE>
-__global__ __launch_bounds__((PIPE || R * NB > 8) ? 512 : 1024) void gemv_i8q4_kernel(GemvParams p) {
+__global__ __launch_bounds__((PIPE || R * NB > 4) ? 512 : 1024) void gemv_i8q4_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblk = p.K / QB;
     const ActI8 a = carve_i8(smem, nblk);
@@ -657,12 +730,160 @@ __global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ decode state
-struct DecodeState {
-    int pos;     // position of the row being forwarded
-    int token;   // its token id
-    int step;    // index into out_tokens
-    int pad;
+// ------------------------------------------------------------------------------------------------ K3: GEMV BF16 weights
+// Dense BF16 model (Mistral-7B, config 4) at M=1.  Reference arithmetic: activations RNE-rounded to BF16
+// (PTO:1624-1628 -> FloatConversions.float32ToBFloat16), both operands widened by <<16, F32 fma accumulate
+// (GemmerBF16 PTO:1279-1311); the LM head multiplies the UN-quantized F32 normed row (GemmerF32BF16 PTO:1511-1538,
+// AbstractModel.java:443-449).  Decode is HBM-bound (2 B/weight): one 16-byte non-temporal load = 8 weights per
+// lane; lane l owns 8-element chunks l, l+64, ...; the activation row sits in LDS as F32 in two float4 planes
+// (conflict-free ds_read_b128).  MFMA is for the batched prefill GEMM, not for this kernel.
+enum { PROB_RMS_BF16 = 0, PROB_QUANT_BF16 = 1, PROB_RMS_F32 = 2, PROB_F32 = 3 };
+struct ActBF {
+    float4* lo;    // [K/8] elements 0..3 of each 8-element chunk
+    float4* hi;    // [K/8] elements 4..7
+    double* red;   // [32]
+    float* bestv;  // [16]
+    int* besti;    // [16]
 };
+__device__ __forceinline__ ActBF carve_bf(char* smem, int K) {
+    ActBF a;
+    a.lo = (float4*)smem;
+    a.hi = a.lo + K / 8;
+    a.red = (double*)(a.hi + K / 8);
+    a.bestv = (float*)(a.red + 32);
+    a.besti = (int*)(a.bestv + 16);
+    return a;
+}
+static inline size_t lds_bytes_bf(int K) { return (size_t)K * 4 + 32 * 8 + 16 * 4 + 16 * 4; }
+
+__device__ __forceinline__ float chunk_dot_bf16(const i32x4& w, const float4& alo, const float4& ahi, float acc) {
+    acc = fmaf(alo.x, __int_as_float(w.x << 16), acc);
+    acc = fmaf(alo.y, __int_as_float(w.x & 0xffff0000), acc);
+    acc = fmaf(alo.z, __int_as_float(w.y << 16), acc);
+    acc = fmaf(alo.w, __int_as_float(w.y & 0xffff0000), acc);
+    acc = fmaf(ahi.x, __int_as_float(w.z << 16), acc);
+    acc = fmaf(ahi.y, __int_as_float(w.z & 0xffff0000), acc);
+    acc = fmaf(ahi.z, __int_as_float(w.w << 16), acc);
+    acc = fmaf(ahi.w, __int_as_float(w.w & 0xffff0000), acc);
+    return acc;
+}
+
+template <int PRO, int EPI, int R, bool ARGMAX>
+__global__ __launch_bounds__(512) void gemv_bf16_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = p.K, nch = K / 8;
+    const ActBF a = carve_bf(smem, K);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int T = blockDim.x;
+    // ---- prologue: x (+ norm weights) in one round trip, branch-free
+    constexpr int UM = 2;
+    float xv[UM][8], wv[UM][8];
+#pragma unroll
+    for (int u = 0; u < UM; u++) {
+        int unit = threadIdx.x + u * T;
+        unit = unit < nch ? unit : nch - 1;
+        const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
+        xv[u][0] = xa.x; xv[u][1] = xa.y; xv[u][2] = xa.z; xv[u][3] = xa.w;
+        xv[u][4] = xb.x; xv[u][5] = xb.y; xv[u][6] = xb.z; xv[u][7] = xb.w;
+        if (PRO == PROB_RMS_BF16 || PRO == PROB_RMS_F32) load8_norm(p.nw, unit * 8, wv[u]);
+    }
+    float fs = 1.0f;
+    if (PRO == PROB_RMS_BF16 || PRO == PROB_RMS_F32) {
+        double ss = 0.0;
+#pragma unroll
+        for (int u = 0; u < UM; u++)
+            if (threadIdx.x + u * T < nch)
+#pragma unroll
+                for (int i = 0; i < 8; i++) ss += (double)(xv[u][i] * xv[u][i]);
+        for (int unit = threadIdx.x + UM * T; unit < nch; unit += T) {
+            const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
+            ss += (double)(xa.x * xa.x); ss += (double)(xa.y * xa.y); ss += (double)(xa.z * xa.z); ss += (double)(xa.w * xa.w);
+            ss += (double)(xb.x * xb.x); ss += (double)(xb.y * xb.y); ss += (double)(xb.z * xb.z); ss += (double)(xb.w * xb.w);
+        }
+        ss = block_sum_d(ss, a.red);
+        ss /= (double)K;
+        ss += (double)p.eps;
+        ss = 1.0 / sqrt(ss);
+        fs = (float)ss;
+    }
+    auto finish_unit = [&](int unit, float (&y)[8]) {
+        if (PRO == PROB_RMS_BF16 || PRO == PROB_QUANT_BF16) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = bf16_to_f32(f32_to_bf16(y[i]));   // quantizeBF16: RNE, then widened again
+        }
+        a.lo[unit] = make_float4(y[0], y[1], y[2], y[3]);
+        a.hi[unit] = make_float4(y[4], y[5], y[6], y[7]);
+    };
+#pragma unroll
+    for (int u = 0; u < UM; u++) {
+        const int unit = threadIdx.x + u * T;
+        if (unit < nch) {
+            float y[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                y[i] = (PRO == PROB_RMS_BF16 || PRO == PROB_RMS_F32) ? wv[u][i] * (fs * xv[u][i]) : xv[u][i];
+            finish_unit(unit, y);
+        }
+    }
+    for (int unit = threadIdx.x + UM * T; unit < nch; unit += T) {
+        const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
+        float y[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        if (PRO == PROB_RMS_BF16 || PRO == PROB_RMS_F32) {
+            float w[8];
+            load8_norm(p.nw, unit * 8, w);
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = w[i] * (fs * y[i]);
+        }
+        finish_unit(unit, y);
+    }
+    lds_barrier();
+
+    const int total = (EPI == EPI_SILU_MUL) ? 2 * p.nrows : p.nrows;
+    const int ngroups = total / R;
+    float bestv = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int g = blockIdx.x * nwaves + wave; g < ngroups; g += gridDim.x * nwaves) {
+        const uint8_t* rowp[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (EPI == EPI_SILU_MUL) rowp[r] = (r < R / 2 ? p.w : p.w2) + (size_t)(g * (R / 2) + r % (R / 2)) * p.ldb;
+            else rowp[r] = p.w + (size_t)(g * R + r) * p.ldb;
+        }
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = 0.0f;
+#pragma unroll 4
+        for (int c = lane; c < nch; c += 64) {
+            const float4 alo = a.lo[c], ahi = a.hi[c];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const i32x4 wv4 = __builtin_nontemporal_load((const i32x4*)rowp[r] + c);
+                acc[r] = chunk_dot_bf16(wv4, alo, ahi, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            acc[r] = wave_sum(acc[r]);
+            if (ARGMAX && acc[r] > bestv) { bestv = acc[r]; besti = g * R + r; }
+        }
+        store_group<EPI, R>(p, g, lane, acc);
+    }
+    if (ARGMAX && p.amax_part) {
+        if (lane == 0) { a.bestv[wave] = bestv; a.besti[wave] = besti; }
+        lds_barrier();
+        if (threadIdx.x == 0) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int w = 0; w < nwaves; w++) {
+                const float v = a.bestv[w];
+                const int i = a.besti[w];
+                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+            }
+            p.amax_part[blockIdx.x] = bv;
+            p.amax_idx[blockIdx.x] = bi;
+        }
+    }
+}
 
 __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
     st->pos = pos; st->token = token; st->step = step;
@@ -747,19 +968,29 @@ struct AttnParams {
     const float* rope;     // [ctx*hs/2][2]
     float* kv_base;        // context page 0 of this layer page; page cp lives at kv_base + cp*page_elems,
     long long page_elems;  //   each page = [layersPerPage, 2, ctxPerPage, KV] F32 (KvBufferCache.java:99-112)
-    int rel_layer_in_page, ctx_per_page;
+    int rel_layer_in_page, ctx_per_page, cpp_shift;   // cpp_shift = log2(ctx_per_page) or -1
     int n_heads, n_kv_heads, head_size;
     const DecodeState* st;
     float scale;
-    float* part;           // [n_heads][max_splits][hs+2]
+    float* part_o;         // [n_heads][part_stride][hs]   slice outputs
+    float* part_ml;        // [n_heads][part_stride][2]    slice (max, sum)
     unsigned* counters;    // [n_kv_heads], zero between launches
-    int max_splits;
-    float* outf;           // [A] attention output ("after_attention" tap; the O projection quantizes it)
+    int max_splits;        // slices in "ticket" mode (long contexts)
+    int part_stride;       // >= max(max_splits, 4)
+    int direct_max;        // contexts up to this length use "direct" mode: <= 4 slices of direct_chunk rows, combined by
+    int direct_chunk;      //   the o-projection's prologue (PRO_ATTN_Q8); 0 disables
+    float* outf;           // [A] attention output, ticket mode only (the o-projection then quantizes it)
     float* tap_q;          // roped q [A] (tap), may be null
+    long long* dbg;        // optional phase timestamps (wall_clock64, 100 MHz) of workgroups with kvh == 0: [split][16]
 };
+#define JH_ATT_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && blockIdx.y == 0) p.dbg[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ const float* kv_row(const AttnParams& p, int which, int t, int kvlen) {
-    const int cp = t / p.ctx_per_page, rc = t - cp * p.ctx_per_page;
+    // page / row-in-page of position t.  ctx_per_page is a power of two for the usual geometries (32, 128): shift
+    // instead of a ~40-instruction integer division per row on the kernel's address-generation critical path.
+    int cp, rc;
+    if (p.cpp_shift >= 0) { cp = t >> p.cpp_shift; rc = t & (p.ctx_per_page - 1); }
+    else { cp = t / p.ctx_per_page; rc = t - cp * p.ctx_per_page; }
     return p.kv_base + (size_t)cp * p.page_elems + ((size_t)(p.rel_layer_in_page * 2 + which) * p.ctx_per_page + rc) * kvlen;
 }
 __device__ __forceinline__ void st_sc1(float* p, float v) {
@@ -769,26 +1000,35 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
     return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+constexpr int ATT_THREADS = 512;
+
 template <int HS, int GROUP>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = ATT_THREADS, NW = NT / 64;
     constexpr int LPR = HS / 4;          // lanes per K/V row (float4 each): 32 for HS=128, 16 for HS=64
-    constexpr int RPS = 256 / LPR;       // rows per workgroup step (scores and PV use the same row->thread map)
-    constexpr int PRE = 4;               // row steps prefetched into registers (covers chunk <= PRE*RPS)
+    constexpr int RPS = NT / LPR;        // rows per workgroup step (scores and PV use the same row->thread map)
+    constexpr int PRE = 8;               // row steps prefetched into registers: PRE*RPS = 128 (HS=128) / 256 rows
     constexpr int half = HS / 2;
-    constexpr int NQ = (GROUP * half + 255) / 256;   // q-rotation pairs per thread
-    constexpr int CS = 16;               // slices combined per batch of in-flight loads
+    constexpr int NQ = (GROUP * half + NT - 1) / NT;   // q-rotation pairs per thread
+    constexpr int CS = 16;               // slices combined per batch of in-flight loads (ticket mode)
+    JH_ATT_STAMP(0);
     const int pos = p.st->pos;
     const int kvh = blockIdx.y, split = blockIdx.x;
     const int n = pos + 1;
-    int S = (n + 31) / 32;
-    if (S > p.max_splits) S = p.max_splits;
+    const bool direct = n <= p.direct_max;
+    int S;
+    if (direct) S = (n + p.direct_chunk - 1) / p.direct_chunk;
+    else {
+        S = (n + 31) / 32;
+        if (S > p.max_splits) S = p.max_splits;
+    }
     if (split >= S) return;
-    const int chunk = (n + S - 1) / S;
+    const int chunk = direct ? p.direct_chunk : (n + S - 1) / S;
     const int t0 = split * chunk;
     int t1 = t0 + chunk;
     if (t1 > n) t1 = n;
-    const int cnt = t1 - t0;  // may be <= 0 for a trailing slice when chunk rounding overshoots
+    const int cnt = t1 - t0;
     const int KV = p.n_kv_heads * HS, A = p.n_heads * HS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rsub = tid / LPR, c4 = tid % LPR;   // thread -> (row within step, float4 column)
@@ -796,10 +1036,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
     float* qs = (float*)smem;                // GROUP*HS roped q, later the slice output
     float* knew = qs + GROUP * HS;           // HS
     float* vnew = knew + HS;                 // HS
-    float* red = vnew + HS;                  // RPS*GROUP*HS = 1024*GROUP floats
+    float* red = vnew + HS;                  // RPS*GROUP*HS floats
     float* ml = red + RPS * GROUP * HS;      // 2*GROUP (m, l)
     int* flag = (int*)(ml + 2 * GROUP);      // 4 ints
-    float* sc = (float*)(flag + 4);          // GROUP*max(chunk_cap, 2*max_splits): scores / weights; combine scratch
+    float* sc = (float*)(flag + 4);          // GROUP*sc_cap: scores / weights; combine scratch
 
     // ---- ONE round trip: every global load of the main phase is issued here, branch-free (clamped addresses), in
     // the order the results are consumed (vmcnt retires oldest-first): q + rope, new k/v, then K rows, then V rows.
@@ -807,7 +1047,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
     float q0[NQ], q1[NQ], qc[NQ], qsn[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; u++) {
-        int i = tid + u * 256;
+        int i = tid + u * NT;
         i = i < GROUP * half ? i : GROUP * half - 1;
         const int gi = i / half, d = i - gi * half;
         const float* qh = p.qkv + (size_t)(kvh * GROUP + gi) * HS;
@@ -832,10 +1072,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
         vreg[k] = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
     }
 
+    JH_ATT_STAMP(1);   // all loads issued
     // ---- RoPE (q for the group's heads, k for this kv head) ------------------------------------------------
 #pragma unroll
     for (int u = 0; u < NQ; u++) {
-        const int i = tid + u * 256;
+        const int i = tid + u * NT;
         if (i < GROUP * half) {
             const int gi = i / half, d = i - gi * half;
             const float r0 = q0[u] * qc[u] - q1[u] * qsn[u];   // contraction is off: mul, mul, sub as in Java
@@ -863,12 +1104,37 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
         }
     }
     lds_barrier();
+    JH_ATT_STAMP(2);   // q/rope arrived, rope done
 
     // ---- scores: LPR lanes x float4 cover one K row ---------------------------------------------------------
     float4 qv[GROUP];
 #pragma unroll
     for (int gi = 0; gi < GROUP; gi++) qv[gi] = ((const float4*)(qs + gi * HS))[c4];
-    auto score_row = [&](int tt, const float4& kv4) {
+    const float4 knew4 = ((const float4*)knew)[c4];   // read once: keeps the LDS address space (no flat loads)
+#pragma unroll
+    for (int k = 0; k < PRE; k++) {
+        const int tt = rsub + k * RPS;
+        if (tt < cnt) {
+            const bool isnew = (t0 + tt == pos);
+            float4 kv4;
+            kv4.x = isnew ? knew4.x : kreg[k].x; kv4.y = isnew ? knew4.y : kreg[k].y;
+            kv4.z = isnew ? knew4.z : kreg[k].z; kv4.w = isnew ? knew4.w : kreg[k].w;
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++) {
+                float s = qv[gi].x * kv4.x;
+                s = fmaf(qv[gi].y, kv4.y, s);
+                s = fmaf(qv[gi].z, kv4.z, s);
+                s = fmaf(qv[gi].w, kv4.w, s);
+#pragma unroll
+                for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                if (c4 == 0) sc[gi * chunk + tt] = s * p.scale;   // ops.scale after the dot (:332): separate rounding
+            }
+        }
+    }
+    for (int k = PRE; rsub + k * RPS < cnt; k++) {   // slices longer than PRE*RPS rows (ticket mode, long contexts)
+        const int tt = rsub + k * RPS, t = t0 + tt;
+        float4 kv4 = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4];
+        if (t == pos) kv4 = knew4;
 #pragma unroll
         for (int gi = 0; gi < GROUP; gi++) {
             float s = qv[gi].x * kv4.x;
@@ -877,23 +1143,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
             s = fmaf(qv[gi].w, kv4.w, s);
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (c4 == 0) sc[gi * chunk + tt] = s * p.scale;   // ops.scale after the dot (:332): separate rounding
+            if (c4 == 0) sc[gi * chunk + tt] = s * p.scale;
         }
-    };
-#pragma unroll
-    for (int k = 0; k < PRE; k++) {
-        const int tt = rsub + k * RPS;
-        if (tt < cnt) score_row(tt, (t0 + tt == pos) ? ((const float4*)knew)[c4] : kreg[k]);
-    }
-    for (int k = PRE; rsub + k * RPS < cnt; k++) {
-        const int tt = rsub + k * RPS, t = t0 + tt;
-        score_row(tt, (t == pos) ? ((const float4*)knew)[c4]
-                                 : ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4]);
     }
     lds_barrier();
+    JH_ATT_STAMP(3);   // K arrived, scores done
 
     // ---- local softmax per head (one wave per head, round-robin) ------------------------------------------
-    for (int gi = wave; gi < GROUP; gi += 4) {
+    for (int gi = wave; gi < GROUP; gi += NW) {
         float m = -INFINITY;
         for (int tt = lane; tt < cnt; tt += 64) m = fmaxf(m, sc[gi * chunk + tt]);
         m = wave_max(m);
@@ -908,13 +1165,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
         if (lane == 0) { ml[2 * gi] = m; ml[2 * gi + 1] = l; }
     }
     lds_barrier();
+    JH_ATT_STAMP(4);   // softmax done
 
     // ---- o = sum_t w[t] * V[t]: thread = (row-in-step, float4 column); fma chain per element ----------------
     {
         float4 acc[GROUP];
 #pragma unroll
         for (int gi = 0; gi < GROUP; gi++) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto pv_row = [&](int tt, const float4& v4) {
+        const float4 vnew4 = ((const float4*)vnew)[c4];
+#pragma unroll
+        for (int k = 0; k < PRE; k++) {
+            const int tt = rsub + k * RPS;
+            if (tt < cnt) {
+                const bool isnew = (t0 + tt == pos);
+                float4 v4;
+                v4.x = isnew ? vnew4.x : vreg[k].x; v4.y = isnew ? vnew4.y : vreg[k].y;
+                v4.z = isnew ? vnew4.z : vreg[k].z; v4.w = isnew ? vnew4.w : vreg[k].w;
+#pragma unroll
+                for (int gi = 0; gi < GROUP; gi++) {
+                    const float w = sc[gi * chunk + tt];
+                    acc[gi].x = fmaf(v4.x, w, acc[gi].x);
+                    acc[gi].y = fmaf(v4.y, w, acc[gi].y);
+                    acc[gi].z = fmaf(v4.z, w, acc[gi].z);
+                    acc[gi].w = fmaf(v4.w, w, acc[gi].w);
+                }
+            }
+        }
+        for (int k = PRE; rsub + k * RPS < cnt; k++) {
+            const int tt = rsub + k * RPS, t = t0 + tt;
+            float4 v4 = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
+            if (t == pos) v4 = vnew4;
 #pragma unroll
             for (int gi = 0; gi < GROUP; gi++) {
                 const float w = sc[gi * chunk + tt];
@@ -923,43 +1203,51 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
                 acc[gi].z = fmaf(v4.z, w, acc[gi].z);
                 acc[gi].w = fmaf(v4.w, w, acc[gi].w);
             }
-        };
-#pragma unroll
-        for (int k = 0; k < PRE; k++) {
-            const int tt = rsub + k * RPS;
-            if (tt < cnt) pv_row(tt, (t0 + tt == pos) ? ((const float4*)vnew)[c4] : vreg[k]);
-        }
-        for (int k = PRE; rsub + k * RPS < cnt; k++) {
-            const int tt = rsub + k * RPS, t = t0 + tt;
-            pv_row(tt, (t == pos) ? ((const float4*)vnew)[c4]
-                                  : ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4]);
         }
 #pragma unroll
         for (int gi = 0; gi < GROUP; gi++) ((float4*)(red + ((size_t)rsub * GROUP + gi) * HS))[c4] = acc[gi];
     }
     lds_barrier();
+    JH_ATT_STAMP(5);   // PV done
     float* oloc = qs;  // reuse q storage for the slice's output [GROUP][HS]
-    for (int i = tid; i < GROUP * HS; i += blockDim.x) {
+    for (int i = tid; i < GROUP * HS; i += NT) {
         float s = 0.0f;
 #pragma unroll
         for (int rg = 0; rg < RPS; rg++) s += red[(size_t)rg * GROUP * HS + i];
         oloc[i] = s;
     }
     lds_barrier();
+    JH_ATT_STAMP(6);   // slice reduced
 
-    if (S > 1) {
-        // publish this slice's (o, m, l) write-through; the last arriver of the kv head combines
-        for (int i = tid; i < GROUP * HS; i += blockDim.x) {
+    float* my_o = p.part_o + ((size_t)(kvh * GROUP) * p.part_stride + split) * HS;   // + gi*part_stride*HS + d
+    if (direct) {
+        // direct mode: publish the slice and finish; the o-projection's prologue combines (kernel boundary = visibility)
+        for (int i = tid; i < GROUP * HS; i += NT) {
             const int gi = i / HS, d = i - gi * HS;
-            st_sc1(p.part + ((size_t)(kvh * GROUP + gi) * p.max_splits + split) * (HS + 2) + d, oloc[i]);
+            my_o[(size_t)gi * p.part_stride * HS + d] = oloc[i];
         }
         if (tid < GROUP) {
-            float* pr = p.part + ((size_t)(kvh * GROUP + tid) * p.max_splits + split) * (HS + 2) + HS;
+            float* pr = p.part_ml + ((size_t)(kvh * GROUP + tid) * p.part_stride + split) * 2;
+            pr[0] = ml[2 * tid];
+            pr[1] = ml[2 * tid + 1];
+        }
+        JH_ATT_STAMP(7);
+        return;
+    }
+    if (S > 1) {
+        // ticket mode: publish this slice's (o, m, l) write-through; the last arriver of the kv head combines
+        for (int i = tid; i < GROUP * HS; i += NT) {
+            const int gi = i / HS, d = i - gi * HS;
+            st_sc1(my_o + (size_t)gi * p.part_stride * HS + d, oloc[i]);
+        }
+        if (tid < GROUP) {
+            float* pr = p.part_ml + ((size_t)(kvh * GROUP + tid) * p.part_stride + split) * 2;
             st_sc1(pr, ml[2 * tid]);
             st_sc1(pr + 1, ml[2 * tid + 1]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
         __syncthreads();
+        JH_ATT_STAMP(7);   // published + drained
         if (tid == 0) {
             const unsigned tk = __hip_atomic_fetch_add(&p.counters[kvh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (tk == (unsigned)(S - 1));
@@ -967,39 +1255,30 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
             flag[0] = last;
         }
         __syncthreads();
+        JH_ATT_STAMP(8);   // ticket drawn
         if (!flag[0]) return;
         // combine: w_s = l_s * exp(m_s - M) / sum_s(l_s * exp(m_s - M)); o = sum_s w_s * o_s.
-        // (m, l) of every slice and the first CS partial outputs of this thread's elements are requested together.
         float* cm = sc;               // [GROUP][S] m_s, then w_s
         float* cl = sc + GROUP * S;   // [GROUP][S] l_s
-        constexpr int EPT = (GROUP * HS + 255) / 256;   // output elements per thread
-        float mreg = 0.f, lreg = 0.f;
-        {
-            int i = tid < GROUP * S ? tid : GROUP * S - 1;
+        constexpr int EPT = (GROUP * HS + NT - 1) / NT;   // output elements per thread
+        for (int i = tid; i < GROUP * S; i += NT) {
             const int gi = i / S, s = i - gi * S;
-            const float* pr = p.part + ((size_t)(kvh * GROUP + gi) * p.max_splits + s) * (HS + 2) + HS;
-            mreg = ld_sc1(pr);
-            lreg = ld_sc1(pr + 1);
+            const float* pr = p.part_ml + ((size_t)(kvh * GROUP + gi) * p.part_stride + s) * 2;
+            cm[i] = ld_sc1(pr);
+            cl[i] = ld_sc1(pr + 1);
         }
         float pv[EPT][CS];
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
-            int i = tid + e * 256;
+            int i = tid + e * NT;
             i = i < GROUP * HS ? i : GROUP * HS - 1;
             const int gi = i / HS, d = i - gi * HS;
-            const float* pb = p.part + (size_t)(kvh * GROUP + gi) * p.max_splits * (HS + 2) + d;
+            const float* pb = p.part_o + (size_t)(kvh * GROUP + gi) * p.part_stride * HS + d;
 #pragma unroll
-            for (int s = 0; s < CS; s++) pv[e][s] = ld_sc1(pb + (size_t)(s < S ? s : S - 1) * (HS + 2));
-        }
-        if (tid < GROUP * S) { cm[tid] = mreg; cl[tid] = lreg; }
-        for (int i = tid + 256; i < GROUP * S; i += 256) {   // GROUP*S > 256 only for GROUP=8 with > 32 slices
-            const int gi = i / S, s = i - gi * S;
-            const float* pr = p.part + ((size_t)(kvh * GROUP + gi) * p.max_splits + s) * (HS + 2) + HS;
-            cm[i] = ld_sc1(pr);
-            cl[i] = ld_sc1(pr + 1);
+            for (int s = 0; s < CS; s++) pv[e][s] = ld_sc1(pb + (size_t)(s < S ? s : S - 1) * HS);
         }
         __syncthreads();
-        for (int gi = wave; gi < GROUP; gi += 4) {
+        for (int gi = wave; gi < GROUP; gi += NW) {
             float m = -INFINITY;
             for (int s = lane; s < S; s += 64) m = fmaxf(m, cm[gi * S + s]);
             m = wave_max(m);
@@ -1015,20 +1294,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
-            const int i = tid + e * 256;
+            const int i = tid + e * NT;
             if (i >= GROUP * HS) break;
             const int gi = i / HS, d = i - gi * HS;
-            const float* pb = p.part + (size_t)(kvh * GROUP + gi) * p.max_splits * (HS + 2) + d;
+            const float* pb = p.part_o + (size_t)(kvh * GROUP + gi) * p.part_stride * HS + d;
             float o = 0.0f;
 #pragma unroll
             for (int s = 0; s < CS; s++)
                 if (s < S) o = fmaf(pv[e][s], cm[gi * S + s], o);
-            for (int s = CS; s < S; s++) o = fmaf(ld_sc1(pb + (size_t)s * (HS + 2)), cm[gi * S + s], o);
+            for (int s = CS; s < S; s++) o = fmaf(ld_sc1(pb + (size_t)s * HS), cm[gi * S + s], o);
             oloc[i] = o;
         }
         __syncthreads();
     }
-    for (int i = tid; i < GROUP * HS; i += blockDim.x) p.outf[(size_t)kvh * GROUP * HS + i] = oloc[i];
+    JH_ATT_STAMP(9);   // combined
+    for (int i = tid; i < GROUP * HS; i += NT) p.outf[(size_t)kvh * GROUP * HS + i] = oloc[i];
 }
 
 // ------------------------------------------------------------------------------------------------ Tier-1 generic kernels

@@ -201,7 +201,7 @@ int launch_gemv_i8q4(const GemvParams& p, LaunchCfg cfg, hipStream_t st) {
     int grid, threads;
     if (pipe == 0) {
         // VGPR budget: 1024-thread blocks are capped at 128 registers
-        int wmax = (R * nb <= 8) ? 16 : 8;   // must match gemv_i8q4_kernel's __launch_bounds__
+        int wmax = (R * nb <= 4) ? 16 : 8;   // must match gemv_i8q4_kernel __launch_bounds__
         if (waves <= 0) {
             waves = (ngroups + cu - 1) / cu;
             if (waves < 4) waves = 4;
@@ -218,6 +218,22 @@ int launch_gemv_i8q4(const GemvParams& p, LaunchCfg cfg, hipStream_t st) {
     if (grid < 1) grid = 1;
     threads = waves * 64;
     return launch_gemv_i8q4_combo<PRO, EPI>(p, R, nb, pipe, grid, threads, st);
+}
+
+template <int PRO, int EPI, bool ARGMAX>
+int launch_gemv_bf16(const GemvParams& p, int grid_cap, int* grid_out, hipStream_t st) {
+    const size_t lds = lds_bytes_bf(p.K);
+    const int total = (EPI == EPI_SILU_MUL) ? 2 * p.nrows : p.nrows;
+    constexpr int R = (EPI == EPI_SILU_MUL) ? 2 : 1;   // 8 x 16-byte loads per row already keep a wave's queue full
+    const int ngroups = total / R, waves = 8;
+    int grid = (ngroups + waves - 1) / waves;
+    if (grid > grid_cap) grid = grid_cap;
+    if (grid < 1) grid = 1;
+    if (grid_out) *grid_out = grid;
+    JHCHK(allow_lds(gemv_bf16_kernel<PRO, EPI, R, ARGMAX>, lds));
+    hipLaunchKernelGGL((gemv_bf16_kernel<PRO, EPI, R, ARGMAX>), dim3(grid), dim3(waves * 64), lds, st, p);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
 }
 
 template <int PRO, int R>
@@ -727,7 +743,8 @@ struct jh_session {
     int max_ctx = 0, max_splits = 32, chunk_cap = 32;
     // activations
     float *x = nullptr, *x1 = nullptr, *qkv = nullptr, *attf = nullptr, *hf = nullptr;
-    float *logits = nullptr, *amax_v = nullptr, *part = nullptr, *tapq = nullptr;
+    float *logits = nullptr, *amax_v = nullptr, *part_o = nullptr, *part_ml = nullptr, *tapq = nullptr;
+    int part_stride = 16, direct_max = 512, direct_chunk = 128;
     int* amax_i = nullptr;
     unsigned* counters = nullptr;
     DecodeState* st = nullptr;
@@ -750,7 +767,7 @@ namespace {
 
 bool is_global_slot(int which) { return which == JH_W_EMBED || which == JH_W_LMHEAD || which == JH_W_FINALNORM; }
 
-int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap) {
+int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg = nullptr) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
     AttnParams p;
@@ -762,20 +779,29 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap) {
     p.page_elems = (long long)s->page_elems;
     p.rel_layer_in_page = rel % s->layers_per_page;
     p.ctx_per_page = s->ctx_per_page;
+    p.cpp_shift = -1;
+    for (int sh = 0; sh < 30; sh++)
+        if ((1 << sh) == s->ctx_per_page) p.cpp_shift = sh;
     p.n_heads = c.n_heads;
     p.n_kv_heads = c.n_kv_heads;
     p.head_size = c.head_size;
     p.st = s->st;
     p.scale = m->attention_scale;
-    p.part = s->part;
+    p.part_o = s->part_o;
+    p.part_ml = s->part_ml;
+    p.part_stride = s->part_stride;
+    p.direct_max = s->direct_max;
+    p.direct_chunk = s->direct_chunk;
     p.counters = s->counters;
     p.max_splits = s->max_splits;
     p.outf = s->attf;
     p.tap_q = tap ? s->tapq : nullptr;
+    p.dbg = dbg;
     const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
     const int sc_cap = s->chunk_cap > 2 * s->max_splits ? s->chunk_cap : 2 * s->max_splits;
-    const size_t lds = ((size_t)group * hs + 2 * hs + 1024 * (size_t)group + 2 * group + 4 + (size_t)group * sc_cap) * 4;
-    dim3 grid(s->max_splits, c.n_kv_heads), block(256);
+    const size_t lds = ((size_t)group * hs + 2 * hs + (size_t)(ATT_THREADS * 4) * group + 2 * group + 4 + (size_t)group * sc_cap) * 4;
+    const int gx = s->max_splits > 4 ? s->max_splits : 4;
+    dim3 grid(gx, c.n_kv_heads), block(ATT_THREADS);
 #define JH_ATTN(HSV, GV)                                                                   \
     if (hs == HSV && group == GV) {                                                        \
         JHCHK(allow_lds(attn_decode_kernel<HSV, GV>, lds));                                \
@@ -816,7 +842,8 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
         p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
-        JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
+        if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st))); }
+        else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
         JHCHK(trace_sync("qkv", st));
     }
     if (tap) {
@@ -832,7 +859,6 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         const float* krow = s->pages_host[(size_t)lp * s->n_ctx_pages + cp] +
                             ((size_t)((rel % s->layers_per_page) * 2 + 0) * s->ctx_per_page + rc) * KV;
         JHCHK(tap_copy(s, JH_TAP_KEY_ROPE, krow, KV, st));
-        JHCHK(tap_copy(s, JH_TAP_AFTER_ATTENTION, s->attf, A, st));
     }
     {   // output projection (:365-376) + residual (TransformerBlock.java:185)
         GemvParams p;
@@ -840,10 +866,24 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = s->x1;
         p.K = A; p.ldb = A / 2; p.ldbf = A / QB;
         p.x = s->attf; p.resid = s->x;   // maybeQuantize(valueBatch) (:364) happens in the prologue
-        JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_o, st)));
+        if (c.weight_dtype == JH_DT_BF16) {
+            p.ldb = A * 2;
+            JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
+        } else if (s->direct_max > 0) {
+            // short contexts: the attention slices are combined here, under the weight prefetch
+            p.part_o = s->part_o; p.part_ml = s->part_ml; p.st = s->st; p.direct_max = s->direct_max;
+            p.direct_chunk = s->direct_chunk; p.part_stride = s->part_stride; p.head_size = hs; p.n_heads = c.n_heads;
+            p.tap_att = tap ? s->attf : nullptr;
+            JHCHK((launch_gemv_i8q4<PRO_ATTN_Q8, EPI_RESID>(p, s->cfg_o, st)));
+        } else {
+            JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_o, st)));
+        }
         JHCHK(trace_sync("oproj", st));
     }
-    if (tap) JHCHK(tap_copy(s, 8, s->x1, E, st));
+    if (tap) {
+        JHCHK(tap_copy(s, JH_TAP_AFTER_ATTENTION, s->attf, A, st));   // written by attention (ticket mode) or by the o-proj prologue
+        JHCHK(tap_copy(s, 8, s->x1, E, st));
+    }
     {   // gate/up (MLPBlock.java:117-142) with fused preFFNorm + maybeQuantize, SiLU*up + maybeQuantize
         GemvParams p;
         memset(&p, 0, sizeof(p));
@@ -852,7 +892,8 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
         p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
         p.out = s->hf;   // silu(gate)*up, F32; the down projection's prologue quantizes it (MLPBlock.java:144)
-        JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
+        if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, g_cu_count * 4, nullptr, st))); }
+        else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
         JHCHK(trace_sync("gateup", st));
     }
     if (tap) JHCHK(tap_copy(s, 10, s->hf, H, st));
@@ -862,6 +903,8 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
         p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x;
         p.K = H; p.ldb = H / 2; p.ldbf = H / QB;
         p.x = s->hf; p.resid = s->x1;
+        if (c.weight_dtype == JH_DT_BF16) { p.ldb = H * 2; JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st))); }
+        else
         JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
         JHCHK(trace_sync("down", st));
     }
@@ -894,6 +937,10 @@ int lmhead_launch(jh_session* s, hipStream_t st) {
     p.eps = c.rms_eps;
     p.amax_part = s->amax_v; p.amax_idx = s->amax_i;
     int grid = 0;
+    if (w->dtype == JH_DT_BF16) {
+        p.ldb = p.K * 2;
+        JHCHK((launch_gemv_bf16<PROB_RMS_F32, EPI_STORE, true>(p, 4096, &grid, st)));   // F32 x BF16 (GemmerF32BF16)
+    } else
     JHCHK((launch_gemv_f32q4<PRO_RMS_F32>(p, s->cfg_lm, &grid, st)));
     s->lm_grid = grid;
     return JH_OK;
@@ -927,8 +974,8 @@ extern "C" {
 
 int jh_model_create(const jh_config* cfg, jh_model** out) {
     if (!cfg || !out) return set_err(JH_ERR_INVALID, "model_create: null");
-    if (cfg->weight_dtype != JH_DT_Q4)
-        return set_err(JH_ERR_UNSUPPORTED, "model_create: only JQ4 (Q4 weights, I8 activations) resident models are built so far");
+    if (cfg->weight_dtype != JH_DT_Q4 && cfg->weight_dtype != JH_DT_BF16)
+        return set_err(JH_ERR_UNSUPPORTED, "model_create: resident models are JQ4 (Q4 weights, I8 activations) or BF16 (BF16 weights and activations)");
     if (cfg->embedding_length % 256 || cfg->hidden_length % 32 || cfg->n_heads % cfg->n_kv_heads ||
         (cfg->head_size != 64 && cfg->head_size != 128) || cfg->layer_start < 0 || cfg->layer_end > cfg->n_layers ||
         cfg->layer_start >= cfg->layer_end)
@@ -987,7 +1034,8 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     else if (dtype == JH_DT_F32) bytes = (size_t)rows * cols * 4;
     else return set_err(JH_ERR_UNSUPPORTED, "set_weight: dtype");
     const bool is_norm = (which == JH_W_NORM1 || which == JH_W_NORM2 || which == JH_W_FINALNORM);
-    if (!is_norm && dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "set_weight: matmul weights must be Q4 in this build");
+    if (!is_norm && dtype != m->c.weight_dtype)
+        return set_err(JH_ERR_UNSUPPORTED, "set_weight: matmul weights must have the model's weight_dtype (Q4 or BF16)");
     std::vector<float> widened;
     void* widened_dev = nullptr;
     if (is_norm && dtype == JH_DT_BF16) {
@@ -1018,21 +1066,24 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
         // same activation; here they become one)
         const int A = m->c.n_heads * m->c.head_size, KV = m->c.n_kv_heads * m->c.head_size, E = m->c.embedding_length;
         const int want_rows = which == JH_W_Q ? A : KV;
-        if (rows != want_rows || cols != E || dtype != JH_DT_Q4) return set_err(JH_ERR_INVALID, "set_weight: q/k/v shape");
+        if (rows != want_rows || cols != E) return set_err(JH_ERR_INVALID, "set_weight: q/k/v shape");
         JWeight& f = m->qkv[(size_t)layer];
+        const size_t row_bytes = dtype == JH_DT_Q4 ? (size_t)E / 2 : (size_t)E * 2;
         if (!f.data) {
             const size_t tot = (size_t)(A + 2 * KV);
-            hipError_t e2 = hipMalloc(&f.data, tot * E / 2 + 64);
+            hipError_t e2 = hipMalloc(&f.data, tot * row_bytes + 64);
             if (e2 != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc qkv: ") + hipGetErrorString(e2));
-            e2 = hipMalloc((void**)&f.scales, tot * (E / QB) * 4 + 64);
-            if (e2 != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc qkv scales: ") + hipGetErrorString(e2));
-            f.dtype = JH_DT_Q4; f.rows = (int)tot; f.cols = E;
+            if (dtype == JH_DT_Q4) {
+                e2 = hipMalloc((void**)&f.scales, tot * (E / QB) * 4 + 64);
+                if (e2 != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc qkv scales: ") + hipGetErrorString(e2));
+            }
+            f.dtype = dtype; f.rows = (int)tot; f.cols = E;
         }
         const size_t row0 = which == JH_W_Q ? 0 : (which == JH_W_K ? (size_t)A : (size_t)(A + KV));
-        uint8_t* dd = (uint8_t*)f.data + row0 * (E / 2);
-        float* ds = f.scales + row0 * (E / QB);
+        uint8_t* dd = (uint8_t*)f.data + row0 * row_bytes;
+        float* ds = f.scales ? f.scales + row0 * (E / QB) : nullptr;
         HIPCHK(hipMemcpy(dd, data, bytes, kind));
-        HIPCHK(hipMemcpy(ds, scales, sbytes, kind));
+        if (sbytes) HIPCHK(hipMemcpy(ds, scales, sbytes, kind));
         if (!w->data) m->weight_bytes += (int64_t)(bytes + sbytes);
         w->data = dd; w->scales = ds; w->dtype = dtype; w->rows = rows; w->cols = cols;
         return JH_OK;
@@ -1095,6 +1146,7 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     if (s->max_splits < 1) s->max_splits = 1;
     s->chunk_cap = (max_ctx + s->max_splits - 1) / s->max_splits;
     if (s->chunk_cap < 32) s->chunk_cap = 32;
+    { const int dc = env_int("JH_ATTN_DIRECT_CHUNK", 128); if (s->chunk_cap < dc) s->chunk_cap = dc; }
     HIPCHK(hipMalloc(&s->x, (size_t)E * 4));
     HIPCHK(hipMalloc(&s->x1, (size_t)E * 4));
     HIPCHK(hipMalloc(&s->qkv, (size_t)(A + 2 * KV) * 4));
@@ -1104,7 +1156,15 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     HIPCHK(hipMalloc(&s->logits, (size_t)c.vocab_size * 4));
     HIPCHK(hipMalloc(&s->amax_v, 4096 * 4));
     HIPCHK(hipMalloc(&s->amax_i, 4096 * 4));
-    HIPCHK(hipMalloc(&s->part, (size_t)c.n_heads * s->max_splits * (c.head_size + 2) * 4));
+    s->part_stride = s->max_splits > 4 ? s->max_splits : 4;
+    // "direct" attention: contexts of up to 4 slices x 128 rows are combined by the o-projection's prologue
+    s->direct_chunk = env_int("JH_ATTN_DIRECT_CHUNK", 128);
+    s->direct_max = env_int("JH_ATTN_DIRECT", 0) ? 4 * s->direct_chunk : 0;   // measured slower on MI355X: off by default
+    if (c.n_heads * 4 > 512 || (A / 8) > 2 * 512) s->direct_max = 0;   // prologue limits (PRO_ATTN_Q8)
+    HIPCHK(hipMalloc(&s->part_o, (size_t)c.n_heads * s->part_stride * c.head_size * 4));
+    HIPCHK(hipMalloc(&s->part_ml, (size_t)c.n_heads * s->part_stride * 2 * 4));
+    HIPCHK(hipMemset(s->part_o, 0, (size_t)c.n_heads * s->part_stride * c.head_size * 4));
+    HIPCHK(hipMemset(s->part_ml, 0, (size_t)c.n_heads * s->part_stride * 2 * 4));
     HIPCHK(hipMalloc(&s->counters, (size_t)c.n_kv_heads * 4));
     HIPCHK(hipMemset(s->counters, 0, (size_t)c.n_kv_heads * 4));
     HIPCHK(hipMalloc(&s->st, sizeof(DecodeState)));
@@ -1118,7 +1178,7 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     s->cfg_o = LaunchCfg{env_int("JH_O_R", 0), env_int("JH_O_WAVES", 0), cu * env_int("JH_O_GRIDX", 1), env_int("JH_O_PIPE", -1)};
     s->cfg_gateup = LaunchCfg{env_int("JH_GATEUP_R", 0), env_int("JH_GATEUP_WAVES", 0), cu * env_int("JH_GATEUP_GRIDX", 1), env_int("JH_GATEUP_PIPE", -1)};
     s->cfg_down = LaunchCfg{env_int("JH_DOWN_R", 0), env_int("JH_DOWN_WAVES", 0), cu * env_int("JH_DOWN_GRIDX", 1), env_int("JH_DOWN_PIPE", -1)};
-    s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 0), env_int("JH_LM_WAVES", 8), cu * env_int("JH_LM_GRIDX", 2), 1};
+    s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 2), env_int("JH_LM_WAVES", 8), cu * env_int("JH_LM_GRIDX", 2), 1};   // tools/sweep_lm.py
     if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
     *out = s;
     return JH_OK;
@@ -1131,7 +1191,7 @@ int jh_session_destroy(jh_session* s) {
     if (s->graph) hipGraphDestroy(s->graph);
     if (s->kv_slab) hipFree(s->kv_slab);
     void* bufs[] = {s->pages_dev, s->x, s->x1, s->qkv, s->attf, s->tapq, s->hf, s->logits,
-                    s->amax_v, s->amax_i, s->part, s->counters, s->st, s->out_tokens};
+                    s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -1146,6 +1206,24 @@ int jh_session_page_info(jh_session* s, int32_t* out4) {
     return JH_OK;
 }
 void* jh_session_stream(jh_session* s) { return s ? (void*)s->stream : nullptr; }
+// Debug: phase timeline of ONE attention launch at position `pos` (layer 0 of the shard): out[split*16 + k] =
+// wall_clock64 ticks (100 MHz) at phase k, -1 where not reached.  See JH_ATT_STAMP in jh_kernels.h.
+int jh_debug_attn_timeline(jh_session* s, int pos, long long* out, int n) {
+    if (!s || !out || n < 16 * 16) return set_err(JH_ERR_INVALID, "attn_timeline: need 256 slots");
+    HIPCHK(hipSetDevice(s->m->device));
+    long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, 256 * 8));
+    HIPCHK(hipMemset(d, 0xff, 256 * 8));
+    hipStream_t st = s->stream;
+    for (int it = 0; it < 3; it++) {   // warm: the last launch's stamps are the ones reported
+        hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, pos, 0, 0);
+        JHCHK(attn_launch(s, 0, st, false, d));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpy(out, d, 256 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d));
+    return JH_OK;
+}
 int jh_session_synchronize(jh_session* s) {
     if (!s) return set_err(JH_ERR_INVALID, "session_synchronize: null");
     HIPCHK(hipSetDevice(s->m->device));
@@ -1158,6 +1236,7 @@ int jh_session_synchronize(jh_session* s) {
 // session's stream.  out_ms = average duration of one launch.
 int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t* out_bytes_per_launch) {
     if (!s || !out_ms || iters <= 0) return set_err(JH_ERR_INVALID, "kernel_bench: bad argument");
+    if (s->m->c.weight_dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "kernel_bench: JQ4 models only");
     jh_model* m = s->m;
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = s->stream;
@@ -1184,7 +1263,13 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
             } else if (which == 2) {
                 p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = s->x1;
                 p.K = A; p.ldb = A / 2; p.ldbf = A / QB; p.x = s->attf; p.resid = s->x;
-                JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_o, st)));
+                if (s->direct_max > 0) {
+                    p.part_o = s->part_o; p.part_ml = s->part_ml; p.st = s->st; p.direct_max = s->direct_max;
+                    p.direct_chunk = s->direct_chunk; p.part_stride = s->part_stride; p.head_size = hs; p.n_heads = c.n_heads;
+                    JHCHK((launch_gemv_i8q4<PRO_ATTN_Q8, EPI_RESID>(p, s->cfg_o, st)));
+                } else {
+                    JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_o, st)));
+                }
             } else if (which == 3) {
                 p.w = (const uint8_t*)W[JH_W_GATE].data; p.ws = W[JH_W_GATE].scales; p.nrows = H;
                 p.w2 = (const uint8_t*)W[JH_W_UP].data; p.ws2 = W[JH_W_UP].scales;

@@ -22,6 +22,9 @@ LLAMA32_1B = dict(embedding_length=2048, hidden_length=8192, n_heads=32, n_kv_he
 LLAMA3_70B = dict(embedding_length=8192, hidden_length=28672, n_heads=64, n_kv_heads=8, head_size=128, n_layers=80,
                   vocab_size=128256, context_length=8192, weight_dtype=DT_Q4, rms_eps=1e-5, rope_theta=500000.0,
                   rope_scaling=1.0, bos_token=128000)
+MISTRAL_7B = dict(embedding_length=4096, hidden_length=14336, n_heads=32, n_kv_heads=8, head_size=128, n_layers=32,
+                  vocab_size=32768, context_length=32768, weight_dtype=DT_BF16, rms_eps=1e-5, rope_theta=1000000.0,
+                  rope_scaling=1.0, bos_token=1)
 TINY = dict(embedding_length=256, hidden_length=512, n_heads=4, n_kv_heads=2, head_size=64, n_layers=2,
             vocab_size=512, context_length=256, weight_dtype=DT_Q4, rms_eps=1e-5, rope_theta=10000.0,
             rope_scaling=1.0, bos_token=1)
@@ -42,6 +45,11 @@ def _q4(rng, rows, cols, sigma):
     return {"dtype": DT_Q4, "data": nib, "scales": sc, "shape": (rows, cols)}
 
 
+def _bf16(rng, rows, cols, sigma):
+    x = rng.standard_normal((rows, cols), dtype=np.float32) * np.float32(sigma)
+    return {"dtype": DT_BF16, "data": jq4.f32_to_bf16(x), "scales": None, "shape": (rows, cols)}
+
+
 def _norm(rng, E):
     w = (1.0 + rng.standard_normal(E, dtype=np.float32) * np.float32(0.01)).astype(np.float32)
     return {"dtype": DT_BF16, "data": jq4.f32_to_bf16(w).reshape(1, E), "scales": None, "shape": (1, E)}
@@ -56,6 +64,8 @@ def make_weights(cfg, seed=0, layers=None):
 
     def rng_for(i):
         return np.random.default_rng(BASE_SEED + seed * 100003 + i)
+
+    _q4 = globals()["_q4"] if cfg["weight_dtype"] == DT_Q4 else _bf16   # BF16 models: RNE of the F32 draw
 
     out[(-1, W_EMBED)] = _q4(rng_for(idx), V, E, 0.02); idx += 1
     for li in range(L):
@@ -84,11 +94,11 @@ def prompt_tokens(cfg, n=128, seed=1234):
 
 
 def weight_bytes(cfg):
-    """Algorithmic bytes of Q4 weights read per decoded token: 0.5 B nibble + 4 B scale / 32 = 0.625 B/weight
+    """Algorithmic bytes of weights read per decoded token: Q4 = 0.5 B nibble + 4 B scale / 32 = 0.625 B/weight, BF16 = 2 B
     (SURVEY.md 8d); the embedding table is a one-row lookup and excluded, the LM head (or tied table) is read once."""
     E, V, L = cfg["embedding_length"], cfg["vocab_size"], cfg["n_layers"]
     per_layer = sum(r * c for r, c in layer_shapes(cfg).values())
-    return int((L * per_layer + V * E) * 0.625)
+    return int((L * per_layer + V * E) * (0.625 if cfg["weight_dtype"] == DT_Q4 else 2.0))
 
 
 def kv_bytes_per_position(cfg):

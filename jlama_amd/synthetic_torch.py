@@ -40,6 +40,15 @@ def _q4(gen, rows, cols, sigma, device, chunk_rows=16384):
     return {"dtype": DT_Q4, "data": torch.cat(nibs), "scales": torch.cat(scs), "shape": (rows, cols)}
 
 
+def _bf16(gen, rows, cols, sigma, device, chunk_rows=16384):
+    parts = []
+    for r0 in range(0, rows, chunk_rows):
+        r = min(chunk_rows, rows - r0)
+        x = torch.randn((r, cols), generator=gen, device=device, dtype=torch.float32) * sigma
+        parts.append(x.to(torch.bfloat16).view(torch.int16))
+    return {"dtype": DT_BF16, "data": torch.cat(parts).contiguous(), "scales": None, "shape": (rows, cols)}
+
+
 def _norm(gen, E, device):
     w = 1.0 + torch.randn(E, generator=gen, device=device, dtype=torch.float32) * 0.01
     h = w.to(torch.bfloat16).view(torch.int16).view(1, E).contiguous()  # RNE, same as FloatConversions.float32ToBFloat16
@@ -51,6 +60,7 @@ def make_weights(cfg, seed=0, layers=None, device="cuda", need_embed=True, need_
     ls, le = layers if layers else (0, L)
     gen = torch.Generator(device=device)
     out = {}
+    _q4 = globals()["_q4"] if cfg["weight_dtype"] == DT_Q4 else _bf16
 
     def reseed(i):
         gen.manual_seed(BASE_SEED + seed * 100003 + i)

@@ -233,3 +233,45 @@ def test_real_shapes_one_layer(gpu, oracle, name):
         no, lo = om.sample(xo[-1])
         assert g == no or lo.max() - lo[g] <= LOGIT_TOL, (i, g, no)
         tok = int(g)
+
+
+@pytest.mark.parametrize("cfgname", ["TINY", "SMALL"])
+def test_bf16_model_parity(gpu, oracle, cfgname):
+    """BF16 dense model (config 4 family: BF16 weights, BF16-rounded activations, F32 accumulate, F32xBF16 LM head):
+    layer-0 taps, teacher-forced logits and greedy ids vs the oracle's GemmerBF16 / GemmerF32BF16 restatement."""
+    from jlama_amd import _native as N, synthetic as S
+    cfg = dict(getattr(S, cfgname))
+    cfg["weight_dtype"] = N.DT_BF16
+    hm, om, _ = _pair(cfg, 5, oracle)
+    prompt = S.prompt_tokens(cfg, n=37, seed=6)
+    E, A = cfg["embedding_length"], cfg["n_heads"] * cfg["head_size"]
+    hs2, os2 = hm.session(64), om.session()
+    hs2.set_tap_layer(0)
+    os2.set_tap_layer(0)
+    hs2.forward([prompt[0]], 0, want_output=False)
+    os2.forward([prompt[0]], 0)
+    for name, n in [("input_emb", E), ("query", A), ("after_attention", A), ("post_ff_res", E)]:
+        assert _rel(hs2.tap(name, n), os2.tap(name, n)) <= 1e-4, name
+    hs, os_ = hm.session(96), om.session()
+    out_h, out_o = hs.batch_forward(prompt, 0), os_.forward(prompt, 0)
+    assert _rel(out_h, out_o) <= TRUNK_TOL
+    tok, lh = hs.sample(0.0, 0.5, want_logits=True)
+    tok_o, lo = om.sample(out_o[-1])
+    assert np.abs(lh - lo).max() <= LOGIT_TOL
+    assert tok == tok_o or lo.max() - lo[tok] <= LOGIT_TOL
+    got = hs.decode_n(tok, prompt.size, 32)
+    for i, g in enumerate(got):
+        xo = os_.forward([tok], prompt.size + i)
+        no, lo = om.sample(xo[-1])
+        assert g == no or lo.max() - lo[g] <= LOGIT_TOL, (i, g, no)
+        tok = int(g)
+
+
+def test_bf16_mistral_shapes_one_layer(gpu, oracle):
+    from jlama_amd import synthetic as S
+    cfg = dict(S.MISTRAL_7B)
+    cfg.update(n_layers=1, vocab_size=2048, context_length=512)
+    hm, om, _ = _pair(cfg, 8, oracle)
+    prompt = S.prompt_tokens(cfg, n=12, seed=3)
+    got, want = hm.session(64).batch_forward(prompt, 0), om.session().forward(prompt, 0)
+    assert _rel(got, want) <= TRUNK_TOL

@@ -1,0 +1,23 @@
+import os, sys, ctypes as C, numpy as np
+sys.path.insert(0, os.getcwd())
+from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
+from jlama_amd.model import HipLlamaModel
+cfg = dict(S.LLAMA3_8B); cfg["n_layers"] = 2
+N.init(0)
+m = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
+names = ["entry", "loads issued", "rope done", "scores", "softmax", "PV", "reduced", "published", "ticket", "combined"]
+for env in ({},):
+    os.environ.update(env)
+    s = m.session(1024)
+    for pos in (384,):
+        out = np.zeros(256, dtype=np.int64)
+        N.check(N.lib().jh_debug_attn_timeline(s.h, pos, N.ptr(out), 256))
+        t = out.reshape(16, 16)
+        base = t[t > 0].min()
+        print(env, "pos", pos)
+        for sp in range(16):
+            if t[sp, 0] <= 0: continue
+            row = [(names[k], round((t[sp, k] - base) / 100.0, 2)) for k in range(10) if t[sp, k] > 0]
+            print("  split", sp, " ".join(f"{n}={v}" for n, v in row))
+    s.close()
+    for k in env: del os.environ[k]
