@@ -237,6 +237,9 @@ int jh_set_tap_layer(jh_session* s, int layer);
 int jh_get_tap(jh_session* s, int which, float* out, int n);
 /* The HIP stream the session launches on (hipStream_t as void*), so callers can record their own events. */
 void* jh_session_stream(jh_session* s);
+/* Throughput probe of the batched (prefill) MFMA GEMMs with device-resident operands: kind 0 = I8xQ4, 1 = BF16xBF16;
+ * `copies` weight matrices are cycled so they stream from HBM.  out_ms = average milliseconds per GEMM. */
+int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* out_ms);
 /* Debug aid: wall-clock (100 MHz) phase stamps of one decode-attention launch at `pos`; out[split*16 + phase]. */
 int jh_debug_attn_timeline(jh_session* s, int pos, long long* out, int n);
 /* Wait for everything queued on the session's stream. */

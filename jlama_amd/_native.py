@@ -101,6 +101,7 @@ _PROTOS = {
     "jh_session_stream": (_p, [_p]),
     "jh_decode_stats": (_i, [_p, _p, _p]),
     "jh_session_synchronize": (_i, [_p]),
+    "jh_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _p]),
     "jh_debug_attn_timeline": (_i, [_p, _i, _p, _i]),
     "jh_kernel_bench": (_i, [_p, _i, _i, _p, _p]),
 }

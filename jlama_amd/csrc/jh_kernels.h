@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace jh {
 
@@ -883,6 +884,234 @@ __global__ __launch_bounds__(512) void gemv_bf16_kernel(GemvParams p) {
             p.amax_idx[blockIdx.x] = bi;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ K3m: batched BF16 GEMM on MFMA
+// batchDotProduct BF16 x BF16 -> F32 for M > 1 (prefill of a dense BF16 model, GemmerBF16 PTO:1233-1311):
+//   C[i, j] = sum_k A[i,k] * W[j,k],  A = BF16 activations [M, lda], W = BF16 weights [N, ldb] (row = output).
+// This is the one place on the path where the matrix cores apply (M=129 => ~129 flop/B).
+// v_mfma_f32_32x32x16_bf16: lane l holds A[m = l&31][k = (l>>5)*8 .. +7] and W[n = l&31][same k]  (8 bf16 = 16 B each);
+// D: col n = l&31, row m = (r&3) + 8*(r>>2) + 4*(l>>5) for accumulator register r (cdna_hip_programming.md §3).
+// Tiling: a wave owns 32 weight rows (one MFMA column tile) and ALL of M (MT <= 8 row tiles => every weight byte is
+// read from HBM exactly once, straight into registers: per 64-wide K slice lane (n, h) loads the 4 chunks
+// k = s*16 + h*8 (s = 0..3), i.e. lanes h=0/1 of a row cover its 128 contiguous bytes).  The A slice [M, 64] is staged
+// through LDS once per workgroup (row stride 144 B: conflict-free ds_read_b128 for the 16-lane groups), double
+// buffered; products are exact in F32, accumulation order differs from Panama's 16-lane order (tolerance, not bits).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct MfmaGemmParams {
+    const uint16_t* a; const uint16_t* w; float* c;
+    int m, n0, n, k, lda, ldb, ldc, roffset;   // same meaning as gemm_bf16 (nc/simd/vector_simd.h:34), offsets pre-applied
+};
+constexpr int MG_KS = 64;            // K slice per stage
+constexpr int MG_ASTRIDE = 144;      // bytes per A row in LDS (128 + 16 pad)
+
+template <int MT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_bf16_mfma_kernel(MfmaGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, h = lane >> 5;
+    const int ntile = blockIdx.x * WAVES + wave;          // 32-column tile of this wave
+    const int ncol0 = p.n0 + ntile * 32;
+    const bool active = ntile * 32 < p.n;
+    constexpr int MROWS = MT * 32;
+    constexpr int ABYTES = MROWS * MG_ASTRIDE;   // one A stage; stage b lives at smem + b*ABYTES
+    const int nslices = p.k / MG_KS;
+
+    // cooperative A slice load: chunk = (row, c8) with 8 x 16-byte chunks per row
+    constexpr int CHUNKS = MROWS * 8, NT = WAVES * 64, CPT = (CHUNKS + NT - 1) / NT;
+    i32x4 areg[CPT];
+    auto load_a = [&](int slice) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            int ch = tid + i * NT;
+            ch = ch < CHUNKS ? ch : CHUNKS - 1;
+            int row = ch >> 3;
+            const int c8 = ch & 7;
+            row = row < p.m ? row : p.m - 1;                 // rows beyond M replicate the last row (never stored)
+            areg[i] = *(const i32x4*)(p.a + (size_t)row * p.lda + slice * MG_KS + c8 * 8);
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int ch = tid + i * NT;
+            if (ch < CHUNKS) *(i32x4*)(smem + buf * ABYTES + (ch >> 3) * MG_ASTRIDE + (ch & 7) * 16) = areg[i];
+        }
+    };
+    const uint16_t* wrow = p.w + (size_t)(active ? (ncol0 + nl) : p.n0) * p.ldb;
+    i32x4 wreg[2][4];
+    auto load_w = [&](int slice, int buf) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            wreg[buf][s] = __builtin_nontemporal_load((const i32x4*)(wrow + slice * MG_KS + s * 16 + h * 8));
+    };
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+
+    load_a(0);
+    load_w(0, 0);
+    store_a(0);
+    __syncthreads();
+    for (int sl = 0; sl < nslices; sl++) {
+        const int cur = sl & 1;
+        if (sl + 1 < nslices) {
+            load_a(sl + 1);
+            load_w(sl + 1, cur ^ 1);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, wreg[cur][s]);
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                const i32x4 av = *(const i32x4*)(smem + cur * ABYTES + (t * 32 + nl) * MG_ASTRIDE + s * 32 + h * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag, acc[t], 0, 0, 0);
+            }
+        }
+        if (sl + 1 < nslices) store_a(cur ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mrow < p.m) p.c[(size_t)p.ldc * mrow + (ncol0 + nl) - p.roffset] = acc[t][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ K2: batched I8 x Q4 GEMM on MFMA
+// batchDotProduct I8 x Q4 -> F32 for M > 1 (prefill of a JQ4 model; GemmerI8Q4_512 2x2 tile PTO:958-1043, C twin
+// nc/simd/vector_simd.c:261-437):  C[i,j] = sum_blk (da[i,blk]*sb[j,blk]) * sum_t a[i,blk,t]*(nib[j,blk,t]-8).
+// v_mfma_i32_32x32x32_i8 has K = 32 = exactly one Q block, so the block sums stay EXACT integers:
+//   A operand  lane (m, h): a[m][blk*32 + h*16 .. +15]           (16 int8)
+//   B operand  lane (n, h): nibbles of W block (n, blk): h = 0 -> low nibbles (elements 0..15), h = 1 -> high nibbles
+//              (elements 16..31)  -- Q4ByteBufferTensor.java:88-106 -- kept unsigned 0..15; the -8 bias is removed as
+//              isum = mfma - 8*sum(a[m,blk]) (exact).
+// then acc = fma(da*sb, (float)isum, acc) per block in ascending K order, like the reference.  A wave owns 32 weight
+// rows and all of M (weights read once from HBM); the A slice [M,128] (4 blocks) goes through LDS with its block
+// scales and 8*sum(a) per (row, block).
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+struct MfmaQ4Params {
+    const int8_t* a; const float* af; const uint8_t* w; const float* ws; float* c;
+    int m, n0, n, k, lda, ldaf, ldb, ldbf, ldc, roffset;   // gemm_q8_q4 meanings (vector_simd.h:22), offsets pre-applied
+};
+constexpr int MQ_ASTRIDE = 48;   // bytes per A row in LDS: 32 int8 + 16 pad (conflict-free ds_read_b128)
+
+// One pipeline stage = ONE Q block (K = 32): small loop body (MT MFMAs + their scaling), so hipcc cannot hoist a whole
+// K slice worth of MFMAs / scale reads and spill (it does with 4 blocks per stage).
+template <int MT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_q8q4_mfma_kernel(MfmaQ4Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, h = lane >> 5;
+    const int ntile = blockIdx.x * WAVES + wave;
+    const int ncol0 = p.n0 + ntile * 32;
+    const bool active = ntile * 32 < p.n;
+    constexpr int MROWS = MT * 32;
+    constexpr int ABYTES = MROWS * MQ_ASTRIDE;            // A stage
+    constexpr int SBYTES = MROWS * 4;                     // da[MROWS] floats / s8[MROWS] ints
+    constexpr int STAGE = ABYTES + 2 * SBYTES;            // stage b at smem + b*STAGE: A | dA | s8
+    const int nblk = p.k / QB;
+    constexpr int CHUNKS = MROWS * 2, NT = WAVES * 64, CPT = (CHUNKS + NT - 1) / NT;   // 2 x 16-byte chunks per row
+    i32x4 areg[CPT];
+    float dreg[CPT];
+    auto load_a = [&](int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            int ch = tid + i * NT;
+            ch = ch < CHUNKS ? ch : CHUNKS - 1;
+            int row = ch >> 1;
+            row = row < p.m ? row : p.m - 1;               // rows beyond M replicate the last row (never stored)
+            areg[i] = *(const i32x4*)(p.a + (size_t)row * p.lda + blk * QB + (ch & 1) * 16);
+            dreg[i] = p.af[(size_t)row * p.ldaf + blk];
+        }
+    };
+    auto store_a = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int ch = tid + i * NT;
+            int s = 0;
+            s = sdot4(areg[i].x, 0x01010101, s); s = sdot4(areg[i].y, 0x01010101, s);
+            s = sdot4(areg[i].z, 0x01010101, s); s = sdot4(areg[i].w, 0x01010101, s);
+            s += __builtin_amdgcn_update_dpp(0, s, 0xB1, 0xf, 0xf, false);   // + the other half block (adjacent thread)
+            if (ch < CHUNKS) {
+                *(i32x4*)(smem + buf * STAGE + (ch >> 1) * MQ_ASTRIDE + (ch & 1) * 16) = areg[i];
+                if ((ch & 1) == 0) {
+                    ((float*)(smem + buf * STAGE + ABYTES))[ch >> 1] = dreg[i];
+                    ((int*)(smem + buf * STAGE + ABYTES + SBYTES))[ch >> 1] = 8 * s;
+                }
+            }
+        }
+    };
+    const int wr = active ? (ncol0 + nl) : p.n0;
+    const uint8_t* wrow = p.w + (size_t)wr * p.ldb;
+    const float* srow = p.ws + (size_t)wr * p.ldbf;
+
+    float acc[MT][16];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    int zk = 0;
+
+    load_a(0);
+    i32x4 wcur = __builtin_nontemporal_load((const i32x4*)wrow);
+    float scur = srow[0];
+    store_a(0);
+    __syncthreads();
+    for (int blk = 0; blk < nblk; blk++) {
+        const int cur = blk & 1;
+        i32x4 wnext = wcur;
+        float snext = scur;
+        if (blk + 1 < nblk) {
+            load_a(blk + 1);
+            wnext = __builtin_nontemporal_load((const i32x4*)(wrow + (size_t)(blk + 1) * 16));
+            snext = srow[blk + 1];
+        }
+        i32x4 bw = wcur;
+        if (h) bw = (bw >> 4);
+        bw = bw & 0x0F0F0F0F;
+        const char* stg = smem + cur * STAGE;
+        const float* dAp = (const float*)(stg + ABYTES);
+        const int* s8p = (const int*)(stg + ABYTES + SBYTES);
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const i32x4 av = *(const i32x4*)(stg + (t * 32 + nl) * MQ_ASTRIDE + h * 16);
+            i32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; r++) z[r] = zk;
+            const i32x16 d = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bw, z, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {   // rows t*32 + 4h + 8j + (0..3)
+                const float4 da4 = *(const float4*)(dAp + t * 32 + 4 * h + 8 * j);
+                const i32x4 s84 = *(const i32x4*)(s8p + t * 32 + 4 * h + 8 * j);
+                acc[t][4 * j + 0] = fmaf(da4.x * scur, (float)(d[4 * j + 0] - s84.x), acc[t][4 * j + 0]);
+                acc[t][4 * j + 1] = fmaf(da4.y * scur, (float)(d[4 * j + 1] - s84.y), acc[t][4 * j + 1]);
+                acc[t][4 * j + 2] = fmaf(da4.z * scur, (float)(d[4 * j + 2] - s84.z), acc[t][4 * j + 2]);
+                acc[t][4 * j + 3] = fmaf(da4.w * scur, (float)(d[4 * j + 3] - s84.w), acc[t][4 * j + 3]);
+            }
+        }
+        asm volatile("" : "+v"(zk));   // opaque zero: the next block's MFMAs cannot be pulled above this point
+        if (blk + 1 < nblk) store_a(cur ^ 1);
+        wcur = wnext;
+        scur = snext;
+        __syncthreads();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mrow < p.m) p.c[(size_t)p.ldc * mrow + (ncol0 + nl) - p.roffset] = acc[t][r];
+        }
 }
 
 __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {

@@ -236,6 +236,53 @@ int launch_gemv_bf16(const GemvParams& p, int grid_cap, int* grid_out, hipStream
     return JH_OK;
 }
 
+template <int MT>
+int launch_gemm_q8q4_mfma_mt(const MfmaQ4Params& g, hipStream_t st) {
+    const int tiles = g.n / 32;
+    const int waves = tiles >= g_cu_count * 4 ? 4 : (tiles >= g_cu_count * 2 ? 2 : 1);
+    const int grid = (tiles + waves - 1) / waves;
+    const size_t lds = (size_t)2 * (MT * 32 * MQ_ASTRIDE + 2 * MT * 32 * 4);
+    if (waves == 4) { JHCHK(allow_lds(gemm_q8q4_mfma_kernel<MT, 4>, lds)); hipLaunchKernelGGL((gemm_q8q4_mfma_kernel<MT, 4>), dim3(grid), dim3(256), lds, st, g); }
+    else if (waves == 2) { JHCHK(allow_lds(gemm_q8q4_mfma_kernel<MT, 2>, lds)); hipLaunchKernelGGL((gemm_q8q4_mfma_kernel<MT, 2>), dim3(grid), dim3(128), lds, st, g); }
+    else { JHCHK(allow_lds(gemm_q8q4_mfma_kernel<MT, 1>, lds)); hipLaunchKernelGGL((gemm_q8q4_mfma_kernel<MT, 1>), dim3(grid), dim3(64), lds, st, g); }
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st) {
+    const int mt = (g.m + 31) / 32;
+    switch (mt) {
+        case 1: return launch_gemm_q8q4_mfma_mt<1>(g, st);
+        case 2: return launch_gemm_q8q4_mfma_mt<2>(g, st);
+        case 3: case 4: return launch_gemm_q8q4_mfma_mt<4>(g, st);
+        case 5: case 6: return launch_gemm_q8q4_mfma_mt<6>(g, st);
+        default: return launch_gemm_q8q4_mfma_mt<8>(g, st);
+    }
+}
+
+template <int MT>
+int launch_gemm_bf16_mfma_mt(const MfmaGemmParams& g, hipStream_t st) {
+    const int tiles = g.n / 32;
+    // enough workgroups to cover the chip: 1, 2 or 4 column tiles (waves) per workgroup
+    const int waves = tiles >= g_cu_count * 4 ? 4 : (tiles >= g_cu_count * 2 ? 2 : 1);
+    const int grid = (tiles + waves - 1) / waves;
+    const size_t lds = (size_t)2 * MT * 32 * MG_ASTRIDE;
+    if (waves == 4) { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 4>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 4>), dim3(grid), dim3(256), lds, st, g); }
+    else if (waves == 2) { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 2>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 2>), dim3(grid), dim3(128), lds, st, g); }
+    else { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 1>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 1>), dim3(grid), dim3(64), lds, st, g); }
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+int launch_gemm_bf16_mfma(const MfmaGemmParams& g, hipStream_t st) {
+    const int mt = (g.m + 31) / 32;
+    switch (mt) {
+        case 1: return launch_gemm_bf16_mfma_mt<1>(g, st);
+        case 2: return launch_gemm_bf16_mfma_mt<2>(g, st);
+        case 3: case 4: return launch_gemm_bf16_mfma_mt<4>(g, st);
+        case 5: case 6: return launch_gemm_bf16_mfma_mt<6>(g, st);
+        default: return launch_gemm_bf16_mfma_mt<8>(g, st);
+    }
+}
+
 template <int PRO, int R>
 int launch_gemv_f32q4_r(const GemvParams& p, int grid, int threads, hipStream_t st) {
     const size_t lds = lds_bytes_f32(p.K);
@@ -419,6 +466,25 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
             if (aoffset % 4) fast = false;
             else JHCHK((launch_gemv_f32q4<PRO_F32>(p, cfgf, nullptr, st)));
         }
+    }
+    if (!fast && kind == G_Q8Q4 && m >= 2 && m <= 256 && (n % 32) == 0 && (aoffset % QB) == 0 && (boffset % 16) == 0 && (lda % 16) == 0 &&
+        (ldb % 16) == 0 && !env_int("JH_TIER1_GENERIC", 0)) {
+        // batched I8 x Q4 GEMM on the matrix cores (prefill shape), exact integer block sums
+        MfmaQ4Params g;
+        g.a = (const int8_t*)dA + aoffset; g.af = (const float*)dAf + aoffset / QB;
+        g.w = dB + boffset; g.ws = dBf + (boffset * 2) / QB; g.c = (float*)dR;
+        g.m = m; g.n0 = n0; g.n = n; g.k = k; g.lda = lda; g.ldaf = ldaf; g.ldb = ldb; g.ldbf = ldbf; g.ldc = ldc; g.roffset = roffset;
+        JHCHK(launch_gemm_q8q4_mfma(g, st));
+        fast = true;
+    }
+    if (!fast && kind == G_BF16 && m >= 2 && m <= 256 && (k % MG_KS) == 0 && (n % 32) == 0 && (aoffset % 8) == 0 && (boffset % 8) == 0 &&
+        (lda % 8) == 0 && (ldb % 8) == 0 && !env_int("JH_TIER1_GENERIC", 0)) {
+        // batched BF16 GEMM on the matrix cores (prefill shape)
+        MfmaGemmParams g;
+        g.a = (const uint16_t*)dA + aoffset; g.w = (const uint16_t*)dB + boffset; g.c = (float*)dR;
+        g.m = m; g.n0 = n0; g.n = n; g.k = k; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.roffset = roffset;
+        JHCHK(launch_gemm_bf16_mfma(g, st));
+        fast = true;
     }
     if (!fast) {
         GemmParams g{dA, (const float*)dAf, dB, dBf, (float*)dR, aoffset, boffset, roffset, m, n0, n, k,
@@ -1223,6 +1289,41 @@ int jh_debug_attn_timeline(jh_session* s, int pos, long long* out, int n) {
     HIPCHK(hipMemcpy(out, d, 256 * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipFree(d));
     return JH_OK;
+}
+// Device-resident timing of the batched (prefill) MFMA GEMMs: kind 0 = I8xQ4, 1 = BF16xBF16.  `copies` distinct weight
+// matrices are cycled so the stream comes from HBM, not the Infinity Cache.  out_ms = average per GEMM.
+int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* out_ms) {
+    if (!out_ms || m < 2 || m > 256 || (n % 32) || (k % 64) || copies < 1 || iters < 1) return set_err(JH_ERR_INVALID, "gemm_bench: bad shape");
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    const size_t wbytes = kind == 0 ? (size_t)n * k / 2 : (size_t)n * k * 2;
+    const size_t sbytes = kind == 0 ? (size_t)n * (k / QB) * 4 : 0;
+    uint8_t *w = nullptr, *a = nullptr; float *ws = nullptr, *af = nullptr, *c = nullptr;
+    HIPCHK(hipMalloc(&w, wbytes * copies)); HIPCHK(hipMemset(w, 0x37, wbytes * copies));
+    if (sbytes) { HIPCHK(hipMalloc(&ws, sbytes * copies)); HIPCHK(hipMemset(ws, 0, sbytes * copies)); }
+    HIPCHK(hipMalloc(&a, (size_t)m * k * 2)); HIPCHK(hipMemset(a, 1, (size_t)m * k * 2));
+    HIPCHK(hipMalloc(&af, (size_t)m * (k / QB) * 4)); HIPCHK(hipMemset(af, 0, (size_t)m * (k / QB) * 4));
+    HIPCHK(hipMalloc(&c, (size_t)m * n * 4));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    int rc = JH_OK;
+    for (int it = -1; it < iters && rc == JH_OK; it++) {
+        if (it == 0) HIPCHK(hipEventRecord(e0, st));
+        for (int l = 0; l < copies && rc == JH_OK; l++) {
+            if (kind == 0) {
+                MfmaQ4Params g{(const int8_t*)a, af, w + l * wbytes, ws + l * (sbytes / 4), c, m, 0, n, k, k, k / QB, k / 2, k / QB, n, 0};
+                rc = launch_gemm_q8q4_mfma(g, st);
+            } else {
+                MfmaGemmParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, m, 0, n, k, k, k, n, 0};
+                rc = launch_gemm_bf16_mfma(g, st);
+            }
+        }
+    }
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *out_ms = (double)ms / ((double)iters * copies);
+    hipFree(w); if (ws) hipFree(ws); hipFree(a); hipFree(af); hipFree(c); hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
 }
 int jh_session_synchronize(jh_session* s) {
     if (!s) return set_err(JH_ERR_INVALID, "session_synchronize: null");

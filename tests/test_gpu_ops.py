@@ -254,3 +254,59 @@ def test_gemv_at_model_shapes_and_linearity(ops, oracle):
         Rf = Tensor.zeros(1, n)
         ops.batchDotProduct(Rf, Tensor.f32(a), B, 0, 0, k)
         _close(Rf.data, oracle.gemm_f32q4(a, B.data, B.scales), 1e-4)
+
+
+@pytest.mark.parametrize("m,n,k", [(129, 1024, 4096), (32, 128, 1024), (256, 256, 512), (5, 64, 256), (129, 4096, 1024)])
+def test_batched_bf16_gemm_on_mfma(ops, oracle, m, n, k):
+    """Prefill-shaped BF16 x BF16 -> F32 GEMM (GemmerBF16) through jh_gemm_bf16: M >= 2 takes the
+    v_mfma_f32_32x32x16_bf16 kernel.  Asymmetric operands (cdna_hip_programming.md §3: a symmetric B hides a
+    row/col swap); products are exact in F32, only the accumulation order differs => 1e-4 of the row scale."""
+    from jlama_amd.jq4 import Tensor
+    rng = np.random.default_rng(m * 7 + n)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) * np.linspace(0.5, 2.0, n)[:, None]).astype(np.float32)
+    A, B = Tensor.bf16(a), Tensor.bf16(w)
+    R = Tensor.zeros(m, n)
+    ops.batchDotProduct(R, A, B, 0, 0, k)
+    want = oracle.gemm_bf16(A.data, B.data)
+    _close(R.data, want, 1e-4)
+    # the identity probe: A = I (bf16 exact) must return W's leading block, transposed -- catches fragment-layout swaps
+    if m >= 32 and k >= 64:
+        eye = np.zeros((m, k), dtype=np.float32)
+        eye[np.arange(min(m, k)), np.arange(min(m, k))] = 1.0
+        R2 = Tensor.zeros(m, n)
+        ops.batchDotProduct(R2, Tensor.bf16(eye), B, 0, 0, k)
+        wb = oracle.bf16_to_f32(B.data)
+        np.testing.assert_array_equal(R2.data[: min(m, k)], wb[:, : min(m, k)].T)
+    # column window + row chunk + result offset through the same kernel
+    if n >= 128 and k >= 512:
+        R3 = Tensor.zeros(m, n)
+        ops.batchDotProduct(R3, A, B, 256, 256, 256, 0, 32, 64)
+        want3 = oracle.gemm_bf16(A.data, B.data, aColOff=256, bColOff=256, K=256, bRowOff=32, N=64, out=np.zeros((m, n), np.float32))
+        _close(R3.data[:, 32:96], want3[:, 32:96], 1e-4)
+        assert (R3.data[:, :32] == 0).all() and (R3.data[:, 96:] == 0).all()
+
+
+@pytest.mark.parametrize("m,n,k", [(129, 1024, 4096), (32, 128, 1024), (192, 256, 512), (256, 64, 256), (5, 64, 64), (2, 4096, 1024)])
+def test_batched_i8q4_gemm_on_mfma(ops, oracle, m, n, k):
+    """Prefill-shaped I8 x Q4 -> F32 GEMM (GemmerI8Q4_512 2x2 tile / gemm_q8_q4) through jh_gemm_q8_q4: M >= 2 takes the
+    v_mfma_i32_32x32x32_i8 kernel (one Q block per MFMA => exact integer block sums).  1e-5 of the row scale."""
+    from jlama_amd.jq4 import Tensor
+    rng = np.random.default_rng(m * 11 + n)
+    a = rng.uniform(-1, 100, (m, k)).astype(np.float32)
+    a[1] = rng.standard_normal(k)          # a row with negatives (sum(a_block) of both signs)
+    w = (rng.uniform(0, 1, (n, k)) * np.linspace(0.5, 2.0, n)[:, None]).astype(np.float32)
+    w[::3] *= -1
+    A = ops.quantize(Tensor.f32(a), 2, 0, k)
+    B = Tensor.q4(w)
+    R = Tensor.zeros(m, n)
+    ops.batchDotProduct(R, A, B, 0, 0, k)
+    want = oracle.gemm_i8q4(A.data, A.scales, B.data, B.scales)
+    _close(R.data, want, 1e-5)
+    if k >= 512 and n >= 128:      # window: column offset 256, rows [32, 96)
+        R3 = Tensor.zeros(m, n)
+        ops.batchDotProduct(R3, A, B, 256, 256, 256, 0, 32, 64)
+        want3 = oracle.gemm_i8q4(A.data, A.scales, B.data, B.scales, aColOff=256, bColOff=256, K=256, bRowOff=32, N=64,
+                                 out=np.zeros((m, n), np.float32))
+        _close(R3.data[:, 32:96], want3[:, 32:96], 1e-5)
+        assert (R3.data[:, :32] == 0).all() and (R3.data[:, 96:] == 0).all()
