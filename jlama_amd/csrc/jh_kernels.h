@@ -1000,33 +1000,36 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_mfma_kernel(MfmaGemmPara
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 struct MfmaQ4Params {
     const int8_t* a; const float* af; const uint8_t* w; const float* ws; float* c;
+    const float* resid;    // optional: C += resid (same layout as C), e.g. the residual stream in prefill
     int m, n0, n, k, lda, ldaf, ldb, ldbf, ldc, roffset;   // gemm_q8_q4 meanings (vector_simd.h:22), offsets pre-applied
 };
 constexpr int MQ_ASTRIDE = 48;   // bytes per A row in LDS: 32 int8 + 16 pad (conflict-free ds_read_b128)
 
-// One pipeline stage = ONE Q block (K = 32): small loop body (MT MFMAs + their scaling), so hipcc cannot hoist a whole
-// K slice worth of MFMAs / scale reads and spill (it does with 4 blocks per stage).
-template <int MT, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gemm_q8q4_mfma_kernel(MfmaQ4Params p) {
+// Workgroup = one 32-column tile x ALL of M; its KSPLIT waves each own a contiguous range of Q blocks (split-K) and run
+// independent, barrier-free pipelines: one stage = ONE Q block (A slice [M,32] + its scales + 8*sum(a) staged in the
+// wave's private LDS region, LDS operations of a wave are ordered), weights straight from HBM to registers.  The small
+// per-stage body also keeps hipcc from hoisting a whole K slice of MFMAs / scale reads and spilling.  Partial
+// accumulators meet in LDS at the end.
+template <int MT, int KSPLIT>
+__global__ __launch_bounds__(KSPLIT * 64) void gemm_q8q4_mfma_kernel(MfmaQ4Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 31, h = lane >> 5;
-    const int ntile = blockIdx.x * WAVES + wave;
-    const int ncol0 = p.n0 + ntile * 32;
-    const bool active = ntile * 32 < p.n;
+    const int ncol0 = p.n0 + blockIdx.x * 32;
     constexpr int MROWS = MT * 32;
-    constexpr int ABYTES = MROWS * MQ_ASTRIDE;            // A stage
-    constexpr int SBYTES = MROWS * 4;                     // da[MROWS] floats / s8[MROWS] ints
-    constexpr int STAGE = ABYTES + 2 * SBYTES;            // stage b at smem + b*STAGE: A | dA | s8
+    constexpr int ABYTES = MROWS * MQ_ASTRIDE;
+    constexpr int SBYTES = MROWS * 4;
+    constexpr int STAGE = ABYTES + 2 * SBYTES;            // A | dA | s8
+    char* const my = smem + ks * 2 * STAGE;               // this wave's two stages
     const int nblk = p.k / QB;
-    constexpr int CHUNKS = MROWS * 2, NT = WAVES * 64, CPT = (CHUNKS + NT - 1) / NT;   // 2 x 16-byte chunks per row
+    const int b0 = (int)((long long)nblk * ks / KSPLIT), b1 = (int)((long long)nblk * (ks + 1) / KSPLIT);
+    constexpr int CHUNKS = MROWS * 2, CPT = CHUNKS / 64;  // 2 x 16-byte chunks per row, 64 lanes
     i32x4 areg[CPT];
     float dreg[CPT];
     auto load_a = [&](int blk) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
-            int ch = tid + i * NT;
-            ch = ch < CHUNKS ? ch : CHUNKS - 1;
+            const int ch = lane + i * 64;
             int row = ch >> 1;
             row = row < p.m ? row : p.m - 1;               // rows beyond M replicate the last row (never stored)
             areg[i] = *(const i32x4*)(p.a + (size_t)row * p.lda + blk * QB + (ch & 1) * 16);
@@ -1036,23 +1039,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_q8q4_mfma_kernel(MfmaQ4Params
     auto store_a = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
-            const int ch = tid + i * NT;
+            const int ch = lane + i * 64;
             int s = 0;
             s = sdot4(areg[i].x, 0x01010101, s); s = sdot4(areg[i].y, 0x01010101, s);
             s = sdot4(areg[i].z, 0x01010101, s); s = sdot4(areg[i].w, 0x01010101, s);
-            s += __builtin_amdgcn_update_dpp(0, s, 0xB1, 0xf, 0xf, false);   // + the other half block (adjacent thread)
-            if (ch < CHUNKS) {
-                *(i32x4*)(smem + buf * STAGE + (ch >> 1) * MQ_ASTRIDE + (ch & 1) * 16) = areg[i];
-                if ((ch & 1) == 0) {
-                    ((float*)(smem + buf * STAGE + ABYTES))[ch >> 1] = dreg[i];
-                    ((int*)(smem + buf * STAGE + ABYTES + SBYTES))[ch >> 1] = 8 * s;
-                }
+            s += __builtin_amdgcn_update_dpp(0, s, 0xB1, 0xf, 0xf, false);   // + the other half block (adjacent lane)
+            *(i32x4*)(my + buf * STAGE + (ch >> 1) * MQ_ASTRIDE + (ch & 1) * 16) = areg[i];
+            if ((ch & 1) == 0) {
+                ((float*)(my + buf * STAGE + ABYTES))[ch >> 1] = dreg[i];
+                ((int*)(my + buf * STAGE + ABYTES + SBYTES))[ch >> 1] = 8 * s;
             }
         }
     };
-    const int wr = active ? (ncol0 + nl) : p.n0;
-    const uint8_t* wrow = p.w + (size_t)wr * p.ldb;
-    const float* srow = p.ws + (size_t)wr * p.ldbf;
+    const uint8_t* wrow = p.w + (size_t)(ncol0 + nl) * p.ldb;
+    const float* srow = p.ws + (size_t)(ncol0 + nl) * p.ldbf;
 
     float acc[MT][16];
 #pragma unroll
@@ -1061,57 +1061,77 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_q8q4_mfma_kernel(MfmaQ4Params
         for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
     int zk = 0;
 
-    load_a(0);
-    i32x4 wcur = __builtin_nontemporal_load((const i32x4*)wrow);
-    float scur = srow[0];
-    store_a(0);
-    __syncthreads();
-    for (int blk = 0; blk < nblk; blk++) {
-        const int cur = blk & 1;
-        i32x4 wnext = wcur;
-        float snext = scur;
-        if (blk + 1 < nblk) {
-            load_a(blk + 1);
-            wnext = __builtin_nontemporal_load((const i32x4*)(wrow + (size_t)(blk + 1) * 16));
-            snext = srow[blk + 1];
-        }
-        i32x4 bw = wcur;
-        if (h) bw = (bw >> 4);
-        bw = bw & 0x0F0F0F0F;
-        const char* stg = smem + cur * STAGE;
-        const float* dAp = (const float*)(stg + ABYTES);
-        const int* s8p = (const int*)(stg + ABYTES + SBYTES);
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const i32x4 av = *(const i32x4*)(stg + (t * 32 + nl) * MQ_ASTRIDE + h * 16);
-            i32x16 z;
-#pragma unroll
-            for (int r = 0; r < 16; r++) z[r] = zk;
-            const i32x16 d = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bw, z, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {   // rows t*32 + 4h + 8j + (0..3)
-                const float4 da4 = *(const float4*)(dAp + t * 32 + 4 * h + 8 * j);
-                const i32x4 s84 = *(const i32x4*)(s8p + t * 32 + 4 * h + 8 * j);
-                acc[t][4 * j + 0] = fmaf(da4.x * scur, (float)(d[4 * j + 0] - s84.x), acc[t][4 * j + 0]);
-                acc[t][4 * j + 1] = fmaf(da4.y * scur, (float)(d[4 * j + 1] - s84.y), acc[t][4 * j + 1]);
-                acc[t][4 * j + 2] = fmaf(da4.z * scur, (float)(d[4 * j + 2] - s84.z), acc[t][4 * j + 2]);
-                acc[t][4 * j + 3] = fmaf(da4.w * scur, (float)(d[4 * j + 3] - s84.w), acc[t][4 * j + 3]);
+    if (b0 < b1) {
+        load_a(b0);
+        i32x4 wcur = __builtin_nontemporal_load((const i32x4*)(wrow + (size_t)b0 * 16));
+        float scur = srow[b0];
+        store_a(0);
+        for (int blk = b0; blk < b1; blk++) {
+            const int cur = (blk - b0) & 1;
+            i32x4 wnext = wcur;
+            float snext = scur;
+            if (blk + 1 < b1) {
+                load_a(blk + 1);
+                wnext = __builtin_nontemporal_load((const i32x4*)(wrow + (size_t)(blk + 1) * 16));
+                snext = srow[blk + 1];
             }
+            i32x4 bw = wcur;
+            if (h) bw = (bw >> 4);
+            bw = bw & 0x0F0F0F0F;
+            const char* stg = my + cur * STAGE;
+            const float* dAp = (const float*)(stg + ABYTES);
+            const int* s8p = (const int*)(stg + ABYTES + SBYTES);
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                const i32x4 av = *(const i32x4*)(stg + (t * 32 + nl) * MQ_ASTRIDE + h * 16);
+                i32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; r++) z[r] = zk;
+                const i32x16 d = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bw, z, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {   // rows t*32 + 4h + 8j + (0..3)
+                    const float4 da4 = *(const float4*)(dAp + t * 32 + 4 * h + 8 * j);
+                    const i32x4 s84 = *(const i32x4*)(s8p + t * 32 + 4 * h + 8 * j);
+                    acc[t][4 * j + 0] = fmaf(da4.x * scur, (float)(d[4 * j + 0] - s84.x), acc[t][4 * j + 0]);
+                    acc[t][4 * j + 1] = fmaf(da4.y * scur, (float)(d[4 * j + 1] - s84.y), acc[t][4 * j + 1]);
+                    acc[t][4 * j + 2] = fmaf(da4.z * scur, (float)(d[4 * j + 2] - s84.z), acc[t][4 * j + 2]);
+                    acc[t][4 * j + 3] = fmaf(da4.w * scur, (float)(d[4 * j + 3] - s84.w), acc[t][4 * j + 3]);
+                }
+            }
+            asm volatile("" : "+v"(zk));   // opaque zero: the next block's MFMAs cannot be pulled above this point
+            if (blk + 1 < b1) store_a(cur ^ 1);
+            wcur = wnext;
+            scur = snext;
         }
-        asm volatile("" : "+v"(zk));   // opaque zero: the next block's MFMAs cannot be pulled above this point
-        if (blk + 1 < nblk) store_a(cur ^ 1);
-        wcur = wnext;
-        scur = snext;
+    }
+    // ---- split-K reduction through LDS: red[ks][t][r][lane]
+    __syncthreads();
+    float* red = (float*)smem;
+    if (KSPLIT > 1) {
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) red[((ks * MT + t) * 16 + r) * 64 + lane] = acc[t][r];
         __syncthreads();
     }
-    if (!active) return;
 #pragma unroll
-    for (int t = 0; t < MT; t++)
+    for (int t = 0; t < MT; t++) {
+        if (KSPLIT > 1 && (t % KSPLIT) != ks) continue;   // wave ks finishes tiles t = ks, ks+KSPLIT, ...
 #pragma unroll
         for (int r = 0; r < 16; r++) {
+            float v = acc[t][r];
+            if (KSPLIT > 1) {
+                v = 0.0f;
+#pragma unroll
+                for (int q = 0; q < KSPLIT; q++) v += red[((q * MT + t) * 16 + r) * 64 + lane];   // ascending K ranges
+            }
             const int mrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (mrow < p.m) p.c[(size_t)p.ldc * mrow + (ncol0 + nl) - p.roffset] = acc[t][r];
+            if (mrow < p.m) {
+                const size_t idx = (size_t)p.ldc * mrow + (ncol0 + nl) - p.roffset;
+                p.c[idx] = p.resid ? v + p.resid[idx] : v;
+            }
         }
+    }
 }
 
 __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {

@@ -239,12 +239,16 @@ int launch_gemv_bf16(const GemvParams& p, int grid_cap, int* grid_out, hipStream
 template <int MT>
 int launch_gemm_q8q4_mfma_mt(const MfmaQ4Params& g, hipStream_t st) {
     const int tiles = g.n / 32;
-    const int waves = tiles >= g_cu_count * 4 ? 4 : (tiles >= g_cu_count * 2 ? 2 : 1);
-    const int grid = (tiles + waves - 1) / waves;
-    const size_t lds = (size_t)2 * (MT * 32 * MQ_ASTRIDE + 2 * MT * 32 * 4);
-    if (waves == 4) { JHCHK(allow_lds(gemm_q8q4_mfma_kernel<MT, 4>, lds)); hipLaunchKernelGGL((gemm_q8q4_mfma_kernel<MT, 4>), dim3(grid), dim3(256), lds, st, g); }
-    else if (waves == 2) { JHCHK(allow_lds(gemm_q8q4_mfma_kernel<MT, 2>, lds)); hipLaunchKernelGGL((gemm_q8q4_mfma_kernel<MT, 2>), dim3(grid), dim3(128), lds, st, g); }
-    else { JHCHK(allow_lds(gemm_q8q4_mfma_kernel<MT, 1>, lds)); hipLaunchKernelGGL((gemm_q8q4_mfma_kernel<MT, 1>), dim3(grid), dim3(64), lds, st, g); }
+    const int nblk = g.k / QB;
+    // split-K so that small N still fills the chip: one workgroup per 32-column tile, KSPLIT waves each
+    const int ksplit = (tiles >= g_cu_count * 4 || nblk < 8) ? 1 : (tiles >= g_cu_count * 2 || nblk < 16 ? 2 : 4);
+    const size_t stage = (size_t)MT * 32 * MQ_ASTRIDE + 2 * (size_t)MT * 32 * 4;
+    const size_t red = ksplit > 1 ? (size_t)ksplit * MT * 16 * 64 * 4 : 0;
+    size_t lds = (size_t)ksplit * 2 * stage;
+    if (red > lds) lds = red;
+    if (ksplit == 4) { JHCHK(allow_lds(gemm_q8q4_mfma_kernel<MT, 4>, lds)); hipLaunchKernelGGL((gemm_q8q4_mfma_kernel<MT, 4>), dim3(tiles), dim3(256), lds, st, g); }
+    else if (ksplit == 2) { JHCHK(allow_lds(gemm_q8q4_mfma_kernel<MT, 2>, lds)); hipLaunchKernelGGL((gemm_q8q4_mfma_kernel<MT, 2>), dim3(tiles), dim3(128), lds, st, g); }
+    else { JHCHK(allow_lds(gemm_q8q4_mfma_kernel<MT, 1>, lds)); hipLaunchKernelGGL((gemm_q8q4_mfma_kernel<MT, 1>), dim3(tiles), dim3(64), lds, st, g); }
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
@@ -472,7 +476,7 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         // batched I8 x Q4 GEMM on the matrix cores (prefill shape), exact integer block sums
         MfmaQ4Params g;
         g.a = (const int8_t*)dA + aoffset; g.af = (const float*)dAf + aoffset / QB;
-        g.w = dB + boffset; g.ws = dBf + (boffset * 2) / QB; g.c = (float*)dR;
+        g.w = dB + boffset; g.ws = dBf + (boffset * 2) / QB; g.c = (float*)dR; g.resid = nullptr;
         g.m = m; g.n0 = n0; g.n = n; g.k = k; g.lda = lda; g.ldaf = ldaf; g.ldb = ldb; g.ldbf = ldbf; g.ldc = ldc; g.roffset = roffset;
         JHCHK(launch_gemm_q8q4_mfma(g, st));
         fast = true;
@@ -1310,7 +1314,7 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
         if (it == 0) HIPCHK(hipEventRecord(e0, st));
         for (int l = 0; l < copies && rc == JH_OK; l++) {
             if (kind == 0) {
-                MfmaQ4Params g{(const int8_t*)a, af, w + l * wbytes, ws + l * (sbytes / 4), c, m, 0, n, k, k, k / QB, k / 2, k / QB, n, 0};
+                MfmaQ4Params g{(const int8_t*)a, af, w + l * wbytes, ws + l * (sbytes / 4), c, nullptr, m, 0, n, k, k, k / QB, k / 2, k / QB, n, 0};
                 rc = launch_gemm_q8q4_mfma(g, st);
             } else {
                 MfmaGemmParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, m, 0, n, k, k, k, n, 0};
