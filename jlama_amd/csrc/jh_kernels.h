@@ -1234,7 +1234,8 @@ struct AttnParams {
 };
 #define JH_ATT_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && blockIdx.y == 0) p.dbg[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
-__device__ __forceinline__ const float* kv_row(const AttnParams& p, int which, int t, int kvlen) {
+template <class P>
+__device__ __forceinline__ const float* kv_row(const P& p, int which, int t, int kvlen) {
     // page / row-in-page of position t.  ctx_per_page is a power of two for the usual geometries (32, 128): shift
     // instead of a ~40-instruction integer division per row on the kernel's address-generation critical path.
     int cp, rc;
@@ -1558,6 +1559,184 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
     }
     JH_ATT_STAMP(9);   // combined
     for (int i = tid; i < GROUP * HS; i += NT) p.outf[(size_t)kvh * GROUP * HS + i] = oloc[i];
+}
+
+// ------------------------------------------------------------------------------------------------ batched prefill
+// AbstractModel.batchForward (core/model/AbstractModel.java:295-312) for a chunk of B <= 256 prompt rows: the
+// projections run as MFMA GEMMs over all rows (gemm_q8q4_mfma_kernel), the per-row work between them is below.
+// Per-row arithmetic is the decode path's (same RMSNorm / Q8 / RoPE / softmax / SiLU expressions).
+struct RowsParams {
+    const float* x; int ldx;        // input rows (F32)
+    const float* x2; int ldx2;      // ROWS_SILU_MUL: the `up` rows
+    const float* nw; float eps;     // ROWS_RMS: norm weights (F32)
+    int K, rows;
+    int8_t* q; int ldq;             // Q8 codes, natural element order
+    float* d; int ldd;              // block scales
+    float* keep;                    // optional: the F32 value that was quantized (row-major, ld = K), taps
+};
+enum { ROWS_QUANT = 0, ROWS_RMS = 1, ROWS_SILU_MUL = 2 };
+
+// One workgroup per row; a quad of lanes owns one Q8 block of 32 (Panama quantizeQ8_512, PTO:1684-1723).
+template <int MODE>
+__global__ __launch_bounds__(256) void rows_quant_kernel(RowsParams p) {
+    __shared__ double red[8];
+    const int row = blockIdx.x, T = blockDim.x;
+    const float* x = p.x + (size_t)row * p.ldx;
+    const int units = p.K / 8;
+    float fs = 1.0f;
+    if (MODE == ROWS_RMS) fs = rms_factor(x, p.K, p.eps, red);
+    for (int unit = threadIdx.x; unit < units; unit += T) {   // units % 4 == 0 and T % 4 == 0: quads stay together
+        const float4 xa = *(const float4*)(x + unit * 8), xb = *(const float4*)(x + unit * 8 + 4);
+        float y[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        if (MODE == ROWS_RMS) {
+            float w[8];
+            load8_norm(p.nw, unit * 8, w);
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = w[i] * (fs * y[i]);
+        }
+        if (MODE == ROWS_SILU_MUL) {
+            const float* u = p.x2 + (size_t)row * p.ldx2 + unit * 8;
+            const float4 ua = *(const float4*)u, ub = *(const float4*)(u + 4);
+            const float uu[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = silu_ref(y[i]) * uu[i];   // MLPBlock.java:131-142
+        }
+        if (p.keep) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) p.keep[(size_t)row * p.K + unit * 8 + i] = y[i];
+        }
+        float amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(y[i]));
+        amax = fmaxf(amax, dpp_f<0xB1>(amax));
+        amax = fmaxf(amax, dpp_f<0x4E>(amax));
+        const float d = amax / 127.0f;
+        const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
+        int q[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float v = y[i] * id;
+            v = v + 0.5f;
+            q[i] = f2b(v);
+        }
+        i32x2 packed;
+        packed.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+        packed.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+        *(i32x2*)(p.q + (size_t)row * p.ldq + unit * 8) = packed;
+        if ((unit & 3) == 0) p.d[(size_t)row * p.ldd + (unit >> 2)] = d;
+    }
+}
+
+__global__ void embed_rows_kernel(const void* table, const float* scales, int dtype, const int* tokens, int E, float* x) {
+    embed_row(table, scales, dtype, tokens[blockIdx.x], E, x + (size_t)blockIdx.x * E);
+}
+
+struct PrefillAttnParams {
+    float* qkv; int ldqkv;        // [rows][A + 2*KV] F32: q | k | v per row (q is rotated in place)
+    const float* rope;
+    float* kv_base; long long page_elems;
+    int rel_layer_in_page, ctx_per_page, cpp_shift;
+    int n_heads, n_kv_heads, head_size;
+    int start_pos, rows;
+    float scale;
+    float* out; int ldo;          // [rows][A]
+};
+
+// RoPE of q (in place) and k, and the KV page writes, for every row of the chunk (CausalSelfAttention.java:199-286;
+// the table offset is position*half + kvHead*headSize for q and k alike -- SURVEY.md 8a "RoPE quirk").
+__global__ __launch_bounds__(256) void rows_rope_kv_kernel(PrefillAttnParams p) {
+    const int row = blockIdx.x, pos = p.start_pos + row;
+    const int HS = p.head_size, half = HS / 2, A = p.n_heads * HS, KV = p.n_kv_heads * HS, group = p.n_heads / p.n_kv_heads;
+    float* r = p.qkv + (size_t)row * p.ldqkv;
+    float* krow = (float*)kv_row(p, 0, pos, KV);
+    float* vrow = (float*)kv_row(p, 1, pos, KV);
+    const int npairs = (p.n_heads + p.n_kv_heads) * half;
+    for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+        const int hh = i / half, d = i - hh * half;
+        const bool isq = hh < p.n_heads;
+        const int kvh = isq ? hh / group : hh - p.n_heads;
+        const float* rf = p.rope + ((size_t)pos * half + (size_t)kvh * HS) * 2;
+        float* v = isq ? r + (size_t)hh * HS : r + A + (size_t)kvh * HS;
+        const float a = v[d], b = v[d + half], c = rf[2 * d], s = rf[2 * d + 1];
+        const float r0 = a * c - b * s;
+        const float r1 = a * s + b * c;
+        if (isq) { v[d] = r0; v[d + half] = r1; }
+        else { krow[(size_t)kvh * HS + d] = r0; krow[(size_t)kvh * HS + d + half] = r1; }
+    }
+    for (int i = threadIdx.x; i < KV; i += blockDim.x) vrow[i] = r[A + KV + i];
+}
+
+// Causal attention of one chunk row against positions [0, start_pos+row]: workgroup = (kv head, row), the GROUP query
+// heads of the kv head share every K/V load.  Scores -> softmax ((float)exp in double, division) -> weighted V sum, as
+// CausalSelfAttention.java:322-362 / attn_decode_kernel.  LDS: scores [GROUP][n].
+constexpr int PF_THREADS = 256;
+template <int HS, int GROUP>
+__global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(PrefillAttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = PF_THREADS, NW = NT / 64, LPR = HS / 4, RPS = NT / LPR;
+    const int kvh = blockIdx.x, row = blockIdx.y;
+    const int pos = p.start_pos + row, n = pos + 1;
+    const int KV = p.n_kv_heads * HS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rsub = tid / LPR, c4 = tid % LPR;
+    float* red = (float*)smem;                 // RPS*GROUP*HS
+    float* sc = red + RPS * GROUP * HS;        // GROUP*n
+    const float* qrow = p.qkv + (size_t)row * p.ldqkv + (size_t)kvh * GROUP * HS;
+    float4 qv[GROUP];
+#pragma unroll
+    for (int gi = 0; gi < GROUP; gi++) qv[gi] = ((const float4*)(qrow + gi * HS))[c4];
+    for (int t = rsub; t < n; t += RPS) {
+        const float4 kv4 = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4];
+#pragma unroll
+        for (int gi = 0; gi < GROUP; gi++) {
+            float s = qv[gi].x * kv4.x;
+            s = fmaf(qv[gi].y, kv4.y, s);
+            s = fmaf(qv[gi].z, kv4.z, s);
+            s = fmaf(qv[gi].w, kv4.w, s);
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (c4 == 0) sc[gi * n + t] = s * p.scale;
+        }
+    }
+    __syncthreads();
+    for (int gi = wave; gi < GROUP; gi += NW) {
+        float m = -INFINITY;
+        for (int t = lane; t < n; t += 64) m = fmaxf(m, sc[gi * n + t]);
+        m = wave_max(m);
+        float l = 0.0f;
+        for (int t = lane; t < n; t += 64) {
+            const float e = (float)exp((double)(sc[gi * n + t] - m));
+            sc[gi * n + t] = e;
+            l += e;
+        }
+        l = wave_sum(l);
+        for (int t = lane; t < n; t += 64) sc[gi * n + t] = sc[gi * n + t] / l;
+    }
+    __syncthreads();
+    float4 acc[GROUP];
+#pragma unroll
+    for (int gi = 0; gi < GROUP; gi++) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = rsub; t < n; t += RPS) {
+        const float4 v4 = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
+#pragma unroll
+        for (int gi = 0; gi < GROUP; gi++) {
+            const float w = sc[gi * n + t];
+            acc[gi].x = fmaf(v4.x, w, acc[gi].x);
+            acc[gi].y = fmaf(v4.y, w, acc[gi].y);
+            acc[gi].z = fmaf(v4.z, w, acc[gi].z);
+            acc[gi].w = fmaf(v4.w, w, acc[gi].w);
+        }
+    }
+#pragma unroll
+    for (int gi = 0; gi < GROUP; gi++) ((float4*)(red + ((size_t)rsub * GROUP + gi) * HS))[c4] = acc[gi];
+    __syncthreads();
+    float* orow = p.out + (size_t)row * p.ldo + (size_t)kvh * GROUP * HS;
+    for (int i = tid; i < GROUP * HS; i += NT) {
+        float s = 0.0f;
+#pragma unroll
+        for (int rg = 0; rg < RPS; rg++) s += red[(size_t)rg * GROUP * HS + i];
+        orow[i] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ Tier-1 generic kernels

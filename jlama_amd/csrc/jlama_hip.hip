@@ -831,6 +831,12 @@ struct jh_session {
     float* taps[TAP_SLOTS] = {nullptr};
     int tap_len[TAP_SLOTS] = {0};
     LaunchCfg cfg_qkv, cfg_o, cfg_gateup, cfg_down, cfg_lm;
+    // batched prefill (lazily allocated): chunk rows x {x, x1, qkv, att, gate, up} F32 + Q8 codes / block scales
+    int pb_rows = 0;
+    float *pb_x = nullptr, *pb_x1 = nullptr, *pb_qkv = nullptr, *pb_att = nullptr, *pb_g = nullptr, *pb_u = nullptr, *pb_ad = nullptr;
+    int8_t* pb_aq = nullptr;
+    int* pb_tok = nullptr;
+    int prefill_batch_min = 4;
 };
 
 namespace {
@@ -986,6 +992,135 @@ int layers_launch(jh_session* s, hipStream_t st, int pos_for_tap) {
     const jh_config& c = s->m->c;
     for (int li = c.layer_start; li < c.layer_end; li++)
         JHCHK(layer_launch(s, li, st, s->tap_layer == li, pos_for_tap));
+    return JH_OK;
+}
+
+// ---- batched prefill -----------------------------------------------------------------------------------------------
+constexpr int PB_MAX_ROWS = 256;   // rows per chunk = the MFMA GEMM's M limit (8 tiles of 32)
+
+bool prefill_batch_ok(jh_session* s) {
+    const jh_config& c = s->m->c;
+    if (s->prefill_batch_min <= 0 || s->tap_layer >= 0 || c.weight_dtype != JH_DT_Q4) return false;
+    const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
+    if (c.embedding_length % 64 || c.hidden_length % 64 || A % 64 || (A + 2 * KV) % 32) return false;
+    if (!((hs == 128 || hs == 64) && (group == 1 || group == 2 || group == 4 || group == 8))) return false;
+    return true;
+}
+size_t prefill_attn_lds(const jh_config& c, int n_keys) {
+    const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
+    const int rps = PF_THREADS / (hs / 4);
+    return ((size_t)rps * group * hs + (size_t)group * n_keys) * 4;
+}
+bool prefill_chunk_fits(jh_session* s, int start_pos, int rows) {   // the score rows of the last position must fit in LDS
+    return prefill_attn_lds(s->m->c, start_pos + rows) <= 150 * 1024;
+}
+int prefill_alloc(jh_session* s) {
+    if (s->pb_rows) return JH_OK;
+    const jh_config& c = s->m->c;
+    const size_t E = c.embedding_length, H = c.hidden_length, A = (size_t)c.n_heads * c.head_size, KV = (size_t)c.n_kv_heads * c.head_size;
+    size_t kmax = E > H ? E : H;
+    if (A > kmax) kmax = A;
+    const size_t R = PB_MAX_ROWS;
+    HIPCHK(hipMalloc(&s->pb_x, R * E * 4));
+    HIPCHK(hipMalloc(&s->pb_x1, R * E * 4));
+    HIPCHK(hipMalloc(&s->pb_qkv, R * (A + 2 * KV) * 4));
+    HIPCHK(hipMalloc(&s->pb_att, R * A * 4));
+    HIPCHK(hipMalloc(&s->pb_g, R * H * 4));
+    HIPCHK(hipMalloc(&s->pb_u, R * H * 4));
+    HIPCHK(hipMalloc(&s->pb_aq, R * kmax));
+    HIPCHK(hipMalloc(&s->pb_ad, R * (kmax / QB) * 4));
+    HIPCHK(hipMalloc(&s->pb_tok, R * 4));
+    s->pb_rows = PB_MAX_ROWS;
+    return JH_OK;
+}
+template <int MODE>
+int rows_quant_launch(const float* x, int ldx, const float* x2, int ldx2, const float* nw, float eps, int K, int rows,
+                      int8_t* q, float* d, hipStream_t st) {
+    RowsParams p{x, ldx, x2, ldx2, nw, eps, K, rows, q, K, d, K / QB, nullptr};
+    hipLaunchKernelGGL((rows_quant_kernel<MODE>), dim3(rows), dim3(256), 0, st, p);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+int prefill_gemm(jh_session* s, const JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
+    MfmaQ4Params g{s->pb_aq, s->pb_ad, (const uint8_t*)W.data, W.scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
+    return launch_gemm_q8q4_mfma(g, st);
+}
+int prefill_attn_launch(jh_session* s, int rel, int start_pos, int rows, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
+    PrefillAttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.qkv = s->pb_qkv; p.ldqkv = A + 2 * KV;
+    p.rope = m->rope;
+    p.kv_base = s->kv_slab + (size_t)(rel / s->layers_per_page) * s->n_ctx_alloc * s->page_elems;
+    p.page_elems = (long long)s->page_elems;
+    p.rel_layer_in_page = rel % s->layers_per_page;
+    p.ctx_per_page = s->ctx_per_page;
+    p.cpp_shift = -1;
+    for (int sh = 0; sh < 30; sh++)
+        if ((1 << sh) == s->ctx_per_page) p.cpp_shift = sh;
+    p.n_heads = c.n_heads; p.n_kv_heads = c.n_kv_heads; p.head_size = hs;
+    p.start_pos = start_pos; p.rows = rows; p.scale = m->attention_scale;
+    p.out = s->pb_att; p.ldo = A;
+    hipLaunchKernelGGL(rows_rope_kv_kernel, dim3(rows), dim3(256), 0, st, p);
+    HIPCHK(hipGetLastError());
+    const size_t lds = prefill_attn_lds(c, start_pos + rows);
+    dim3 grid(c.n_kv_heads, rows), block(PF_THREADS);
+#define JH_PATTN(HSV, GV)                                                                  \
+    if (hs == HSV && group == GV) {                                                        \
+        JHCHK(allow_lds(attn_prefill_kernel<HSV, GV>, lds));                               \
+        hipLaunchKernelGGL((attn_prefill_kernel<HSV, GV>), grid, block, lds, st, p);       \
+        HIPCHK(hipGetLastError());                                                         \
+        return JH_OK;                                                                      \
+    }
+    JH_PATTN(128, 4) JH_PATTN(128, 8) JH_PATTN(64, 4) JH_PATTN(128, 1) JH_PATTN(128, 2) JH_PATTN(64, 1) JH_PATTN(64, 2) JH_PATTN(64, 8)
+#undef JH_PATTN
+    return set_err(JH_ERR_UNSUPPORTED, "prefill attention: unsupported head geometry");
+}
+// One chunk of `rows` prompt rows at positions [start_pos, start_pos+rows) through this shard's layers.
+int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool x_in_dev, int rows, int start_pos,
+                  float* x_out, bool x_out_dev, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    JHCHK(prefill_alloc(s));
+    const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
+    const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    if (tokens) {
+        const JWeight& emb = m->global_w[JH_W_EMBED];
+        HIPCHK(hipMemcpyAsync(s->pb_tok, tokens, (size_t)rows * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(embed_rows_kernel, dim3(rows), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                           (const int*)s->pb_tok, E, s->pb_x);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpyAsync(s->pb_x, x_in, (size_t)rows * E * 4, x_in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    }
+    for (int li = c.layer_start; li < c.layer_end; li++) {
+        const int rel = li - c.layer_start;
+        const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+        const JWeight& F = m->qkv[(size_t)li];
+        if (!F.data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data)
+            return set_err(JH_ERR_INVALID, "layer: weights not set");
+        // preAttentionNorm + maybeQuantize, q|k|v projections (CausalSelfAttention.java:161-171)
+        JHCHK((rows_quant_launch<ROWS_RMS>(s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, s->pb_aq, s->pb_ad, st)));
+        JHCHK(prefill_gemm(s, F, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, st));
+        JHCHK(prefill_attn_launch(s, rel, start_pos, rows, st));
+        // maybeQuantize(valueBatch) + output projection + residual (:364-376, TransformerBlock.java:185)
+        JHCHK((rows_quant_launch<ROWS_QUANT>(s->pb_att, A, nullptr, 0, nullptr, 0.f, A, rows, s->pb_aq, s->pb_ad, st)));
+        JHCHK(prefill_gemm(s, W[JH_W_O], E, A, rows, s->pb_x1, E, s->pb_x, st));
+        // preFFNorm + maybeQuantize, gate / up, SiLU*up + maybeQuantize, down + residual (MLPBlock.java:117-158)
+        JHCHK((rows_quant_launch<ROWS_RMS>(s->pb_x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, s->pb_aq, s->pb_ad, st)));
+        JHCHK(prefill_gemm(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, st));
+        JHCHK(prefill_gemm(s, W[JH_W_UP], H, E, rows, s->pb_u, H, nullptr, st));
+        JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, s->pb_aq, s->pb_ad, st)));
+        JHCHK(prefill_gemm(s, W[JH_W_DOWN], E, H, rows, s->pb_x, E, s->pb_x1, st));
+        JHCHK(trace_sync("prefill layer", st));
+    }
+    // the chunk's last row is the session's current row (what sample() / the next shard's hand-off reads)
+    HIPCHK(hipMemcpyAsync(s->x, s->pb_x + (size_t)(rows - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, start_pos + rows - 1, tokens ? tokens[rows - 1] : 0, 0);
+    if (x_out)
+        HIPCHK(hipMemcpyAsync(x_out, s->pb_x, (size_t)rows * E * 4, x_out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     return JH_OK;
 }
 
@@ -1250,6 +1385,7 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     s->cfg_down = LaunchCfg{env_int("JH_DOWN_R", 0), env_int("JH_DOWN_WAVES", 0), cu * env_int("JH_DOWN_GRIDX", 1), env_int("JH_DOWN_PIPE", -1)};
     s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 2), env_int("JH_LM_WAVES", 8), cu * env_int("JH_LM_GRIDX", 2), 1};   // tools/sweep_lm.py
     if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
+    s->prefill_batch_min = env_int("JH_PREFILL_BATCH_MIN", 4);   // chunks of fewer rows go row by row; 0 disables batching
     *out = s;
     return JH_OK;
 }
@@ -1264,6 +1400,7 @@ int jh_session_destroy(jh_session* s) {
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
+    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_u, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok}) if (b) hipFree(b);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -1424,9 +1561,20 @@ static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in,
     if (tokens)
         for (int i = 0; i < n; i++)
             if (tokens[i] < 0 || tokens[i] >= m->c.vocab_size) return set_err(JH_ERR_INVALID, "forward: token id out of range");
-    // batchForwardSlow order (core/model/AbstractModel.java:282-290): rows one position at a time -- per-row
-    // arithmetic is identical to the batched path (attention is per position there too, CausalSelfAttention.java:199).
-    for (int i = 0; i < n; i++) {
+    // Chunks of >= prefill_batch_min rows take the batched path (MFMA GEMMs over all rows, AbstractModel.java:295-312);
+    // the rest -- and every call while a tap layer is set -- goes one position at a time (batchForwardSlow order,
+    // :282-290; per-row arithmetic is the same, attention is per position there too, CausalSelfAttention.java:199).
+    int done = 0;
+    if (prefill_batch_ok(s)) {
+        while (n - done >= s->prefill_batch_min) {
+            const int rows = n - done < PB_MAX_ROWS ? n - done : PB_MAX_ROWS;
+            if (!prefill_chunk_fits(s, start_pos + done, rows)) break;
+            JHCHK(prefill_chunk(s, tokens ? tokens + done : nullptr, x_in ? x_in + (size_t)done * E : nullptr, x_in_dev, rows,
+                                start_pos + done, x_out ? x_out + (size_t)done * E : nullptr, x_out_dev, st));
+            done += rows;
+        }
+    }
+    for (int i = done; i < n; i++) {
         hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, start_pos + i, tokens ? tokens[i] : 0, 0);
         if (tokens) {
             hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,

@@ -275,3 +275,45 @@ def test_bf16_mistral_shapes_one_layer(gpu, oracle):
     prompt = S.prompt_tokens(cfg, n=12, seed=3)
     got, want = hm.session(64).batch_forward(prompt, 0), om.session().forward(prompt, 0)
     assert _rel(got, want) <= TRUNK_TOL
+
+
+def test_batched_prefill_matches_row_path_and_oracle(gpu, oracle, monkeypatch):
+    """batchForward (AbstractModel.java:295-312): prompt chunks of up to 256 rows run as MFMA GEMMs over all rows +
+    causal attention per row; the result must agree with the one-position-at-a-time path (batchForwardSlow order,
+    :282-290) and with the oracle, including a 300-row prompt (two chunks) and a continuation at start_pos > 0, and
+    must leave the KV pages / current row in the state the decode path expects."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.SMALL)
+    hm, om, _ = _pair(cfg, 21, oracle)
+    prompt = S.prompt_tokens(cfg, n=300, seed=22)
+    want = om.session().forward(prompt, 0)
+    monkeypatch.setenv("JH_PREFILL_BATCH_MIN", "0")
+    s_row = hm.session(512)
+    rows = s_row.forward(prompt, 0)
+    monkeypatch.delenv("JH_PREFILL_BATCH_MIN")
+    s_bat = hm.session(512)
+    bat = s_bat.forward(prompt, 0)
+    assert bat.shape == rows.shape == want.shape
+    assert _rel(bat, want) <= TRUNK_TOL and _rel(rows, want) <= TRUNK_TOL
+    assert _rel(bat, rows) <= TRUNK_TOL
+    assert np.abs(bat - rows)[:4].max() <= 1e-5   # short contexts, before any I8 code flips: float-ordering noise only
+    # split call: [0,100) then [100,300) at start_pos=100 (chunked prefill against existing KV pages)
+    s_two = hm.session(512)
+    a = s_two.forward(prompt[:100], 0)
+    b = s_two.forward(prompt[100:], 100)
+    assert _rel(np.concatenate([a, b]), want) <= TRUNK_TOL
+    # sampling + graph decode continue from the batched prefill's state
+    ob = om.session()
+    ob.forward(prompt, 0)
+    for s in (s_bat, s_two):
+        th, lh = s.sample(0.0, 0.5, want_logits=True)
+        to, lo = om.sample(want[-1])
+        assert np.abs(lh - lo).max() <= LOGIT_TOL
+        assert th == to or lo.max() - lo[th] <= LOGIT_TOL
+    got = s_bat.decode_n(th, prompt.size, 12)
+    tok = th
+    for i, g in enumerate(got):
+        xo = ob.forward([tok], prompt.size + i)
+        no, lo = om.sample(xo[-1])
+        assert g == no or lo.max() - lo[g] <= LOGIT_TOL, (i, g, no)
+        tok = int(g)
