@@ -475,7 +475,7 @@ __device__ __forceinline__ void store_group(const GemvParams& p, int g, int lane
 //           GEMV is requested from HBM at t=0 and the prologue hides under the first-byte latency);
 // PIPE = 1: a wave walks several groups, loading group g+1 into a second register set while it reduces group g.
 template <int PRO, int EPI, int R, int NB, int PIPE>
-__global__ __launch_bounds__((PIPE || R * NB > 4) ? 512 : 1024) void gemv_i8q4_kernel(GemvParams p) {
+__global__ __launch_bounds__((R * NB > 4) ? 512 : 1024) void gemv_i8q4_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblk = p.K / QB;
     const ActI8 a = carve_i8(smem, nblk);
@@ -530,6 +530,10 @@ __global__ __launch_bounds__((PIPE || R * NB > 4) ? 512 : 1024) void gemv_i8q4_k
             const int blk = lane + 64 * i;
             alo[i] = a.lo[blk]; ahi[i] = a.hi[blk]; adv[i] = a.d[blk]; as8[i] = 8 * a.asum[blk];
         }
+        // EPI_SILU_MUL: the double-precision SiLU costs ~500 SIMD cycles per evaluation, so the wave parks each group's
+        // (gate, up) sums in lane `nbuf + r` and evaluates SiLU*up ONCE for up to 64 hidden units (one coalesced store)
+        float gsel = 0.0f, usel = 0.0f;
+        int nbuf = 0, obase = g0 * (R / 2);
         for (int g = g0; g < g1; g++) {
             if (g + 1 < g1) load_group<EPI, R, NB>(p, g + 1, lane, nxt);
             float acc[R];
@@ -544,7 +548,20 @@ __global__ __launch_bounds__((PIPE || R * NB > 4) ? 512 : 1024) void gemv_i8q4_k
                 }
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
-            store_group<EPI, R>(p, g, lane, acc);
+            if constexpr (EPI == EPI_SILU_MUL) {
+#pragma unroll
+                for (int r = 0; r < R / 2; r++)
+                    if (lane == nbuf + r) { gsel = acc[r]; usel = acc[r + R / 2]; }
+                nbuf += R / 2;
+                if (nbuf + R / 2 > 64 || g + 1 == g1) {
+                    const float h = silu_ref(gsel) * usel;
+                    if (lane < nbuf) p.out[obase + lane] = h;
+                    obase += nbuf;
+                    nbuf = 0;
+                }
+            } else {
+                store_group<EPI, R>(p, g, lane, acc);
+            }
             cur = nxt;
         }
     } else {

@@ -210,7 +210,9 @@ int launch_gemv_i8q4(const GemvParams& p, LaunchCfg cfg, hipStream_t st) {
         if (waves > wmax) waves = wmax;
         grid = (ngroups + waves - 1) / waves;
     } else {
-        if (waves <= 0 || waves > 8) waves = 8;
+        const int wmax = (nb > 0 && R * nb <= 4) ? 16 : 8;   // must match gemv_i8q4_kernel __launch_bounds__
+        if (waves <= 0) waves = 8;
+        if (waves > wmax) waves = wmax;
         grid = (ngroups + waves - 1) / waves;
         const int cap = cfg.grid_cap > 0 ? cfg.grid_cap : cu;
         if (grid > cap) grid = cap;
@@ -1523,8 +1525,31 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                 p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x1;
                 p.K = H; p.ldb = H / 2; p.ldbf = H / QB; p.x = s->hf; p.resid = s->x;
                 JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
+            } else if (which >= 5 && which <= 8) {
+                // the same GEMVs fed a pre-quantized activation row (PRO_Q8): what the fused prologue costs
+                JHCHK(prefill_alloc(s));
+                p.aq = s->pb_aq; p.ad = s->pb_ad;
+                if (which == 5) {
+                    const JWeight& F = m->qkv[(size_t)li];
+                    p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
+                    p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
+                    JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
+                } else if (which == 6) {
+                    p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = s->x1;
+                    p.K = A; p.ldb = A / 2; p.ldbf = A / QB; p.resid = s->x;
+                    JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_o, st)));
+                } else if (which == 7) {
+                    p.w = (const uint8_t*)W[JH_W_GATE].data; p.ws = W[JH_W_GATE].scales; p.nrows = H;
+                    p.w2 = (const uint8_t*)W[JH_W_UP].data; p.ws2 = W[JH_W_UP].scales;
+                    p.K = E; p.ldb = E / 2; p.ldbf = E / QB; p.out = s->hf;
+                    JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
+                } else {
+                    p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x1;
+                    p.K = H; p.ldb = H / 2; p.ldbf = H / QB; p.resid = s->x;
+                    JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_down, st)));
+                }
             } else {
-                return set_err(JH_ERR_INVALID, "kernel_bench: which in 0..4 (qkv, attn, oproj, gateup, down)");
+                return set_err(JH_ERR_INVALID, "kernel_bench: which in 0..8 (qkv, attn, oproj, gateup, down; 5..8 = the GEMVs with pre-quantized input)");
             }
             if (it >= 0) launches++;
         }
@@ -1540,7 +1565,9 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
         if (which == 0) b = (int64_t)((double)(A + 2 * KV) * E * bpw);
         else if (which == 1) b = (int64_t)2 * (s->max_ctx / 2 + 1) * KV * 4 + (int64_t)2 * KV * 4;
         else if (which == 2) b = (int64_t)((double)E * A * bpw);
-        else if (which == 3) b = (int64_t)((double)2 * H * E * bpw);
+        else if (which == 3 || which == 7) b = (int64_t)((double)2 * H * E * bpw);
+        else if (which == 5) b = (int64_t)((double)(A + 2 * KV) * E * bpw);
+        else if (which == 6) b = (int64_t)((double)E * A * bpw);
         else b = (int64_t)((double)E * H * bpw);
         *out_bytes_per_launch = b;
     }

@@ -7,7 +7,7 @@ from jlama_amd.model import HipLlamaModel
 cfg = dict(getattr(S, os.environ.get("SWEEP_CFG", "LLAMA3_8B"))); cfg["n_layers"] = int(os.environ.get("SWEEP_LAYERS", "8"))
 N.init(0)
 m = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
-names = ["qkv", "attn", "oproj", "gateup", "down"]
+names = ["qkv", "attn", "oproj", "gateup", "down", "qkv_preq", "oproj_preq", "gateup_preq", "down_preq"]
 def run(env, k, ctx=512):
     for kk, v in env.items(): os.environ[kk] = str(v)
     s = m.session(ctx); ms, b = s.kernel_bench(k, 5); s.close()
