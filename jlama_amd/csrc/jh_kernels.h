@@ -920,6 +920,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 struct MfmaGemmParams {
     const uint16_t* a; const uint16_t* w; float* c;
     int m, n0, n, k, lda, ldb, ldc, roffset;   // same meaning as gemm_bf16 (nc/simd/vector_simd.h:34), offsets pre-applied
+    const float* resid;                        // optional: C += resid (same layout as C), the residual stream in prefill
 };
 constexpr int MG_KS = 64;            // K slice per stage
 constexpr int MG_ASTRIDE = 144;      // bytes per A row in LDS (128 + 16 pad)
@@ -999,7 +1000,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_mfma_kernel(MfmaGemmPara
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int mrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (mrow < p.m) p.c[(size_t)p.ldc * mrow + (ncol0 + nl) - p.roffset] = acc[t][r];
+            if (mrow < p.m) {
+                const size_t idx = (size_t)p.ldc * mrow + (ncol0 + nl) - p.roffset;
+                p.c[idx] = p.resid ? acc[t][r] + p.resid[idx] : acc[t][r];
+            }
         }
 }
 
@@ -1641,6 +1645,42 @@ __global__ __launch_bounds__(256) void rows_quant_kernel(RowsParams p) {
         packed.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
         *(i32x2*)(p.q + (size_t)row * p.ldq + unit * 8) = packed;
         if ((unit & 3) == 0) p.d[(size_t)row * p.ldd + (unit >> 2)] = d;
+    }
+}
+
+// BF16 models (config 4): the activation rows are RNE-rounded to BF16 instead (FloatConversions.java:35-60) -- same
+// modes, output [rows][K] bf16 in p.q (ldq in elements).
+template <int MODE>
+__global__ __launch_bounds__(256) void rows_bf16_kernel(RowsParams p) {
+    __shared__ double red[8];
+    const int row = blockIdx.x, T = blockDim.x;
+    const float* x = p.x + (size_t)row * p.ldx;
+    const int units = p.K / 8;
+    float fs = 1.0f;
+    if (MODE == ROWS_RMS) fs = rms_factor(x, p.K, p.eps, red);
+    uint16_t* out = (uint16_t*)p.q + (size_t)row * p.ldq;
+    for (int unit = threadIdx.x; unit < units; unit += T) {
+        const float4 xa = *(const float4*)(x + unit * 8), xb = *(const float4*)(x + unit * 8 + 4);
+        float y[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        if (MODE == ROWS_RMS) {
+            float w[8];
+            load8_norm(p.nw, unit * 8, w);
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = w[i] * (fs * y[i]);
+        }
+        if (MODE == ROWS_SILU_MUL) {
+            const float* u = p.x2 + (size_t)row * p.ldx2 + unit * 8;
+            const float4 ua = *(const float4*)u, ub = *(const float4*)(u + 4);
+            const float uu[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = silu_ref(y[i]) * uu[i];
+        }
+        i32x4 packed;
+        packed.x = (int)f32_to_bf16(y[0]) | ((int)f32_to_bf16(y[1]) << 16);
+        packed.y = (int)f32_to_bf16(y[2]) | ((int)f32_to_bf16(y[3]) << 16);
+        packed.z = (int)f32_to_bf16(y[4]) | ((int)f32_to_bf16(y[5]) << 16);
+        packed.w = (int)f32_to_bf16(y[6]) | ((int)f32_to_bf16(y[7]) << 16);
+        *(i32x4*)(out + unit * 8) = packed;
     }
 }
 

@@ -488,7 +488,7 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         // batched BF16 GEMM on the matrix cores (prefill shape)
         MfmaGemmParams g;
         g.a = (const uint16_t*)dA + aoffset; g.w = (const uint16_t*)dB + boffset; g.c = (float*)dR;
-        g.m = m; g.n0 = n0; g.n = n; g.k = k; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.roffset = roffset;
+        g.m = m; g.n0 = n0; g.n = n; g.k = k; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.roffset = roffset; g.resid = nullptr;
         JHCHK(launch_gemm_bf16_mfma(g, st));
         fast = true;
     }
@@ -1002,7 +1002,7 @@ constexpr int PB_MAX_ROWS = 256;   // rows per chunk = the MFMA GEMM's M limit (
 
 bool prefill_batch_ok(jh_session* s) {
     const jh_config& c = s->m->c;
-    if (s->prefill_batch_min <= 0 || s->tap_layer >= 0 || c.weight_dtype != JH_DT_Q4) return false;
+    if (s->prefill_batch_min <= 0 || s->tap_layer >= 0 || (c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16)) return false;
     const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
     if (c.embedding_length % 64 || c.hidden_length % 64 || A % 64 || (A + 2 * KV) % 32) return false;
     if (!((hs == 128 || hs == 64) && (group == 1 || group == 2 || group == 4 || group == 8))) return false;
@@ -1029,21 +1029,27 @@ int prefill_alloc(jh_session* s) {
     HIPCHK(hipMalloc(&s->pb_att, R * A * 4));
     HIPCHK(hipMalloc(&s->pb_g, R * H * 4));
     HIPCHK(hipMalloc(&s->pb_u, R * H * 4));
-    HIPCHK(hipMalloc(&s->pb_aq, R * kmax));
+    HIPCHK(hipMalloc(&s->pb_aq, R * kmax * (c.weight_dtype == JH_DT_BF16 ? 2 : 1)));   // Q8 codes, or BF16 rows for a BF16 model
     HIPCHK(hipMalloc(&s->pb_ad, R * (kmax / QB) * 4));
     HIPCHK(hipMalloc(&s->pb_tok, R * 4));
     s->pb_rows = PB_MAX_ROWS;
     return JH_OK;
 }
 template <int MODE>
-int rows_quant_launch(const float* x, int ldx, const float* x2, int ldx2, const float* nw, float eps, int K, int rows,
-                      int8_t* q, float* d, hipStream_t st) {
-    RowsParams p{x, ldx, x2, ldx2, nw, eps, K, rows, q, K, d, K / QB, nullptr};
-    hipLaunchKernelGGL((rows_quant_kernel<MODE>), dim3(rows), dim3(256), 0, st, p);
+int rows_quant_launch(jh_session* s, const float* x, int ldx, const float* x2, int ldx2, const float* nw, float eps, int K, int rows,
+                      hipStream_t st) {
+    RowsParams p{x, ldx, x2, ldx2, nw, eps, K, rows, s->pb_aq, K, s->pb_ad, K / QB, nullptr};
+    if (s->m->c.weight_dtype == JH_DT_BF16) hipLaunchKernelGGL((rows_bf16_kernel<MODE>), dim3(rows), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((rows_quant_kernel<MODE>), dim3(rows), dim3(256), 0, st, p);
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
+// out[rows, N] = act[rows, K] x W[N, K]^T (+ resid): I8 x Q4 (exact integer MFMA) or BF16 x BF16 (MFMA), by model dtype
 int prefill_gemm(jh_session* s, const JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
+    if (s->m->c.weight_dtype == JH_DT_BF16) {
+        MfmaGemmParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.data, out, rows, 0, N, K, K, K, ldc, 0, resid};
+        return launch_gemm_bf16_mfma(g, st);
+    }
     MfmaQ4Params g{s->pb_aq, s->pb_ad, (const uint8_t*)W.data, W.scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
     return launch_gemm_q8q4_mfma(g, st);
 }
@@ -1104,17 +1110,17 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
         if (!F.data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data)
             return set_err(JH_ERR_INVALID, "layer: weights not set");
         // preAttentionNorm + maybeQuantize, q|k|v projections (CausalSelfAttention.java:161-171)
-        JHCHK((rows_quant_launch<ROWS_RMS>(s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, s->pb_aq, s->pb_ad, st)));
+        JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
         JHCHK(prefill_gemm(s, F, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, st));
         JHCHK(prefill_attn_launch(s, rel, start_pos, rows, st));
         // maybeQuantize(valueBatch) + output projection + residual (:364-376, TransformerBlock.java:185)
-        JHCHK((rows_quant_launch<ROWS_QUANT>(s->pb_att, A, nullptr, 0, nullptr, 0.f, A, rows, s->pb_aq, s->pb_ad, st)));
+        JHCHK((rows_quant_launch<ROWS_QUANT>(s, s->pb_att, A, nullptr, 0, nullptr, 0.f, A, rows, st)));
         JHCHK(prefill_gemm(s, W[JH_W_O], E, A, rows, s->pb_x1, E, s->pb_x, st));
         // preFFNorm + maybeQuantize, gate / up, SiLU*up + maybeQuantize, down + residual (MLPBlock.java:117-158)
-        JHCHK((rows_quant_launch<ROWS_RMS>(s->pb_x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, s->pb_aq, s->pb_ad, st)));
+        JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
         JHCHK(prefill_gemm(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, st));
         JHCHK(prefill_gemm(s, W[JH_W_UP], H, E, rows, s->pb_u, H, nullptr, st));
-        JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, s->pb_aq, s->pb_ad, st)));
+        JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, st)));
         JHCHK(prefill_gemm(s, W[JH_W_DOWN], E, H, rows, s->pb_x, E, s->pb_x1, st));
         JHCHK(trace_sync("prefill layer", st));
     }
@@ -1456,7 +1462,7 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
                 MfmaQ4Params g{(const int8_t*)a, af, w + l * wbytes, ws + l * (sbytes / 4), c, nullptr, m, 0, n, k, k, k / QB, k / 2, k / QB, n, 0};
                 rc = launch_gemm_q8q4_mfma(g, st);
             } else {
-                MfmaGemmParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, m, 0, n, k, k, k, n, 0};
+                MfmaGemmParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, m, 0, n, k, k, k, n, 0, nullptr};
                 rc = launch_gemm_bf16_mfma(g, st);
             }
         }

@@ -277,13 +277,16 @@ def test_bf16_mistral_shapes_one_layer(gpu, oracle):
     assert _rel(got, want) <= TRUNK_TOL
 
 
-def test_batched_prefill_matches_row_path_and_oracle(gpu, oracle, monkeypatch):
+@pytest.mark.parametrize("dtype", ["Q4", "BF16"])
+def test_batched_prefill_matches_row_path_and_oracle(gpu, oracle, monkeypatch, dtype):
     """batchForward (AbstractModel.java:295-312): prompt chunks of up to 256 rows run as MFMA GEMMs over all rows +
     causal attention per row; the result must agree with the one-position-at-a-time path (batchForwardSlow order,
     :282-290) and with the oracle, including a 300-row prompt (two chunks) and a continuation at start_pos > 0, and
     must leave the KV pages / current row in the state the decode path expects."""
-    from jlama_amd import synthetic as S
+    from jlama_amd import _native as N, synthetic as S
     cfg = dict(S.SMALL)
+    if dtype == "BF16":
+        cfg["weight_dtype"] = N.DT_BF16   # BF16 x BF16 MFMA GEMMs, activations RNE-rounded per row
     hm, om, _ = _pair(cfg, 21, oracle)
     prompt = S.prompt_tokens(cfg, n=300, seed=22)
     want = om.session().forward(prompt, 0)
@@ -296,7 +299,8 @@ def test_batched_prefill_matches_row_path_and_oracle(gpu, oracle, monkeypatch):
     assert bat.shape == rows.shape == want.shape
     assert _rel(bat, want) <= TRUNK_TOL and _rel(rows, want) <= TRUNK_TOL
     assert _rel(bat, rows) <= TRUNK_TOL
-    assert np.abs(bat - rows)[:4].max() <= 1e-5   # short contexts, before any I8 code flips: float-ordering noise only
+    if dtype == "Q4":   # short contexts, before any I8 code flips: float-ordering noise only (BF16 rounding flips at once)
+        assert np.abs(bat - rows)[:4].max() <= 1e-5
     # split call: [0,100) then [100,300) at start_pos=100 (chunked prefill against existing KV pages)
     s_two = hm.session(512)
     a = s_two.forward(prompt[:100], 0)

@@ -4,6 +4,9 @@ from jlama_amd import synthetic as S
 from jlama_amd.model import HipLlamaModel
 from oracle import oracle
 cfg = dict(S.SMALL)
+if len(sys.argv) > 1 and sys.argv[1] == "BF16":
+    from jlama_amd import _native as N
+    cfg["weight_dtype"] = N.DT_BF16
 w = S.make_weights(cfg, seed=21)
 hm = HipLlamaModel(cfg, w); om = oracle.OracleModel(cfg, w)
 prompt = S.prompt_tokens(cfg, n=300, seed=22)
