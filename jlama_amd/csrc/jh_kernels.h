@@ -1019,6 +1019,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_mfma_kernel(MfmaGemmPara
 // rows and all of M (weights read once from HBM); the A slice [M,128] (4 blocks) goes through LDS with its block
 // scales and 8*sum(a) per (row, block).
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct MfmaQ4Params {
     const int8_t* a; const float* af; const uint8_t* w; const float* ws; float* c;
     const float* resid;    // optional: C += resid (same layout as C), e.g. the residual stream in prefill
@@ -1151,6 +1152,121 @@ __global__ __launch_bounds__(KSPLIT * 64) void gemm_q8q4_mfma_kernel(MfmaQ4Param
                 const size_t idx = (size_t)p.ldc * mrow + (ncol0 + nl) - p.roffset;
                 p.c[idx] = p.resid ? v + p.resid[idx] : v;
             }
+        }
+    }
+}
+
+// ---- K2b: the same GEMM with one 32x32 output tile per workgroup (the default for K % 128 == 0).
+// gemm_q8q4_mfma_kernel above keeps ALL of M in one wave's accumulators: few, fat, serial waves (<= 1 per SIMD).  The
+// per-block F32 scaling that the reference arithmetic demands -- acc = fma(da*sb, (float)isum, acc) for every output and
+// every Q block -- is 3 VALU ops per output per block against one 32-cycle MFMA, so the kernel is VALU-bound and
+// wants many independent waves whose VALU work overlaps the others' MFMAs and loads.  Here:
+//   workgroup = output tile (32 rows of M) x (32 weight rows), its S waves split K (S*4 | K/32) and meet in LDS;
+//   operands go global -> registers directly (A is L2-resident, W streams from HBM once per XCD: blockIdx is mapped so
+//   that all row tiles of a weight tile run on the SAME XCD and share its L2);  no barrier in the main loop;
+//   nibbles are unpacked to int8 16*(nib-8) = ((nib << 4) ^ 0x80), so the MFMA sums 16*isum exactly and the -8 bias
+//   needs no correction term; 1/16 is folded into the weight scale (a power of two: every rounding is unchanged);
+//   the wave's activation block scales sit transposed in its private LDS slice ([blk][32 rows]) so the 16 rows a lane
+//   owns are 4 broadcast ds_read_b128 per block.
+// TILED: both operands are stored in MFMA order (prefill path: the activation rows are written that way by
+// rows_quant_kernel, the weights are a re-tiled resident copy made at first use):
+//   A  [row tile][blk][h][m][16 B]   -> lane (m, h) reads ONE contiguous 1 KB per block per wave
+//   W  [col tile][blk][n][16 B], scales [col tile][blk][n]   -> 512 B / 128 B contiguous per block per wave
+// Row-major operands (Tier-1 callers) touch 32 cache lines per load and use 16-32 B of each: ~8x the L2->L1 traffic.
+template <int S, bool TILED>
+__global__ __launch_bounds__(S * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_q8q4_tile_kernel(MfmaQ4Params p, int mtiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, h = lane >> 5;
+    // blockIdx.x = c_lo + 8*(rt + mtiles*c_hi), column tile ct = c_hi*8 + c_lo: consecutive workgroups go to
+    // consecutive XCDs, so XCD = c_lo for every row tile of a column tile
+    const int c_lo = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int rt = rest % mtiles, ct = (rest / mtiles) * 8 + c_lo;
+    if (ct * 32 >= p.n) return;
+    const int ncol = p.n0 + ct * 32 + nl;
+    int arow = rt * 32 + nl;
+    arow = arow < p.m ? arow : p.m - 1;                   // rows beyond M replicate the last row (never stored)
+    const int nblk = p.k / QB, nbr = nblk / S, b0 = ks * nbr;
+    float* dA = (float*)smem + (size_t)ks * nbr * 32;     // this wave's slice: [nbr][32 rows]
+    {   // stage da[row][b0 .. b0+nbr) transposed; lane (row, h) covers half of its row's blocks
+        const float* src = p.af + (size_t)arow * p.ldaf + b0;
+        for (int i = h; i < nbr; i += 2) dA[i * 32 + nl] = src[i];
+    }
+    // per-block strides: row-major A/W advance 32 / 16 bytes and 1 scale per block; tiled operands 1 KB / 512 B / 32 scales
+    const int8_t* ap = TILED ? p.a + (((size_t)rt * nblk + b0) * 64 + lane) * 16 : p.a + (size_t)arow * p.lda + (size_t)b0 * QB + h * 16;
+    const uint8_t* wp = TILED ? p.w + (((size_t)(p.n0 / 32 + ct) * nblk + b0) * 32 + nl) * 16 : p.w + (size_t)ncol * p.ldb + (size_t)b0 * 16;
+    const float* sp = TILED ? p.ws + ((size_t)(p.n0 / 32 + ct) * nblk + b0) * 32 + nl : p.ws + (size_t)ncol * p.ldbf + b0;
+    constexpr int ASTEP = TILED ? 1024 : QB, WSTEP = TILED ? 512 : 16, SSTEP = TILED ? 32 : 1;
+    // ring of 4 block slots (A 16 B, W 16 B, scale), refilled right after use => loads run 3..4 blocks ahead
+    i32x4 a_s[4], w_s[4];
+    float s_s[4];
+    const int last = nbr - 1;
+    auto load_slot = [&](int q, int blk) __attribute__((always_inline)) {
+        blk = blk < last ? blk : last;                        // branch-free: blocks past the range reload the last one
+        a_s[q] = *(const i32x4*)(ap + (size_t)blk * ASTEP);
+        w_s[q] = __builtin_nontemporal_load((const i32x4*)(wp + (size_t)blk * WSTEP));
+        s_s[q] = sp[(size_t)blk * SSTEP];
+    };
+    const int sh = h ? 0 : 4;
+    auto block_mfma = [&](int q) __attribute__((always_inline)) -> i32x16 {
+        i32x4 bw = w_s[q] << sh;
+        bw = (bw & (int)0xF0F0F0F0) ^ (int)0x80808080;     // int8 16*(nib-8): low nibbles for h=0, high for h=1
+        const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // inline-constant C operand
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a_s[q], bw, z, 0, 0, 0);
+    };
+    f32x2 acc2[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) acc2[r] = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 4; q++) load_slot(q, q);
+    for (int c = 0; c < nbr; c += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int blk = c + q;
+            const i32x16 d = block_mfma(q);     // other waves' VALU work covers this MFMA's latency (3-4 waves per SIMD)
+            const float s16 = s_s[q] * 0.0625f;
+            load_slot(q, blk + 4);              // slot consumed: refill it 4 blocks ahead
+            const float* dr = dA + blk * 32 + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {   // rows 4h + 8j + (0..3)
+                const float4 da4 = *(const float4*)(dr + 8 * j);
+                const f32x2 p01 = f32x2{da4.x, da4.y} * s16, p23 = f32x2{da4.z, da4.w} * s16;
+                const f32x2 d01 = f32x2{(float)d[4 * j + 0], (float)d[4 * j + 1]};
+                const f32x2 d23 = f32x2{(float)d[4 * j + 2], (float)d[4 * j + 3]};
+                acc2[2 * j + 0] = __builtin_elementwise_fma(p01, d01, acc2[2 * j + 0]);
+                acc2[2 * j + 1] = __builtin_elementwise_fma(p23, d23, acc2[2 * j + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one block's MFMA result live at a time (no hoisting across steps)
+        }
+    }
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { acc[2 * r] = acc2[r].x; acc[2 * r + 1] = acc2[r].y; }
+    // ---- split-K partials meet in LDS (after every wave is done with its scale slice); wave ks finishes registers
+    // r = ks*(16/S) ..., summing the K ranges in ascending order
+    float* red = (float*)smem;
+    if (S > 1) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[(ks * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+    }
+    constexpr int RP = 16 / S;
+#pragma unroll
+    for (int i = 0; i < RP; i++) {
+        const int r = S > 1 ? ks * RP + i : i;
+        float v;
+        if (S > 1) {
+            v = 0.0f;
+#pragma unroll
+            for (int q = 0; q < S; q++) v += red[(q * 16 + r) * 64 + lane];
+        } else {
+            v = acc[i];
+        }
+        const int mrow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (mrow < p.m) {
+            const size_t idx = (size_t)p.ldc * mrow + ncol - p.roffset;
+            p.c[idx] = p.resid ? v + p.resid[idx] : v;
         }
     }
 }
@@ -1591,7 +1707,7 @@ struct RowsParams {
     const float* x2; int ldx2;      // ROWS_SILU_MUL: the `up` rows
     const float* nw; float eps;     // ROWS_RMS: norm weights (F32)
     int K, rows;
-    int8_t* q; int ldq;             // Q8 codes, natural element order
+    int8_t* q; int ldq;             // Q8 codes, natural element order; ldq < 0: MFMA-tiled [row tile][blk][h][m][16 B]
     float* d; int ldd;              // block scales
     float* keep;                    // optional: the F32 value that was quantized (row-major, ld = K), taps
 };
@@ -1643,7 +1759,13 @@ __global__ __launch_bounds__(256) void rows_quant_kernel(RowsParams p) {
         i32x2 packed;
         packed.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
         packed.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
-        *(i32x2*)(p.q + (size_t)row * p.ldq + unit * 8) = packed;
+        if (p.ldq < 0) {   // element e = unit*8 of block blk = unit/4: half h = (unit&3)>>1, 8-byte slot (unit&1)
+            const size_t nblk = p.K / QB;
+            const size_t off = ((((size_t)(row >> 5) * nblk + (unit >> 2)) * 2 + ((unit & 3) >> 1)) * 32 + (row & 31)) * 16 + (unit & 1) * 8;
+            *(i32x2*)(p.q + off) = packed;
+        } else {
+            *(i32x2*)(p.q + (size_t)row * p.ldq + unit * 8) = packed;
+        }
         if ((unit & 3) == 0) p.d[(size_t)row * p.ldd + (unit >> 2)] = d;
     }
 }
@@ -1682,6 +1804,17 @@ __global__ __launch_bounds__(256) void rows_bf16_kernel(RowsParams p) {
         packed.w = (int)f32_to_bf16(y[6]) | ((int)f32_to_bf16(y[7]) << 16);
         *(i32x4*)(out + unit * 8) = packed;
     }
+}
+
+// Re-tile a row-major Q4 weight [N][K/2] (+ scales [N][K/32]) into MFMA order for the prefill GEMM:
+//   wt [N/32][K/32][32][16 B],  st [N/32][K/32][32].   One thread per (row, block).
+__global__ void retile_q4_kernel(const uint8_t* w, const float* ws, int N, int nblk, uint8_t* wt, float* st) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * nblk) return;
+    const int row = (int)(i / nblk), blk = (int)(i % nblk);
+    const size_t dst = ((size_t)(row >> 5) * nblk + blk) * 32 + (row & 31);
+    ((i32x4*)wt)[dst] = ((const i32x4*)(w + (size_t)row * nblk * 16))[blk];
+    st[dst] = ws[(size_t)row * nblk + blk];
 }
 
 __global__ void embed_rows_kernel(const void* table, const float* scales, int dtype, const int* tokens, int E, float* x) {

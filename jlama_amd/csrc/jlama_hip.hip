@@ -254,8 +254,42 @@ int launch_gemm_q8q4_mfma_mt(const MfmaQ4Params& g, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
-int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st) {
+template <int S, bool TILED>
+int launch_gemm_q8q4_tile(const MfmaQ4Params& g, int mtiles, hipStream_t st) {
+    const int ctiles = g.n / 32, cgroups = (ctiles + 7) / 8;
+    const size_t lds_scales = (size_t)(g.k / QB) * 32 * 4, lds_red = S > 1 ? (size_t)S * 16 * 64 * 4 : 0;
+    const size_t lds = lds_scales > lds_red ? lds_scales : lds_red;
+    JHCHK(allow_lds((gemm_q8q4_tile_kernel<S, TILED>), lds));
+    hipLaunchKernelGGL((gemm_q8q4_tile_kernel<S, TILED>), dim3(8 * mtiles * cgroups), dim3(S * 64), lds, st, g, mtiles);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+
+// tiled = both operands already in MFMA order (see gemm_q8q4_tile_kernel)
+int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = false) {
     const int mt = (g.m + 31) / 32;
+    const int nblk = g.k / QB;
+    if (nblk % 4 == 0 && (size_t)nblk * 128 <= 150 * 1024 && (tiled || (g.lda % 16) == 0) && (tiled || !env_int("JH_GEMM_FAT", 0))) {
+        // one 32x32 output tile per workgroup; split K over S waves until the chip has >= ~8 waves per CU
+        const long long tiles = (long long)mt * (g.n / 32);
+        int S = 1;
+        while (S < 8 && tiles * S < (long long)g_cu_count * 8 && nblk % (8 * S) == 0) S *= 2;
+        if (tiled) {
+            switch (S) {
+                case 1: return launch_gemm_q8q4_tile<1, true>(g, mt, st);
+                case 2: return launch_gemm_q8q4_tile<2, true>(g, mt, st);
+                case 4: return launch_gemm_q8q4_tile<4, true>(g, mt, st);
+                default: return launch_gemm_q8q4_tile<8, true>(g, mt, st);
+            }
+        }
+        switch (S) {
+            case 1: return launch_gemm_q8q4_tile<1, false>(g, mt, st);
+            case 2: return launch_gemm_q8q4_tile<2, false>(g, mt, st);
+            case 4: return launch_gemm_q8q4_tile<4, false>(g, mt, st);
+            default: return launch_gemm_q8q4_tile<8, false>(g, mt, st);
+        }
+    }
+    if (tiled) return set_err(JH_ERR_UNSUPPORTED, "tiled I8xQ4 GEMM needs K % 128 == 0");
     switch (mt) {
         case 1: return launch_gemm_q8q4_mfma_mt<1>(g, st);
         case 2: return launch_gemm_q8q4_mfma_mt<2>(g, st);
@@ -792,6 +826,8 @@ struct JWeight {
     void* data = nullptr;
     float* scales = nullptr;
     int rows = 0, cols = 0;
+    uint8_t* tiled = nullptr;        // Q4 only: resident copy in MFMA order for the prefill GEMM (made at first use)
+    float* tiled_scales = nullptr;
 };
 struct jh_model {
     jh_config c;
@@ -1035,20 +1071,45 @@ int prefill_alloc(jh_session* s) {
     s->pb_rows = PB_MAX_ROWS;
     return JH_OK;
 }
+// The prefill GEMM wants both operands in MFMA order (gemm_q8q4_tile_kernel, TILED): possible when K % 128 == 0
+bool prefill_tiled(jh_session* s, int K) {
+    static const int enabled = env_int("JH_PREFILL_TILED", 1);
+    const int nblk = K / QB;
+    return enabled && s->m->c.weight_dtype == JH_DT_Q4 && nblk % 4 == 0 && (size_t)nblk * 128 <= 150 * 1024;
+}
+// resident re-tiled copy of a Q4 weight, made on first use (costs a second copy of the weights in HBM)
+int ensure_tiled(JWeight& W, hipStream_t st) {
+    if (W.tiled) return JH_OK;
+    if (W.dtype != JH_DT_Q4 || (W.rows % 32) || (W.cols % QB)) return set_err(JH_ERR_INVALID, "tiled copy: shape");
+    const int nblk = W.cols / QB;
+    hipError_t e = hipMalloc((void**)&W.tiled, (size_t)W.rows * nblk * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&W.tiled_scales, (size_t)W.rows * nblk * 4);
+    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled weight copy");
+    const size_t n = (size_t)W.rows * nblk;
+    hipLaunchKernelGGL(retile_q4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)W.data, (const float*)W.scales,
+                       W.rows, nblk, W.tiled, W.tiled_scales);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
 template <int MODE>
 int rows_quant_launch(jh_session* s, const float* x, int ldx, const float* x2, int ldx2, const float* nw, float eps, int K, int rows,
                       hipStream_t st) {
-    RowsParams p{x, ldx, x2, ldx2, nw, eps, K, rows, s->pb_aq, K, s->pb_ad, K / QB, nullptr};
+    RowsParams p{x, ldx, x2, ldx2, nw, eps, K, rows, s->pb_aq, prefill_tiled(s, K) ? -1 : K, s->pb_ad, K / QB, nullptr};
     if (s->m->c.weight_dtype == JH_DT_BF16) hipLaunchKernelGGL((rows_bf16_kernel<MODE>), dim3(rows), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((rows_quant_kernel<MODE>), dim3(rows), dim3(256), 0, st, p);
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
 // out[rows, N] = act[rows, K] x W[N, K]^T (+ resid): I8 x Q4 (exact integer MFMA) or BF16 x BF16 (MFMA), by model dtype
-int prefill_gemm(jh_session* s, const JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
+int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
     if (s->m->c.weight_dtype == JH_DT_BF16) {
         MfmaGemmParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.data, out, rows, 0, N, K, K, K, ldc, 0, resid};
         return launch_gemm_bf16_mfma(g, st);
+    }
+    if (prefill_tiled(s, K)) {
+        JHCHK(ensure_tiled(W, st));
+        MfmaQ4Params g{s->pb_aq, s->pb_ad, W.tiled, W.tiled_scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
+        return launch_gemm_q8q4_mfma(g, st, true);
     }
     MfmaQ4Params g{s->pb_aq, s->pb_ad, (const uint8_t*)W.data, W.scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
     return launch_gemm_q8q4_mfma(g, st);
@@ -1105,8 +1166,8 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     }
     for (int li = c.layer_start; li < c.layer_end; li++) {
         const int rel = li - c.layer_start;
-        const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
-        const JWeight& F = m->qkv[(size_t)li];
+        JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+        JWeight& F = m->qkv[(size_t)li];
         if (!F.data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data)
             return set_err(JH_ERR_INVALID, "layer: weights not set");
         // preAttentionNorm + maybeQuantize, q|k|v projections (CausalSelfAttention.java:161-171)
@@ -1219,8 +1280,10 @@ int jh_model_destroy(jh_model* m) {
         auto& w = m->layer_w[i];
         if (w.data) hipFree(w.data);
         if (w.scales) hipFree(w.scales);
+        if (w.tiled) hipFree(w.tiled);
+        if (w.tiled_scales) hipFree(w.tiled_scales);
     }
-    for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
+    for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); }
     for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
     if (m->rope) hipFree(m->rope);
     delete m;
@@ -1292,6 +1355,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
             }
             f.dtype = dtype; f.rows = (int)tot; f.cols = E;
         }
+        if (f.tiled) { hipFree(f.tiled); hipFree(f.tiled_scales); f.tiled = nullptr; f.tiled_scales = nullptr; }
         const size_t row0 = which == JH_W_Q ? 0 : (which == JH_W_K ? (size_t)A : (size_t)(A + KV));
         uint8_t* dd = (uint8_t*)f.data + row0 * row_bytes;
         float* ds = f.scales ? f.scales + row0 * (E / QB) : nullptr;
@@ -1303,6 +1367,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     }
     if (w->data) hipFree(w->data);
     if (w->scales) hipFree(w->scales);
+    if (w->tiled) { hipFree(w->tiled); hipFree(w->tiled_scales); w->tiled = nullptr; w->tiled_scales = nullptr; }
     w->data = nullptr; w->scales = nullptr;
     hipError_t e = hipMalloc(&w->data, bytes + 64);
     if (e != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc weight: ") + hipGetErrorString(e));
@@ -1445,12 +1510,13 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
     if (!out_ms || m < 2 || m > 256 || (n % 32) || (k % 64) || copies < 1 || iters < 1) return set_err(JH_ERR_INVALID, "gemm_bench: bad shape");
     JHCHK(ensure_ctx());
     hipStream_t st = tctx.stream;
-    const size_t wbytes = kind == 0 ? (size_t)n * k / 2 : (size_t)n * k * 2;
-    const size_t sbytes = kind == 0 ? (size_t)n * (k / QB) * 4 : 0;
+    const bool q4 = (kind == 0 || kind == 2);   // kind 2 = I8xQ4 with both operands in MFMA-tiled order (prefill path)
+    const size_t wbytes = q4 ? (size_t)n * k / 2 : (size_t)n * k * 2;
+    const size_t sbytes = q4 ? (size_t)n * (k / QB) * 4 : 0;
     uint8_t *w = nullptr, *a = nullptr; float *ws = nullptr, *af = nullptr, *c = nullptr;
     HIPCHK(hipMalloc(&w, wbytes * copies)); HIPCHK(hipMemset(w, 0x37, wbytes * copies));
     if (sbytes) { HIPCHK(hipMalloc(&ws, sbytes * copies)); HIPCHK(hipMemset(ws, 0, sbytes * copies)); }
-    HIPCHK(hipMalloc(&a, (size_t)m * k * 2)); HIPCHK(hipMemset(a, 1, (size_t)m * k * 2));
+    HIPCHK(hipMalloc(&a, (size_t)(m + 32) * k * 2)); HIPCHK(hipMemset(a, 1, (size_t)(m + 32) * k * 2));
     HIPCHK(hipMalloc(&af, (size_t)m * (k / QB) * 4)); HIPCHK(hipMemset(af, 0, (size_t)m * (k / QB) * 4));
     HIPCHK(hipMalloc(&c, (size_t)m * n * 4));
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1458,9 +1524,9 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
     for (int it = -1; it < iters && rc == JH_OK; it++) {
         if (it == 0) HIPCHK(hipEventRecord(e0, st));
         for (int l = 0; l < copies && rc == JH_OK; l++) {
-            if (kind == 0) {
+            if (q4) {
                 MfmaQ4Params g{(const int8_t*)a, af, w + l * wbytes, ws + l * (sbytes / 4), c, nullptr, m, 0, n, k, k, k / QB, k / 2, k / QB, n, 0};
-                rc = launch_gemm_q8q4_mfma(g, st);
+                rc = launch_gemm_q8q4_mfma(g, st, kind == 2);
             } else {
                 MfmaGemmParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, m, 0, n, k, k, k, n, 0, nullptr};
                 rc = launch_gemm_bf16_mfma(g, st);
