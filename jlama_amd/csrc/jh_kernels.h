@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(KSPLIT * 64) void gemm_q8q4_mfma_kernel(MfmaQ4Param
 //   W  [col tile][blk][n][16 B], scales [col tile][blk][n]   -> 512 B / 128 B contiguous per block per wave
 // Row-major operands (Tier-1 callers) touch 32 cache lines per load and use 16-32 B of each: ~8x the L2->L1 traffic.
 template <int S, bool TILED>
-__global__ __launch_bounds__(S * 64) __attribute__((amdgpu_waves_per_eu(2))) void gemm_q8q4_tile_kernel(MfmaQ4Params p, int mtiles) {
+__global__ __launch_bounds__(S * 64) __attribute__((amdgpu_waves_per_eu(3))) void gemm_q8q4_tile_kernel(MfmaQ4Params p, int mtiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nl = lane & 31, h = lane >> 5;
@@ -1197,36 +1197,34 @@ __global__ __launch_bounds__(S * 64) __attribute__((amdgpu_waves_per_eu(2))) voi
     const uint8_t* wp = TILED ? p.w + (((size_t)(p.n0 / 32 + ct) * nblk + b0) * 32 + nl) * 16 : p.w + (size_t)ncol * p.ldb + (size_t)b0 * 16;
     const float* sp = TILED ? p.ws + ((size_t)(p.n0 / 32 + ct) * nblk + b0) * 32 + nl : p.ws + (size_t)ncol * p.ldbf + b0;
     constexpr int ASTEP = TILED ? 1024 : QB, WSTEP = TILED ? 512 : 16, SSTEP = TILED ? 32 : 1;
-    // ring of 4 block slots (A 16 B, W 16 B, scale), refilled right after use => loads run 3..4 blocks ahead
-    i32x4 a_s[4], w_s[4];
-    float s_s[4];
+    // two register sets of 4 blocks each (A 16 B, W 16 B, scale per block), ping-pong: the loads of chunk c+1 are issued
+    // before chunk c is computed, so they have ~250 instructions of cover; the loop is unrolled over both sets (no copies)
+    i32x4 a0[4], w0[4], a1[4], w1[4];
+    float s0[4], s1[4];
     const int last = nbr - 1;
-    auto load_slot = [&](int q, int blk) __attribute__((always_inline)) {
-        blk = blk < last ? blk : last;                        // branch-free: blocks past the range reload the last one
-        a_s[q] = *(const i32x4*)(ap + (size_t)blk * ASTEP);
-        w_s[q] = __builtin_nontemporal_load((const i32x4*)(wp + (size_t)blk * WSTEP));
-        s_s[q] = sp[(size_t)blk * SSTEP];
+    auto load_chunk = [&](i32x4 (&av)[4], i32x4 (&wv)[4], float (&sv)[4], int blk0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int blk = blk0 + q;
+            blk = blk < last ? blk : last;                    // branch-free: blocks past the range reload the last one
+            av[q] = *(const i32x4*)(ap + (size_t)blk * ASTEP);
+            wv[q] = __builtin_nontemporal_load((const i32x4*)(wp + (size_t)blk * WSTEP));
+            sv[q] = sp[(size_t)blk * SSTEP];
+        }
     };
     const int sh = h ? 0 : 4;
-    auto block_mfma = [&](int q) __attribute__((always_inline)) -> i32x16 {
-        i32x4 bw = w_s[q] << sh;
-        bw = (bw & (int)0xF0F0F0F0) ^ (int)0x80808080;     // int8 16*(nib-8): low nibbles for h=0, high for h=1
-        const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // inline-constant C operand
-        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a_s[q], bw, z, 0, 0, 0);
-    };
     f32x2 acc2[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) acc2[r] = f32x2{0.0f, 0.0f};
-#pragma unroll
-    for (int q = 0; q < 4; q++) load_slot(q, q);
-    for (int c = 0; c < nbr; c += 4) {
+    auto compute_chunk = [&](const i32x4 (&av)[4], const i32x4 (&wv)[4], const float (&sv)[4], int blk0) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int blk = c + q;
-            const i32x16 d = block_mfma(q);     // other waves' VALU work covers this MFMA's latency (3-4 waves per SIMD)
-            const float s16 = s_s[q] * 0.0625f;
-            load_slot(q, blk + 4);              // slot consumed: refill it 4 blocks ahead
-            const float* dr = dA + blk * 32 + 4 * h;
+            i32x4 bw = wv[q] << sh;
+            bw = (bw & (int)0xF0F0F0F0) ^ (int)0x80808080;     // int8 16*(nib-8): low nibbles for h=0, high for h=1
+            const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // inline-constant C operand
+            const i32x16 d = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[q], bw, z, 0, 0, 0);
+            const float s16 = sv[q] * 0.0625f;
+            const float* dr = dA + (blk0 + q) * 32 + 4 * h;
 #pragma unroll
             for (int j = 0; j < 4; j++) {   // rows 4h + 8j + (0..3)
                 const float4 da4 = *(const float4*)(dr + 8 * j);
@@ -1236,8 +1234,17 @@ __global__ __launch_bounds__(S * 64) __attribute__((amdgpu_waves_per_eu(2))) voi
                 acc2[2 * j + 0] = __builtin_elementwise_fma(p01, d01, acc2[2 * j + 0]);
                 acc2[2 * j + 1] = __builtin_elementwise_fma(p23, d23, acc2[2 * j + 1]);
             }
-            __builtin_amdgcn_sched_barrier(0);   // one block's MFMA result live at a time (no hoisting across steps)
+            // pin this block's scaling here (the optimizer otherwise sinks all four blocks' VALU work below the fourth
+            // MFMA and keeps four result tiles live): the accumulators pass through an opaque asm
+            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(acc2[2]), "+v"(acc2[3]), "+v"(acc2[4]), "+v"(acc2[5]), "+v"(acc2[6]), "+v"(acc2[7]));
         }
+    };
+    load_chunk(a0, w0, s0, 0);
+    for (int c = 0; c < nbr; c += 8) {   // host guarantees nbr % 8 == 0
+        load_chunk(a1, w1, s1, c + 4);
+        compute_chunk(a0, w0, s0, c);
+        load_chunk(a0, w0, s0, c + 8);
+        compute_chunk(a1, w1, s1, c + 4);
     }
     float acc[16];
 #pragma unroll

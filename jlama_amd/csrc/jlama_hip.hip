@@ -269,11 +269,11 @@ int launch_gemm_q8q4_tile(const MfmaQ4Params& g, int mtiles, hipStream_t st) {
 int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = false) {
     const int mt = (g.m + 31) / 32;
     const int nblk = g.k / QB;
-    if (nblk % 4 == 0 && (size_t)nblk * 128 <= 150 * 1024 && (tiled || (g.lda % 16) == 0) && (tiled || !env_int("JH_GEMM_FAT", 0))) {
+    if (nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024 && (tiled || (g.lda % 16) == 0) && (tiled || !env_int("JH_GEMM_FAT", 0))) {
         // one 32x32 output tile per workgroup; split K over S waves until the chip has >= ~8 waves per CU
         const long long tiles = (long long)mt * (g.n / 32);
         int S = 1;
-        while (S < 8 && tiles * S < (long long)g_cu_count * 8 && nblk % (8 * S) == 0) S *= 2;
+        while (S < 8 && tiles * S < (long long)g_cu_count * 8 && nblk % (16 * S) == 0) S *= 2;   // nblk/S stays a multiple of 8
         if (tiled) {
             switch (S) {
                 case 1: return launch_gemm_q8q4_tile<1, true>(g, mt, st);
@@ -289,7 +289,7 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
             default: return launch_gemm_q8q4_tile<8, false>(g, mt, st);
         }
     }
-    if (tiled) return set_err(JH_ERR_UNSUPPORTED, "tiled I8xQ4 GEMM needs K % 128 == 0");
+    if (tiled) return set_err(JH_ERR_UNSUPPORTED, "tiled I8xQ4 GEMM needs K % 256 == 0");
     switch (mt) {
         case 1: return launch_gemm_q8q4_mfma_mt<1>(g, st);
         case 2: return launch_gemm_q8q4_mfma_mt<2>(g, st);
@@ -1075,7 +1075,7 @@ int prefill_alloc(jh_session* s) {
 bool prefill_tiled(jh_session* s, int K) {
     static const int enabled = env_int("JH_PREFILL_TILED", 1);
     const int nblk = K / QB;
-    return enabled && s->m->c.weight_dtype == JH_DT_Q4 && nblk % 4 == 0 && (size_t)nblk * 128 <= 150 * 1024;
+    return enabled && s->m->c.weight_dtype == JH_DT_Q4 && nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024;
 }
 // resident re-tiled copy of a Q4 weight, made on first use (costs a second copy of the weights in HBM)
 int ensure_tiled(JWeight& W, hipStream_t st) {
