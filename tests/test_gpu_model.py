@@ -321,3 +321,34 @@ def test_batched_prefill_matches_row_path_and_oracle(gpu, oracle, monkeypatch, d
         no, lo = om.sample(xo[-1])
         assert g == no or lo.max() - lo[g] <= LOGIT_TOL, (i, g, no)
         tok = int(g)
+
+
+@pytest.mark.parametrize("shards", [1, 2])
+def test_checkpoint_loads_straight_into_hbm(gpu, oracle, tmp_path, shards):
+    """f1: a JQ4 safetensors checkpoint directory (config.json + model.safetensors[.index.json]) -> resident model via
+    the mmap'd bytes; identical bits to the model built from the in-memory tensors, and oracle parity on top."""
+    from jlama_amd import safetensors_jq4 as ST, synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    cfg = dict(S.SMALL)
+    w = S.make_weights(cfg, seed=31)
+    d = str(tmp_path / "ckpt")
+    ST.write_llama_checkpoint(d, cfg, w, shards=shards)
+    prompt = S.prompt_tokens(cfg, n=20, seed=9)
+    ref = HipLlamaModel(cfg, w)
+    got = ST.load_llama(d)
+    assert got.weight_bytes() == ref.weight_bytes()
+    sr, sg = ref.session(64), got.session(64)
+    np.testing.assert_array_equal(sg.forward(prompt, 0), sr.forward(prompt, 0))
+    tr, lr = sr.sample(0.0, 0.5, want_logits=True)
+    tg, lg = sg.sample(0.0, 0.5, want_logits=True)
+    assert tr == tg
+    np.testing.assert_array_equal(lg, lr)
+    np.testing.assert_array_equal(sg.decode_n(tg, prompt.size, 8), sr.decode_n(tr, prompt.size, 8))
+    # layer shards read only their own tensors and chain to the same result
+    x = None
+    for k, rng in enumerate(((0, 1), (1, 3))):
+        m = ST.load_llama(d, layer_range=rng)
+        x = m.session(64).forward(tokens=prompt if k == 0 else None, start_pos=0, x=x)
+    np.testing.assert_array_equal(x, ref.session(64).forward(prompt, 0))
+    om = oracle.OracleModel(cfg, w)
+    assert _rel(x, om.session().forward(prompt, 0)) <= TRUNK_TOL
