@@ -1459,6 +1459,16 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 2), env_int("JH_LM_WAVES", 8), cu * env_int("JH_LM_GRIDX", 2), 1};   // tools/sweep_lm.py
     if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
     s->prefill_batch_min = env_int("JH_PREFILL_BATCH_MIN", 4);   // chunks of fewer rows go row by row; 0 disables batching
+    if (prefill_batch_ok(s)) {
+        // the MFMA-ordered weight copies of the prefill GEMM are made here, once per model, not inside the first prompt
+        for (int li = c.layer_start; li < c.layer_end; li++) {
+            JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+            JWeight* list[] = {&m->qkv[(size_t)li], &W[JH_W_O], &W[JH_W_GATE], &W[JH_W_UP], &W[JH_W_DOWN]};
+            for (JWeight* w : list)
+                if (w->data && w->dtype == JH_DT_Q4 && prefill_tiled(s, w->cols) && (w->rows % 32) == 0) JHCHK(ensure_tiled(*w, s->stream));
+        }
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
     *out = s;
     return JH_OK;
 }
