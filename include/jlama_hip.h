@@ -210,6 +210,18 @@ int jh_session_destroy(jh_session* s);
 /* out4 = {layersPerPage, ctxPerPage, nLayerPages, nCtxPages} */
 int jh_session_page_info(jh_session* s, int32_t* out4);
 
+/* ---- Tensor-parallel (head-split) shard, SURVEY.md 8(e)/f2.  Replaces the reference's model-shard workers
+ * (DistributedContext.java:79-98; the partial results are combined by tensorReducer, CausalSelfAttention.java:378,
+ * MLPBlock.java:160).  The shard's jh_config carries its LOCAL n_heads / n_kv_heads / hidden_length and the weights are
+ * the matching windows: q,k,v,gate,up by rows, o,down by K columns.  Between the halves the CALLER sums the partial
+ * [E] F32 vectors over shards (RCCL all-reduce).  Asynchronous on the session's stream; device pointers. */
+int jh_model_set_kv_head_offset(jh_model* m, int kv_head_offset);   /* global index of local kv head 0 (RoPE rows, CausalSelfAttention.java:260-283) */
+int jh_tp_set_row(jh_session* s, int32_t token, const float* x_dev, int pos);  /* x = embedding row of token (or x_dev), position pos */
+int jh_tp_attn(jh_session* s, int layer, float* partial_out_dev);  /* norm, q|k|v, KV write+RoPE, attention, o-proj partial (no residual) */
+int jh_tp_ffn(jh_session* s, int layer, const float* reduced_attn_dev, float* partial_out_dev);  /* x1 = x + reduced; norm, gate/up, SiLU*up, down partial */
+int jh_tp_finish_layer(jh_session* s, const float* reduced_ffn_dev);  /* x = x1 + reduced */
+int jh_session_get_row(jh_session* s, float* out, int to_device);   /* the session's current row x [E] */
+
 /* batchForward (AbstractModel.java:295-312): run rows through this shard's layers at positions
  * [start_pos, start_pos+n).  tokens != NULL: rows come from the embedding table (first shard);
  * else x_in (HOST, [n,E] F32) is the previous shard's output.  x_out (HOST [n,E], may be NULL) receives the

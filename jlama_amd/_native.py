@@ -96,6 +96,12 @@ _PROTOS = {
     "jh_decode_n_async": (_i, [_p, _i, _i, _i]),
     "jh_decode_wait": (_i, [_p, _p, _i]),
     "jh_get_logits": (_i, [_p, _p]),
+    "jh_model_set_kv_head_offset": (_i, [_p, _i]),
+    "jh_tp_set_row": (_i, [_p, _i, _p, _i]),
+    "jh_tp_attn": (_i, [_p, _i, _p]),
+    "jh_tp_ffn": (_i, [_p, _i, _p, _p]),
+    "jh_tp_finish_layer": (_i, [_p, _p]),
+    "jh_session_get_row": (_i, [_p, _p, _i]),
     "jh_set_tap_layer": (_i, [_p, _i]),
     "jh_get_tap": (_i, [_p, _i, _p, _i]),
     "jh_session_stream": (_p, [_p]),

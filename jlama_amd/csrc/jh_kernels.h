@@ -1278,6 +1278,10 @@ __global__ __launch_bounds__(S * 64) __attribute__((amdgpu_waves_per_eu(3))) voi
     }
 }
 
+__global__ void add_rows_kernel(const float* a, const float* b, float* out, int n) {   // out = a + b (residual add)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
 __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
     st->pos = pos; st->token = token; st->step = step;
 }
@@ -1363,6 +1367,7 @@ struct AttnParams {
     long long page_elems;  //   each page = [layersPerPage, 2, ctxPerPage, KV] F32 (KvBufferCache.java:99-112)
     int rel_layer_in_page, ctx_per_page, cpp_shift;   // cpp_shift = log2(ctx_per_page) or -1
     int n_heads, n_kv_heads, head_size;
+    int kv_head_offset;    // tensor-parallel shard: global index of local kv head 0 (RoPE rows are indexed globally)
     const DecodeState* st;
     float scale;
     float* part_o;         // [n_heads][part_stride][hs]   slice outputs
@@ -1437,7 +1442,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
 
     // ---- ONE round trip: every global load of the main phase is issued here, branch-free (clamped addresses), in
     // the order the results are consumed (vmcnt retires oldest-first): q + rope, new k/v, then K rows, then V rows.
-    const float* rf = p.rope + ((size_t)pos * half + (size_t)kvh * HS) * 2;  // rf[poffset + g], g = kvh*HS + i
+    const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;  // rf[poffset + g], g = kvHead*HS + i
     float q0[NQ], q1[NQ], qc[NQ], qsn[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; u++) {
@@ -1833,7 +1838,7 @@ struct PrefillAttnParams {
     const float* rope;
     float* kv_base; long long page_elems;
     int rel_layer_in_page, ctx_per_page, cpp_shift;
-    int n_heads, n_kv_heads, head_size;
+    int n_heads, n_kv_heads, head_size, kv_head_offset;
     int start_pos, rows;
     float scale;
     float* out; int ldo;          // [rows][A]
@@ -1852,7 +1857,7 @@ __global__ __launch_bounds__(256) void rows_rope_kv_kernel(PrefillAttnParams p) 
         const int hh = i / half, d = i - hh * half;
         const bool isq = hh < p.n_heads;
         const int kvh = isq ? hh / group : hh - p.n_heads;
-        const float* rf = p.rope + ((size_t)pos * half + (size_t)kvh * HS) * 2;
+        const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
         float* v = isq ? r + (size_t)hh * HS : r + A + (size_t)kvh * HS;
         const float a = v[d], b = v[d + half], c = rf[2 * d], s = rf[2 * d + 1];
         const float r0 = a * c - b * s;

@@ -838,6 +838,7 @@ struct jh_model {
     float* rope = nullptr;
     float attention_scale;
     int64_t weight_bytes = 0;
+    int kv_head_offset = 0;   // tensor-parallel shard (jh_model_set_kv_head_offset)
 };
 enum { TAP_SLOTS = 12 };
 struct jh_session {
@@ -899,6 +900,7 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     p.n_heads = c.n_heads;
     p.n_kv_heads = c.n_kv_heads;
     p.head_size = c.head_size;
+    p.kv_head_offset = m->kv_head_offset;
     p.st = s->st;
     p.scale = m->attention_scale;
     p.part_o = s->part_o;
@@ -940,12 +942,14 @@ int tap_copy(jh_session* s, int which, const float* src, int n, hipStream_t st) 
 
 // One TransformerBlock.forward (core/model/TransformerBlock.java:158-215) for the row described by s->st:
 // 5 launches -- qkv(+rmsnorm+q8) | attention(+rope+kv write+q8) | o-proj(+residual) | gate/up(+rmsnorm+q8,+silu*up+q8) | down(+residual)
-int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_tap) {
+// in two halves, split where tensor-parallel shards synchronise (tensorReducer: CausalSelfAttention.java:378,
+// MLPBlock.java:160).  resid == nullptr => the projection's partial result is stored WITHOUT the residual.
+int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_tap, float* out, const float* resid) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
     const int rel = li - c.layer_start;
     const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
-    const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
+    const int E = c.embedding_length, hs = c.head_size;
     const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
     if (tap) JHCHK(tap_copy(s, JH_TAP_INPUT_EMB, s->x, E, st));
     {   // q,k,v projections (CausalSelfAttention.java:161-171) with fused preAttentionNorm + maybeQuantize
@@ -977,12 +981,15 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
     {   // output projection (:365-376) + residual (TransformerBlock.java:185)
         GemvParams p;
         memset(&p, 0, sizeof(p));
-        p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = s->x1;
+        p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = out;
         p.K = A; p.ldb = A / 2; p.ldbf = A / QB;
-        p.x = s->attf; p.resid = s->x;   // maybeQuantize(valueBatch) (:364) happens in the prologue
+        p.x = s->attf; p.resid = resid;   // maybeQuantize(valueBatch) (:364) happens in the prologue
         if (c.weight_dtype == JH_DT_BF16) {
             p.ldb = A * 2;
-            JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
+            if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
+            else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
+        } else if (!resid) {
+            JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_STORE>(p, s->cfg_o, st)));
         } else if (s->direct_max > 0) {
             // short contexts: the attention slices are combined here, under the weight prefetch
             p.part_o = s->part_o; p.part_ml = s->part_ml; p.st = s->st; p.direct_max = s->direct_max;
@@ -996,8 +1003,16 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
     }
     if (tap) {
         JHCHK(tap_copy(s, JH_TAP_AFTER_ATTENTION, s->attf, A, st));   // written by attention (ticket mode) or by the o-proj prologue
-        JHCHK(tap_copy(s, 8, s->x1, E, st));
+        JHCHK(tap_copy(s, 8, out, E, st));
     }
+    return JH_OK;
+}
+// feed-forward half: reads s->x1, writes `out` (+ resid)
+int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out, const float* resid) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    const int E = c.embedding_length, H = c.hidden_length;
     {   // gate/up (MLPBlock.java:117-142) with fused preFFNorm + maybeQuantize, SiLU*up + maybeQuantize
         GemvParams p;
         memset(&p, 0, sizeof(p));
@@ -1014,15 +1029,26 @@ int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_ta
     {   // down projection (:147-158) + residual (TransformerBlock.java:203)
         GemvParams p;
         memset(&p, 0, sizeof(p));
-        p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x;
+        p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = out;
         p.K = H; p.ldb = H / 2; p.ldbf = H / QB;
-        p.x = s->hf; p.resid = s->x1;
-        if (c.weight_dtype == JH_DT_BF16) { p.ldb = H * 2; JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st))); }
-        else
-        JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
+        p.x = s->hf; p.resid = resid;
+        if (c.weight_dtype == JH_DT_BF16) {
+            p.ldb = H * 2;
+            if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
+            else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
+        } else if (resid) {
+            JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
+        } else {
+            JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_STORE>(p, s->cfg_down, st)));
+        }
         JHCHK(trace_sync("down", st));
     }
-    if (tap) JHCHK(tap_copy(s, JH_TAP_POST_FF_RES, s->x, E, st));
+    return JH_OK;
+}
+int layer_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_tap) {
+    JHCHK(layer_attn_launch(s, li, st, tap, pos_for_tap, s->x1, s->x));
+    JHCHK(layer_ffn_launch(s, li, st, tap, s->x, s->x1));
+    if (tap) JHCHK(tap_copy(s, JH_TAP_POST_FF_RES, s->x, s->m->c.embedding_length, st));
     return JH_OK;
 }
 
@@ -1129,7 +1155,7 @@ int prefill_attn_launch(jh_session* s, int rel, int start_pos, int rows, hipStre
     p.cpp_shift = -1;
     for (int sh = 0; sh < 30; sh++)
         if ((1 << sh) == s->ctx_per_page) p.cpp_shift = sh;
-    p.n_heads = c.n_heads; p.n_kv_heads = c.n_kv_heads; p.head_size = hs;
+    p.n_heads = c.n_heads; p.n_kv_heads = c.n_kv_heads; p.head_size = hs; p.kv_head_offset = m->kv_head_offset;
     p.start_pos = start_pos; p.rows = rows; p.scale = m->attention_scale;
     p.out = s->pb_att; p.ldo = A;
     hipLaunchKernelGGL(rows_rope_kv_kernel, dim3(rows), dim3(256), 0, st, p);
@@ -1704,6 +1730,66 @@ int jh_forward(jh_session* s, const int32_t* tokens, const float* x_in, int n, i
 }
 int jh_forward_device(jh_session* s, const int32_t* tokens, const float* x_in_dev, int n, int start_pos, float* x_out_dev) {
     return forward_impl(s, tokens, x_in_dev, true, n, start_pos, x_out_dev, true);
+}
+
+// ---- tensor-parallel (head-split) shard: the model is created with its LOCAL head counts / hidden length and holds
+// the matching row / column windows of the weights (DistributedContext.java:79-98); the caller all-reduces the partial
+// [E] results between the halves (tensorReducer, CausalSelfAttention.java:378, MLPBlock.java:160).  All calls are
+// asynchronous on the session's stream; pointers are device pointers.
+int jh_model_set_kv_head_offset(jh_model* m, int kv_head_offset) {
+    if (!m || kv_head_offset < 0) return set_err(JH_ERR_INVALID, "set_kv_head_offset: bad argument");
+    m->kv_head_offset = kv_head_offset;
+    return JH_OK;
+}
+int jh_tp_set_row(jh_session* s, int32_t token, const float* x_dev, int pos) {
+    if (!s || pos < 0 || pos >= s->max_ctx) return set_err(JH_ERR_INVALID, "tp_set_row: bad argument");
+    jh_model* m = s->m;
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = s->stream;
+    const int E = m->c.embedding_length;
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, pos, token >= 0 ? token : 0, 0);
+    if (x_dev) {
+        HIPCHK(hipMemcpyAsync(s->x, x_dev, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+    } else {
+        const JWeight& emb = m->global_w[JH_W_EMBED];
+        if (!emb.data) return set_err(JH_ERR_INVALID, "tp_set_row: this shard has no embedding table");
+        if (token < 0 || token >= m->c.vocab_size) return set_err(JH_ERR_INVALID, "tp_set_row: token id out of range");
+        hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                           (const DecodeState*)s->st, E, s->x);
+    }
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+int jh_tp_attn(jh_session* s, int layer, float* partial_out_dev) {
+    if (!s || !partial_out_dev || layer < s->m->c.layer_start || layer >= s->m->c.layer_end) return set_err(JH_ERR_INVALID, "tp_attn: bad argument");
+    HIPCHK(hipSetDevice(s->m->device));
+    return layer_attn_launch(s, layer, s->stream, false, 0, partial_out_dev, nullptr);
+}
+int jh_tp_ffn(jh_session* s, int layer, const float* reduced_attn_dev, float* partial_out_dev) {
+    if (!s || !reduced_attn_dev || !partial_out_dev || layer < s->m->c.layer_start || layer >= s->m->c.layer_end)
+        return set_err(JH_ERR_INVALID, "tp_ffn: bad argument");
+    HIPCHK(hipSetDevice(s->m->device));
+    const int E = s->m->c.embedding_length;
+    // residual (TransformerBlock.java:185) after the reduction: x1 = x + sum_shards(o-proj partial)
+    hipLaunchKernelGGL(add_rows_kernel, dim3((E + 255) / 256), dim3(256), 0, s->stream, (const float*)s->x, reduced_attn_dev, s->x1, E);
+    HIPCHK(hipGetLastError());
+    return layer_ffn_launch(s, layer, s->stream, false, partial_out_dev, nullptr);
+}
+int jh_tp_finish_layer(jh_session* s, const float* reduced_ffn_dev) {
+    if (!s || !reduced_ffn_dev) return set_err(JH_ERR_INVALID, "tp_finish_layer: bad argument");
+    HIPCHK(hipSetDevice(s->m->device));
+    const int E = s->m->c.embedding_length;
+    // residual (TransformerBlock.java:203): x = x1 + sum_shards(down partial)
+    hipLaunchKernelGGL(add_rows_kernel, dim3((E + 255) / 256), dim3(256), 0, s->stream, (const float*)s->x1, reduced_ffn_dev, s->x, E);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+int jh_session_get_row(jh_session* s, float* out, int to_device) {
+    if (!s || !out) return set_err(JH_ERR_INVALID, "get_row: null");
+    HIPCHK(hipSetDevice(s->m->device));
+    HIPCHK(hipMemcpyAsync(out, s->x, (size_t)s->m->c.embedding_length * 4, to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s->stream));
+    if (!to_device) HIPCHK(hipStreamSynchronize(s->stream));
+    return JH_OK;
 }
 
 int jh_get_logits(jh_session* s, float* out_v) {

@@ -138,6 +138,158 @@ def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_pe
     return out
 
 
+# ------------------------------------------------------------------------------------------------ tensor parallel (f2)
+# Head split, SURVEY.md 8(e): DistributedContext.java:79-98 gives model shard r of N the attention heads
+# [r*heads/N, (r+1)*heads/N), the kv heads [r*kvHeads/N, ...) and the hidden rows [r*H/N, ...); q/k/v/gate/up are split by
+# OUTPUT rows (Weights.getLoadOffsets row windows), o/down by INPUT columns (attentionSegment / hiddenSegment of
+# dotProductChunk, CausalSelfAttention.java:365-376, MLPBlock.java:147-158); the partial [B,E] results are summed over
+# shards (tensorReducer :378 / :160) before the residual.  The reference caps N at the number of kv heads
+# (JlamaService.java:65-68).  Here the sum is one RCCL all-reduce of 16 KiB (E=4096) per half layer; with 2 per layer it
+# is latency-bound, so this path raises capacity (a 70B model over 8 GPUs without pipeline bubbles), not batch-1 speed.
+
+def tp_shard_config(cfg, rank, size):
+    """(local cfg, kv_head_offset) of model shard `rank` of `size`."""
+    if cfg["n_kv_heads"] % size or cfg["n_heads"] % size or cfg["hidden_length"] % (32 * size):
+        raise ValueError(f"cannot split {cfg['n_heads']} heads / {cfg['n_kv_heads']} kv heads / H={cfg['hidden_length']} over {size} shards")
+    c = dict(cfg)
+    c["n_heads"] = cfg["n_heads"] // size
+    c["n_kv_heads"] = cfg["n_kv_heads"] // size
+    c["hidden_length"] = cfg["hidden_length"] // size
+    return c, rank * c["n_kv_heads"]
+
+
+def _rows(w, r0, n):
+    out = dict(w)
+    out["data"] = np.ascontiguousarray(w["data"][r0:r0 + n])
+    out["scales"] = None if w.get("scales") is None else np.ascontiguousarray(w["scales"][r0:r0 + n])
+    out["shape"] = (n, w["shape"][1])
+    return out
+
+
+def _cols(w, c0, n):
+    """K-column window [c0, c0+n) of a weight; Q4 nibbles are [rows, cols/2] bytes in blocks of 32 columns = 16 bytes."""
+    from . import _native as N
+    out = dict(w)
+    if w["dtype"] == N.DT_Q4:
+        assert c0 % 32 == 0 and n % 32 == 0
+        out["data"] = np.ascontiguousarray(w["data"][:, c0 // 2:(c0 + n) // 2])
+        out["scales"] = np.ascontiguousarray(w["scales"][:, c0 // 32:(c0 + n) // 32])
+    else:
+        out["data"] = np.ascontiguousarray(w["data"][:, c0:c0 + n])
+    out["shape"] = (w["shape"][0], n)
+    return out
+
+
+def tp_shard_weights(cfg, weights, rank, size):
+    """The windows of `weights` (full model, host arrays) that model shard `rank` holds.  Norm weights, the embedding
+    table and the LM head are replicated (every shard computes the same residual stream; rank 0 samples)."""
+    from . import synthetic as S
+    hs = cfg["head_size"]
+    A, KV, H = cfg["n_heads"] * hs // size, cfg["n_kv_heads"] * hs // size, cfg["hidden_length"] // size
+    out = {}
+    for (layer, slot), w in weights.items():
+        if layer < 0 or slot in (S.W_NORM1, S.W_NORM2):
+            out[(layer, slot)] = w
+        elif slot == S.W_Q:
+            out[(layer, slot)] = _rows(w, rank * A, A)
+        elif slot in (S.W_K, S.W_V):
+            out[(layer, slot)] = _rows(w, rank * KV, KV)
+        elif slot in (S.W_GATE, S.W_UP):
+            out[(layer, slot)] = _rows(w, rank * H, H)
+        elif slot == S.W_O:
+            out[(layer, slot)] = _cols(w, rank * A, A)
+        elif slot == S.W_DOWN:
+            out[(layer, slot)] = _cols(w, rank * H, H)
+    return out
+
+
+class TPEngine:
+    """What a tensor-parallel shard provides; buffers are torch tensors on the engine's device ([E] float32)."""
+
+    def set_row(self, token, pos):
+        raise NotImplementedError
+
+    def attn(self, layer, partial):                 # partial <- this shard's o-projection partial
+        raise NotImplementedError
+
+    def ffn(self, layer, reduced, partial):         # x1 = x + reduced; partial <- this shard's down-projection partial
+        raise NotImplementedError
+
+    def finish_layer(self, reduced):                # x = x1 + reduced
+        raise NotImplementedError
+
+    def sample(self):                               # rank 0: greedy token of the current row
+        raise NotImplementedError
+
+
+class HipTPEngine(TPEngine):
+    """One head-split shard resident on one MI355X (Tier-2 C ABI); one session (batch 1)."""
+
+    def __init__(self, cfg, weights, rank, size, device_index, max_ctx):
+        import torch
+        from .model import HipLlamaModel
+        self.torch = torch
+        lcfg, off = tp_shard_config(cfg, rank, size)
+        self.model = HipLlamaModel(lcfg, tp_shard_weights(cfg, weights, rank, size), device=device_index, kv_head_offset=off)
+        self.s = self.model.session(max_ctx)
+
+    def _after_torch(self):
+        self.torch.cuda.current_stream().synchronize()   # the all-reduce ran on torch's stream
+
+    def set_row(self, token, pos):
+        self.s.tp_set_row(token, pos)
+
+    def attn(self, layer, partial):
+        self.s.tp_attn(layer, partial.data_ptr())
+        self.s.synchronize()
+
+    def ffn(self, layer, reduced, partial):
+        self._after_torch()
+        self.s.tp_ffn(layer, reduced.data_ptr(), partial.data_ptr())
+        self.s.synchronize()
+
+    def finish_layer(self, reduced):
+        self._after_torch()
+        self.s.tp_finish_layer(reduced.data_ptr())
+
+    def sample(self):
+        return self.s.sample(0.0, 0.5)
+
+
+def tp_forward_row(dist, engine, token, pos, layers, buf):
+    """One row through all layers on every shard: 2 all-reduces (sum) per layer.  buf: [E] float32 on the engine's device."""
+    engine.set_row(token, pos)
+    for li in range(*layers):
+        engine.attn(li, buf)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        engine.ffn(li, buf, buf)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        engine.finish_layer(buf)
+
+
+def tp_generate(dist, engine, rank, prompt, n_gen, cfg, device, dtype):
+    """Greedy generation with every rank holding a head-split shard: rows are fed one position at a time
+    (batchForwardSlow order), rank 0 samples (Coordinator.java:184) and broadcasts the token id."""
+    import torch
+    buf = torch.empty(cfg["embedding_length"], dtype=dtype, device=device)
+    tok = torch.zeros(1, dtype=torch.int32, device=device)
+    layers = (0, cfg["n_layers"])
+    out = []
+    pos = 0
+    for t in prompt:
+        tp_forward_row(dist, engine, int(t), pos, layers, buf)
+        pos += 1
+    for _ in range(n_gen):
+        if rank == 0:
+            tok[0] = engine.sample()
+        dist.broadcast(tok, src=0)
+        nxt = int(tok.item())
+        out.append(nxt)
+        tp_forward_row(dist, engine, nxt, pos, layers, buf)
+        pos += 1
+    return np.asarray(out, dtype=np.int32)
+
+
 def bench_pipeline(args, cfg):
     """bench.py's N>1 leg (one rank per GPU under torch.distributed.run).  Returns the JSON dict on rank 0."""
     import torch

@@ -15,9 +15,11 @@ MAX_BATCH_SIZE = 256  # jlama.max_batch_size (AbstractModel.java:57)
 
 
 class HipLlamaModel:
-    def __init__(self, cfg: dict, weights: dict, layer_range=None, device=0):
+    def __init__(self, cfg: dict, weights: dict, layer_range=None, device=0, kv_head_offset=0):
         """weights: {(layer|-1, slot): {dtype, data, scales, shape}} with numpy arrays (host) or
-        objects exposing ``data_ptr()`` (device tensors); layer_range = this shard's [start, end)."""
+        objects exposing ``data_ptr()`` (device tensors); layer_range = this shard's [start, end).
+        kv_head_offset: tensor-parallel shard only (cfg then carries the LOCAL head counts / hidden length, see
+        distributed.tp_shard_config) -- global index of its first kv head."""
         N.init(device)
         L = cfg["n_layers"]
         ls, le = layer_range if layer_range else (0, L)
@@ -28,6 +30,8 @@ class HipLlamaModel:
                           cfg["rms_eps"], cfg["rope_theta"], cfg.get("rope_scaling", 1.0))
         self.h = C.c_void_p()
         N.check(N.lib().jh_model_create(C.byref(self.c), C.byref(self.h)))
+        if kv_head_offset:
+            N.check(N.lib().jh_model_set_kv_head_offset(self.h, int(kv_head_offset)))
         for (layer, slot), w in weights.items():
             if layer >= 0 and not (ls <= layer < le):
                 continue
@@ -107,6 +111,24 @@ class HipSession:
         for i in range(0, tokens.size, MAX_BATCH_SIZE):
             last = self.forward(tokens[i:i + MAX_BATCH_SIZE], start_pos + i)
         return last
+
+    # -- tensor-parallel halves (device pointers; asynchronous on the session's stream) ---------------------
+    def tp_set_row(self, token, pos, x_ptr=None):
+        N.check(N.lib().jh_tp_set_row(self.h, int(token) if token is not None else -1, C.c_void_p(x_ptr) if x_ptr else None, pos))
+
+    def tp_attn(self, layer, partial_ptr):
+        N.check(N.lib().jh_tp_attn(self.h, layer, C.c_void_p(partial_ptr)))
+
+    def tp_ffn(self, layer, reduced_ptr, partial_ptr):
+        N.check(N.lib().jh_tp_ffn(self.h, layer, C.c_void_p(reduced_ptr), C.c_void_p(partial_ptr)))
+
+    def tp_finish_layer(self, reduced_ptr):
+        N.check(N.lib().jh_tp_finish_layer(self.h, C.c_void_p(reduced_ptr)))
+
+    def current_row(self):
+        out = np.empty(self.model.cfg["embedding_length"], dtype=np.float32)
+        N.check(N.lib().jh_session_get_row(self.h, N.ptr(out), 0))
+        return out
 
     # -- AbstractModel.sample ---------------------------------------------------------------------------
     def sample(self, temperature=0.0, u=0.5, want_logits=False):

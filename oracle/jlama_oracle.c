@@ -485,6 +485,7 @@ typedef struct jo_model {
     jo_ref_f32q4_fn ref_f32q4;
     int ref_flags;
     int nthreads;       /* pchunk split for ref GEMMs (core/math/VectorMath.java:38-67) */
+    int kv_head_offset; /* tensor-parallel shard: global index of local kv head 0 (DistributedContext.groupHeadStart) */
 } jo_model;
 
 typedef struct jo_session {
@@ -524,6 +525,7 @@ int jo_model_set_weight(jo_model* m, int layer, int which, int dtype, const void
     w->dtype = dtype; w->data = data; w->scales = scales; w->rows = rows; w->cols = cols;
     return 0;
 }
+void jo_model_set_kv_head_offset(jo_model* m, int off) { m->kv_head_offset = off; }
 void jo_model_set_ref_gemm(jo_model* m, void* q8q4, void* f32q4, int flags, int nthreads) {
     m->ref_q8q4 = (jo_ref_q8q4_fn)q8q4;
     m->ref_f32q4 = (jo_ref_f32q4_fn)f32q4;
@@ -666,140 +668,211 @@ static void jo_embed(jo_model* m, int token, float* out) {
     }
 }
 
-/* forward a batch of B rows through layers [layer_start, layer_end).  x: [B,E] in/out.
- * If tokens != NULL the rows are first filled from the embedding table. */
-int jo_forward(jo_session* s, const int32_t* tokens, float* x, int B, int start_pos) {
+/* ---- one TransformerBlock in two halves, split where the reference's tensor-parallel shards synchronise
+ * (tensorReducer: CausalSelfAttention.java:378, MLPBlock.java:160).  A shard model carries its LOCAL heads / kv heads /
+ * hidden rows (DistributedContext.java:79-98); the partial [B,E] results are summed over shards BEFORE the residual. */
+
+/* attention half: preAttentionNorm -> q,k,v -> KV write + RoPE -> per-head attention -> o-projection over this
+ * shard's attention segment.  x: [B,E] in;  att_out: [B,E] out (no residual). */
+static void jo_layer_attn(jo_session* s, int li, const float* x, int B, int start_pos, float* att_out) {
     jo_model* m = s->m;
     const jo_config* c = &m->c;
-    int E = c->embedding_length, H = c->hidden_length, hs = c->head_size;
+    int E = c->embedding_length, hs = c->head_size;
     int A = c->n_heads * hs, KV = c->n_kv_heads * hs, half = hs / 2;
     int group = c->n_heads / c->n_kv_heads;
-    if (tokens)
-        for (int b = 0; b < B; b++) jo_embed(m, tokens[b], x + (size_t)b * E);
-
+    int rel = li - c->layer_start;
+    const jo_weight* W = &m->layer_w[(size_t)li * JO_W_COUNT];
     float* ln = (float*)malloc(sizeof(float) * (size_t)B * E);
     float* q = (float*)malloc(sizeof(float) * (size_t)B * A);
     float* k = (float*)malloc(sizeof(float) * (size_t)B * KV);
     float* v = (float*)malloc(sizeof(float) * (size_t)B * KV);
     float* val = (float*)malloc(sizeof(float) * (size_t)B * A);
-    float* att_out = (float*)malloc(sizeof(float) * (size_t)B * E);
-    float* g = (float*)malloc(sizeof(float) * (size_t)B * H);
-    float* u = (float*)malloc(sizeof(float) * (size_t)B * H);
-    float* ff = (float*)malloc(sizeof(float) * (size_t)B * E);
     float* nw = (float*)malloc(sizeof(float) * (size_t)E);
     int max_ctx_alloc = ((start_pos + B) / s->ctx_per_page + 1) * s->ctx_per_page;
     float* attn_all = (float*)malloc(sizeof(float) * (size_t)max_ctx_alloc * (size_t)jo_num_threads());
 
-    for (int li = c->layer_start; li < c->layer_end; li++) {
-        int rel = li - c->layer_start;
-        const jo_weight* W = &m->layer_w[(size_t)li * JO_W_COUNT];
-        jo_tap(s, li, JO_TAP_INPUT_EMB, x, B * E);
-        /* preAttentionNorm TransformerBlock.java:167 */
-        jo_load_norm(&W[JO_W_NORM1], E, nw);
-        for (int b = 0; b < B; b++) jo_rmsnorm(x + (size_t)b * E, nw, 0.0f, E, c->rms_eps, ln + (size_t)b * E);
-        jo_tap(s, li, JO_TAP_LN_EMB, ln, B * E);
-        jo_act qa;
-        jo_maybe_quantize(m, ln, B, E, &qa); /* :172 */
-        /* Q,K,V GEMMs CausalSelfAttention.java:161-171 */
-        jo_weight_gemm(m, &qa, B, &W[JO_W_Q], 0, E, q, A);
-        jo_weight_gemm(m, &qa, B, &W[JO_W_K], 0, E, k, KV);
-        jo_weight_gemm(m, &qa, B, &W[JO_W_V], 0, E, v, KV);
-        jo_act_free(&qa);
-        jo_tap(s, li, JO_TAP_QUERY, q, B * A);
-        jo_tap(s, li, JO_TAP_KEY, k, B * KV);
-        jo_tap(s, li, JO_TAP_VALUE, v, B * KV);
-        memset(val, 0, sizeof(float) * (size_t)B * A); /* TensorCache buffers are zeroed on release (TensorCache.java:104-111) */
+    jo_tap(s, li, JO_TAP_INPUT_EMB, x, B * E);
+    /* preAttentionNorm TransformerBlock.java:167 */
+    jo_load_norm(&W[JO_W_NORM1], E, nw);
+    for (int b = 0; b < B; b++) jo_rmsnorm(x + (size_t)b * E, nw, 0.0f, E, c->rms_eps, ln + (size_t)b * E);
+    jo_tap(s, li, JO_TAP_LN_EMB, ln, B * E);
+    jo_act qa;
+    jo_maybe_quantize(m, ln, B, E, &qa); /* :172 */
+    /* Q,K,V GEMMs CausalSelfAttention.java:161-171 */
+    jo_weight_gemm(m, &qa, B, &W[JO_W_Q], 0, E, q, A);
+    jo_weight_gemm(m, &qa, B, &W[JO_W_K], 0, E, k, KV);
+    jo_weight_gemm(m, &qa, B, &W[JO_W_V], 0, E, v, KV);
+    jo_act_free(&qa);
+    jo_tap(s, li, JO_TAP_QUERY, q, B * A);
+    jo_tap(s, li, JO_TAP_KEY, k, B * KV);
+    jo_tap(s, li, JO_TAP_VALUE, v, B * KV);
+    memset(val, 0, sizeof(float) * (size_t)B * A); /* TensorCache buffers are zeroed on release (TensorCache.java:104-111) */
 
-        for (int bi = 0, position = start_pos; bi < B; bi++, position++) {
-            float* key = jo_kv_row(s, rel, 0, position);
-            float* vrow = jo_kv_row(s, rel, 1, position);
-            memcpy(key, k + (size_t)bi * KV, sizeof(float) * KV);  /* :226-241 copyFrom (KV dtype == working dtype F32) */
-            memcpy(vrow, v + (size_t)bi * KV, sizeof(float) * KV);
-            float* query = q + (size_t)bi * A;
-            float* value = val + (size_t)bi * A;
-            /* RoPE :247-286 (GQA branch). table index poffset + g, g over kvHead*hs + [0,half)
-             * => effective position pos + 2*kvHead (quirk kept). */
-            int poffset = position * half;
-            for (int h = 0; h < c->n_heads; h++) {
-                int offset = h * hs, goffset = (h / group) * hs; /* Config.maybeMapToGroupHead */
-                for (int i = offset, gg = goffset; i < offset + half; i++, gg++) {
-                    float q0 = query[i], q1 = query[i + half];
-                    float fcr = m->rope[(size_t)(poffset + gg) * 2], fci = m->rope[(size_t)(poffset + gg) * 2 + 1];
-                    query[i] = q0 * fcr - q1 * fci;
-                    query[i + half] = q0 * fci + q1 * fcr;
-                }
-            }
-            for (int h = 0; h < c->n_kv_heads; h++) {
-                int offset = h * hs;
-                for (int i = offset; i < offset + half; i++) {
-                    float k0 = key[i], k1 = key[i + half];
-                    float fcr = m->rope[(size_t)(poffset + i) * 2], fci = m->rope[(size_t)(poffset + i) * 2 + 1];
-                    key[i] = k0 * fcr - k1 * fci;
-                    key[i + half] = k0 * fci + k1 * fcr;
-                }
-            }
-            if (bi == B - 1) {
-                jo_tap(s, li, JO_TAP_QUERY_ROPE, query, A);
-                jo_tap(s, li, JO_TAP_KEY_ROPE, key, KV);
-            }
-            /* attention per head :314-356 */
-            int npages = position / s->ctx_per_page + 1;
-            for (int pg = 0; pg < npages; pg++) { (void)jo_kv_row(s, rel, 0, pg * s->ctx_per_page); } /* materialise pages before the parallel loop */
-            /* VectorMath.pfor(headStart, headEnd, ...) core/math/VectorMath.java:34-36 */
-#pragma omp parallel for schedule(static) if (c->n_heads >= 8 && position >= 64)
-            for (int h = 0; h < c->n_heads; h++) {
-                float* attn = attn_all + (size_t)max_ctx_alloc * (size_t)jo_thread_id();
-                int xoffset = (h / group) * hs, yoffset = h * hs;
-                for (int pg = 0; pg < npages; pg++) {
-                    int len = s->ctx_per_page, off = pg * len;
-                    int size = pg == npages - 1 ? (position + 1) - off : len;
-                    float* kpage = jo_kv_row(s, rel, 0, off);
-                    /* batchDotProduct(attn, query, kvp[i], yoffset, xoffset, headSize, offset, 0, size) :328-329 */
-                    jo_gemm_f32(query, A, kpage, KV, attn, 0, 1, yoffset, xoffset, hs, off, 0, size);
-                }
-                jo_scale_f32(m->attention_scale, attn, 0, position + 1); /* :332 */
-                jo_softmax(attn, 0, position + 1);                      /* :345 */
-                for (int pg = 0; pg < npages; pg++) {
-                    int len = s->ctx_per_page, off = pg * len;
-                    int size = pg == npages - 1 ? (position + 1) - off : len;
-                    float* vpage = jo_kv_row(s, rel, 1, off);
-                    /* saxpy(attn, vvp[i], value, xoffset, yoffset, headSize, offset, 0, size) :349-354 */
-                    jo_saxpy_batch_f32(attn, vpage, KV, value, xoffset, yoffset, hs, off, 0, size);
-                }
+    for (int bi = 0, position = start_pos; bi < B; bi++, position++) {
+        float* key = jo_kv_row(s, rel, 0, position);
+        float* vrow = jo_kv_row(s, rel, 1, position);
+        memcpy(key, k + (size_t)bi * KV, sizeof(float) * KV);  /* :226-241 copyFrom (KV dtype == working dtype F32) */
+        memcpy(vrow, v + (size_t)bi * KV, sizeof(float) * KV);
+        float* query = q + (size_t)bi * A;
+        float* value = val + (size_t)bi * A;
+        /* RoPE :247-286 (GQA branch). table index poffset + g, g over kvHead*hs + [0,half) with the GLOBAL kv head
+         * index (dctx.groupHeadStart.. :275) => effective position pos + 2*kvHead (quirk kept). */
+        int poffset = position * half + m->kv_head_offset * hs;
+        for (int h = 0; h < c->n_heads; h++) {
+            int offset = h * hs, goffset = (h / group) * hs; /* Config.maybeMapToGroupHead */
+            for (int i = offset, gg = goffset; i < offset + half; i++, gg++) {
+                float q0 = query[i], q1 = query[i + half];
+                float fcr = m->rope[(size_t)(poffset + gg) * 2], fci = m->rope[(size_t)(poffset + gg) * 2 + 1];
+                query[i] = q0 * fcr - q1 * fci;
+                query[i + half] = q0 * fci + q1 * fcr;
             }
         }
-        jo_tap(s, li, JO_TAP_AFTER_ATTENTION, val, B * A);
-        /* O projection :363-376 */
-        jo_act va;
-        jo_maybe_quantize(m, val, B, A, &va);
-        jo_weight_gemm(m, &va, B, &W[JO_W_O], 0, A, att_out, E);
-        jo_act_free(&va);
-        jo_tap(s, li, JO_TAP_POST_ATTN, att_out, B * E);
+        for (int h = 0; h < c->n_kv_heads; h++) {
+            int offset = h * hs;
+            for (int i = offset; i < offset + half; i++) {
+                float k0 = key[i], k1 = key[i + half];
+                float fcr = m->rope[(size_t)(poffset + i) * 2], fci = m->rope[(size_t)(poffset + i) * 2 + 1];
+                key[i] = k0 * fcr - k1 * fci;
+                key[i + half] = k0 * fci + k1 * fcr;
+            }
+        }
+        if (bi == B - 1) {
+            jo_tap(s, li, JO_TAP_QUERY_ROPE, query, A);
+            jo_tap(s, li, JO_TAP_KEY_ROPE, key, KV);
+        }
+        /* attention per head :314-356 */
+        int npages = position / s->ctx_per_page + 1;
+        for (int pg = 0; pg < npages; pg++) { (void)jo_kv_row(s, rel, 0, pg * s->ctx_per_page); } /* materialise pages before the parallel loop */
+        /* VectorMath.pfor(headStart, headEnd, ...) core/math/VectorMath.java:34-36 */
+#pragma omp parallel for schedule(static) if (c->n_heads >= 8 && position >= 64)
+        for (int h = 0; h < c->n_heads; h++) {
+            float* attn = attn_all + (size_t)max_ctx_alloc * (size_t)jo_thread_id();
+            int xoffset = (h / group) * hs, yoffset = h * hs;
+            for (int pg = 0; pg < npages; pg++) {
+                int len = s->ctx_per_page, off = pg * len;
+                int size = pg == npages - 1 ? (position + 1) - off : len;
+                float* kpage = jo_kv_row(s, rel, 0, off);
+                /* batchDotProduct(attn, query, kvp[i], yoffset, xoffset, headSize, offset, 0, size) :328-329 */
+                jo_gemm_f32(query, A, kpage, KV, attn, 0, 1, yoffset, xoffset, hs, off, 0, size);
+            }
+            jo_scale_f32(m->attention_scale, attn, 0, position + 1); /* :332 */
+            jo_softmax(attn, 0, position + 1);                      /* :345 */
+            for (int pg = 0; pg < npages; pg++) {
+                int len = s->ctx_per_page, off = pg * len;
+                int size = pg == npages - 1 ? (position + 1) - off : len;
+                float* vpage = jo_kv_row(s, rel, 1, off);
+                /* saxpy(attn, vvp[i], value, xoffset, yoffset, headSize, offset, 0, size) :349-354 */
+                jo_saxpy_batch_f32(attn, vpage, KV, value, xoffset, yoffset, hs, off, 0, size);
+            }
+        }
+    }
+    jo_tap(s, li, JO_TAP_AFTER_ATTENTION, val, B * A);
+    /* O projection :363-376 (over this shard's attention segment) */
+    jo_act va;
+    jo_maybe_quantize(m, val, B, A, &va);
+    jo_weight_gemm(m, &va, B, &W[JO_W_O], 0, A, att_out, E);
+    jo_act_free(&va);
+    jo_tap(s, li, JO_TAP_POST_ATTN, att_out, B * E);
+    free(ln); free(q); free(k); free(v); free(val); free(nw); free(attn_all);
+}
+
+/* feed-forward half: preFFNorm -> gate, up -> SiLU*up -> down over this shard's hidden segment.
+ * att_res: [B,E] in (= attention output + residual);  ff: [B,E] out (no residual). */
+static void jo_layer_ffn(jo_session* s, int li, const float* att_res, int B, float* ff) {
+    jo_model* m = s->m;
+    const jo_config* c = &m->c;
+    int E = c->embedding_length, H = c->hidden_length;
+    const jo_weight* W = &m->layer_w[(size_t)li * JO_W_COUNT];
+    float* ln = (float*)malloc(sizeof(float) * (size_t)B * E);
+    float* g = (float*)malloc(sizeof(float) * (size_t)B * H);
+    float* u = (float*)malloc(sizeof(float) * (size_t)B * H);
+    float* nw = (float*)malloc(sizeof(float) * (size_t)E);
+    /* preFFNorm :187 */
+    jo_load_norm(&W[JO_W_NORM2], E, nw);
+    for (int b = 0; b < B; b++) jo_rmsnorm(att_res + (size_t)b * E, nw, 0.0f, E, c->rms_eps, ln + (size_t)b * E);
+    jo_tap(s, li, JO_TAP_PRE_FF_NORM, ln, B * E);
+    jo_act fa;
+    jo_maybe_quantize(m, ln, B, E, &fa); /* :192 */
+    /* MLPBlock.forward MLPBlock.java:117-142 */
+    jo_weight_gemm(m, &fa, B, &W[JO_W_GATE], 0, E, g, H);
+    jo_weight_gemm(m, &fa, B, &W[JO_W_UP], 0, E, u, H);
+    jo_act_free(&fa);
+    for (size_t t = 0; t < (size_t)B * H; t++) g[t] = jo_silu(g[t]);
+    jo_maccumulate_f32(g, u, 0, B * H);
+    jo_act ha;
+    jo_maybe_quantize(m, g, B, H, &ha); /* :144 */
+    jo_weight_gemm(m, &ha, B, &W[JO_W_DOWN], 0, H, ff, E);
+    jo_act_free(&ha);
+    jo_tap(s, li, JO_TAP_POST_FF, ff, B * E);
+    free(ln); free(g); free(u); free(nw);
+}
+
+/* forward a batch of B rows through layers [layer_start, layer_end).  x: [B,E] in/out.
+ * If tokens != NULL the rows are first filled from the embedding table. */
+int jo_forward(jo_session* s, const int32_t* tokens, float* x, int B, int start_pos) {
+    jo_model* m = s->m;
+    const jo_config* c = &m->c;
+    int E = c->embedding_length;
+    if (tokens)
+        for (int b = 0; b < B; b++) jo_embed(m, tokens[b], x + (size_t)b * E);
+    float* att_out = (float*)malloc(sizeof(float) * (size_t)B * E);
+    float* ff = (float*)malloc(sizeof(float) * (size_t)B * E);
+    for (int li = c->layer_start; li < c->layer_end; li++) {
+        jo_layer_attn(s, li, x, B, start_pos, att_out);
         /* residual TransformerBlock.java:185: lnattn += embedding */
         for (int b = 0; b < B; b++) jo_accumulate_f32(att_out + (size_t)b * E, x + (size_t)b * E, 0, E);
-        /* preFFNorm :187 */
-        jo_load_norm(&W[JO_W_NORM2], E, nw);
-        for (int b = 0; b < B; b++) jo_rmsnorm(att_out + (size_t)b * E, nw, 0.0f, E, c->rms_eps, ln + (size_t)b * E);
-        jo_tap(s, li, JO_TAP_PRE_FF_NORM, ln, B * E);
-        jo_act fa;
-        jo_maybe_quantize(m, ln, B, E, &fa); /* :192 */
-        /* MLPBlock.forward MLPBlock.java:117-142 */
-        jo_weight_gemm(m, &fa, B, &W[JO_W_GATE], 0, E, g, H);
-        jo_weight_gemm(m, &fa, B, &W[JO_W_UP], 0, E, u, H);
-        jo_act_free(&fa);
-        for (size_t t = 0; t < (size_t)B * H; t++) g[t] = jo_silu(g[t]);
-        jo_maccumulate_f32(g, u, 0, B * H);
-        jo_act ha;
-        jo_maybe_quantize(m, g, B, H, &ha); /* :144 */
-        jo_weight_gemm(m, &ha, B, &W[JO_W_DOWN], 0, H, ff, E);
-        jo_act_free(&ha);
-        jo_tap(s, li, JO_TAP_POST_FF, ff, B * E);
+        jo_layer_ffn(s, li, att_out, B, ff);
         /* residual TransformerBlock.java:203: lnpostFF += lnattn */
         for (int b = 0; b < B; b++) jo_accumulate_f32(ff + (size_t)b * E, att_out + (size_t)b * E, 0, E);
         jo_tap(s, li, JO_TAP_POST_FF_RES, ff, B * E);
         memcpy(x, ff, sizeof(float) * (size_t)B * E);
     }
-    free(ln); free(q); free(k); free(v); free(val); free(att_out); free(g); free(u); free(ff); free(nw); free(attn_all);
+    free(att_out); free(ff);
+    return 0;
+}
+
+/* The two halves on their own, for a tensor-parallel engine that reduces the partial results between them (one shard
+ * per process; the sum over shards is the caller's all-reduce). */
+int jo_tp_attn(jo_session* s, int layer, const float* x, int B, int start_pos, float* partial) {
+    if (layer < s->m->c.layer_start || layer >= s->m->c.layer_end) return -1;
+    jo_layer_attn(s, layer, x, B, start_pos, partial);
+    return 0;
+}
+int jo_tp_ffn(jo_session* s, int layer, const float* att_res, int B, float* partial) {
+    if (layer < s->m->c.layer_start || layer >= s->m->c.layer_end) return -1;
+    jo_layer_ffn(s, layer, att_res, B, partial);
+    return 0;
+}
+void jo_embed_rows(jo_model* m, const int32_t* tokens, int B, float* x) {
+    for (int b = 0; b < B; b++) jo_embed(m, tokens[b], x + (size_t)b * m->c.embedding_length);
+}
+
+/* All model shards in one process, in lock step (head split, DistributedContext.java:79-98): shard r holds heads
+ * [r*heads/N, ...), kv heads [r*kvHeads/N, ...), hidden rows [r*H/N, ...) and the matching K columns of the o / down
+ * projections; partial results are summed in shard order 0..N-1, then the residual is added
+ * (CausalSelfAttention.java:378, MLPBlock.java:160, TransformerBlock.java:185,203). */
+int jo_forward_tp(jo_session** shards, int nshards, const int32_t* tokens, float* x, int B, int start_pos) {
+    jo_model* m0 = shards[0]->m;
+    const jo_config* c = &m0->c;
+    int E = c->embedding_length;
+    if (tokens) jo_embed_rows(m0, tokens, B, x);
+    float* part = (float*)malloc(sizeof(float) * (size_t)B * E);
+    float* att_out = (float*)malloc(sizeof(float) * (size_t)B * E);
+    float* ff = (float*)malloc(sizeof(float) * (size_t)B * E);
+    for (int li = c->layer_start; li < c->layer_end; li++) {
+        for (int r = 0; r < nshards; r++) {
+            jo_layer_attn(shards[r], li, x, B, start_pos, r == 0 ? att_out : part);
+            if (r > 0) jo_accumulate_f32(att_out, part, 0, B * E);
+        }
+        for (int b = 0; b < B; b++) jo_accumulate_f32(att_out + (size_t)b * E, x + (size_t)b * E, 0, E);
+        for (int r = 0; r < nshards; r++) {
+            jo_layer_ffn(shards[r], li, att_out, B, r == 0 ? ff : part);
+            if (r > 0) jo_accumulate_f32(ff, part, 0, B * E);
+        }
+        for (int b = 0; b < B; b++) jo_accumulate_f32(ff + (size_t)b * E, att_out + (size_t)b * E, 0, E);
+        memcpy(x, ff, sizeof(float) * (size_t)B * E);
+    }
+    free(part); free(att_out); free(ff);
     return 0;
 }
 

@@ -293,7 +293,9 @@ def kv_page_geometry(max_page_bytes, n_layers, context_length, kv_length, dtype_
 class OracleModel:
     """CPU restatement of AbstractModel.generate()/forward() for Llama-family models."""
 
-    def __init__(self, cfg: dict, weights: dict, layer_range=None):
+    def __init__(self, cfg: dict, weights: dict, layer_range=None, kv_head_offset=0):
+        """kv_head_offset: for a tensor-parallel shard (cfg carries the LOCAL head counts / hidden length), the global
+        index of its first kv head (DistributedContext.groupHeadStart) -- RoPE table rows are indexed globally."""
         L = cfg["n_layers"]
         ls, le = layer_range if layer_range else (0, L)
         self.cfg = cfg
@@ -307,6 +309,14 @@ class OracleModel:
             rows, cols = w["shape"]
             rc = lib().jo_model_set_weight(self.m, layer, which, dtype, _p(data), _p(scales), rows, cols)
             assert rc == 0
+        if kv_head_offset:
+            lib().jo_model_set_kv_head_offset(self.m, int(kv_head_offset))
+
+    def embed_rows(self, tokens):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        x = np.empty((tokens.size, self.cfg["embedding_length"]), dtype=np.float32)
+        lib().jo_embed_rows(self.m, _p(tokens), tokens.size, _p(x))
+        return x
 
     def use_reference_gemm(self, nthreads):
         r = ref_lib()
@@ -332,6 +342,20 @@ class OracleModel:
             pass
 
 
+def forward_tp(sessions, tokens, start_pos, x=None):
+    """All tensor-parallel shards in one process, partials summed in shard order (jo_forward_tp)."""
+    E = sessions[0].model.cfg["embedding_length"]
+    arr = (C.c_void_p * len(sessions))(*[s.s for s in sessions])
+    if x is None:
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        x = np.empty((tokens.size, E), dtype=np.float32)
+        lib().jo_forward_tp(arr, len(sessions), _p(tokens), _p(x), tokens.size, start_pos)
+    else:
+        x = np.ascontiguousarray(x, dtype=np.float32).copy()
+        lib().jo_forward_tp(arr, len(sessions), None, _p(x), x.shape[0], start_pos)
+    return x
+
+
 class OracleSession:
     def __init__(self, model, max_page_bytes):
         self.model = model
@@ -354,6 +378,19 @@ class OracleSession:
             x = np.ascontiguousarray(x, dtype=np.float32).copy()
             lib().jo_forward(self.s, None, _p(x), x.shape[0], start_pos)
         return x
+
+    # tensor-parallel halves of one layer (partial [B,E] results, no residual): the caller sums over shards
+    def tp_attn(self, layer, x, start_pos):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        assert lib().jo_tp_attn(self.s, layer, _p(x), x.shape[0], start_pos, _p(out)) == 0
+        return out
+
+    def tp_ffn(self, layer, att_res):
+        att_res = np.ascontiguousarray(att_res, dtype=np.float32)
+        out = np.empty_like(att_res)
+        assert lib().jo_tp_ffn(self.s, layer, _p(att_res), att_res.shape[0], _p(out)) == 0
+        return out
 
     def set_tap_layer(self, layer):
         lib().jo_session_set_tap_layer(self.s, layer)

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:   # torch bundles its own HIP runtime: when a test mixes torch.cuda with libjlamahip.so, torch must be loaded first
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

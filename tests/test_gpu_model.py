@@ -352,3 +352,53 @@ def test_checkpoint_loads_straight_into_hbm(gpu, oracle, tmp_path, shards):
     np.testing.assert_array_equal(x, ref.session(64).forward(prompt, 0))
     om = oracle.OracleModel(cfg, w)
     assert _rel(x, om.session().forward(prompt, 0)) <= TRUNK_TOL
+
+
+@pytest.mark.parametrize("dtype", ["Q4", "BF16"])
+def test_tensor_parallel_shards_loopback(gpu, oracle, dtype):
+    """f2: two head-split shards (local heads / kv heads / hidden rows, o/down K windows, global RoPE head index) resident
+    on ONE device, the all-reduce replaced by an in-order sum of the two partial vectors: must agree with the oracle's
+    lock-step shard restatement (jo_forward_tp) and sit within the Q8 noise floor of the un-sharded model."""
+    import torch
+    from jlama_amd import _native as N, distributed as D, synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    cfg = dict(S.SMALL)
+    if dtype == "BF16":
+        cfg["weight_dtype"] = N.DT_BF16
+    w = S.make_weights(cfg, seed=41)
+    prompt = S.prompt_tokens(cfg, n=12, seed=7)
+    size, E, L = 2, cfg["embedding_length"], cfg["n_layers"]
+    shards, osess = [], []
+    for r in range(size):
+        lc, off = D.tp_shard_config(cfg, r, size)
+        sw = D.tp_shard_weights(cfg, w, r, size)
+        shards.append(HipLlamaModel(lc, sw, kv_head_offset=off).session(64))
+        osess.append(oracle.OracleModel(lc, sw, kv_head_offset=off).session())
+    dev = torch.device("cuda", 0)
+    part = [torch.empty(E, dtype=torch.float32, device=dev) for _ in range(size)]
+    rows = []
+    for pos, tok in enumerate(prompt):
+        for s in shards:
+            s.tp_set_row(int(tok), pos)
+        for li in range(L):
+            for s, p in zip(shards, part):
+                s.tp_attn(li, p.data_ptr())
+                s.synchronize()
+            red = part[0] + part[1]
+            torch.cuda.synchronize()
+            for s, p in zip(shards, part):
+                s.tp_ffn(li, red.data_ptr(), p.data_ptr())
+                s.synchronize()
+            red2 = part[0] + part[1]
+            torch.cuda.synchronize()
+            for s in shards:
+                s.tp_finish_layer(red2.data_ptr())
+                s.synchronize()
+        rows.append(shards[0].current_row())
+        np.testing.assert_array_equal(rows[-1], shards[1].current_row())     # every shard holds the same residual stream
+    got = np.stack(rows)
+    want_tp = oracle.forward_tp(osess, prompt, 0)
+    assert _rel(got, want_tp) <= TRUNK_TOL
+    assert np.abs(got[0] - want_tp[0]).max() <= (1e-4 if dtype == "Q4" else 3e-2) * np.abs(want_tp[0]).max()
+    full = oracle.OracleModel(cfg, w)
+    assert _rel(got, full.session().forward(prompt, 0)) <= TRUNK_TOL

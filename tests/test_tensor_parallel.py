@@ -1,0 +1,138 @@
+"""Tensor-parallel (head-split) path, SURVEY.md 8(e)/f2 -- CPU tests with the ORACLE as the shard engine.
+
+* shard geometry + weight windows (DistributedContext.java:79-98, Weights.getLoadOffsets :101-120);
+* the oracle's lock-step N-shard forward (partials summed in shard order before the residual) stays within the Q8
+  noise floor of the un-sharded forward, and is EXACTLY the un-sharded forward for N=1;
+* world_size-2 gloo run of jlama_amd.distributed.tp_generate == the lock-step oracle, bit for bit (a two-term sum is
+  order-independent)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from jlama_amd import distributed as D, jq4, synthetic as S
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_geometry_and_windows():
+    cfg = dict(S.SMALL)   # 8 heads, 2 kv heads, hs 128, E 512, H 1024
+    w = S.make_weights(cfg, seed=1)
+    with pytest.raises(ValueError):
+        D.tp_shard_config(cfg, 0, 4)   # more shards than kv heads (JlamaService.java:65-68)
+    full_o = jq4.dequantize_q4(w[(0, S.W_O)]["data"], w[(0, S.W_O)]["scales"])
+    full_q = jq4.dequantize_q4(w[(0, S.W_Q)]["data"], w[(0, S.W_Q)]["scales"])
+    full_d = jq4.dequantize_q4(w[(1, S.W_DOWN)]["data"], w[(1, S.W_DOWN)]["scales"])
+    for r in range(2):
+        lc, off = D.tp_shard_config(cfg, r, 2)
+        assert (lc["n_heads"], lc["n_kv_heads"], lc["hidden_length"], off) == (4, 1, 512, r)
+        sw = D.tp_shard_weights(cfg, w, r, 2)
+        A = lc["n_heads"] * lc["head_size"]
+        assert sw[(0, S.W_Q)]["shape"] == (A, 512) and sw[(0, S.W_K)]["shape"] == (128, 512)
+        assert sw[(0, S.W_O)]["shape"] == (512, A) and sw[(1, S.W_DOWN)]["shape"] == (512, 512)
+        np.testing.assert_array_equal(jq4.dequantize_q4(sw[(0, S.W_Q)]["data"], sw[(0, S.W_Q)]["scales"]), full_q[r * A:(r + 1) * A])
+        np.testing.assert_array_equal(jq4.dequantize_q4(sw[(0, S.W_O)]["data"], sw[(0, S.W_O)]["scales"]), full_o[:, r * A:(r + 1) * A])
+        np.testing.assert_array_equal(jq4.dequantize_q4(sw[(1, S.W_DOWN)]["data"], sw[(1, S.W_DOWN)]["scales"]), full_d[:, r * 512:(r + 1) * 512])
+        assert sw[(-1, S.W_EMBED)] is w[(-1, S.W_EMBED)] and sw[(0, S.W_NORM1)] is w[(0, S.W_NORM1)]
+
+
+def _shard_models(O, cfg, w, size):
+    ms = []
+    for r in range(size):
+        lc, off = D.tp_shard_config(cfg, r, size)
+        ms.append(O.OracleModel(lc, D.tp_shard_weights(cfg, w, r, size), kv_head_offset=off))
+    return ms
+
+
+def test_oracle_lockstep_tp_matches_unsharded(oracle):
+    cfg = dict(S.SMALL)
+    w = S.make_weights(cfg, seed=12)
+    prompt = S.prompt_tokens(cfg, n=24, seed=5)
+    full = oracle.OracleModel(cfg, w)
+    want = full.session().forward(prompt, 0)
+    one = _shard_models(oracle, cfg, w, 1)
+    np.testing.assert_array_equal(oracle.forward_tp([one[0].session()], prompt, 0), want)   # N=1: the same arithmetic
+    two = _shard_models(oracle, cfg, w, 2)
+    got = oracle.forward_tp([m.session() for m in two], prompt, 0)
+    # the K split changes the float grouping of o/down (partial sums per shard): Q8-noise-level agreement, and the
+    # first row (no earlier code flips) to float rounding
+    assert np.abs(got - want).max() <= 4e-2 * np.abs(want).max()
+    assert np.abs(got[0] - want[0]).max() <= 1e-4 * np.abs(want[0]).max()
+    lt, lw = full.sample(got[-1])[1], full.sample(want[-1])[1]
+    assert np.abs(lt - lw).max() <= 4e-2
+
+
+def _tp_worker(rank, world, port, cfg, prompt, n_gen, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+
+    class OracleTPEngine(D.TPEngine):
+        def __init__(self):
+            w = S.make_weights(cfg, seed=12)
+            lc, off = D.tp_shard_config(cfg, rank, world)
+            self.full = O.OracleModel(cfg, w) if rank == 0 else None     # rank 0 samples with the replicated head
+            self.m = O.OracleModel(lc, D.tp_shard_weights(cfg, w, rank, world), kv_head_offset=off)
+            self.s = self.m.session()
+            self.x = self.x1 = None
+            self.pos = 0
+
+        def set_row(self, token, pos):
+            self.x, self.pos = self.m.embed_rows([token]), pos
+
+        def attn(self, layer, partial):
+            partial.copy_(torch.from_numpy(self.s.tp_attn(layer, self.x, self.pos)[0]))
+
+        def ffn(self, layer, reduced, partial):
+            self.x1 = self.x + reduced.numpy()[None, :]
+            partial.copy_(torch.from_numpy(self.s.tp_ffn(layer, self.x1)[0]))
+
+        def finish_layer(self, reduced):
+            self.x = self.x1 + reduced.numpy()[None, :]
+
+        def sample(self):
+            return self.full.sample(self.x[0])[0]
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    toks = D.tp_generate(dist, OracleTPEngine(), rank, prompt, n_gen, cfg, "cpu", torch.float32)
+    if rank == 0:
+        q.put(toks.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_tp_equals_lockstep_oracle(oracle):
+    import torch.multiprocessing as mp
+    cfg = dict(S.TINY)   # 4 heads, 2 kv heads
+    prompt = S.prompt_tokens(cfg, n=6, seed=2)
+    n_gen = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_tp_worker, args=(r, 2, port, cfg, prompt, n_gen, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = q.get(timeout=240)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # lock-step reference: both shards in this process, partials summed r=0 then r=1
+    w = S.make_weights(cfg, seed=12)
+    full = oracle.OracleModel(cfg, w)
+    sess = [m.session() for m in _shard_models(oracle, cfg, w, 2)]
+    x = oracle.forward_tp(sess, prompt, 0)
+    want, pos = [], prompt.size
+    for _ in range(n_gen):
+        t = full.sample(x[-1])[0]
+        want.append(t)
+        x = oracle.forward_tp(sess, [t], pos)
+        pos += 1
+    assert got == want
