@@ -265,8 +265,12 @@ __device__ __forceinline__ void quad_quantize_store(const float (&y)[8], int uni
 // 8-element units per thread kept in registers);  stage_finish() reduces, quantizes and fills LDS.
 // Order matters: s_waitcnt vmcnt retires loads oldest-first, so x must be requested BEFORE the (much larger) weight
 // stream or the prologue would wait for every weight byte.
-constexpr int UMAX = 2;
-struct ActRegs {
+// register-resident units per thread: 2 covers K <= 8192 at 512 threads; the plain-quantize prologue (o-proj, down:
+// K up to 14336 = 1792 units) keeps 4 so that no unit needs a second, serialised global round trip
+template <int PRO> struct UMaxFor { static constexpr int v = 2; };
+template <> struct UMaxFor<PRO_QUANT_Q8> { static constexpr int v = 4; };
+template <int UMAX>
+struct ActRegsT {
     float xv[UMAX][8];
     float wv[UMAX][8];
     float po[UMAX][4][8];   // PRO_ATTN_Q8: this thread's 8 output elements of up to 4 slices
@@ -274,7 +278,8 @@ struct ActRegs {
     int n;                  // context length pos+1
 };
 template <int PRO>
-__device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegs& r) {
+__device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegsT<UMaxFor<PRO>::v>& r) {
+    constexpr int UMAX = UMaxFor<PRO>::v;
     if (PRO == PRO_Q8) return;
     const int units = p.K / 8, T = blockDim.x;
     // branch-free (clamped) addresses: a guarded load would make hipcc wait for it at the end of its basic block,
@@ -308,7 +313,8 @@ __device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegs& r) {
     }
 }
 template <int PRO>
-__device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a, ActRegs& r) {
+__device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a, ActRegsT<UMaxFor<PRO>::v>& r) {
+    constexpr int UMAX = UMaxFor<PRO>::v;
     const int K = p.K, nblk = K / QB;
     if (PRO == PRO_Q8) {
         for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
@@ -491,7 +497,7 @@ __global__ __launch_bounds__((R * NB > 4) ? 512 : 1024) void gemv_i8q4_kernel(Ge
 
     if constexpr (NB > 0 && PIPE == 0) {
         WBuf<R, NB> cur;
-        ActRegs ar;
+        ActRegsT<UMaxFor<PRO>::v> ar;
         const int g = gw;   // host launches >= ngroups waves
         stage_issue<PRO>(p, ar);                                    // activation loads first (retire first) ...
         load_group<EPI, R, NB>(p, g < ngroups ? g : ngroups - 1, lane, cur);   // ... then this wave's whole weight stream
@@ -518,7 +524,7 @@ __global__ __launch_bounds__((R * NB > 4) ? 512 : 1024) void gemv_i8q4_kernel(Ge
         }
     } else if constexpr (NB > 0) {
         WBuf<R, NB> cur, nxt;
-        ActRegs ar;
+        ActRegsT<UMaxFor<PRO>::v> ar;
         stage_issue<PRO>(p, ar);
         load_group<EPI, R, NB>(p, g0 < ngroups ? g0 : ngroups - 1, lane, cur);   // first group in flight across the prologue
         stage_finish<PRO>(p, a, ar);
@@ -566,7 +572,7 @@ __global__ __launch_bounds__((R * NB > 4) ? 512 : 1024) void gemv_i8q4_kernel(Ge
         }
     } else {
         // generic K (any multiple of 32): activation re-read from LDS per block, no register double buffering
-        ActRegs ar;
+        ActRegsT<UMaxFor<PRO>::v> ar;
         stage_issue<PRO>(p, ar);
         stage_finish<PRO>(p, a, ar);
         for (int g = g0; g < g1; g++) {
