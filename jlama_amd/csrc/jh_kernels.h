@@ -927,6 +927,8 @@ struct MfmaGemmParams {
     const uint16_t* a; const uint16_t* w; float* c;
     int m, n0, n, k, lda, ldb, ldc, roffset;   // same meaning as gemm_bf16 (nc/simd/vector_simd.h:34), offsets pre-applied
     const float* resid;                        // optional: C += resid (same layout as C), the residual stream in prefill
+    float* ws; int nsplit;                     // split-K: workgroup row blockIdx.y handles K slices [y*k/nsplit, ...) and
+                                               // writes its partial [m][n] (ld = n) to ws + y*m*n; splitk_reduce_kernel sums
 };
 constexpr int MG_KS = 64;            // K slice per stage
 constexpr int MG_ASTRIDE = 144;      // bytes per A row in LDS (128 + 16 pad)
@@ -941,7 +943,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_mfma_kernel(MfmaGemmPara
     const bool active = ntile * 32 < p.n;
     constexpr int MROWS = MT * 32;
     constexpr int ABYTES = MROWS * MG_ASTRIDE;   // one A stage; stage b lives at smem + b*ABYTES
-    const int nslices = p.k / MG_KS;
+    const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    const int nslices = p.k / MG_KS / nsplit, slice0 = blockIdx.y * nslices;
 
     // cooperative A slice load: chunk = (row, c8) with 8 x 16-byte chunks per row
     constexpr int CHUNKS = MROWS * 8, NT = WAVES * 64, CPT = (CHUNKS + NT - 1) / NT;
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_mfma_kernel(MfmaGemmPara
             int row = ch >> 3;
             const int c8 = ch & 7;
             row = row < p.m ? row : p.m - 1;                 // rows beyond M replicate the last row (never stored)
-            areg[i] = *(const i32x4*)(p.a + (size_t)row * p.lda + slice * MG_KS + c8 * 8);
+            areg[i] = *(const i32x4*)(p.a + (size_t)row * p.lda + (size_t)(slice0 + slice) * MG_KS + c8 * 8);
         }
     };
     auto store_a = [&](int buf) {
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_mfma_kernel(MfmaGemmPara
     auto load_w = [&](int slice, int buf) {
 #pragma unroll
         for (int s = 0; s < 4; s++)
-            wreg[buf][s] = __builtin_nontemporal_load((const i32x4*)(wrow + slice * MG_KS + s * 16 + h * 8));
+            wreg[buf][s] = __builtin_nontemporal_load((const i32x4*)(wrow + (size_t)(slice0 + slice) * MG_KS + s * 16 + h * 8));
     };
 
     f32x16 acc[MT];
@@ -1007,10 +1010,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_mfma_kernel(MfmaGemmPara
         for (int r = 0; r < 16; r++) {
             const int mrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (mrow < p.m) {
-                const size_t idx = (size_t)p.ldc * mrow + (ncol0 + nl) - p.roffset;
-                p.c[idx] = p.resid ? acc[t][r] + p.resid[idx] : acc[t][r];
+                if (nsplit > 1) {
+                    p.ws[((size_t)blockIdx.y * p.m + mrow) * p.n + (ncol0 - p.n0 + nl)] = acc[t][r];
+                } else {
+                    const size_t idx = (size_t)p.ldc * mrow + (ncol0 + nl) - p.roffset;
+                    p.c[idx] = p.resid ? acc[t][r] + p.resid[idx] : acc[t][r];
+                }
             }
         }
+}
+// second pass of a split-K GEMM: C[i][j] = sum_s ws[s][i][j] (ascending K ranges => deterministic) (+ resid)
+__global__ void splitk_reduce_kernel(const float* ws, int nsplit, int m, int n, int n0, float* c, int ldc, int roffset, const float* resid) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)m * n) return;
+    const int row = (int)(i / n), col = (int)(i % n);
+    float v = 0.0f;
+    for (int s = 0; s < nsplit; s++) v += ws[(size_t)s * m * n + i];
+    const size_t idx = (size_t)ldc * row + (n0 + col) - roffset;
+    c[idx] = resid ? v + resid[idx] : v;
 }
 
 // ------------------------------------------------------------------------------------------------ K2: batched I8 x Q4 GEMM on MFMA

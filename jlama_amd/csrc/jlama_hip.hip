@@ -300,18 +300,34 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
 }
 
 template <int MT>
-int launch_gemm_bf16_mfma_mt(const MfmaGemmParams& g, hipStream_t st) {
+int launch_gemm_bf16_mfma_mt(const MfmaGemmParams& g0, hipStream_t st) {
+    MfmaGemmParams g = g0;
     const int tiles = g.n / 32;
-    // enough workgroups to cover the chip: 1, 2 or 4 column tiles (waves) per workgroup
+    // enough workgroups to cover the chip: 1, 2 or 4 column tiles (waves) per workgroup; few tiles => split K over
+    // workgroup rows (partials to the caller's workspace, splitk_reduce_kernel adds them in K order)
     const int waves = tiles >= g_cu_count * 4 ? 4 : (tiles >= g_cu_count * 2 ? 2 : 1);
     const int grid = (tiles + waves - 1) / waves;
+    int S = 1;
+    if (g.ws) {
+        const int nslices = g.k / MG_KS;
+        while (S < 8 && grid * S < g_cu_count * 4 && nslices % (2 * S) == 0 && nslices / (2 * S) >= 4) S *= 2;
+    }
+    g.nsplit = S;
     const size_t lds = (size_t)2 * MT * 32 * MG_ASTRIDE;
-    if (waves == 4) { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 4>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 4>), dim3(grid), dim3(256), lds, st, g); }
-    else if (waves == 2) { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 2>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 2>), dim3(grid), dim3(128), lds, st, g); }
-    else { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 1>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 1>), dim3(grid), dim3(64), lds, st, g); }
+    if (waves == 4) { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 4>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 4>), dim3(grid, S), dim3(256), lds, st, g); }
+    else if (waves == 2) { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 2>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 2>), dim3(grid, S), dim3(128), lds, st, g); }
+    else { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 1>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 1>), dim3(grid, S), dim3(64), lds, st, g); }
     HIPCHK(hipGetLastError());
+    if (S > 1) {
+        const size_t tot = (size_t)g.m * g.n;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)g.ws, S, g.m, g.n, g.n0, g.c, g.ldc,
+                           g.roffset, g.resid);
+        HIPCHK(hipGetLastError());
+    }
     return JH_OK;
 }
+constexpr size_t BF16_SPLITK_WS_BYTES = (size_t)8 * 256 * 16384 * 4;   // 8 splits x 256 rows x N <= 16384 (larger N never splits)
+
 int launch_gemm_bf16_mfma(const MfmaGemmParams& g, hipStream_t st) {
     const int mt = (g.m + 31) / 32;
     switch (mt) {
@@ -523,6 +539,8 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         MfmaGemmParams g;
         g.a = (const uint16_t*)dA + aoffset; g.w = (const uint16_t*)dB + boffset; g.c = (float*)dR;
         g.m = m; g.n0 = n0; g.n = n; g.k = k; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.roffset = roffset; g.resid = nullptr;
+        g.ws = nullptr; g.nsplit = 1;
+        if (n <= 16384) { void* wsp = nullptr; JHCHK(dev_buf(7, BF16_SPLITK_WS_BYTES, &wsp)); g.ws = (float*)wsp; }
         JHCHK(launch_gemm_bf16_mfma(g, st));
         fast = true;
     }
@@ -874,6 +892,7 @@ struct jh_session {
     int pb_rows = 0;
     float *pb_x = nullptr, *pb_x1 = nullptr, *pb_qkv = nullptr, *pb_att = nullptr, *pb_g = nullptr, *pb_u = nullptr, *pb_ad = nullptr;
     int8_t* pb_aq = nullptr;
+    float* pb_ws = nullptr;   // split-K workspace of the BF16 prefill GEMM
     int* pb_tok = nullptr;
     int prefill_batch_min = 4;
 };
@@ -1094,6 +1113,7 @@ int prefill_alloc(jh_session* s) {
     HIPCHK(hipMalloc(&s->pb_aq, R * kmax * (c.weight_dtype == JH_DT_BF16 ? 2 : 1)));   // Q8 codes, or BF16 rows for a BF16 model
     HIPCHK(hipMalloc(&s->pb_ad, R * (kmax / QB) * 4));
     HIPCHK(hipMalloc(&s->pb_tok, R * 4));
+    if (c.weight_dtype == JH_DT_BF16) HIPCHK(hipMalloc(&s->pb_ws, BF16_SPLITK_WS_BYTES));
     s->pb_rows = PB_MAX_ROWS;
     return JH_OK;
 }
@@ -1129,7 +1149,7 @@ int rows_quant_launch(jh_session* s, const float* x, int ldx, const float* x2, i
 // out[rows, N] = act[rows, K] x W[N, K]^T (+ resid): I8 x Q4 (exact integer MFMA) or BF16 x BF16 (MFMA), by model dtype
 int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
     if (s->m->c.weight_dtype == JH_DT_BF16) {
-        MfmaGemmParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.data, out, rows, 0, N, K, K, K, ldc, 0, resid};
+        MfmaGemmParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.data, out, rows, 0, N, K, K, K, ldc, 0, resid, N <= 16384 ? s->pb_ws : nullptr, 1};
         return launch_gemm_bf16_mfma(g, st);
     }
     if (prefill_tiled(s, K)) {
@@ -1509,7 +1529,7 @@ int jh_session_destroy(jh_session* s) {
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
-    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_u, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok}) if (b) hipFree(b);
+    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_u, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws}) if (b) hipFree(b);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -1555,6 +1575,8 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
     HIPCHK(hipMalloc(&a, (size_t)(m + 32) * k * 2)); HIPCHK(hipMemset(a, 1, (size_t)(m + 32) * k * 2));
     HIPCHK(hipMalloc(&af, (size_t)m * (k / QB) * 4)); HIPCHK(hipMemset(af, 0, (size_t)m * (k / QB) * 4));
     HIPCHK(hipMalloc(&c, (size_t)m * n * 4));
+    float* bf16_ws = nullptr;
+    if (kind == 1 && n <= 16384) HIPCHK(hipMalloc(&bf16_ws, BF16_SPLITK_WS_BYTES));
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     int rc = JH_OK;
     for (int it = -1; it < iters && rc == JH_OK; it++) {
@@ -1564,7 +1586,7 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
                 MfmaQ4Params g{(const int8_t*)a, af, w + l * wbytes, ws + l * (sbytes / 4), c, nullptr, m, 0, n, k, k, k / QB, k / 2, k / QB, n, 0};
                 rc = launch_gemm_q8q4_mfma(g, st, kind == 2);
             } else {
-                MfmaGemmParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, m, 0, n, k, k, k, n, 0, nullptr};
+                MfmaGemmParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, m, 0, n, k, k, k, n, 0, nullptr, bf16_ws, 1};
                 rc = launch_gemm_bf16_mfma(g, st);
             }
         }
@@ -1573,7 +1595,7 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
     HIPCHK(hipStreamSynchronize(st));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     *out_ms = (double)ms / ((double)iters * copies);
-    hipFree(w); if (ws) hipFree(ws); hipFree(a); hipFree(af); hipFree(c); hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(w); if (ws) hipFree(ws); if (bf16_ws) hipFree(bf16_ws); hipFree(a); hipFree(af); hipFree(c); hipEventDestroy(e0); hipEventDestroy(e1);
     return rc;
 }
 int jh_session_synchronize(jh_session* s) {
