@@ -880,6 +880,8 @@ struct jh_session {
     int lm_grid = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipGraph_t row_graph = nullptr;        // this shard's layers only: single-row forward (pipeline stages)
+    hipGraphExec_t row_exec = nullptr;
     int pending_n = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms_per_token = 0;
@@ -1524,6 +1526,8 @@ int jh_session_destroy(jh_session* s) {
     if (s->stream) hipStreamSynchronize(s->stream);
     if (s->exec) hipGraphExecDestroy(s->exec);
     if (s->graph) hipGraphDestroy(s->graph);
+    if (s->row_exec) hipGraphExecDestroy(s->row_exec);
+    if (s->row_graph) hipGraphDestroy(s->row_graph);
     if (s->kv_slab) hipFree(s->kv_slab);
     void* bufs[] = {s->pages_dev, s->x, s->x1, s->qkv, s->attf, s->tapq, s->hf, s->logits,
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
@@ -1705,6 +1709,19 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
     return JH_OK;
 }
 
+static int build_row_graph(jh_session* s) {
+    if (s->row_exec) return JH_OK;
+    hipStream_t st = s->stream;
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = layers_launch(s, st, 0);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != JH_OK) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    s->row_graph = g;
+    HIPCHK(hipGraphInstantiate(&s->row_exec, g, nullptr, nullptr, 0));
+    return JH_OK;
+}
 static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in, bool x_in_dev, int n, int start_pos,
                         float* x_out, bool x_out_dev) {
     if (!s || n <= 0 || start_pos < 0 || (!tokens && !x_in)) return set_err(JH_ERR_INVALID, "forward: bad argument");
@@ -1740,7 +1757,14 @@ static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in,
             HIPCHK(hipMemcpyAsync(s->x, x_in + (size_t)i * E, (size_t)E * 4, x_in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         }
         HIPCHK(hipGetLastError());
-        JHCHK(layers_launch(s, st, start_pos + i));
+        if (s->tap_layer < 0 && !env_int("JH_NO_GRAPH", 0)) {
+            // the layers read the position from the device-resident state, so ONE captured graph serves every row:
+            // a pipeline stage pays 1 launch per tick instead of 5 per layer
+            JHCHK(build_row_graph(s));
+            HIPCHK(hipGraphLaunch(s->row_exec, st));
+        } else {
+            JHCHK(layers_launch(s, st, start_pos + i));
+        }
         if (x_out)
             HIPCHK(hipMemcpyAsync(x_out + (size_t)i * E, s->x, (size_t)E * 4, x_out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     }

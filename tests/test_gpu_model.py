@@ -208,7 +208,7 @@ def test_layer_sharded_loopback_is_bit_identical(gpu, oracle):
         np.testing.assert_array_equal(x, ref)
 
 
-@pytest.mark.parametrize("name", ["LLAMA32_1B", "LLAMA3_8B"])
+@pytest.mark.parametrize("name", ["LLAMA32_1B", "LLAMA3_8B", "LLAMA3_70B"])
 def test_real_shapes_one_layer(gpu, oracle, name):
     """BASELINE.json configs[1]/[2] shapes (E, H, heads, head size, vocab) on a 1-layer slice with a reduced vocab:
     exercises the exact kernel instantiations the bench uses (NB=1/2/7 blocks per lane, head size 64/128)."""
