@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--config", default="LLAMA3_8B")
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-steps", type=int, default=256)   # ~12 s of CPU work at the reference path's ~21 tok/s
     ap.add_argument("--probe-iters", type=int, default=3)
     return ap.parse_args()
 
@@ -163,7 +163,7 @@ def run_single(args, cfg):
         cb, cpu_toks, cpu_prompt, cpu_logits = cpu_baseline(cfg, host_w, 8, args.cpu_steps)
         out["cpu_baseline"] = cb
         # end-to-end parity at FULL size on the same weights: logits after the sample prompt and the greedy ids
-        ps = model.session(64)
+        ps = model.session(cpu_prompt.size + args.cpu_steps + 8)
         ps.batch_forward(cpu_prompt, 0)
         gfirst, glogits = ps.sample(0.0, 0.5, want_logits=True)
         gtoks = np.concatenate([[gfirst], ps.decode_n(gfirst, cpu_prompt.size, args.cpu_steps)])
