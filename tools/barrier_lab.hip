@@ -12,6 +12,25 @@ __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
     }
     __syncthreads();
 }
+// flag barrier: every workgroup publishes its own epoch word (write-through store, distinct addresses => no atomic
+// serialisation) and 256 threads poll the 256 words with one coalesced sc1 load per round
+__device__ __forceinline__ void flag_barrier(unsigned* flags, unsigned epoch) {
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {
+        int spins = 0;
+        for (;;) {
+            bool ok = true;
+            for (unsigned i = threadIdx.x; i < gridDim.x; i += 64)
+                ok = ok && (__hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= epoch);
+            if (__all(ok) || ++spins > (1 << 20)) break;
+        }
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(512) void kf(unsigned* flags, int n) {
+    for (int i = 0; i < n; i++) flag_barrier(flags, (unsigned)(i + 1));
+}
 // VAR 0: barrier only.  VAR 1: barrier + every workgroup writes 16 floats (sc1) before and reads all 4096 (sc1) after.
 template <int VAR>
 __global__ __launch_bounds__(512) void k(unsigned* ctr, float* buf, int n, float* out) {
@@ -47,5 +66,16 @@ int main() {
             unsigned c; CK(hipMemcpy(&c, ctr, 4, hipMemcpyDeviceToHost));
             printf("var %d threads %3d: %6.2f us per barrier  (counter %u, expect %u)\n", var, threads, ms * 1e3 / n, c, 256u * n);
         }
+    unsigned* flags; CK(hipMalloc(&flags, 1024 * 4));
+    for (int threads : {64, 512}) {
+        for (int it = 0; it < 2; it++) {
+            CK(hipMemset(flags, 0, 1024 * 4));
+            CK(hipEventRecord(t0));
+            kf<<<256, threads>>>(flags, n);
+            CK(hipEventRecord(t1)); CK(hipEventSynchronize(t1));
+        }
+        float ms; CK(hipEventElapsedTime(&ms, t0, t1));
+        printf("flag barrier threads %3d: %6.2f us per barrier\n", threads, ms * 1e3 / n);
+    }
     return 0;
 }
