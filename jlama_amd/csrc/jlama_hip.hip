@@ -184,7 +184,7 @@ int launch_gemv_i8q4(const GemvParams& p, LaunchCfg cfg, hipStream_t st) {
             pipe = bytes_per_cu <= 200e3 ? 0 : 1;
         }
         if (R <= 0) {
-            if (pipe == 1) R = (nb == 1) ? 4 : 2;
+            if (pipe >= 1) R = (nb == 1) ? 4 : 2;
             else {
                 const int need = (total + cu * 16 - 1) / (cu * 16);
                 static const int oneshot[] = {1, 2, 4, 8, 14};
