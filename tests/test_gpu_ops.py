@@ -310,3 +310,36 @@ def test_batched_i8q4_gemm_on_mfma(ops, oracle, m, n, k):
                                  out=np.zeros((m, n), np.float32))
         _close(R3.data[:, 32:96], want3[:, 32:96], 1e-5)
         assert (R3.data[:, :32] == 0).all() and (R3.data[:, 96:] == 0).all()
+
+
+def test_against_vectors_from_the_reference_library(ops):
+    """tests/golden/ref_gemm_vectors.npz = outputs of the reference's OWN C SIMD GEMM (vector_simd.c compiled as-is,
+    flags = the _512 kernels; generated by tests/golden/make_ref_gemm_vectors.py in the build container).  No oracle in
+    this test: libjlamahip.so vs the reference.  I8xQ4: identical integer block sums, float grouping differs (8 lanes of
+    4-element sums in C vs a 64-lane DPP tree here) => 1e-5; F32xQ4 / F32xF32 => 1e-4 of the row scale.  The device
+    Q8 quantizer must reproduce the codes the reference consumed, bit for bit."""
+    import os
+    from jlama_amd import _native as N
+    from jlama_amd.jq4 import Tensor
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_gemm_vectors.npz"))
+    B = Tensor(N.DT_Q4, np.ascontiguousarray(g["nib"]), np.ascontiguousarray(g["scales"]))
+    X = Tensor.f32(g["x"])
+    A = ops.quantize(X, 2, 0, X.cols)
+    np.testing.assert_array_equal(A.data, g["aq"])
+    np.testing.assert_array_equal(A.scales, g["ad"])
+    n, k = B.rows, B.cols
+    R = Tensor.zeros(1, n)
+    ops.batchDotProduct(R, A, B, 0, 0, k)
+    _close(R.data, g["q8q4_full"], 1e-5)
+    R = Tensor.zeros(1, n)
+    ops.batchDotProduct(R, X, B, 0, 0, k)
+    _close(R.data, g["f32q4_full"], 1e-4)
+    for kind, src, tol in (("q8q4_window", A, 1e-5), ("f32q4_window", X, 1e-4)):
+        R = Tensor.zeros(1, 96)
+        ops.batchDotProduct(R, src, B, 512, 512, 512, 0, 32, 64)
+        _close(R.data[:, 32:96], g[kind][:, 32:96], tol)
+        assert (R.data[:, :32] == 0).all()
+    Q, KP = Tensor.f32(g["f32_q"]), Tensor.f32(g["f32_kpage"])
+    R = Tensor.zeros(1, 48)
+    ops.batchDotProduct(R, Q, KP, 128, 128, 128)
+    _close(R.data, g["f32_scores"], 1e-4)

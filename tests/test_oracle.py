@@ -218,3 +218,22 @@ def test_reference_gemm_driven_model_matches_panama_order_at_m1(oracle):
     assert np.abs(x1 - x2).max() <= 1e-5 * np.abs(x1).max()
     (t1, l1), (t2, l2) = m1.sample(x1[-1]), m2.sample(x2[-1])
     assert t1 == t2 and np.abs(l1 - l2).max() <= 1e-5
+
+
+def test_oracle_matches_committed_reference_vectors(oracle):
+    """The committed outputs of the reference's C GEMM (tests/golden/ref_gemm_vectors.npz) pin the oracle even where
+    oracle/_ref cannot be rebuilt (no /root/reference): F32xQ4 and F32xF32 bit-exact (same 16-lane FMA order and
+    halving-tree reduce), I8xQ4 within 2e-6 of the row scale (integer sums identical; the C kernel groups 4-element
+    int32 sums over 8 lanes, Panama/the oracle 2-element sums over 16)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_gemm_vectors.npz"))
+    aq, ad = oracle.q8_quantize(g["x"])
+    np.testing.assert_array_equal(aq, g["aq"])
+    np.testing.assert_array_equal(ad, g["ad"])
+    got = oracle.gemm_i8q4(g["aq"], g["ad"], g["nib"], g["scales"])
+    assert np.abs(got - g["q8q4_full"]).max() <= 2e-6 * np.abs(g["q8q4_full"]).max()
+    np.testing.assert_array_equal(oracle.gemm_f32q4(g["x"], g["nib"], g["scales"]), g["f32q4_full"])
+    got = oracle.gemm_f32q4(g["x"], g["nib"], g["scales"], aColOff=512, bColOff=512, K=512, bRowOff=32, N=64,
+                            out=np.zeros((1, 96), np.float32))
+    np.testing.assert_array_equal(got[:, 32:96], g["f32q4_window"][:, 32:96])
+    np.testing.assert_array_equal(oracle.gemm_f32(g["f32_q"], g["f32_kpage"], aColOff=128, bColOff=128, K=128), g["f32_scores"])
