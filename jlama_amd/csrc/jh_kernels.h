@@ -1196,25 +1196,30 @@ __global__ __launch_bounds__(KSPLIT * 64) void gemm_q8q4_mfma_kernel(MfmaQ4Param
 //   A  [row tile][blk][h][m][16 B]   -> lane (m, h) reads ONE contiguous 1 KB per block per wave
 //   W  [col tile][blk][n][16 B], scales [col tile][blk][n]   -> 512 B / 128 B contiguous per block per wave
 // Row-major operands (Tier-1 callers) touch 32 cache lines per load and use 16-32 B of each: ~8x the L2->L1 traffic.
-template <int S, bool TILED>
-__global__ __launch_bounds__(S * 64) __attribute__((amdgpu_waves_per_eu(3))) void gemm_q8q4_tile_kernel(MfmaQ4Params p, int mtiles) {
+// CW: column tiles per workgroup.  The CW*S waves of a workgroup share the row tile: the A tile of a block is fetched
+// once into the CU's L1 and hit by the other CW-1 waves (the kernel is bound by the per-CU L1 miss path, A is 2/3 of
+// its traffic), and the activation-scale slices in LDS are shared too.  The host guarantees n % (32*CW) == 0.
+template <int S, bool TILED, int CW>
+__global__ __launch_bounds__(S * CW * 64) __attribute__((amdgpu_waves_per_eu(3))) void gemm_q8q4_tile_kernel(MfmaQ4Params p, int mtiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wv_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = wv_id % S, cw = wv_id / S;
     const int nl = lane & 31, h = lane >> 5;
-    // blockIdx.x = c_lo + 8*(rt + mtiles*c_hi), column tile ct = c_hi*8 + c_lo: consecutive workgroups go to
-    // consecutive XCDs, so XCD = c_lo for every row tile of a column tile
-    const int c_lo = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int rt = rest % mtiles, ct = (rest / mtiles) * 8 + c_lo;
-    if (ct * 32 >= p.n) return;
+    // blockIdx.x = g_lo + 8*(rt + mtiles*g_hi), column group cg = g_hi*8 + g_lo (CW tiles): consecutive workgroups go
+    // to consecutive XCDs, so XCD = g_lo for every row tile of a column group (they share the weights in its L2)
+    const int g_lo = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int rt = rest % mtiles, ct = ((rest / mtiles) * 8 + g_lo) * CW + cw;
+    if (ct * 32 >= p.n) return;                           // whole workgroups only (n % (32*CW) == 0)
     const int ncol = p.n0 + ct * 32 + nl;
     int arow = rt * 32 + nl;
     arow = arow < p.m ? arow : p.m - 1;                   // rows beyond M replicate the last row (never stored)
     const int nblk = p.k / QB, nbr = nblk / S, b0 = ks * nbr;
-    float* dA = (float*)smem + (size_t)ks * nbr * 32;     // this wave's slice: [nbr][32 rows]
-    {   // stage da[row][b0 .. b0+nbr) transposed; lane (row, h) covers half of its row's blocks
+    float* dA = (float*)smem + (size_t)ks * nbr * 32;     // the K range's slice: [nbr][32 rows], shared by the CW waves
+    {   // stage da[row][b0 .. b0+nbr) transposed; lane (row, h) of wave cw covers blocks h + 2*cw, step 2*CW
         const float* src = p.af + (size_t)arow * p.ldaf + b0;
-        for (int i = h; i < nbr; i += 2) dA[i * 32 + nl] = src[i];
+        for (int i = h + 2 * cw; i < nbr; i += 2 * CW) dA[i * 32 + nl] = src[i];
     }
+    if (CW > 1) __syncthreads();
     // per-block strides: row-major A/W advance 32 / 16 bytes and 1 scale per block; tiled operands 1 KB / 512 B / 32 scales
     const int8_t* ap = TILED ? p.a + (((size_t)rt * nblk + b0) * 64 + lane) * 16 : p.a + (size_t)arow * p.lda + (size_t)b0 * QB + h * 16;
     const uint8_t* wp = TILED ? p.w + (((size_t)(p.n0 / 32 + ct) * nblk + b0) * 32 + nl) * 16 : p.w + (size_t)ncol * p.ldb + (size_t)b0 * 16;
@@ -1274,7 +1279,7 @@ __global__ __launch_bounds__(S * 64) __attribute__((amdgpu_waves_per_eu(3))) voi
     for (int r = 0; r < 8; r++) { acc[2 * r] = acc2[r].x; acc[2 * r + 1] = acc2[r].y; }
     // ---- split-K partials meet in LDS (after every wave is done with its scale slice); wave ks finishes registers
     // r = ks*(16/S) ..., summing the K ranges in ascending order
-    float* red = (float*)smem;
+    float* red = (float*)smem + (size_t)cw * S * 16 * 64;   // one reduction region per column tile of the workgroup
     if (S > 1) {
         __syncthreads();
 #pragma unroll
@@ -1305,6 +1310,7 @@ __global__ void add_rows_kernel(const float* a, const float* b, float* out, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
 }
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
 __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
     st->pos = pos; st->token = token; st->step = step;
 }
@@ -1862,7 +1868,8 @@ struct PrefillAttnParams {
     float* kv_base; long long page_elems;
     int rel_layer_in_page, ctx_per_page, cpp_shift;
     int n_heads, n_kv_heads, head_size, kv_head_offset;
-    int start_pos, rows;
+    const int* start_pos;  // device word: position of the chunk's first row (read at run time => one captured graph per
+    int rows;              //   chunk shape serves every chunk position)
     float scale;
     float* out; int ldo;          // [rows][A]
 };
@@ -1870,7 +1877,7 @@ struct PrefillAttnParams {
 // RoPE of q (in place) and k, and the KV page writes, for every row of the chunk (CausalSelfAttention.java:199-286;
 // the table offset is position*half + kvHead*headSize for q and k alike -- SURVEY.md 8a "RoPE quirk").
 __global__ __launch_bounds__(256) void rows_rope_kv_kernel(PrefillAttnParams p) {
-    const int row = blockIdx.x, pos = p.start_pos + row;
+    const int row = blockIdx.x, pos = p.start_pos[0] + row;
     const int HS = p.head_size, half = HS / 2, A = p.n_heads * HS, KV = p.n_kv_heads * HS, group = p.n_heads / p.n_kv_heads;
     float* r = p.qkv + (size_t)row * p.ldqkv;
     float* krow = (float*)kv_row(p, 0, pos, KV);
@@ -1900,7 +1907,7 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(PrefillAttnPar
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = PF_THREADS, NW = NT / 64, LPR = HS / 4, RPS = NT / LPR;
     const int kvh = blockIdx.x, row = blockIdx.y;
-    const int pos = p.start_pos + row, n = pos + 1;
+    const int pos = p.start_pos[0] + row, n = pos + 1;
     const int KV = p.n_kv_heads * HS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rsub = tid / LPR, c4 = tid % LPR;

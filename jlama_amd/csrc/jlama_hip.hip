@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <map>
 #include <vector>
 
 #include "jh_kernels.h"
@@ -254,13 +255,13 @@ int launch_gemm_q8q4_mfma_mt(const MfmaQ4Params& g, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
-template <int S, bool TILED>
+template <int S, bool TILED, int CW>
 int launch_gemm_q8q4_tile(const MfmaQ4Params& g, int mtiles, hipStream_t st) {
-    const int ctiles = g.n / 32, cgroups = (ctiles + 7) / 8;
-    const size_t lds_scales = (size_t)(g.k / QB) * 32 * 4, lds_red = S > 1 ? (size_t)S * 16 * 64 * 4 : 0;
+    const int cgroups = g.n / (32 * CW), gg = (cgroups + 7) / 8;
+    const size_t lds_scales = (size_t)(g.k / QB) * 32 * 4, lds_red = S > 1 ? (size_t)CW * S * 16 * 64 * 4 : 0;
     const size_t lds = lds_scales > lds_red ? lds_scales : lds_red;
-    JHCHK(allow_lds((gemm_q8q4_tile_kernel<S, TILED>), lds));
-    hipLaunchKernelGGL((gemm_q8q4_tile_kernel<S, TILED>), dim3(8 * mtiles * cgroups), dim3(S * 64), lds, st, g, mtiles);
+    JHCHK(allow_lds((gemm_q8q4_tile_kernel<S, TILED, CW>), lds));
+    hipLaunchKernelGGL((gemm_q8q4_tile_kernel<S, TILED, CW>), dim3(8 * mtiles * gg), dim3(S * CW * 64), lds, st, g, mtiles);
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
@@ -270,24 +271,21 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
     const int mt = (g.m + 31) / 32;
     const int nblk = g.k / QB;
     if (nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024 && (tiled || (g.lda % 16) == 0) && (tiled || !env_int("JH_GEMM_FAT", 0))) {
-        // one 32x32 output tile per workgroup; split K over S waves until the chip has >= ~8 waves per CU
+        // one 32x32 output tile per wave; split K over S waves until the chip has >= ~8 waves per CU; CW column tiles per
+        // workgroup share the A tile through L1 (S*CW <= 8 waves: several workgroups per CU keep the CUs evenly loaded)
         const long long tiles = (long long)mt * (g.n / 32);
         int S = 1;
         while (S < 8 && tiles * S < (long long)g_cu_count * 8 && nblk % (16 * S) == 0) S *= 2;   // nblk/S stays a multiple of 8
+        static const int cw_env = env_int("JH_GEMM_CW", 0);
+        int CW = 1;
         if (tiled) {
-            switch (S) {
-                case 1: return launch_gemm_q8q4_tile<1, true>(g, mt, st);
-                case 2: return launch_gemm_q8q4_tile<2, true>(g, mt, st);
-                case 4: return launch_gemm_q8q4_tile<4, true>(g, mt, st);
-                default: return launch_gemm_q8q4_tile<8, true>(g, mt, st);
-            }
+            CW = cw_env > 0 ? cw_env : (S == 1 ? 4 : (S <= 4 ? 2 : 1));
+            while (CW > 1 && (g.n % (32 * CW)) != 0) CW >>= 1;
         }
-        switch (S) {
-            case 1: return launch_gemm_q8q4_tile<1, false>(g, mt, st);
-            case 2: return launch_gemm_q8q4_tile<2, false>(g, mt, st);
-            case 4: return launch_gemm_q8q4_tile<4, false>(g, mt, st);
-            default: return launch_gemm_q8q4_tile<8, false>(g, mt, st);
-        }
+#define JH_TILE(SV, CV) if (S == SV && CW == CV) return tiled ? launch_gemm_q8q4_tile<SV, true, CV>(g, mt, st) : launch_gemm_q8q4_tile<SV, false, 1>(g, mt, st);
+        JH_TILE(1, 1) JH_TILE(2, 1) JH_TILE(4, 1) JH_TILE(8, 1) JH_TILE(1, 2) JH_TILE(2, 2) JH_TILE(4, 2) JH_TILE(1, 4) JH_TILE(2, 4) JH_TILE(8, 2)
+#undef JH_TILE
+        return set_err(JH_ERR_INVALID, "tile GEMM: no instantiation for this (S, CW)");
     }
     if (tiled) return set_err(JH_ERR_UNSUPPORTED, "tiled I8xQ4 GEMM needs K % 256 == 0");
     switch (mt) {
@@ -896,6 +894,9 @@ struct jh_session {
     int8_t* pb_aq = nullptr;
     float* pb_ws = nullptr;   // split-K workspace of the BF16 prefill GEMM
     int* pb_tok = nullptr;
+    int* pb_start = nullptr;  // device word: start position of the chunk being prefilled
+    std::map<uint64_t, hipGraphExec_t> pb_graphs;   // captured layer loops, key = rows | key-count bucket << 32
+    std::vector<hipGraph_t> pb_graph_src;
     int prefill_batch_min = 4;
 };
 
@@ -1115,6 +1116,7 @@ int prefill_alloc(jh_session* s) {
     HIPCHK(hipMalloc(&s->pb_aq, R * kmax * (c.weight_dtype == JH_DT_BF16 ? 2 : 1)));   // Q8 codes, or BF16 rows for a BF16 model
     HIPCHK(hipMalloc(&s->pb_ad, R * (kmax / QB) * 4));
     HIPCHK(hipMalloc(&s->pb_tok, R * 4));
+    HIPCHK(hipMalloc(&s->pb_start, 64));
     if (c.weight_dtype == JH_DT_BF16) HIPCHK(hipMalloc(&s->pb_ws, BF16_SPLITK_WS_BYTES));
     s->pb_rows = PB_MAX_ROWS;
     return JH_OK;
@@ -1162,7 +1164,8 @@ int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, 
     MfmaQ4Params g{s->pb_aq, s->pb_ad, (const uint8_t*)W.data, W.scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
     return launch_gemm_q8q4_mfma(g, st);
 }
-int prefill_attn_launch(jh_session* s, int rel, int start_pos, int rows, hipStream_t st) {
+// nkeys_bound >= start_pos + rows sizes the score rows in LDS (the position itself is read from s->pb_start)
+int prefill_attn_launch(jh_session* s, int rel, int nkeys_bound, int rows, hipStream_t st) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
     const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
@@ -1178,11 +1181,11 @@ int prefill_attn_launch(jh_session* s, int rel, int start_pos, int rows, hipStre
     for (int sh = 0; sh < 30; sh++)
         if ((1 << sh) == s->ctx_per_page) p.cpp_shift = sh;
     p.n_heads = c.n_heads; p.n_kv_heads = c.n_kv_heads; p.head_size = hs; p.kv_head_offset = m->kv_head_offset;
-    p.start_pos = start_pos; p.rows = rows; p.scale = m->attention_scale;
+    p.start_pos = s->pb_start; p.rows = rows; p.scale = m->attention_scale;
     p.out = s->pb_att; p.ldo = A;
     hipLaunchKernelGGL(rows_rope_kv_kernel, dim3(rows), dim3(256), 0, st, p);
     HIPCHK(hipGetLastError());
-    const size_t lds = prefill_attn_lds(c, start_pos + rows);
+    const size_t lds = prefill_attn_lds(c, nkeys_bound);
     dim3 grid(c.n_kv_heads, rows), block(PF_THREADS);
 #define JH_PATTN(HSV, GV)                                                                  \
     if (hs == HSV && group == GV) {                                                        \
@@ -1194,6 +1197,35 @@ int prefill_attn_launch(jh_session* s, int rel, int start_pos, int rows, hipStre
     JH_PATTN(128, 4) JH_PATTN(128, 8) JH_PATTN(64, 4) JH_PATTN(128, 1) JH_PATTN(128, 2) JH_PATTN(64, 1) JH_PATTN(64, 2) JH_PATTN(64, 8)
 #undef JH_PATTN
     return set_err(JH_ERR_UNSUPPORTED, "prefill attention: unsupported head geometry");
+}
+// the layer loop of one chunk (also what the prefill graphs capture)
+int prefill_layers(jh_session* s, int rows, int nkeys_bound, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
+    const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    for (int li = c.layer_start; li < c.layer_end; li++) {
+        const int rel = li - c.layer_start;
+        JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+        JWeight& F = m->qkv[(size_t)li];
+        if (!F.data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data)
+            return set_err(JH_ERR_INVALID, "layer: weights not set");
+        // preAttentionNorm + maybeQuantize, q|k|v projections (CausalSelfAttention.java:161-171)
+        JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
+        JHCHK(prefill_gemm(s, F, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, st));
+        JHCHK(prefill_attn_launch(s, rel, nkeys_bound, rows, st));
+        // maybeQuantize(valueBatch) + output projection + residual (:364-376, TransformerBlock.java:185)
+        JHCHK((rows_quant_launch<ROWS_QUANT>(s, s->pb_att, A, nullptr, 0, nullptr, 0.f, A, rows, st)));
+        JHCHK(prefill_gemm(s, W[JH_W_O], E, A, rows, s->pb_x1, E, s->pb_x, st));
+        // preFFNorm + maybeQuantize, gate / up, SiLU*up + maybeQuantize, down + residual (MLPBlock.java:117-158)
+        JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
+        JHCHK(prefill_gemm(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, st));
+        JHCHK(prefill_gemm(s, W[JH_W_UP], H, E, rows, s->pb_u, H, nullptr, st));
+        JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, st)));
+        JHCHK(prefill_gemm(s, W[JH_W_DOWN], E, H, rows, s->pb_x, E, s->pb_x1, st));
+        JHCHK(trace_sync("prefill layer", st));
+    }
+    return JH_OK;
 }
 // One chunk of `rows` prompt rows at positions [start_pos, start_pos+rows) through this shard's layers.
 int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool x_in_dev, int rows, int start_pos,
@@ -1212,26 +1244,33 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     } else {
         HIPCHK(hipMemcpyAsync(s->pb_x, x_in, (size_t)rows * E * 4, x_in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
-    for (int li = c.layer_start; li < c.layer_end; li++) {
-        const int rel = li - c.layer_start;
-        JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
-        JWeight& F = m->qkv[(size_t)li];
-        if (!F.data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data)
-            return set_err(JH_ERR_INVALID, "layer: weights not set");
-        // preAttentionNorm + maybeQuantize, q|k|v projections (CausalSelfAttention.java:161-171)
-        JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
-        JHCHK(prefill_gemm(s, F, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, st));
-        JHCHK(prefill_attn_launch(s, rel, start_pos, rows, st));
-        // maybeQuantize(valueBatch) + output projection + residual (:364-376, TransformerBlock.java:185)
-        JHCHK((rows_quant_launch<ROWS_QUANT>(s, s->pb_att, A, nullptr, 0, nullptr, 0.f, A, rows, st)));
-        JHCHK(prefill_gemm(s, W[JH_W_O], E, A, rows, s->pb_x1, E, s->pb_x, st));
-        // preFFNorm + maybeQuantize, gate / up, SiLU*up + maybeQuantize, down + residual (MLPBlock.java:117-158)
-        JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
-        JHCHK(prefill_gemm(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, st));
-        JHCHK(prefill_gemm(s, W[JH_W_UP], H, E, rows, s->pb_u, H, nullptr, st));
-        JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, st)));
-        JHCHK(prefill_gemm(s, W[JH_W_DOWN], E, H, rows, s->pb_x, E, s->pb_x1, st));
-        JHCHK(trace_sync("prefill layer", st));
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, st, s->pb_start, start_pos);
+    HIPCHK(hipGetLastError());
+    // ~15 launches per layer, many of them 5 us kernels: replay a captured graph of the layer loop.  The graph depends on
+    // the chunk's row count (grids) and on an LDS bound for the score rows, not on the position: every full 256-row chunk
+    // of a long prompt replays the same graph
+    int bound = 1024;
+    while (bound < start_pos + rows) bound *= 2;
+    if (!prefill_chunk_fits(s, 0, bound)) bound = start_pos + rows;
+    static const int use_graph = env_int("JH_PREFILL_GRAPH", 1);
+    if (use_graph && !env_int("JH_TRACE", 0)) {
+        const uint64_t key = (uint64_t)rows | ((uint64_t)bound << 32);
+        auto it = s->pb_graphs.find(key);
+        if (it == s->pb_graphs.end()) {
+            HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const int rc = prefill_layers(s, rows, bound, st);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc != JH_OK) { if (g) hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture (prefill): ") + hipGetErrorString(e));
+            hipGraphExec_t ex = nullptr;
+            HIPCHK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            s->pb_graph_src.push_back(g);
+            it = s->pb_graphs.emplace(key, ex).first;
+        }
+        HIPCHK(hipGraphLaunch(it->second, st));
+    } else {
+        JHCHK(prefill_layers(s, rows, bound, st));
     }
     // the chunk's last row is the session's current row (what sample() / the next shard's hand-off reads)
     HIPCHK(hipMemcpyAsync(s->x, s->pb_x + (size_t)(rows - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
@@ -1533,7 +1572,9 @@ int jh_session_destroy(jh_session* s) {
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
-    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_u, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws}) if (b) hipFree(b);
+    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_u, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start}) if (b) hipFree(b);
+    for (auto& kv : s->pb_graphs) hipGraphExecDestroy(kv.second);
+    for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
     if (s->stream) hipStreamDestroy(s->stream);
