@@ -279,11 +279,12 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
         static const int cw_env = env_int("JH_GEMM_CW", 0);
         int CW = 1;
         if (tiled) {
-            CW = cw_env > 0 ? cw_env : (S == 1 ? 4 : (S <= 4 ? 2 : 1));
+            CW = S <= 4 ? 4 : 2;                       // S*CW <= 16 waves
+            if (cw_env > 0 && cw_env * S <= 16) CW = cw_env;
             while (CW > 1 && (g.n % (32 * CW)) != 0) CW >>= 1;
         }
 #define JH_TILE(SV, CV) if (S == SV && CW == CV) return tiled ? launch_gemm_q8q4_tile<SV, true, CV>(g, mt, st) : launch_gemm_q8q4_tile<SV, false, 1>(g, mt, st);
-        JH_TILE(1, 1) JH_TILE(2, 1) JH_TILE(4, 1) JH_TILE(8, 1) JH_TILE(1, 2) JH_TILE(2, 2) JH_TILE(4, 2) JH_TILE(1, 4) JH_TILE(2, 4) JH_TILE(8, 2)
+        JH_TILE(1, 1) JH_TILE(2, 1) JH_TILE(4, 1) JH_TILE(8, 1) JH_TILE(1, 2) JH_TILE(2, 2) JH_TILE(4, 2) JH_TILE(1, 4) JH_TILE(2, 4) JH_TILE(8, 2) JH_TILE(1, 8) JH_TILE(4, 4)
 #undef JH_TILE
         return set_err(JH_ERR_INVALID, "tile GEMM: no instantiation for this (S, CW)");
     }
