@@ -302,14 +302,16 @@ template <int MT>
 int launch_gemm_bf16_mfma_mt(const MfmaGemmParams& g0, hipStream_t st) {
     MfmaGemmParams g = g0;
     const int tiles = g.n / 32;
-    // enough workgroups to cover the chip: 1, 2 or 4 column tiles (waves) per workgroup; few tiles => split K over
-    // workgroup rows (partials to the caller's workspace, splitk_reduce_kernel adds them in K order)
-    const int waves = tiles >= g_cu_count * 4 ? 4 : (tiles >= g_cu_count * 2 ? 2 : 1);
+    // 4 column tiles (waves) per workgroup share one staged A slice (A is 6x the W bytes per slice at M=192, so a
+    // single-wave workgroup spends its time re-staging A); parallelism comes from splitting K over workgroup rows
+    // (partials to the caller's workspace, splitk_reduce_kernel adds them in K order)
+    const int waves = tiles >= 4 ? 4 : (tiles >= 2 ? 2 : 1);
     const int grid = (tiles + waves - 1) / waves;
     int S = 1;
     if (g.ws) {
         const int nslices = g.k / MG_KS;
-        while (S < 8 && grid * S < g_cu_count * 4 && nslices % (2 * S) == 0 && nslices / (2 * S) >= 4) S *= 2;
+        while (S < 16 && grid * S < g_cu_count * 3 && nslices % (2 * S) == 0 && nslices / (2 * S) >= 2 &&
+               (size_t)(2 * S) * g.n <= (size_t)8 * 16384) S *= 2;
     }
     g.nsplit = S;
     const size_t lds = (size_t)2 * MT * 32 * MG_ASTRIDE;
@@ -325,7 +327,7 @@ int launch_gemm_bf16_mfma_mt(const MfmaGemmParams& g0, hipStream_t st) {
     }
     return JH_OK;
 }
-constexpr size_t BF16_SPLITK_WS_BYTES = (size_t)8 * 256 * 16384 * 4;   // 8 splits x 256 rows x N <= 16384 (larger N never splits)
+constexpr size_t BF16_SPLITK_WS_BYTES = (size_t)8 * 256 * 16384 * 4;   // S x 256 rows x N floats with S*N <= 8*16384 (enforced by the launcher)
 
 int launch_gemm_bf16_mfma(const MfmaGemmParams& g, hipStream_t st) {
     const int mt = (g.m + 31) / 32;
@@ -539,7 +541,7 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         g.a = (const uint16_t*)dA + aoffset; g.w = (const uint16_t*)dB + boffset; g.c = (float*)dR;
         g.m = m; g.n0 = n0; g.n = n; g.k = k; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.roffset = roffset; g.resid = nullptr;
         g.ws = nullptr; g.nsplit = 1;
-        if (n <= 16384) { void* wsp = nullptr; JHCHK(dev_buf(7, BF16_SPLITK_WS_BYTES, &wsp)); g.ws = (float*)wsp; }
+        { void* wsp = nullptr; JHCHK(dev_buf(7, BF16_SPLITK_WS_BYTES, &wsp)); g.ws = (float*)wsp; }
         JHCHK(launch_gemm_bf16_mfma(g, st));
         fast = true;
     }
@@ -1154,7 +1156,7 @@ int rows_quant_launch(jh_session* s, const float* x, int ldx, const float* x2, i
 // out[rows, N] = act[rows, K] x W[N, K]^T (+ resid): I8 x Q4 (exact integer MFMA) or BF16 x BF16 (MFMA), by model dtype
 int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
     if (s->m->c.weight_dtype == JH_DT_BF16) {
-        MfmaGemmParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.data, out, rows, 0, N, K, K, K, ldc, 0, resid, N <= 16384 ? s->pb_ws : nullptr, 1};
+        MfmaGemmParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.data, out, rows, 0, N, K, K, K, ldc, 0, resid, s->pb_ws, 1};
         return launch_gemm_bf16_mfma(g, st);
     }
     if (prefill_tiled(s, K)) {
@@ -1622,7 +1624,7 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
     HIPCHK(hipMalloc(&af, (size_t)m * (k / QB) * 4)); HIPCHK(hipMemset(af, 0, (size_t)m * (k / QB) * 4));
     HIPCHK(hipMalloc(&c, (size_t)m * n * 4));
     float* bf16_ws = nullptr;
-    if (kind == 1 && n <= 16384) HIPCHK(hipMalloc(&bf16_ws, BF16_SPLITK_WS_BYTES));
+    if (kind == 1) HIPCHK(hipMalloc(&bf16_ws, BF16_SPLITK_WS_BYTES));
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     int rc = JH_OK;
     for (int it = -1; it < iters && rc == JH_OK; it++) {
