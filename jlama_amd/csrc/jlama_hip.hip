@@ -311,7 +311,7 @@ int launch_gemm_bf16_mfma_mt(const MfmaGemmParams& g0, hipStream_t st) {
     if (g.ws) {
         const int nslices = g.k / MG_KS;
         while (S < 16 && grid * S < g_cu_count * 3 && nslices % (2 * S) == 0 && nslices / (2 * S) >= 2 &&
-               (size_t)(2 * S) * g.n <= (size_t)8 * 16384) S *= 2;
+               (size_t)(2 * S) * g.n <= (size_t)8 * 16384 && (g.n <= 8192 || 2 * S * g.m <= 640)) S *= 2;   // wide outputs: the reduce pass costs S*M*N*8 bytes
     }
     g.nsplit = S;
     const size_t lds = (size_t)2 * MT * 32 * MG_ASTRIDE;
