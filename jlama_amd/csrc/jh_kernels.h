@@ -9,7 +9,7 @@
 //   * the I8 activation row is quantized ONCE per workgroup into LDS (fused RMSNorm+Q8 prologue) and then
 //     held in registers by the lane that owns the matching K blocks;
 //   * block sums are exact integers (v_dot4_i32_i8), the -8 nibble bias is folded in as -8*sum(a_block);
-//   * the K reduction is a wave64 butterfly (__shfl_xor), epilogues (residual add, SiLU*up+Q8) are fused.
+//   * the K reduction is a wave64 DPP reduction (no LDS permutes), epilogues (residual add, SiLU*up+Q8) are fused.
 // Compiled with -ffp-contract=off: every FMA is explicit (fmaf) where the reference calls FloatVector.fma().
 #pragma once
 #include <hip/hip_runtime.h>
@@ -23,29 +23,44 @@ using i32x4 = int __attribute__((ext_vector_type(4)));
 using i32x2 = int __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------ helpers
-// 64-lane butterfly reductions on the VALU's DPP path (quad_perm / row_half_mirror / row_mirror stay inside a
-// 16-lane row; the two cross-row steps use ds_swizzle-free v_permlane/bpermute via __shfl_xor).  Every lane ends up
-// with the full result.
+// 64-lane reductions entirely on the VALU's DPP path: quad_perm / row_half_mirror / row_mirror inside a 16-lane row,
+// then row_bcast15 (rows 1,3 += last lane of rows 0,2) and row_bcast31 (rows 2,3 += lane 31): lane 63 holds the total,
+// v_readlane hands it to every lane as a scalar.  No LDS permute (ds_bpermute costs a ~100-cycle round trip per step).
+// Same value as the xor butterfly: ((r3+r2)+(r1+r0)) vs ((r0+r1)+(r2+r3)), float addition commutes.
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_fm(float v, float old) {   // rows outside ROWMASK receive `old`
+    return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(old), __float_as_uint(v), CTRL, ROWMASK, 0xf, false));
 }
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
     v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
     v += dpp_f<0x141>(v);   // row_half_mirror      (pairs lanes across 4)
     v += dpp_f<0x140>(v);   // row_mirror           (pairs lanes across 8)
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    v += dpp_fm<0x142, 0xA>(v, 0.0f);   // row_bcast15
+    v += dpp_fm<0x143, 0xC>(v, 0.0f);   // row_bcast31
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_f<0xB1>(v));
     v = fmaxf(v, dpp_f<0x4E>(v));
     v = fmaxf(v, dpp_f<0x141>(v));
     v = fmaxf(v, dpp_f<0x140>(v));
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
+    v = fmaxf(v, dpp_fm<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_fm<0x143, 0xC>(v, v));
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
+}
+// sum over groups of LPR = 16 or 32 consecutive lanes; the result is valid in the LAST lane of every group
+template <int LPR>
+__device__ __forceinline__ float group_sum_last(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    if (LPR == 32) v += dpp_fm<0x142, 0xA>(v, 0.0f);
     return v;
 }
 template <int CTRL>
@@ -55,14 +70,23 @@ __device__ __forceinline__ double dpp_d(double v) {
     const unsigned hi = __builtin_amdgcn_update_dpp(0, (unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_dm(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0, (unsigned)u, CTRL, ROWMASK, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0, (unsigned)(u >> 32), CTRL, ROWMASK, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
     v += dpp_d<0xB1>(v);
     v += dpp_d<0x4E>(v);
     v += dpp_d<0x141>(v);
     v += dpp_d<0x140>(v);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    v += dpp_dm<0x142, 0xA>(v);   // row_bcast15 (other rows receive +0.0)
+    v += dpp_dm<0x143, 0xC>(v);   // row_bcast31
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 63), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 63);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 // Workgroup barrier for LDS hand-offs ONLY.  __syncthreads() carries a workgroup-scope fence, for which hipcc emits
 // s_waitcnt vmcnt(0): every global load in flight (our whole prefetched weight stream) would have to land before the
@@ -1558,9 +1582,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
                 s = fmaf(qv[gi].y, kv4.y, s);
                 s = fmaf(qv[gi].z, kv4.z, s);
                 s = fmaf(qv[gi].w, kv4.w, s);
-#pragma unroll
-                for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-                if (c4 == 0) sc[gi * chunk + tt] = s * p.scale;   // ops.scale after the dot (:332): separate rounding
+                s = group_sum_last<LPR>(s);
+                if (c4 == LPR - 1) sc[gi * chunk + tt] = s * p.scale;   // ops.scale after the dot (:332): separate rounding
             }
         }
     }
@@ -1574,9 +1597,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
             s = fmaf(qv[gi].y, kv4.y, s);
             s = fmaf(qv[gi].z, kv4.z, s);
             s = fmaf(qv[gi].w, kv4.w, s);
-#pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (c4 == 0) sc[gi * chunk + tt] = s * p.scale;
+            s = group_sum_last<LPR>(s);
+            if (c4 == LPR - 1) sc[gi * chunk + tt] = s * p.scale;
         }
     }
     lds_barrier();
@@ -1922,17 +1944,27 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(PrefillAttnPar
     float4 qv[GROUP];
 #pragma unroll
     for (int gi = 0; gi < GROUP; gi++) qv[gi] = ((const float4*)(qrow + gi * HS))[c4];
-    for (int t = rsub; t < n; t += RPS) {
-        const float4 kv4 = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4];
+    constexpr int UN = 4;   // K rows in flight per thread (branch-free clamped loads: one round trip per UN steps)
+    for (int t0 = rsub; t0 < n; t0 += RPS * UN) {
+        float4 kreg[UN];
 #pragma unroll
-        for (int gi = 0; gi < GROUP; gi++) {
-            float s = qv[gi].x * kv4.x;
-            s = fmaf(qv[gi].y, kv4.y, s);
-            s = fmaf(qv[gi].z, kv4.z, s);
-            s = fmaf(qv[gi].w, kv4.w, s);
+        for (int u = 0; u < UN; u++) {
+            int t = t0 + u * RPS;
+            t = t < n ? t : n - 1;
+            kreg[u] = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4];
+        }
 #pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (c4 == 0) sc[gi * n + t] = s * p.scale;
+        for (int u = 0; u < UN; u++) {
+            const int t = t0 + u * RPS;
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++) {
+                float s = qv[gi].x * kreg[u].x;
+                s = fmaf(qv[gi].y, kreg[u].y, s);
+                s = fmaf(qv[gi].z, kreg[u].z, s);
+                s = fmaf(qv[gi].w, kreg[u].w, s);
+                s = group_sum_last<LPR>(s);
+                if (c4 == LPR - 1 && t < n) sc[gi * n + t] = s * p.scale;
+            }
         }
     }
     __syncthreads();
@@ -1953,15 +1985,27 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(PrefillAttnPar
     float4 acc[GROUP];
 #pragma unroll
     for (int gi = 0; gi < GROUP; gi++) acc[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = rsub; t < n; t += RPS) {
-        const float4 v4 = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
+    for (int t0 = rsub; t0 < n; t0 += RPS * UN) {
+        float4 vreg[UN];
 #pragma unroll
-        for (int gi = 0; gi < GROUP; gi++) {
-            const float w = sc[gi * n + t];
-            acc[gi].x = fmaf(v4.x, w, acc[gi].x);
-            acc[gi].y = fmaf(v4.y, w, acc[gi].y);
-            acc[gi].z = fmaf(v4.z, w, acc[gi].z);
-            acc[gi].w = fmaf(v4.w, w, acc[gi].w);
+        for (int u = 0; u < UN; u++) {
+            int t = t0 + u * RPS;
+            t = t < n ? t : n - 1;
+            vreg[u] = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int t = t0 + u * RPS;
+            if (t < n) {
+#pragma unroll
+                for (int gi = 0; gi < GROUP; gi++) {
+                    const float w = sc[gi * n + t];
+                    acc[gi].x = fmaf(vreg[u].x, w, acc[gi].x);
+                    acc[gi].y = fmaf(vreg[u].y, w, acc[gi].y);
+                    acc[gi].z = fmaf(vreg[u].z, w, acc[gi].z);
+                    acc[gi].w = fmaf(vreg[u].w, w, acc[gi].w);
+                }
+            }
         }
     }
 #pragma unroll
