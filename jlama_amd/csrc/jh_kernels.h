@@ -1459,13 +1459,16 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
 
 constexpr int ATT_THREADS = 512;
 
-template <int HS, int GROUP>
+// PRE = row steps prefetched into registers before anything else (branch-free, clamped): PRE*RPS rows per slice
+// (HS=128: 16 rows per step).  Contexts of <= max_splits*32 rows have slices of <= 32 rows, for which PRE=2 issues a
+// quarter of the load instructions of PRE=8 (the texture path needs ~16 cycles per 16-byte wave load); the host picks
+// the variant per token from the position it already knows.  Any PRE is correct for any context (tail loops).
+template <int HS, int GROUP, int PRE>
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = ATT_THREADS, NW = NT / 64;
     constexpr int LPR = HS / 4;          // lanes per K/V row (float4 each): 32 for HS=128, 16 for HS=64
     constexpr int RPS = NT / LPR;        // rows per workgroup step (scores and PV use the same row->thread map)
-    constexpr int PRE = 8;               // row steps prefetched into registers: PRE*RPS = 128 (HS=128) / 256 rows
     constexpr int half = HS / 2;
     constexpr int NQ = (GROUP * half + NT - 1) / NT;   // q-rotation pairs per thread
     constexpr int CS = 16;               // slices combined per batch of in-flight loads (ticket mode)

@@ -879,10 +879,12 @@ struct jh_session {
     int* out_tokens = nullptr;
     int out_cap = 0;
     int lm_grid = 0;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipGraph_t row_graph = nullptr;        // this shard's layers only: single-row forward (pipeline stages)
-    hipGraphExec_t row_exec = nullptr;
+    // graphs exist per attention variant (0: PRE=8 rows steps prefetched, 1: PRE=2 for short contexts)
+    int attn_variant = 0;
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    hipGraph_t row_graph[2] = {nullptr, nullptr};   // this shard's layers only: single-row forward (pipeline stages)
+    hipGraphExec_t row_exec[2] = {nullptr, nullptr};
     int pending_n = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms_per_token = 0;
@@ -902,6 +904,8 @@ struct jh_session {
     std::vector<hipGraph_t> pb_graph_src;
     int prefill_batch_min = 4;
 };
+
+static int attn_variant_for(const jh_session* s, int pos);
 
 namespace {
 
@@ -945,8 +949,13 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     dim3 grid(gx, c.n_kv_heads), block(ATT_THREADS);
 #define JH_ATTN(HSV, GV)                                                                   \
     if (hs == HSV && group == GV) {                                                        \
-        JHCHK(allow_lds(attn_decode_kernel<HSV, GV>, lds));                                \
-        hipLaunchKernelGGL((attn_decode_kernel<HSV, GV>), grid, block, lds, st, p);        \
+        if (s->attn_variant == 1) {                                                        \
+            JHCHK(allow_lds((attn_decode_kernel<HSV, GV, 2>), lds));                       \
+            hipLaunchKernelGGL((attn_decode_kernel<HSV, GV, 2>), grid, block, lds, st, p); \
+        } else {                                                                           \
+            JHCHK(allow_lds((attn_decode_kernel<HSV, GV, 8>), lds));                       \
+            hipLaunchKernelGGL((attn_decode_kernel<HSV, GV, 8>), grid, block, lds, st, p); \
+        }                                                                                  \
         HIPCHK(hipGetLastError());                                                         \
         return JH_OK;                                                                      \
     }
@@ -1325,9 +1334,9 @@ int ensure_out_tokens(jh_session* s, int n) {
     if (s->out_tokens) HIPCHK(hipFree(s->out_tokens));
     HIPCHK(hipMalloc(&s->out_tokens, (size_t)n * sizeof(int)));
     s->out_cap = n;
-    if (s->exec) {  // out_tokens pointer is baked into the captured graph
-        hipGraphExecDestroy(s->exec); s->exec = nullptr;
-        hipGraphDestroy(s->graph); s->graph = nullptr;
+    for (int v = 0; v < 2; v++) if (s->exec[v]) {  // out_tokens pointer is baked into the captured graphs
+        hipGraphExecDestroy(s->exec[v]); s->exec[v] = nullptr;
+        hipGraphDestroy(s->graph[v]); s->graph[v] = nullptr;
     }
     return JH_OK;
 }
@@ -1566,10 +1575,12 @@ int jh_session_destroy(jh_session* s) {
     if (!s) return JH_OK;
     hipSetDevice(s->m->device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    if (s->exec) hipGraphExecDestroy(s->exec);
-    if (s->graph) hipGraphDestroy(s->graph);
-    if (s->row_exec) hipGraphExecDestroy(s->row_exec);
-    if (s->row_graph) hipGraphDestroy(s->row_graph);
+    for (int v = 0; v < 2; v++) {
+        if (s->exec[v]) hipGraphExecDestroy(s->exec[v]);
+        if (s->graph[v]) hipGraphDestroy(s->graph[v]);
+        if (s->row_exec[v]) hipGraphExecDestroy(s->row_exec[v]);
+        if (s->row_graph[v]) hipGraphDestroy(s->row_graph[v]);
+    }
     if (s->kv_slab) hipFree(s->kv_slab);
     void* bufs[] = {s->pages_dev, s->x, s->x1, s->qkv, s->attf, s->tapq, s->hf, s->logits,
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
@@ -1601,6 +1612,7 @@ int jh_debug_attn_timeline(jh_session* s, int pos, long long* out, int n) {
     hipStream_t st = s->stream;
     for (int it = 0; it < 3; it++) {   // warm: the last launch's stamps are the ones reported
         hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, pos, 0, 0);
+        s->attn_variant = attn_variant_for(s, pos);
         JHCHK(attn_launch(s, 0, st, false, d));
     }
     HIPCHK(hipStreamSynchronize(st));
@@ -1667,6 +1679,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
     const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
     const int nl = c.layer_end - c.layer_start;
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, s->max_ctx / 2, 0, 0);
+    s->attn_variant = attn_variant_for(s, s->max_ctx / 2);
     int launches = 0;
     for (int it = -1; it < iters; it++) {
         if (it == 0) HIPCHK(hipEventRecord(s->ev0, st));
@@ -1753,8 +1766,13 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
     return JH_OK;
 }
 
-static int build_row_graph(jh_session* s) {
-    if (s->row_exec) return JH_OK;
+// which attention variant serves position pos: slices of <= 32 rows need only 2 prefetched row steps
+static int attn_variant_for(const jh_session* s, int pos) {
+    return (s->direct_max == 0 && pos + 1 <= s->max_splits * 32) ? 1 : 0;
+}
+static int build_row_graph(jh_session* s, int v) {
+    if (s->row_exec[v]) return JH_OK;
+    s->attn_variant = v;
     hipStream_t st = s->stream;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = layers_launch(s, st, 0);
@@ -1762,8 +1780,8 @@ static int build_row_graph(jh_session* s) {
     const hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != JH_OK) { if (g) hipGraphDestroy(g); return rc; }
     if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    s->row_graph = g;
-    HIPCHK(hipGraphInstantiate(&s->row_exec, g, nullptr, nullptr, 0));
+    s->row_graph[v] = g;
+    HIPCHK(hipGraphInstantiate(&s->row_exec[v], g, nullptr, nullptr, 0));
     return JH_OK;
 }
 static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in, bool x_in_dev, int n, int start_pos,
@@ -1804,9 +1822,11 @@ static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in,
         if (s->tap_layer < 0 && !env_int("JH_NO_GRAPH", 0)) {
             // the layers read the position from the device-resident state, so ONE captured graph serves every row:
             // a pipeline stage pays 1 launch per tick instead of 5 per layer
-            JHCHK(build_row_graph(s));
-            HIPCHK(hipGraphLaunch(s->row_exec, st));
+            const int v = attn_variant_for(s, start_pos + i);
+            JHCHK(build_row_graph(s, v));
+            HIPCHK(hipGraphLaunch(s->row_exec[v], st));
         } else {
+            s->attn_variant = attn_variant_for(s, start_pos + i);
             JHCHK(layers_launch(s, st, start_pos + i));
         }
         if (x_out)
@@ -1837,6 +1857,7 @@ int jh_tp_set_row(jh_session* s, int32_t token, const float* x_dev, int pos) {
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = s->stream;
     const int E = m->c.embedding_length;
+    s->attn_variant = attn_variant_for(s, pos);
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, pos, token >= 0 ? token : 0, 0);
     if (x_dev) {
         HIPCHK(hipMemcpyAsync(s->x, x_dev, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
@@ -1935,8 +1956,9 @@ int jh_decode_step(jh_session* s, int32_t token, int pos, int32_t* next_token) {
     return jh_sample(s, 0.0f, 0.5f, next_token, nullptr);
 }
 
-static int build_graph(jh_session* s) {
-    if (s->exec) return JH_OK;
+static int build_graph(jh_session* s, int v) {
+    if (s->exec[v]) return JH_OK;
+    s->attn_variant = v;
     hipStream_t st = s->stream;
     const jh_config& c = s->m->c;
     const int saved_tap = s->tap_layer;
@@ -1951,8 +1973,8 @@ static int build_graph(jh_session* s) {
     s->tap_layer = saved_tap;
     if (rc != JH_OK) { if (g) hipGraphDestroy(g); return rc; }
     if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    s->graph = g;
-    HIPCHK(hipGraphInstantiate(&s->exec, g, nullptr, nullptr, 0));
+    s->graph[v] = g;
+    HIPCHK(hipGraphInstantiate(&s->exec[v], g, nullptr, nullptr, 0));
     s->kernels_per_token = (c.layer_end - c.layer_start) * 5 + (has_out ? 2 : 0);
     return JH_OK;
 }
@@ -1968,17 +1990,20 @@ int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) 
     JHCHK(ensure_out_tokens(s, n));
     hipStream_t st = s->stream;
     const bool use_graph = !env_int("JH_NO_GRAPH", 0);
-    if (use_graph) JHCHK(build_graph(s));
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, start_pos, first_token, 0);
     hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
                        (const DecodeState*)s->st, m->c.embedding_length, s->x);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev0, st));
     for (int i = 0; i < n; i++) {
-        if (use_graph) HIPCHK(hipGraphLaunch(s->exec, st));
-        else {
+        const int v = attn_variant_for(s, start_pos + i);   // the host knows every token's position in advance
+        if (use_graph) {
+            JHCHK(build_graph(s, v));
+            HIPCHK(hipGraphLaunch(s->exec[v], st));
+        } else {
             const int saved = s->tap_layer;
             s->tap_layer = -1;
+            s->attn_variant = v;
             int rc = layers_launch(s, st, 0);
             if (rc == JH_OK) rc = lmhead_launch(s, st);
             if (rc == JH_OK) rc = finish_launch(s, st, 1);
