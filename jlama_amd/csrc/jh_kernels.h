@@ -653,31 +653,26 @@ __device__ __forceinline__ ActF32 carve_f32(char* smem, int nblk) {
 }
 static inline size_t lds_bytes_f32(int K) { return (size_t)K * 4 + 32 * 8 + 16 * 4 + 16 * 4; }
 
-// packed F32 math (v_pk_fma_f32: two IEEE FMAs per instruction): w = fma(scale, nib, -8*scale) for two weights at once,
-// then one FMA chain per half of the pair (even / odd elements), joined at the end of the block.  3 -> 2 VALU ops per
-// weight; the LM head is VALU-bound at 3.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float q4_block_dot_f32(const i32x4& w, float scale, const float4 (&y)[8], float acc) {
-    const f32x2_t s2 = {scale, scale}, m82 = {-8.0f * scale, -8.0f * scale};
+    const float m8 = -8.0f * scale;
     const int wl[4] = {w.x & 0x0F0F0F0F, w.y & 0x0F0F0F0F, w.z & 0x0F0F0F0F, w.w & 0x0F0F0F0F};
     const int wh[4] = {(w.x >> 4) & 0x0F0F0F0F, (w.y >> 4) & 0x0F0F0F0F, (w.z >> 4) & 0x0F0F0F0F,
                        (w.w >> 4) & 0x0F0F0F0F};
-    f32x2_t a2 = {acc, 0.0f};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const f32x2_t n01 = {(float)(wl[c] & 0xff), (float)((wl[c] >> 8) & 0xff)};
-        const f32x2_t n23 = {(float)((wl[c] >> 16) & 0xff), (float)((wl[c] >> 24) & 0xff)};
-        a2 = __builtin_elementwise_fma(f32x2_t{y[c].x, y[c].y}, __builtin_elementwise_fma(s2, n01, m82), a2);
-        a2 = __builtin_elementwise_fma(f32x2_t{y[c].z, y[c].w}, __builtin_elementwise_fma(s2, n23, m82), a2);
+        acc = fmaf(y[c].x, fmaf(scale, (float)(wl[c] & 0xff), m8), acc);
+        acc = fmaf(y[c].y, fmaf(scale, (float)((wl[c] >> 8) & 0xff), m8), acc);
+        acc = fmaf(y[c].z, fmaf(scale, (float)((wl[c] >> 16) & 0xff), m8), acc);
+        acc = fmaf(y[c].w, fmaf(scale, (float)((wl[c] >> 24) & 0xff), m8), acc);
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const f32x2_t n01 = {(float)(wh[c] & 0xff), (float)((wh[c] >> 8) & 0xff)};
-        const f32x2_t n23 = {(float)((wh[c] >> 16) & 0xff), (float)((wh[c] >> 24) & 0xff)};
-        a2 = __builtin_elementwise_fma(f32x2_t{y[4 + c].x, y[4 + c].y}, __builtin_elementwise_fma(s2, n01, m82), a2);
-        a2 = __builtin_elementwise_fma(f32x2_t{y[4 + c].z, y[4 + c].w}, __builtin_elementwise_fma(s2, n23, m82), a2);
+        acc = fmaf(y[4 + c].x, fmaf(scale, (float)(wh[c] & 0xff), m8), acc);
+        acc = fmaf(y[4 + c].y, fmaf(scale, (float)((wh[c] >> 8) & 0xff), m8), acc);
+        acc = fmaf(y[4 + c].z, fmaf(scale, (float)((wh[c] >> 16) & 0xff), m8), acc);
+        acc = fmaf(y[4 + c].w, fmaf(scale, (float)((wh[c] >> 24) & 0xff), m8), acc);
     }
-    return a2.x + a2.y;
+    return acc;
 }
 
 template <int PRO, int R, int NB>
