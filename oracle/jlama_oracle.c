@@ -531,6 +531,12 @@ void jo_model_set_ref_gemm(jo_model* m, void* q8q4, void* f32q4, int flags, int 
     m->ref_f32q4 = (jo_ref_f32q4_fn)f32q4;
     m->ref_flags = flags;
     m->nthreads = nthreads > 0 ? nthreads : 1;
+#ifdef _OPENMP
+    /* one team size for every parallel region (GEMM chunks, heads): libgomp tears its thread pool down and rebuilds it
+     * whenever consecutive regions ask for different team sizes, which cost milliseconds per layer once the heads loop
+     * went parallel (position >= 64) */
+    omp_set_num_threads(m->nthreads);
+#endif
 }
 
 jo_session* jo_session_create(jo_model* m, int64_t max_page_bytes) {
