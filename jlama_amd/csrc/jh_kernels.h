@@ -1054,6 +1054,83 @@ __global__ void splitk_reduce_kernel(const float* ws, int nsplit, int m, int n, 
     c[idx] = resid ? v + resid[idx] : v;
 }
 
+// ---- K3t: BF16 GEMM on MFMA-ordered operands (the prefill path of a BF16 model).
+// Both operands are tiled so that one wave-load is one MFMA operand, 1 KB contiguous:
+//   A  [row tile][k slice of 16][h][m][8 bf16]     written by rows_bf16_kernel (ldq < 0)
+//   W  [col tile][k slice of 16][h][n][8 bf16]     resident re-tiled copy (retile_bf16_kernel)
+// A wave owns one column tile and ALL row tiles (MT accumulator tiles): every weight byte is fetched once, straight into
+// registers; per k slice it loads one W fragment and MT A fragments (no LDS, no barrier).  The CWB waves of a
+// workgroup take adjacent column tiles and walk K in step, so an A fragment missed by one wave is an L1 hit for the
+// others.  K can be split over workgroup rows (partials to the workspace, splitk_reduce_kernel).
+struct MfmaBf16TileParams {
+    const uint16_t* a; const uint16_t* w; float* c; const float* resid;
+    int m, n, k, ldc;
+    float* ws; int nsplit;
+};
+template <int MT, int CWB>
+__global__ __launch_bounds__(CWB * 64) void gemm_bf16_tile_kernel(MfmaBf16TileParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, h = lane >> 5;
+    const int ct = blockIdx.x * CWB + wv;
+    if (ct * 32 >= p.n) return;
+    const int nks = p.k / 16, nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    const int per = nks / nsplit, s0 = blockIdx.y * per;
+    const i32x4* wp = (const i32x4*)p.w + ((size_t)ct * nks + s0) * 64 + lane;
+    const i32x4* ap = (const i32x4*)p.a + (size_t)s0 * 64 + lane;          // + (rt*nks + s)*64
+    const size_t a_rt = (size_t)nks * 64;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    // two register sets of one k slice each (W fragment + MT A fragments), ping-pong: the next slice's 1+MT loads are
+    // issued before the current slice's MT MFMAs
+    i32x4 w0, w1, a0[MT], a1[MT];
+    auto load_slice = [&](int s, i32x4& wv, i32x4 (&av)[MT]) __attribute__((always_inline)) {
+        s = s < per ? s : per - 1;                                           // clamped: the last prefetch reloads
+        wv = __builtin_nontemporal_load(wp + (size_t)s * 64);
+#pragma unroll
+        for (int t = 0; t < MT; t++) av[t] = ap[(size_t)t * a_rt + (size_t)s * 64];
+    };
+    auto mma_slice = [&](const i32x4& wv, const i32x4 (&av)[MT]) __attribute__((always_inline)) {
+        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, wv);
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[t]), bfrag, acc[t], 0, 0, 0);
+    };
+    load_slice(0, w0, a0);
+    for (int s = 0; s < per; s += 2) {   // host guarantees per % 2 == 0
+        load_slice(s + 1, w1, a1);
+        mma_slice(w0, a0);
+        load_slice(s + 2, w0, a0);
+        mma_slice(w1, a1);
+    }
+    const int ncol = ct * 32 + nl;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mrow < p.m) {
+                if (nsplit > 1) {
+                    p.ws[((size_t)blockIdx.y * p.m + mrow) * p.n + ncol] = acc[t][r];
+                } else {
+                    const size_t idx = (size_t)p.ldc * mrow + ncol;
+                    p.c[idx] = p.resid ? acc[t][r] + p.resid[idx] : acc[t][r];
+                }
+            }
+        }
+}
+// row-major BF16 weight [N][K] -> MFMA order [N/32][K/16][h][n][8]; one thread per 16-byte chunk
+__global__ void retile_bf16_kernel(const uint16_t* w, int N, int K, uint16_t* wt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t chunks = (size_t)N * (K / 8);
+    if (i >= chunks) return;
+    const int row = (int)(i / (K / 8)), c8 = (int)(i % (K / 8));
+    const int ksl = c8 >> 1, hh = c8 & 1;
+    const size_t dst = (((size_t)(row >> 5) * (K / 16) + ksl) * 2 + hh) * 32 + (row & 31);
+    ((i32x4*)wt)[dst] = ((const i32x4*)w)[i];
+}
+
 // ------------------------------------------------------------------------------------------------ K2: batched I8 x Q4 GEMM on MFMA
 // batchDotProduct I8 x Q4 -> F32 for M > 1 (prefill of a JQ4 model; GemmerI8Q4_512 2x2 tile PTO:958-1043, C twin
 // nc/simd/vector_simd.c:261-437):  C[i,j] = sum_blk (da[i,blk]*sb[j,blk]) * sum_t a[i,blk,t]*(nib[j,blk,t]-8).
@@ -1868,7 +1945,12 @@ __global__ __launch_bounds__(256) void rows_bf16_kernel(RowsParams p) {
         packed.y = (int)f32_to_bf16(y[2]) | ((int)f32_to_bf16(y[3]) << 16);
         packed.z = (int)f32_to_bf16(y[4]) | ((int)f32_to_bf16(y[5]) << 16);
         packed.w = (int)f32_to_bf16(y[6]) | ((int)f32_to_bf16(y[7]) << 16);
-        *(i32x4*)(out + unit * 8) = packed;
+        if (p.ldq < 0) {   // MFMA order: unit = 8 consecutive k = one lane's operand: k slice unit/2, half unit&1
+            const size_t nks = p.K / 16;
+            ((i32x4*)p.q)[(((size_t)(row >> 5) * nks + (unit >> 1)) * 2 + (unit & 1)) * 32 + (row & 31)] = packed;
+        } else {
+            *(i32x4*)(out + unit * 8) = packed;
+        }
     }
 }
 

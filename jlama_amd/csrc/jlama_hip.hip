@@ -340,6 +340,51 @@ int launch_gemm_bf16_mfma(const MfmaGemmParams& g, hipStream_t st) {
     }
 }
 
+template <int MT, int CWB>
+int launch_gemm_bf16_tile_mc(MfmaBf16TileParams g, int S, hipStream_t st) {
+    const int tiles = g.n / 32, grid = (tiles + CWB - 1) / CWB;
+    g.nsplit = S;
+    hipLaunchKernelGGL((gemm_bf16_tile_kernel<MT, CWB>), dim3(grid, S), dim3(CWB * 64), 0, st, g);
+    HIPCHK(hipGetLastError());
+    if (S > 1) {
+        const size_t tot = (size_t)g.m * g.n;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)g.ws, S, g.m, g.n, 0, g.c, g.ldc, 0,
+                           g.resid);
+        HIPCHK(hipGetLastError());
+    }
+    return JH_OK;
+}
+// both operands in MFMA order (gemm_bf16_tile_kernel); n % 32 == 0, k % 16 == 0
+int launch_gemm_bf16_tile(const MfmaBf16TileParams& g, hipStream_t st) {
+    const int mt = (g.m + 31) / 32, tiles = g.n / 32, nks = g.k / 16;
+    // waves per workgroup (column tiles sharing the A fragments through L1) vs workgroups: want >= ~2 workgroups per CU
+    // before splitting K, because the split's reduce pass moves S*M*N*8 bytes
+    static const int cwb_env = env_int("JH_BF16_CWB", 0), s_env = env_int("JH_BF16_S", 0);
+    int cwb = 8;
+    while (cwb > 1 && ((tiles % cwb) != 0 || tiles / cwb < g_cu_count * 2)) cwb >>= 1;
+    if (cwb < 4 && tiles % 4 == 0 && nks >= 512) cwb = 4;      // long K, few tiles: measured best (tools/gemm_bench.py)
+    if (cwb < 2 && tiles % 2 == 0) cwb = 2;
+    if (cwb_env > 0 && tiles % cwb_env == 0) cwb = cwb_env;
+    int S = 1;
+    if (g.ws)
+        while (S < 16 && (tiles / cwb) * S < g_cu_count * 2 && nks % (4 * S) == 0 && nks / (2 * S) >= 8 &&   // nks/S stays even
+               (size_t)(2 * S) * g.n <= (size_t)8 * 16384 && (g.n <= 8192 || 2 * S * g.m <= 640)) S *= 2;
+    if (s_env > 0 && g.ws && nks % (2 * s_env) == 0 && (size_t)s_env * g.n <= (size_t)8 * 16384) S = s_env;
+    if ((nks / S) % 2) return set_err(JH_ERR_UNSUPPORTED, "tiled BF16 GEMM needs K % 32 == 0");
+#define JH_BT(MV) { if (cwb == 8) return launch_gemm_bf16_tile_mc<MV, 8>(g, S, st); if (cwb == 4) return launch_gemm_bf16_tile_mc<MV, 4>(g, S, st); \
+                    if (cwb == 2) return launch_gemm_bf16_tile_mc<MV, 2>(g, S, st); return launch_gemm_bf16_tile_mc<MV, 1>(g, S, st); }
+    switch (mt) {
+        case 1: JH_BT(1)
+        case 2: JH_BT(2)
+        case 3: JH_BT(3)
+        case 4: JH_BT(4)
+        case 5: JH_BT(5)
+        case 6: JH_BT(6)
+        default: JH_BT(8)
+    }
+#undef JH_BT
+}
+
 template <int PRO, int R>
 int launch_gemv_f32q4_r(const GemvParams& p, int grid, int threads, hipStream_t st) {
     const size_t lds = lds_bytes_f32(p.K);
@@ -1137,11 +1182,21 @@ int prefill_alloc(jh_session* s) {
 bool prefill_tiled(jh_session* s, int K) {
     static const int enabled = env_int("JH_PREFILL_TILED", 1);
     const int nblk = K / QB;
+    if (s->m->c.weight_dtype == JH_DT_BF16) return enabled && (K % 32) == 0;
     return enabled && s->m->c.weight_dtype == JH_DT_Q4 && nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024;
 }
 // resident re-tiled copy of a Q4 weight, made on first use (costs a second copy of the weights in HBM)
 int ensure_tiled(JWeight& W, hipStream_t st) {
     if (W.tiled) return JH_OK;
+    if (W.dtype == JH_DT_BF16) {
+        if ((W.rows % 32) || (W.cols % 16)) return set_err(JH_ERR_INVALID, "tiled copy: shape");
+        hipError_t e2 = hipMalloc((void**)&W.tiled, (size_t)W.rows * W.cols * 2);
+        if (e2 != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled weight copy");
+        const size_t chunks = (size_t)W.rows * (W.cols / 8);
+        hipLaunchKernelGGL(retile_bf16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const uint16_t*)W.data, W.rows, W.cols, (uint16_t*)W.tiled);
+        HIPCHK(hipGetLastError());
+        return JH_OK;
+    }
     if (W.dtype != JH_DT_Q4 || (W.rows % 32) || (W.cols % QB)) return set_err(JH_ERR_INVALID, "tiled copy: shape");
     const int nblk = W.cols / QB;
     hipError_t e = hipMalloc((void**)&W.tiled, (size_t)W.rows * nblk * 16);
@@ -1165,6 +1220,11 @@ int rows_quant_launch(jh_session* s, const float* x, int ldx, const float* x2, i
 // out[rows, N] = act[rows, K] x W[N, K]^T (+ resid): I8 x Q4 (exact integer MFMA) or BF16 x BF16 (MFMA), by model dtype
 int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
     if (s->m->c.weight_dtype == JH_DT_BF16) {
+        if (prefill_tiled(s, K) && (N % 32) == 0) {
+            JHCHK(ensure_tiled(W, st));
+            MfmaBf16TileParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.tiled, out, resid, rows, N, K, ldc, s->pb_ws, 1};
+            return launch_gemm_bf16_tile(g, st);
+        }
         MfmaGemmParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.data, out, rows, 0, N, K, K, K, ldc, 0, resid, s->pb_ws, 1};
         return launch_gemm_bf16_mfma(g, st);
     }
@@ -1564,7 +1624,7 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
             JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
             JWeight* list[] = {&m->qkv[(size_t)li], &W[JH_W_O], &W[JH_W_GATE], &W[JH_W_UP], &W[JH_W_DOWN]};
             for (JWeight* w : list)
-                if (w->data && w->dtype == JH_DT_Q4 && prefill_tiled(s, w->cols) && (w->rows % 32) == 0) JHCHK(ensure_tiled(*w, s->stream));
+                if (w->data && (w->dtype == JH_DT_Q4 || w->dtype == JH_DT_BF16) && prefill_tiled(s, w->cols) && (w->rows % 32) == 0) JHCHK(ensure_tiled(*w, s->stream));
         }
         HIPCHK(hipStreamSynchronize(s->stream));
     }
@@ -1636,7 +1696,7 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
     HIPCHK(hipMalloc(&af, (size_t)m * (k / QB) * 4)); HIPCHK(hipMemset(af, 0, (size_t)m * (k / QB) * 4));
     HIPCHK(hipMalloc(&c, (size_t)m * n * 4));
     float* bf16_ws = nullptr;
-    if (kind == 1) HIPCHK(hipMalloc(&bf16_ws, BF16_SPLITK_WS_BYTES));
+    if (kind == 1 || kind == 3) HIPCHK(hipMalloc(&bf16_ws, BF16_SPLITK_WS_BYTES));   // kind 3 = BF16 with MFMA-ordered operands
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     int rc = JH_OK;
     for (int it = -1; it < iters && rc == JH_OK; it++) {
@@ -1645,6 +1705,9 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
             if (q4) {
                 MfmaQ4Params g{(const int8_t*)a, af, w + l * wbytes, ws + l * (sbytes / 4), c, nullptr, m, 0, n, k, k, k / QB, k / 2, k / QB, n, 0};
                 rc = launch_gemm_q8q4_mfma(g, st, kind == 2);
+            } else if (kind == 3) {
+                MfmaBf16TileParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, nullptr, m, n, k, n, bf16_ws, 1};
+                rc = launch_gemm_bf16_tile(g, st);
             } else {
                 MfmaGemmParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, m, 0, n, k, k, k, n, 0, nullptr, bf16_ws, 1};
                 rc = launch_gemm_bf16_mfma(g, st);

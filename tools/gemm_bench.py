@@ -2,8 +2,13 @@ import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 from jlama_amd import _native as N
 N.init(0)
-for kind, name, bpw in ((2, "I8xQ4t", 0.625), (0, "I8xQ4", 0.625), (1, "BF16", 2.0)):
-    for (m, n, k) in ((129, 4096, 4096), (129, 28672, 4096), (129, 4096, 14336), (256, 28672, 4096), (32, 28672, 4096)):
+for kind, name, bpw in ((2, "I8xQ4t", 0.625), (3, "BF16t", 2.0), (0, "I8xQ4", 0.625), (1, "BF16", 2.0)):
+    shapes = ((129, 4096, 4096), (129, 28672, 4096), (129, 4096, 14336), (256, 28672, 4096), (32, 28672, 4096))
+    if os.environ.get("GB_MODEL_SHAPES"):
+        shapes = ((129, 6144, 4096), (129, 4096, 4096), (129, 14336, 4096), (129, 4096, 14336), (256, 14336, 4096))
+    if os.environ.get("GB_KINDS") and str(kind) not in os.environ["GB_KINDS"].split(","):
+        continue
+    for (m, n, k) in shapes:
         copies = max(1, int(600e6 / (n * k * bpw)))
         ms = C.c_double()
         N.check(N.lib().jh_gemm_bench(kind, m, n, k, copies, 3, C.byref(ms)))
