@@ -276,7 +276,8 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
         const long long tiles = (long long)mt * (g.n / 32);
         int S = 1;
         while (S < 8 && tiles * S < (long long)g_cu_count * 8 && nblk % (16 * S) == 0) S *= 2;   // nblk/S stays a multiple of 8
-        static const int cw_env = env_int("JH_GEMM_CW", 0);
+        static const int cw_env = env_int("JH_GEMM_CW", 0), s_env = env_int("JH_GEMM_S", 0);
+        if (s_env > 0 && nblk % (8 * s_env) == 0) S = s_env;
         int CW = 1;
         if (tiled) {
             CW = S <= 4 ? 4 : 2;                       // S*CW <= 16 waves
