@@ -135,6 +135,12 @@ int jh_rmsnorm_f32(const float* x, const float* w, float weight_adj, int n, floa
 int jh_softmax_f32(float* x, int offset, int length);
 /* SiLU(x)*up (ActivationFunction.java:31 + MLPBlock.java:132-142): g[i] = silu(g[i]) * u[i]. */
 int jh_silu_mul_f32(float* g, const float* u, int n);
+/* GPT-2 family (BASELINE.json configs[0]): LayerNorm.forward (jlama-core/.../model/LayerNorm.java:41-67) over columns
+ * [offset, offset+length) of `rows` rows (leading dimension ld, divisor = embeddingLength; float sums in index order),
+ * and the tanh-GELU of ActivationFunction.java:32-34 (double), in place. */
+int jh_layernorm_f32(const float* x, const float* w, const float* b, int rows, int ld, int offset, int length, int divisor,
+                     float eps, float* out);
+int jh_gelu_f32(float* x, int n);
 /* VectorMath.precomputeFreqsCis (VectorMath.java:148-165): out [end*dim/2][2] = (cos, sin). Host-side. */
 int jh_rope_table(int dim, int end, double theta, double scaling, float* out);
 /* RoPE rotation of one q row [n_heads*head_size] and one k row [n_kv_heads*head_size] at `position`

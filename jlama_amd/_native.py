@@ -78,6 +78,8 @@ _PROTOS = {
     "jh_rmsnorm_f32": (_i, [_p, _p, _f, _i, _f, _p]),
     "jh_softmax_f32": (_i, [_p, _i, _i]),
     "jh_silu_mul_f32": (_i, [_p, _p, _i]),
+    "jh_layernorm_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "jh_gelu_f32": (_i, [_p, _i]),
     "jh_rope_table": (_i, [_i, _i, _d, _d, _p]),
     "jh_rope_apply_f32": (_i, [_p, _p, _p, _i, _i, _i, _i]),
     "jh_kv_page_geometry": (_i, [_l, _i, _i, _i, _i, _p]),

@@ -2230,6 +2230,37 @@ __global__ __launch_bounds__(1024) void rmsnorm_kernel(const float* x, const flo
     for (int j = threadIdx.x; j < n; j += blockDim.x) out[j] = (adj + w[j]) * (fs * x[j]);
 }
 // VectorMath.softMax (core/math/VectorMath.java:69-90), single workgroup
+// LayerNorm.forward (core/model/LayerNorm.java:41-67), GPT-2's norm: FLOAT sums accumulated in index order (one lane
+// walks the row so the running sums round exactly as the Java loop's), var = sumSq/E - mean^2,
+// 1/(float)sqrt(var+eps), then ((x-mean)*inv)*w + b with no fused multiply-add.  One wave per row.
+__global__ __launch_bounds__(64) void layernorm_kernel(const float* x, const float* w, const float* b, int ld, int offset, int length,
+                                                       int divisor, float eps, float* out) {
+    const float* row = x + (size_t)blockIdx.x * ld;
+    float* orow = out + (size_t)blockIdx.x * ld;
+    __shared__ float stats[2];
+    if (threadIdx.x == 0) {
+        float sum = 0.0f, sumsq = 0.0f;
+        for (int i = offset; i < offset + length; i++) {
+            const float v = row[i];
+            sum += v;
+            sumsq += v * v;
+        }
+        const float mean = sum / (float)divisor;
+        const float variance = sumsq / (float)divisor - mean * mean;
+        stats[0] = mean;
+        stats[1] = 1.0f / (float)sqrt((double)(variance + eps));
+    }
+    __syncthreads();
+    const float mean = stats[0], inv = stats[1];
+    for (int i = offset + threadIdx.x; i < offset + length; i += blockDim.x) orow[i] = (row[i] - mean) * inv * w[i] + b[i];
+}
+// ActivationFunction.eval GELU (core/math/ActivationFunction.java:32-34): tanh approximation evaluated in double
+__global__ void gelu_kernel(float* x, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = (double)x[i];
+    x[i] = (float)(0.5 * v * (1.0 + tanh(sqrt(2.0 / 3.14159265358979323846) * (v + 0.044715 * pow(v, 3.0)))));
+}
 __global__ __launch_bounds__(1024) void softmax_kernel(float* x, int offset, int length) {
     __shared__ float redf[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;

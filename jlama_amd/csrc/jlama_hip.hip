@@ -805,6 +805,44 @@ int jh_rmsnorm_f32(const float* x, const float* w, float weight_adj, int n, floa
     HIPCHK(hipStreamSynchronize(st));
     return JH_OK;
 }
+// GPT-2 family pieces (BASELINE config 0): LayerNorm (core/model/LayerNorm.java:41-67) over [offset, offset+length) of each
+// of `rows` rows with leading dimension ld; divisor = embeddingLength.  GELU in place.
+int jh_layernorm_f32(const float* x, const float* w, const float* b, int rows, int ld, int offset, int length, int divisor,
+                     float eps, float* out) {
+    if (!x || !w || !b || !out || rows <= 0 || ld <= 0 || offset < 0 || length <= 0 || offset + length > ld || divisor <= 0)
+        return set_err(JH_ERR_INVALID, "layernorm: bad argument");
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    void *dX = nullptr, *dW = nullptr, *dB = nullptr, *dO = nullptr;
+    const size_t nb = (size_t)rows * ld * 4;
+    JHCHK(dev_buf(0, nb, &dX));
+    JHCHK(dev_buf(1, (size_t)ld * 4, &dW));
+    JHCHK(dev_buf(2, (size_t)ld * 4, &dB));
+    JHCHK(dev_buf(4, nb, &dO));
+    HIPCHK(hipMemcpyAsync(dX, x, nb, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dO, out, nb, hipMemcpyHostToDevice, st));   // columns outside the window keep the caller's values
+    HIPCHK(hipMemcpyAsync(dW, w, (size_t)ld * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dB, b, (size_t)ld * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(64), 0, st, (const float*)dX, (const float*)dW, (const float*)dB, ld, offset, length,
+                       divisor, eps, (float*)dO);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dO, nb, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
+int jh_gelu_f32(float* x, int n) {
+    if (!x || n <= 0) return set_err(JH_ERR_INVALID, "gelu: bad argument");
+    JHCHK(ensure_ctx());
+    hipStream_t st = tctx.stream;
+    void* dX = nullptr;
+    JHCHK(dev_buf(0, (size_t)n * 4, &dX));
+    HIPCHK(hipMemcpyAsync(dX, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gelu_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (float*)dX, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(x, dX, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return JH_OK;
+}
 int jh_softmax_f32(float* x, int offset, int length) {
     if (!x || length <= 0 || offset < 0) return set_err(JH_ERR_INVALID, "softmax: bad argument");
     JHCHK(ensure_ctx());

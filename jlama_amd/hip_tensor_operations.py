@@ -167,6 +167,24 @@ class HipTensorOperations:
         N.check(self._lib.jh_silu_mul_f32(N.ptr(g), N.ptr(u), g.size))
         return g
 
+    def layer_norm(self, x, w, b, eps, offset=0, length=None, divisor=None):
+        """LayerNorm.forward (core/model/LayerNorm.java:41-67) per row of x [rows, E]; GPT-2 family."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        x = x.reshape(1, -1) if x.ndim == 1 else x
+        rows, ld = x.shape
+        length = ld - offset if length is None else length
+        out = x.copy()
+        N.check(self._lib.jh_layernorm_f32(N.ptr(x), N.ptr(np.ascontiguousarray(w, dtype=np.float32)),
+                                           N.ptr(np.ascontiguousarray(b, dtype=np.float32)), rows, ld, offset, length,
+                                           ld if divisor is None else divisor, eps, N.ptr(out)))
+        return out
+
+    def gelu(self, x):
+        """ActivationFunction.eval(GELU) (core/math/ActivationFunction.java:32-34)."""
+        x = np.ascontiguousarray(x, dtype=np.float32).copy()
+        N.check(self._lib.jh_gelu_f32(N.ptr(x), x.size))
+        return x
+
     def rope_table(self, dim, end, theta, scaling=1.0):
         out = np.empty((end * (dim // 2), 2), dtype=np.float32)
         N.check(self._lib.jh_rope_table(dim, end, theta, scaling, N.ptr(out)))

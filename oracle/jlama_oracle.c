@@ -391,6 +391,25 @@ void jo_rmsnorm(const float* x, const float* w, float weight_adj, int E, float e
  * a8. RoPE table -- core/math/VectorMath.java:148-165 (precomputeFreqsCis)
  * out: [end * dim/2][2] = (cos, sin)
  * ---------------------------------------------------------------------------------- */
+/* LayerNorm.forward core/model/LayerNorm.java:41-67 (GPT-2): float running sums in index order */
+void jo_layernorm(const float* x, const float* w, const float* b, int offset, int length, int divisor, float eps, float* out) {
+    float sum = 0.0f, sumSq = 0.0f;
+    for (int i = offset; i < offset + length; i++) {
+        float v = x[i];
+        sum += v;
+        sumSq += v * v;
+    }
+    float mean = sum / (float)divisor;
+    float variance = sumSq / (float)divisor - mean * mean;
+    float invStddev = 1.0f / (float)sqrt((double)(variance + eps));
+    for (int i = offset; i < offset + length; i++) out[i] = (x[i] - mean) * invStddev * w[i] + b[i];
+}
+/* ActivationFunction.eval(GELU) core/math/ActivationFunction.java:32-34 */
+float jo_gelu(float x) {
+    double v = (double)x;
+    return (float)(0.5 * v * (1.0 + tanh(sqrt(2.0 / 3.14159265358979323846) * (v + 0.044715 * pow(v, 3.0)))));
+}
+
 void jo_rope_table(int dim, int end, double theta, double scaling, float* out) {
     int half = dim / 2;
     float* freqs = (float*)malloc(sizeof(float) * half);

@@ -76,6 +76,8 @@ def lib():
         _lib.jo_f32_to_bf16.argtypes = [C.c_float]
         _lib.jo_silu.restype = C.c_float
         _lib.jo_silu.argtypes = [C.c_float]
+        _lib.jo_gelu.restype = C.c_float
+        _lib.jo_gelu.argtypes = [C.c_float]
         _lib.jo_model_create.restype = C.c_void_p
         _lib.jo_session_create.restype = C.c_void_p
         _lib.jo_session_create.argtypes = [C.c_void_p, C.c_int64]
@@ -256,6 +258,23 @@ def rmsnorm(x, w, eps, weight_adj=0.0):
     out = np.empty_like(x)
     lib().jo_rmsnorm(_p(x), _p(w), C.c_float(weight_adj), x.size, C.c_float(eps), _p(out))
     return out
+
+
+def layernorm(x, w, b, eps, offset=0, length=None, divisor=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    x = x.reshape(1, -1) if x.ndim == 1 else x
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    length = x.shape[1] - offset if length is None else length
+    out = x.copy()
+    for r in range(x.shape[0]):
+        lib().jo_layernorm(_p(x[r]), _p(w), _p(b), offset, length, x.shape[1] if divisor is None else divisor, C.c_float(eps), _p(out[r]))
+    return out
+
+
+def gelu(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return np.array([lib().jo_gelu(C.c_float(v)) for v in x.reshape(-1)], dtype=np.float32).reshape(x.shape)
 
 
 def rope_table(dim, end, theta, scaling=1.0):

@@ -343,3 +343,24 @@ def test_against_vectors_from_the_reference_library(ops):
     R = Tensor.zeros(1, 48)
     ops.batchDotProduct(R, Q, KP, 128, 128, 128)
     _close(R.data, g["f32_scores"], 1e-4)
+
+
+def test_gpt2_family_pieces(ops, oracle):
+    """BASELINE configs[0] (GPT-2 small: E=768, F32 weights, LayerNorm + bias, tanh-GELU): the pieces outside the GEMM.
+    LayerNorm is bit-exact (float sums in index order, as LayerNorm.java:47-53; no FMA in the affine step); GELU is
+    evaluated in double and cast (ActivationFunction.java:32-34): bit-exact against the libm restatement.  The F32xF32
+    GEMM with bias accumulate is covered by test_batch_dot_product_dense / test_elementwise_bit_exact."""
+    rng = np.random.default_rng(77)
+    E = 768
+    x = (rng.standard_normal((5, E)) * 3 + 0.5).astype(np.float32)
+    w = (1 + rng.standard_normal(E) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(E) * 0.1).astype(np.float32)
+    np.testing.assert_array_equal(ops.layer_norm(x, w, b, 1e-5), oracle.layernorm(x, w, b, 1e-5))
+    # the offset/length form (forward(input, offset, length)): statistics over the window, divisor stays E
+    got = ops.layer_norm(x, w, b, 1e-5, offset=256, length=256)
+    want = oracle.layernorm(x, w, b, 1e-5, offset=256, length=256)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got[:, :256], x[:, :256])
+    g = (rng.standard_normal(4096) * 4).astype(np.float32)
+    np.testing.assert_array_equal(ops.gelu(g), oracle.gelu(g))
+    assert ops.gelu(np.zeros(3, np.float32)).tolist() == [0.0, 0.0, 0.0]

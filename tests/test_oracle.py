@@ -237,3 +237,26 @@ def test_oracle_matches_committed_reference_vectors(oracle):
                             out=np.zeros((1, 96), np.float32))
     np.testing.assert_array_equal(got[:, 32:96], g["f32q4_window"][:, 32:96])
     np.testing.assert_array_equal(oracle.gemm_f32(g["f32_q"], g["f32_kpage"], aColOff=128, bColOff=128, K=128), g["f32_scores"])
+
+
+def test_layernorm_and_gelu_restatements(oracle):
+    """LayerNorm.java:41-67 / ActivationFunction.java:32-34 against straightforward numpy float32 / float64 evaluations."""
+    rng = np.random.default_rng(5)
+    E = 96
+    x = rng.standard_normal((2, E)).astype(np.float32)
+    w = rng.standard_normal(E).astype(np.float32)
+    b = rng.standard_normal(E).astype(np.float32)
+    got = oracle.layernorm(x, w, b, 1e-5)
+    for r in range(2):
+        s = np.float32(0); q = np.float32(0)
+        for v in x[r]:
+            s = np.float32(s + v); q = np.float32(q + np.float32(v * v))
+        mean = np.float32(s / np.float32(E))
+        var = np.float32(np.float32(q / np.float32(E)) - np.float32(mean * mean))
+        inv = np.float32(np.float32(1.0) / np.float32(np.sqrt(np.float64(np.float32(var + np.float32(1e-5))))))
+        want = (((x[r] - mean).astype(np.float32) * inv).astype(np.float32) * w).astype(np.float32) + b
+        np.testing.assert_array_equal(got[r], want.astype(np.float32))
+    g = rng.standard_normal(64).astype(np.float32) * 3
+    v = g.astype(np.float64)
+    want = (0.5 * v * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (v + 0.044715 * v ** 3)))).astype(np.float32)
+    assert np.abs(oracle.gelu(g) - want).max() <= 1e-6
