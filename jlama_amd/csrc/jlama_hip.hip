@@ -2092,6 +2092,10 @@ int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) 
     JHCHK(ensure_out_tokens(s, n));
     hipStream_t st = s->stream;
     const bool use_graph = !env_int("JH_NO_GRAPH", 0);
+    if (use_graph) {   // capture the graph variants this call needs before the timed region (a capture costs milliseconds)
+        JHCHK(build_graph(s, attn_variant_for(s, start_pos)));
+        JHCHK(build_graph(s, attn_variant_for(s, start_pos + n - 1)));
+    }
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, start_pos, first_token, 0);
     hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
                        (const DecodeState*)s->st, m->c.embedding_length, s->x);
