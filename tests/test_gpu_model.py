@@ -402,3 +402,38 @@ def test_tensor_parallel_shards_loopback(gpu, oracle, dtype):
     assert np.abs(got[0] - want_tp[0]).max() <= (1e-4 if dtype == "Q4" else 3e-2) * np.abs(want_tp[0]).max()
     full = oracle.OracleModel(cfg, w)
     assert _rel(got, full.session().forward(prompt, 0)) <= TRUNK_TOL
+
+
+@pytest.mark.parametrize("cfgname", ["TINY", "SMALL"])
+def test_decode_across_attention_variants_and_long_context(gpu, oracle, cfgname):
+    """The decode attention kernel has a short-context variant (2 prefetched row steps, contexts <= 16*32 rows) and the
+    general one; the host switches graphs per token.  Greedy decode from position ~500 to ~530 crosses the switch, and a
+    second run decodes at ~1300 rows where slices are longer than the prefetched rows (tail loops): teacher-forced
+    against the oracle, ids equal wherever the oracle's margin is meaningful."""
+    from jlama_amd import synthetic as S
+    cfg = dict(getattr(S, cfgname))
+    cfg["context_length"] = 2048
+    hm, om, _ = _pair(cfg, 13, oracle)
+    for n_prompt, n_dec in ((499, 30), (1290, 10)):
+        prompt = S.prompt_tokens(cfg, n=n_prompt, seed=17)
+        hs, os_ = hm.session(n_prompt + n_dec + 8), om.session()
+        got, want = hs.batch_forward(prompt, 0), os_.forward(prompt, 0)
+        assert _rel(got[-1], want[-1]) <= TRUNK_TOL
+        th, lh = hs.sample(0.0, 0.5, want_logits=True)
+        to, lo = om.sample(want[-1])
+        assert th == to or lo.max() - lo[th] <= LOGIT_TOL
+        toks = hs.decode_n(th, prompt.size, n_dec)
+        tok = th
+        for i, g in enumerate(toks):
+            xo = os_.forward([tok], prompt.size + i)
+            no, lo = om.sample(xo[-1])
+            assert g == no or lo.max() - lo[g] <= LOGIT_TOL, (n_prompt, i, g, no)
+            tok = int(g)
+        # the same positions through the host loop (jh_forward row graph + jh_sample) give the same ids
+        hs2 = hm.session(n_prompt + n_dec + 8)
+        hs2.batch_forward(prompt, 0)
+        tok2 = hs2.sample(0.0, 0.5)
+        assert tok2 == th
+        for i in range(min(6, n_dec)):
+            tok2 = hs2.decode_step(tok2, prompt.size + i)
+            assert tok2 == toks[i], (n_prompt, i)
