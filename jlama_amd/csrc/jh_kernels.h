@@ -1510,6 +1510,7 @@ struct AttnParams {
     float* outf;           // [A] attention output, ticket mode only (the o-projection then quantizes it)
     float* tap_q;          // roped q [A] (tap), may be null
     long long* dbg;        // optional phase timestamps (wall_clock64, 100 MHz) of workgroups with kvh == 0: [split][16]
+    int combine_kernel;    // 1: slices only publish (plain stores); attn_combine_kernel merges them after the kernel edge
 };
 #define JH_ATT_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && blockIdx.y == 0) p.dbg[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
@@ -1750,8 +1751,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
     JH_ATT_STAMP(6);   // slice reduced
 
     float* my_o = p.part_o + ((size_t)(kvh * GROUP) * p.part_stride + split) * HS;   // + gi*part_stride*HS + d
-    if (direct) {
-        // direct mode: publish the slice and finish; the o-projection's prologue combines (kernel boundary = visibility)
+    if (direct || p.combine_kernel) {
+        // publish the slice and finish: the o-projection's prologue (direct mode) or attn_combine_kernel merges the
+        // slices after the kernel boundary (= visibility, no write-through stores, no ticket)
         for (int i = tid; i < GROUP * HS; i += NT) {
             const int gi = i / HS, d = i - gi * HS;
             my_o[(size_t)gi * p.part_stride * HS + d] = oloc[i];
@@ -1839,6 +1841,57 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
     }
     JH_ATT_STAMP(9);   // combined
     for (int i = tid; i < GROUP * HS; i += NT) p.outf[(size_t)kvh * GROUP * HS + i] = oloc[i];
+}
+
+// Merge the slices of attn_decode_kernel (combine_kernel mode): w_s = l_s*exp(m_s - M) / sum_s(l_s*exp(m_s - M)),
+// o = sum_s w_s*o_s in slice order.  One workgroup per kv head.  The in-kernel alternative (write-through publish +
+// ticket + last-arriver combine) costs ~4.1 us of dependent round trips; a kernel edge costs 1.55 us.
+template <int HS, int GROUP>
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
+    __shared__ float wts[GROUP * 64];
+    const int kvh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.st->pos + 1;
+    int S = (n + 31) / 32;
+    if (S > p.max_splits) S = p.max_splits;
+    for (int gi = wave; gi < GROUP; gi += 4) {
+        const float* pr = p.part_ml + ((size_t)(kvh * GROUP + gi) * p.part_stride) * 2;
+        float m = -INFINITY;
+        for (int s = lane; s < S; s += 64) m = fmaxf(m, pr[2 * s]);
+        m = wave_max(m);
+        float L = 0.0f;
+        for (int s = lane; s < S; s += 64) {
+            const float w = pr[2 * s + 1] * (float)exp((double)(pr[2 * s] - m));
+            wts[gi * 64 + s] = w;
+            L += w;
+        }
+        L = wave_sum(L);
+        for (int s = lane; s < S; s += 64) wts[gi * 64 + s] = wts[gi * 64 + s] / L;
+    }
+    constexpr int CS = 16, EPT = (GROUP * HS + 255) / 256;   // slices loaded per batch (all in flight), elements per thread
+    float pv[EPT][CS];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        int i = tid + e * 256;
+        i = i < GROUP * HS ? i : GROUP * HS - 1;
+        const int gi = i / HS, d = i - gi * HS;
+        const float* pb = p.part_o + (size_t)(kvh * GROUP + gi) * p.part_stride * HS + d;
+#pragma unroll
+        for (int s = 0; s < CS; s++) pv[e][s] = pb[(size_t)(s < S ? s : S - 1) * HS];   // branch-free: one round trip
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int i = tid + e * 256;
+        if (i >= GROUP * HS) break;
+        const int gi = i / HS, d = i - gi * HS;
+        const float* pb = p.part_o + (size_t)(kvh * GROUP + gi) * p.part_stride * HS + d;
+        float o = 0.0f;
+#pragma unroll
+        for (int s = 0; s < CS; s++)
+            if (s < S) o = fmaf(pv[e][s], wts[gi * 64 + s], o);
+        for (int s = CS; s < S; s++) o = fmaf(pb[(size_t)s * HS], wts[gi * 64 + s], o);
+        p.outf[(size_t)kvh * GROUP * HS + i] = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ batched prefill

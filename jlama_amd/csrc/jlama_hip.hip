@@ -965,6 +965,7 @@ struct jh_session {
     int lm_grid = 0;
     // graphs exist per attention variant (0: PRE=8 rows steps prefetched, 1: PRE=2 for short contexts)
     int attn_variant = 0;
+    int attn_combine = 0;   // 1: slices merged by attn_combine_kernel after the kernel edge (0: in-kernel ticket + last arriver)
     hipGraph_t graph[2] = {nullptr, nullptr};
     hipGraphExec_t exec[2] = {nullptr, nullptr};
     hipGraph_t row_graph[2] = {nullptr, nullptr};   // this shard's layers only: single-row forward (pipeline stages)
@@ -1026,6 +1027,7 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     p.outf = s->attf;
     p.tap_q = tap ? s->tapq : nullptr;
     p.dbg = dbg;
+    p.combine_kernel = (s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0;
     const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
     const int sc_cap = s->chunk_cap > 2 * s->max_splits ? s->chunk_cap : 2 * s->max_splits;
     const size_t lds = ((size_t)group * hs + 2 * hs + (size_t)(ATT_THREADS * 4) * group + 2 * group + 4 + (size_t)group * sc_cap) * 4;
@@ -1041,6 +1043,10 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
             hipLaunchKernelGGL((attn_decode_kernel<HSV, GV, 8>), grid, block, lds, st, p); \
         }                                                                                  \
         HIPCHK(hipGetLastError());                                                         \
+        if (p.combine_kernel) {                                                            \
+            hipLaunchKernelGGL((attn_combine_kernel<HSV, GV>), dim3(c.n_kv_heads), dim3(256), 0, st, p); \
+            HIPCHK(hipGetLastError());                                                     \
+        }                                                                                  \
         return JH_OK;                                                                      \
     }
     JH_ATTN(128, 4) JH_ATTN(128, 8) JH_ATTN(64, 4) JH_ATTN(128, 1) JH_ATTN(128, 2) JH_ATTN(64, 1) JH_ATTN(64, 2) JH_ATTN(64, 8)
@@ -1618,6 +1624,7 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     s->page_elems = page_elems;
     HIPCHK(hipMalloc(&s->pages_dev, s->pages_host.size() * sizeof(float*)));
     HIPCHK(hipMemcpy(s->pages_dev, s->pages_host.data(), s->pages_host.size() * sizeof(float*), hipMemcpyHostToDevice));
+    s->attn_combine = env_int("JH_ATTN_COMBINE_KERNEL", 0);   // measured slower than the in-kernel last arriver
     s->max_splits = env_int("JH_ATTN_SPLITS", 16);
     if (s->max_splits < 1) s->max_splits = 1;
     s->chunk_cap = (max_ctx + s->max_splits - 1) / s->max_splits;
@@ -2077,7 +2084,8 @@ static int build_graph(jh_session* s, int v) {
     if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     s->graph[v] = g;
     HIPCHK(hipGraphInstantiate(&s->exec[v], g, nullptr, nullptr, 0));
-    s->kernels_per_token = (c.layer_end - c.layer_start) * 5 + (has_out ? 2 : 0);
+    const int per_layer = 5 + ((s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0);
+    s->kernels_per_token = (c.layer_end - c.layer_start) * per_layer + (has_out ? 2 : 0);
     return JH_OK;
 }
 
