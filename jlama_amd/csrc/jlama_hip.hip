@@ -942,6 +942,7 @@ struct jh_model {
     float attention_scale;
     int64_t weight_bytes = 0;
     int kv_head_offset = 0;   // tensor-parallel shard (jh_model_set_kv_head_offset)
+    int weights_version = 0;  // bumped by jh_model_set_weight: sessions drop graphs that captured the old device pointers
 };
 enum { TAP_SLOTS = 12 };
 struct jh_session {
@@ -965,6 +966,7 @@ struct jh_session {
     int lm_grid = 0;
     // graphs exist per attention variant (0: PRE=8 rows steps prefetched, 1: PRE=2 for short contexts)
     int attn_variant = 0;
+    int graphs_version = 0;   // jh_model::weights_version the cached graphs were captured against
     int attn_combine = 0;   // 1: slices merged by attn_combine_kernel after the kernel edge (0: in-kernel ticket + last arriver)
     hipGraph_t graph[2] = {nullptr, nullptr};
     hipGraphExec_t exec[2] = {nullptr, nullptr};
@@ -991,6 +993,7 @@ struct jh_session {
 };
 
 static int attn_variant_for(const jh_session* s, int pos);
+static void drop_stale_graphs(jh_session* s);
 
 namespace {
 
@@ -1253,6 +1256,19 @@ int ensure_tiled(JWeight& W, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
+// every weight the prefill GEMMs of this shard will touch (allocation must not happen inside a graph capture)
+int ensure_all_tiled(jh_session* s, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    for (int li = c.layer_start; li < c.layer_end; li++) {
+        JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+        JWeight* list[] = {&m->qkv[(size_t)li], &W[JH_W_O], &W[JH_W_GATE], &W[JH_W_UP], &W[JH_W_DOWN]};
+        for (JWeight* w : list)
+            if (w->data && !w->tiled && (w->dtype == JH_DT_Q4 || w->dtype == JH_DT_BF16) && prefill_tiled(s, w->cols) && (w->rows % 32) == 0)
+                JHCHK(ensure_tiled(*w, st));
+    }
+    return JH_OK;
+}
 template <int MODE>
 int rows_quant_launch(jh_session* s, const float* x, int ldx, const float* x2, int ldx2, const float* nw, float eps, int K, int rows,
                       hipStream_t st) {
@@ -1350,8 +1366,8 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     jh_model* m = s->m;
     const jh_config& c = m->c;
     JHCHK(prefill_alloc(s));
-    const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
-    const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    JHCHK(ensure_all_tiled(s, st));
+    const int E = c.embedding_length;
     if (tokens) {
         const JWeight& emb = m->global_w[JH_W_EMBED];
         HIPCHK(hipMemcpyAsync(s->pb_tok, tokens, (size_t)rows * 4, hipMemcpyHostToDevice, st));
@@ -1371,6 +1387,7 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     if (!prefill_chunk_fits(s, 0, bound)) bound = start_pos + rows;
     static const int use_graph = env_int("JH_PREFILL_GRAPH", 1);
     if (use_graph && !env_int("JH_TRACE", 0)) {
+        drop_stale_graphs(s);
         const uint64_t key = (uint64_t)rows | ((uint64_t)bound << 32);
         auto it = s->pb_graphs.find(key);
         if (it == s->pb_graphs.end()) {
@@ -1567,6 +1584,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
         if (sbytes) HIPCHK(hipMemcpy(ds, scales, sbytes, kind));
         if (!w->data) m->weight_bytes += (int64_t)(bytes + sbytes);
         w->data = dd; w->scales = ds; w->dtype = dtype; w->rows = rows; w->cols = cols;
+        m->weights_version++;
         return JH_OK;
     }
     if (w->data) hipFree(w->data);
@@ -1584,6 +1602,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     if (widened_dev) hipFree(widened_dev);
     w->dtype = dtype; w->rows = rows; w->cols = cols;
     if (!is_norm && which != JH_W_EMBED) m->weight_bytes += (int64_t)(bytes + sbytes);
+    m->weights_version++;
     return JH_OK;
 }
 int64_t jh_model_weight_bytes(jh_model* m) { return m ? m->weight_bytes : 0; }
@@ -1664,14 +1683,10 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 2), env_int("JH_LM_WAVES", 8), cu * env_int("JH_LM_GRIDX", 2), 1};   // tools/sweep_lm.py
     if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
     s->prefill_batch_min = env_int("JH_PREFILL_BATCH_MIN", 4);   // chunks of fewer rows go row by row; 0 disables batching
+    s->graphs_version = m->weights_version;
     if (prefill_batch_ok(s)) {
         // the MFMA-ordered weight copies of the prefill GEMM are made here, once per model, not inside the first prompt
-        for (int li = c.layer_start; li < c.layer_end; li++) {
-            JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
-            JWeight* list[] = {&m->qkv[(size_t)li], &W[JH_W_O], &W[JH_W_GATE], &W[JH_W_UP], &W[JH_W_DOWN]};
-            for (JWeight* w : list)
-                if (w->data && (w->dtype == JH_DT_Q4 || w->dtype == JH_DT_BF16) && prefill_tiled(s, w->cols) && (w->rows % 32) == 0) JHCHK(ensure_tiled(*w, s->stream));
-        }
+        JHCHK(ensure_all_tiled(s, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
     }
     *out = s;
@@ -1875,11 +1890,27 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
     return JH_OK;
 }
 
+// captured graphs hold raw device pointers of the weights: drop them all if a weight was replaced since the capture
+static void drop_stale_graphs(jh_session* s) {
+    if (s->graphs_version == s->m->weights_version) return;
+    for (int v = 0; v < 2; v++) {
+        if (s->exec[v]) { hipGraphExecDestroy(s->exec[v]); s->exec[v] = nullptr; }
+        if (s->graph[v]) { hipGraphDestroy(s->graph[v]); s->graph[v] = nullptr; }
+        if (s->row_exec[v]) { hipGraphExecDestroy(s->row_exec[v]); s->row_exec[v] = nullptr; }
+        if (s->row_graph[v]) { hipGraphDestroy(s->row_graph[v]); s->row_graph[v] = nullptr; }
+    }
+    for (auto& kv : s->pb_graphs) hipGraphExecDestroy(kv.second);
+    s->pb_graphs.clear();
+    for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
+    s->pb_graph_src.clear();
+    s->graphs_version = s->m->weights_version;
+}
 // which attention variant serves position pos: slices of <= 32 rows need only 2 prefetched row steps
 static int attn_variant_for(const jh_session* s, int pos) {
     return (s->direct_max == 0 && pos + 1 <= s->max_splits * 32) ? 1 : 0;
 }
 static int build_row_graph(jh_session* s, int v) {
+    drop_stale_graphs(s);
     if (s->row_exec[v]) return JH_OK;
     s->attn_variant = v;
     hipStream_t st = s->stream;
@@ -2066,6 +2097,7 @@ int jh_decode_step(jh_session* s, int32_t token, int pos, int32_t* next_token) {
 }
 
 static int build_graph(jh_session* s, int v) {
+    drop_stale_graphs(s);
     if (s->exec[v]) return JH_OK;
     s->attn_variant = v;
     hipStream_t st = s->stream;

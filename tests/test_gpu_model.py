@@ -437,3 +437,29 @@ def test_decode_across_attention_variants_and_long_context(gpu, oracle, cfgname)
         for i in range(min(6, n_dec)):
             tok2 = hs2.decode_step(tok2, prompt.size + i)
             assert tok2 == toks[i], (n_prompt, i)
+
+
+def test_replacing_a_weight_invalidates_captured_graphs(gpu, oracle):
+    """Captured decode / prefill graphs and the MFMA-ordered weight copies hold device pointers: after
+    jh_model_set_weight on a live model the session must re-capture and re-tile, and match a model built from the new
+    weights from scratch."""
+    from jlama_amd import synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    cfg = dict(S.SMALL)
+    w_a, w_b = S.make_weights(cfg, seed=51), S.make_weights(cfg, seed=52)
+    prompt = S.prompt_tokens(cfg, n=40, seed=3)
+    m = HipLlamaModel(cfg, w_a)
+    s = m.session(96)
+    s.batch_forward(prompt, 0)
+    t = s.sample(0.0, 0.5)
+    s.decode_n(t, prompt.size, 4)                       # graphs of every kind now exist for the old weights
+    for key in ((1, S.W_GATE), (1, S.W_UP), (0, S.W_Q), (2, S.W_DOWN)):
+        m.set_weight(key[0], key[1], w_b[key])
+    w_mix = dict(w_a)
+    for key in ((1, S.W_GATE), (1, S.W_UP), (0, S.W_Q), (2, S.W_DOWN)):
+        w_mix[key] = w_b[key]
+    ref = HipLlamaModel(cfg, w_mix).session(96)
+    np.testing.assert_array_equal(s.forward(prompt, 0), ref.forward(prompt, 0))
+    ta, tb = s.sample(0.0, 0.5), ref.sample(0.0, 0.5)
+    assert ta == tb
+    np.testing.assert_array_equal(s.decode_n(ta, prompt.size, 6), ref.decode_n(tb, prompt.size, 6))
