@@ -2043,7 +2043,8 @@ __global__ __launch_bounds__(256) void rows_rope_kv_kernel(PrefillAttnParams p) 
     float* krow = (float*)kv_row(p, 0, pos, KV);
     float* vrow = (float*)kv_row(p, 1, pos, KV);
     const int npairs = (p.n_heads + p.n_kv_heads) * half;
-    for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+    const int t0 = blockIdx.y * blockDim.x + threadIdx.x, tstep = blockDim.x * gridDim.y;   // gridDim.y workgroups per row
+    for (int i = t0; i < npairs; i += tstep) {
         const int hh = i / half, d = i - hh * half;
         const bool isq = hh < p.n_heads;
         const int kvh = isq ? hh / group : hh - p.n_heads;
@@ -2055,7 +2056,7 @@ __global__ __launch_bounds__(256) void rows_rope_kv_kernel(PrefillAttnParams p) 
         if (isq) { v[d] = r0; v[d + half] = r1; }
         else { krow[(size_t)kvh * HS + d] = r0; krow[(size_t)kvh * HS + d + half] = r1; }
     }
-    for (int i = threadIdx.x; i < KV; i += blockDim.x) vrow[i] = r[A + KV + i];
+    for (int i = t0; i < KV; i += tstep) vrow[i] = r[A + KV + i];
 }
 
 // Causal attention of one chunk row against positions [0, start_pos+row]: workgroup = (kv head, row), the GROUP query

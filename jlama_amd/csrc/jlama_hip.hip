@@ -1316,7 +1316,7 @@ int prefill_attn_launch(jh_session* s, int rel, int nkeys_bound, int rows, hipSt
     p.n_heads = c.n_heads; p.n_kv_heads = c.n_kv_heads; p.head_size = hs; p.kv_head_offset = m->kv_head_offset;
     p.start_pos = s->pb_start; p.rows = rows; p.scale = m->attention_scale;
     p.out = s->pb_att; p.ldo = A;
-    hipLaunchKernelGGL(rows_rope_kv_kernel, dim3(rows), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(rows_rope_kv_kernel, dim3(rows, 4), dim3(256), 0, st, p);   // 4 workgroups per row: the pair loop is latency-bound
     HIPCHK(hipGetLastError());
     const size_t lds = prefill_attn_lds(c, nkeys_bound);
     dim3 grid(c.n_kv_heads, rows), block(PF_THREADS);
