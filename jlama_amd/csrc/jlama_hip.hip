@@ -937,6 +937,7 @@ struct jh_model {
     int device;
     std::vector<JWeight> layer_w;  // [n_layers][JH_W_COUNT]; Q/K/V entries alias slices of qkv[layer]
     std::vector<JWeight> qkv;      // [n_layers] q|k|v stacked along N in ONE allocation => one GEMV, no tensor switch
+    std::vector<JWeight> gateup;   // [n_layers] prefill only: gate|up stacked along N in MFMA order (`tiled`), one GEMM for both
     JWeight global_w[JH_W_COUNT];
     float* rope = nullptr;
     float attention_scale;
@@ -1216,8 +1217,8 @@ int prefill_alloc(jh_session* s) {
     HIPCHK(hipMalloc(&s->pb_x1, R * E * 4));
     HIPCHK(hipMalloc(&s->pb_qkv, R * (A + 2 * KV) * 4));
     HIPCHK(hipMalloc(&s->pb_att, R * A * 4));
-    HIPCHK(hipMalloc(&s->pb_g, R * H * 4));
-    HIPCHK(hipMalloc(&s->pb_u, R * H * 4));
+    HIPCHK(hipMalloc(&s->pb_g, R * 2 * H * 4));   // [rows][gate | up] when the fused gate|up GEMM runs, else gate [rows][H] + up behind it
+    s->pb_u = s->pb_g + R * H;
     HIPCHK(hipMalloc(&s->pb_aq, R * kmax * (c.weight_dtype == JH_DT_BF16 ? 2 : 1)));   // Q8 codes, or BF16 rows for a BF16 model
     HIPCHK(hipMalloc(&s->pb_ad, R * (kmax / QB) * 4));
     HIPCHK(hipMalloc(&s->pb_tok, R * 4));
@@ -1256,16 +1257,52 @@ int ensure_tiled(JWeight& W, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
+// gate and up stacked along N in ONE MFMA-ordered copy: the prefill runs a single [rows, 2H] GEMM for both
+// (MLPBlock.java:117-130 issues them over the same quantized activation), out[:, :H] = gate, out[:, H:] = up
+int ensure_gateup_tiled(jh_session* s, int li, hipStream_t st) {
+    jh_model* m = s->m;
+    JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    JWeight& G = W[JH_W_GATE];
+    JWeight& U = W[JH_W_UP];
+    JWeight& F = m->gateup[(size_t)li];
+    if (F.tiled || !G.data || !U.data) return JH_OK;
+    if (G.rows != U.rows || G.cols != U.cols || G.dtype != U.dtype || (G.rows % 32) || !prefill_tiled(s, G.cols)) return JH_OK;
+    const size_t H = (size_t)G.rows, K = (size_t)G.cols;
+    F.dtype = G.dtype; F.rows = (int)(2 * H); F.cols = (int)K;
+    if (G.dtype == JH_DT_BF16) {
+        hipError_t e = hipMalloc((void**)&F.tiled, 2 * H * K * 2);
+        if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled gate|up copy");
+        const size_t chunks = H * (K / 8);
+        hipLaunchKernelGGL(retile_bf16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const uint16_t*)G.data, (int)H, (int)K, (uint16_t*)F.tiled);
+        hipLaunchKernelGGL(retile_bf16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const uint16_t*)U.data, (int)H, (int)K,
+                           (uint16_t*)F.tiled + H * K);
+        HIPCHK(hipGetLastError());
+        return JH_OK;
+    }
+    if (G.dtype != JH_DT_Q4) return JH_OK;
+    const size_t nblk = K / QB;
+    hipError_t e = hipMalloc((void**)&F.tiled, 2 * H * nblk * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&F.tiled_scales, 2 * H * nblk * 4);
+    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled gate|up copy");
+    const size_t n = H * nblk;
+    hipLaunchKernelGGL(retile_q4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)G.data, (const float*)G.scales, (int)H,
+                       (int)nblk, F.tiled, F.tiled_scales);
+    hipLaunchKernelGGL(retile_q4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)U.data, (const float*)U.scales, (int)H,
+                       (int)nblk, F.tiled + H * nblk * 16, F.tiled_scales + H * nblk);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
 // every weight the prefill GEMMs of this shard will touch (allocation must not happen inside a graph capture)
 int ensure_all_tiled(jh_session* s, hipStream_t st) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
     for (int li = c.layer_start; li < c.layer_end; li++) {
         JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
-        JWeight* list[] = {&m->qkv[(size_t)li], &W[JH_W_O], &W[JH_W_GATE], &W[JH_W_UP], &W[JH_W_DOWN]};
+        JWeight* list[] = {&m->qkv[(size_t)li], &W[JH_W_O], &W[JH_W_DOWN]};
         for (JWeight* w : list)
             if (w->data && !w->tiled && (w->dtype == JH_DT_Q4 || w->dtype == JH_DT_BF16) && prefill_tiled(s, w->cols) && (w->rows % 32) == 0)
                 JHCHK(ensure_tiled(*w, st));
+        JHCHK(ensure_gateup_tiled(s, li, st));
     }
     return JH_OK;
 }
@@ -1277,6 +1314,15 @@ int rows_quant_launch(jh_session* s, const float* x, int ldx, const float* x2, i
     else hipLaunchKernelGGL((rows_quant_kernel<MODE>), dim3(rows), dim3(256), 0, st, p);
     HIPCHK(hipGetLastError());
     return JH_OK;
+}
+// the same on a weight that exists only as an MFMA-ordered copy (fused gate|up)
+int prefill_gemm_tiled(jh_session* s, const JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
+    if (W.dtype == JH_DT_BF16) {
+        MfmaBf16TileParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.tiled, out, resid, rows, N, K, ldc, s->pb_ws, 1};
+        return launch_gemm_bf16_tile(g, st);
+    }
+    MfmaQ4Params g{s->pb_aq, s->pb_ad, W.tiled, W.tiled_scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
+    return launch_gemm_q8q4_mfma(g, st, true);
 }
 // out[rows, N] = act[rows, K] x W[N, K]^T (+ resid): I8 x Q4 (exact integer MFMA) or BF16 x BF16 (MFMA), by model dtype
 int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
@@ -1352,9 +1398,14 @@ int prefill_layers(jh_session* s, int rows, int nkeys_bound, hipStream_t st) {
         JHCHK(prefill_gemm(s, W[JH_W_O], E, A, rows, s->pb_x1, E, s->pb_x, st));
         // preFFNorm + maybeQuantize, gate / up, SiLU*up + maybeQuantize, down + residual (MLPBlock.java:117-158)
         JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
-        JHCHK(prefill_gemm(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, st));
-        JHCHK(prefill_gemm(s, W[JH_W_UP], H, E, rows, s->pb_u, H, nullptr, st));
-        JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, st)));
+        if (m->gateup[(size_t)li].tiled) {   // one GEMM for gate|up: out[:, :H] = gate, out[:, H:] = up
+            JHCHK(prefill_gemm_tiled(s, m->gateup[(size_t)li], 2 * H, E, rows, s->pb_g, 2 * H, nullptr, st));
+            JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, 2 * H, s->pb_g + H, 2 * H, nullptr, 0.f, H, rows, st)));
+        } else {
+            JHCHK(prefill_gemm(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, st));
+            JHCHK(prefill_gemm(s, W[JH_W_UP], H, E, rows, s->pb_u, H, nullptr, st));
+            JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, st)));
+        }
         JHCHK(prefill_gemm(s, W[JH_W_DOWN], E, H, rows, s->pb_x, E, s->pb_x1, st));
         JHCHK(trace_sync("prefill layer", st));
     }
@@ -1481,6 +1532,7 @@ int jh_model_create(const jh_config* cfg, jh_model** out) {
     m->device = tctx.device;
     m->layer_w.resize((size_t)cfg->n_layers * JH_W_COUNT);
     m->qkv.resize((size_t)cfg->n_layers);
+    m->gateup.resize((size_t)cfg->n_layers);
     // Config ctor (core/safetensors/Config.java:270-274): table over the whole context
     const int half = cfg->head_size / 2;
     std::vector<float> table((size_t)cfg->context_length * half * 2);
@@ -1505,6 +1557,7 @@ int jh_model_destroy(jh_model* m) {
         if (w.tiled_scales) hipFree(w.tiled_scales);
     }
     for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); }
+    for (auto& w : m->gateup) { if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); }
     for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
     if (m->rope) hipFree(m->rope);
     delete m;
@@ -1590,6 +1643,10 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     if (w->data) hipFree(w->data);
     if (w->scales) hipFree(w->scales);
     if (w->tiled) { hipFree(w->tiled); hipFree(w->tiled_scales); w->tiled = nullptr; w->tiled_scales = nullptr; }
+    if (layer >= 0 && (which == JH_W_GATE || which == JH_W_UP)) {
+        JWeight& gu = m->gateup[(size_t)layer];
+        if (gu.tiled) { hipFree(gu.tiled); hipFree(gu.tiled_scales); gu.tiled = nullptr; gu.tiled_scales = nullptr; }
+    }
     w->data = nullptr; w->scales = nullptr;
     hipError_t e = hipMalloc(&w->data, bytes + 64);
     if (e != hipSuccess) return set_err(JH_ERR_OOM, std::string("hipMalloc weight: ") + hipGetErrorString(e));
@@ -1707,7 +1764,7 @@ int jh_session_destroy(jh_session* s) {
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
-    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_u, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start}) if (b) hipFree(b);
+    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start}) if (b) hipFree(b);
     for (auto& kv : s->pb_graphs) hipGraphExecDestroy(kv.second);
     for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
     if (s->ev0) hipEventDestroy(s->ev0);
