@@ -1918,7 +1918,8 @@ __global__ __launch_bounds__(256) void rows_quant_kernel(RowsParams p) {
     const int units = p.K / 8;
     float fs = 1.0f;
     if (MODE == ROWS_RMS) fs = rms_factor(x, p.K, p.eps, red);
-    for (int unit = threadIdx.x; unit < units; unit += T) {   // units % 4 == 0 and T % 4 == 0: quads stay together
+    // gridDim.y workgroups share a row (blocks are independent; ROWS_RMS needs the whole row and is launched with y = 1)
+    for (int unit = blockIdx.y * T + threadIdx.x; unit < units; unit += T * gridDim.y) {   // units, T multiples of 4: quads stay together
         const float4 xa = *(const float4*)(x + unit * 8), xb = *(const float4*)(x + unit * 8 + 4);
         float y[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
         if (MODE == ROWS_RMS) {
@@ -1977,7 +1978,7 @@ __global__ __launch_bounds__(256) void rows_bf16_kernel(RowsParams p) {
     float fs = 1.0f;
     if (MODE == ROWS_RMS) fs = rms_factor(x, p.K, p.eps, red);
     uint16_t* out = (uint16_t*)p.q + (size_t)row * p.ldq;
-    for (int unit = threadIdx.x; unit < units; unit += T) {
+    for (int unit = blockIdx.y * T + threadIdx.x; unit < units; unit += T * gridDim.y) {
         const float4 xa = *(const float4*)(x + unit * 8), xb = *(const float4*)(x + unit * 8 + 4);
         float y[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
         if (MODE == ROWS_RMS) {

@@ -1310,8 +1310,9 @@ template <int MODE>
 int rows_quant_launch(jh_session* s, const float* x, int ldx, const float* x2, int ldx2, const float* nw, float eps, int K, int rows,
                       hipStream_t st) {
     RowsParams p{x, ldx, x2, ldx2, nw, eps, K, rows, s->pb_aq, prefill_tiled(s, K) ? -1 : K, s->pb_ad, K / QB, nullptr};
-    if (s->m->c.weight_dtype == JH_DT_BF16) hipLaunchKernelGGL((rows_bf16_kernel<MODE>), dim3(rows), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((rows_quant_kernel<MODE>), dim3(rows), dim3(256), 0, st, p);
+    const dim3 grid(rows, MODE == ROWS_RMS ? 1 : (K >= 8192 ? 4 : 2));   // few rows: split the independent blocks of a row over workgroups
+    if (s->m->c.weight_dtype == JH_DT_BF16) hipLaunchKernelGGL((rows_bf16_kernel<MODE>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((rows_quant_kernel<MODE>), grid, dim3(256), 0, st, p);
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
