@@ -1316,7 +1316,10 @@ __global__ __launch_bounds__(S * CW * 64) __attribute__((amdgpu_waves_per_eu(3))
     arow = arow < p.m ? arow : p.m - 1;                   // rows beyond M replicate the last row (never stored)
     const int nblk = p.k / QB, nbr = nblk / S, b0 = ks * nbr;
     float* dA = (float*)smem + (size_t)ks * nbr * 32;     // the K range's slice: [nbr][32 rows], shared by the CW waves
-    {   // stage da[row][b0 .. b0+nbr) transposed; lane (row, h) of wave cw covers blocks h + 2*cw, step 2*CW
+    if (TILED) {   // block scales arrive as [row tile][blk][32 rows] (rows_quant_kernel, tiled): a straight, coalesced copy
+        const float4* src = (const float4*)(p.af + ((size_t)rt * nblk + b0) * 32);
+        for (int i4 = lane + 64 * cw; i4 < nbr * 8; i4 += 64 * CW) ((float4*)dA)[i4] = src[i4];
+    } else {       // row-major da[row][blk]: transpose while staging; lane (row, h) of wave cw covers blocks h + 2*cw, step 2*CW
         const float* src = p.af + (size_t)arow * p.ldaf + b0;
         for (int i = h + 2 * cw; i < nbr; i += 2 * CW) dA[i * 32 + nl] = src[i];
     }
@@ -1963,7 +1966,10 @@ __global__ __launch_bounds__(256) void rows_quant_kernel(RowsParams p) {
         } else {
             *(i32x2*)(p.q + (size_t)row * p.ldq + unit * 8) = packed;
         }
-        if ((unit & 3) == 0) p.d[(size_t)row * p.ldd + (unit >> 2)] = d;
+        if ((unit & 3) == 0) {
+            if (p.ldq < 0) p.d[(((size_t)(row >> 5) * (p.K / QB)) + (unit >> 2)) * 32 + (row & 31)] = d;   // [row tile][blk][32 rows]
+            else p.d[(size_t)row * p.ldd + (unit >> 2)] = d;
+        }
     }
 }
 

@@ -1812,7 +1812,7 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
     HIPCHK(hipMalloc(&w, wbytes * copies)); HIPCHK(hipMemset(w, 0x37, wbytes * copies));
     if (sbytes) { HIPCHK(hipMalloc(&ws, sbytes * copies)); HIPCHK(hipMemset(ws, 0, sbytes * copies)); }
     HIPCHK(hipMalloc(&a, (size_t)(m + 32) * k * 2)); HIPCHK(hipMemset(a, 1, (size_t)(m + 32) * k * 2));
-    HIPCHK(hipMalloc(&af, (size_t)m * (k / QB) * 4)); HIPCHK(hipMemset(af, 0, (size_t)m * (k / QB) * 4));
+    HIPCHK(hipMalloc(&af, (size_t)(m + 32) * (k / QB) * 4)); HIPCHK(hipMemset(af, 0, (size_t)(m + 32) * (k / QB) * 4));
     HIPCHK(hipMalloc(&c, (size_t)m * n * 4));
     float* bf16_ws = nullptr;
     if (kind == 1 || kind == 3) HIPCHK(hipMalloc(&bf16_ws, BF16_SPLITK_WS_BYTES));   // kind 3 = BF16 with MFMA-ordered operands
