@@ -1666,18 +1666,33 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
             }
         }
     }
-    for (int k = PRE; rsub + k * RPS < cnt; k++) {   // slices longer than PRE*RPS rows (ticket mode, long contexts)
-        const int tt = rsub + k * RPS, t = t0 + tt;
-        float4 kv4 = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4];
-        if (t == pos) kv4 = knew4;
+    // slices longer than PRE*RPS rows (long contexts): further rounds of TR row steps, every load of a round issued
+    // (branch-free, clamped) before the first one is consumed -- a step-at-a-time loop pays the full memory latency per step
+    constexpr int TR = 8;
+    for (int kb = PRE; kb * RPS < cnt; kb += TR) {   // cnt is uniform across the workgroup: no divergence on the round count
+        float4 kt[TR];
 #pragma unroll
-        for (int gi = 0; gi < GROUP; gi++) {
-            float s = qv[gi].x * kv4.x;
-            s = fmaf(qv[gi].y, kv4.y, s);
-            s = fmaf(qv[gi].z, kv4.z, s);
-            s = fmaf(qv[gi].w, kv4.w, s);
-            s = group_sum_last<LPR>(s);
-            if (c4 == LPR - 1) sc[gi * chunk + tt] = s * p.scale;
+        for (int u = 0; u < TR; u++) {
+            int t = t0 + rsub + (kb + u) * RPS;
+            t = t > pos ? pos : t;
+            kt[u] = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[c4];
+        }
+#pragma unroll
+        for (int u = 0; u < TR; u++) {
+            const int tt = rsub + (kb + u) * RPS, t = t0 + tt;
+            if (tt < cnt) {
+                float4 kv4 = kt[u];
+                if (t == pos) kv4 = knew4;
+#pragma unroll
+                for (int gi = 0; gi < GROUP; gi++) {
+                    float s = qv[gi].x * kv4.x;
+                    s = fmaf(qv[gi].y, kv4.y, s);
+                    s = fmaf(qv[gi].z, kv4.z, s);
+                    s = fmaf(qv[gi].w, kv4.w, s);
+                    s = group_sum_last<LPR>(s);
+                    if (c4 == LPR - 1) sc[gi * chunk + tt] = s * p.scale;
+                }
+            }
         }
     }
     lds_barrier();
@@ -1725,17 +1740,29 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
                 }
             }
         }
-        for (int k = PRE; rsub + k * RPS < cnt; k++) {
-            const int tt = rsub + k * RPS, t = t0 + tt;
-            float4 v4 = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
-            if (t == pos) v4 = vnew4;
+        for (int kb = PRE; kb * RPS < cnt; kb += TR) {
+            float4 vt[TR];
 #pragma unroll
-            for (int gi = 0; gi < GROUP; gi++) {
-                const float w = sc[gi * chunk + tt];
-                acc[gi].x = fmaf(v4.x, w, acc[gi].x);
-                acc[gi].y = fmaf(v4.y, w, acc[gi].y);
-                acc[gi].z = fmaf(v4.z, w, acc[gi].z);
-                acc[gi].w = fmaf(v4.w, w, acc[gi].w);
+            for (int u = 0; u < TR; u++) {
+                int t = t0 + rsub + (kb + u) * RPS;
+                t = t > pos ? pos : t;
+                vt[u] = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[c4];
+            }
+#pragma unroll
+            for (int u = 0; u < TR; u++) {
+                const int tt = rsub + (kb + u) * RPS, t = t0 + tt;
+                if (tt < cnt) {
+                    float4 v4 = vt[u];
+                    if (t == pos) v4 = vnew4;
+#pragma unroll
+                    for (int gi = 0; gi < GROUP; gi++) {
+                        const float w = sc[gi * chunk + tt];
+                        acc[gi].x = fmaf(v4.x, w, acc[gi].x);
+                        acc[gi].y = fmaf(v4.y, w, acc[gi].y);
+                        acc[gi].z = fmaf(v4.z, w, acc[gi].z);
+                        acc[gi].w = fmaf(v4.w, w, acc[gi].w);
+                    }
+                }
             }
         }
 #pragma unroll

@@ -463,3 +463,41 @@ def test_replacing_a_weight_invalidates_captured_graphs(gpu, oracle):
     ta, tb = s.sample(0.0, 0.5), ref.sample(0.0, 0.5)
     assert ta == tb
     np.testing.assert_array_equal(s.decode_n(ta, prompt.size, 6), ref.decode_n(tb, prompt.size, 6))
+
+
+def test_decode_attention_long_slices(gpu, oracle):
+    """Decode at a 2300-row context: with 16 slices a slice holds 144 rows, with JH_ATTN_SPLITS=4 575 rows -- more than the
+    128 rows the kernel prefetches, so the batched tail rounds of the score and PV loops run.  Teacher-forced vs the oracle."""
+    import os
+    from jlama_amd import synthetic as S
+    cfg = dict(S.SMALL)
+    cfg["context_length"] = 4096
+    hm, om, _ = _pair(cfg, 19, oracle)
+    prompt = S.prompt_tokens(cfg, n=2299, seed=23)
+    os_ = om.session()
+    want = os_.forward(prompt, 0)
+    first, lo = om.sample(want[-1])
+    ref_toks, ref_margin, tok = [], [], first
+    for i in range(5):
+        xo = os_.forward([tok], prompt.size + i)
+        tok, lg = om.sample(xo[-1])
+        top2 = np.partition(lg, -2)[-2:]
+        ref_toks.append(tok)
+        ref_margin.append(float(top2[1] - top2[0]))
+    for splits in (None, "4"):
+        if splits:
+            os.environ["JH_ATTN_SPLITS"] = splits
+        try:
+            hs = hm.session(2400)
+            got = hs.batch_forward(prompt, 0)
+            assert _rel(got[-1], want[prompt.size - got.shape[0]:][-1]) <= TRUNK_TOL
+            t0, lh = hs.sample(0.0, 0.5, want_logits=True)
+            assert np.abs(lh - lo).max() <= LOGIT_TOL
+            toks = [first]   # teacher-forced: feed the oracle's tokens, compare each sampled id
+            for i in range(5):
+                g = hs.decode_step(toks[-1], prompt.size + i)
+                assert g == ref_toks[i] or ref_margin[i] <= LOGIT_TOL, (splits, i, g, ref_toks[i])
+                toks.append(ref_toks[i])
+        finally:
+            if splits:
+                del os.environ["JH_ATTN_SPLITS"]
