@@ -92,3 +92,19 @@ def test_product_never_touches_the_oracle():
     from jlama_amd import _native as N
     ldd = subprocess.run(["ldd", N.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in ldd and "torch" not in ldd
+
+
+def test_ctypes_prototypes_have_the_headers_arity():
+    """Every prototype in jlama_amd/_native.py must take as many arguments as the declaration in include/jlama_hip.h
+    (a drifted binding would pass garbage through the C ABI instead of failing)."""
+    from jlama_amd import _native as N
+    hdr = open(os.path.join(ROOT, "include", "jlama_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", "", hdr)
+    arity = {}
+    for m in re.finditer(r"\b(jh_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        arity[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    assert set(arity) == set(N.EXPORTS)
+    bad = {name: (len(proto[1]), arity[name]) for name, proto in N._PROTOS.items() if len(proto[1]) != arity[name]}
+    assert not bad, bad
