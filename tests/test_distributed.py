@@ -58,14 +58,14 @@ def _worker(rank, world, port, cfg, n_prompt, steps, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_layer_sharded_pipeline_matches_single_process(world):
     import torch.multiprocessing as mp
     from jlama_amd import distributed as D, synthetic as S
     from oracle import oracle as O
     cfg = dict(S.TINY)
-    cfg["n_layers"] = 4
-    n_prompt, steps = 6, 5
+    cfg["n_layers"] = 8 if world == 8 else 4     # world 8 = the driver's largest launch (one layer per rank here)
+    n_prompt, steps = (4, 3) if world == 8 else (6, 5)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
