@@ -466,14 +466,15 @@ def test_replacing_a_weight_invalidates_captured_graphs(gpu, oracle):
 
 
 def test_decode_attention_long_slices(gpu, oracle):
-    """Decode at a 2300-row context: with 16 slices a slice holds 144 rows, with JH_ATTN_SPLITS=4 575 rows -- more than the
-    128 rows the kernel prefetches, so the batched tail rounds of the score and PV loops run.  Teacher-forced vs the oracle."""
+    """Decode where a slice of the context holds more rows than the kernel prefetches (128 for head size 128), so the
+    batched tail rounds of the score and PV loops run: a 700-row context cut into 4 slices (175 rows) and 2 slices
+    (350 rows) via JH_ATTN_SPLITS.  Teacher-forced vs the oracle."""
     import os
     from jlama_amd import synthetic as S
     cfg = dict(S.SMALL)
-    cfg["context_length"] = 4096
+    cfg["context_length"] = 1024
     hm, om, _ = _pair(cfg, 19, oracle)
-    prompt = S.prompt_tokens(cfg, n=2299, seed=23)
+    prompt = S.prompt_tokens(cfg, n=699, seed=23)
     os_ = om.session()
     want = os_.forward(prompt, 0)
     first, lo = om.sample(want[-1])
@@ -484,13 +485,12 @@ def test_decode_attention_long_slices(gpu, oracle):
         top2 = np.partition(lg, -2)[-2:]
         ref_toks.append(tok)
         ref_margin.append(float(top2[1] - top2[0]))
-    for splits in (None, "4"):
-        if splits:
-            os.environ["JH_ATTN_SPLITS"] = splits
+    for splits in ("4", "2"):
+        os.environ["JH_ATTN_SPLITS"] = splits
         try:
-            hs = hm.session(2400)
+            hs = hm.session(800)
             got = hs.batch_forward(prompt, 0)
-            assert _rel(got[-1], want[prompt.size - got.shape[0]:][-1]) <= TRUNK_TOL
+            assert _rel(got[-1], want[-1]) <= TRUNK_TOL
             t0, lh = hs.sample(0.0, 0.5, want_logits=True)
             assert np.abs(lh - lo).max() <= LOGIT_TOL
             toks = [first]   # teacher-forced: feed the oracle's tokens, compare each sampled id
@@ -499,5 +499,4 @@ def test_decode_attention_long_slices(gpu, oracle):
                 assert g == ref_toks[i] or ref_margin[i] <= LOGIT_TOL, (splits, i, g, ref_toks[i])
                 toks.append(ref_toks[i])
         finally:
-            if splits:
-                del os.environ["JH_ATTN_SPLITS"]
+            del os.environ["JH_ATTN_SPLITS"]
