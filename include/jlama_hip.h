@@ -61,6 +61,8 @@ int jh_parallel_split_size(void);
 /* TensorOperations.preferredWorkingQuantizedType() :32-34 -> JH_DT_I8 */
 int jh_preferred_working_qtype(void);
 const char* jh_last_error(void);
+/* Hash of the sources this binary was compiled from (lets the host side detect a stale library). */
+const char* jh_source_hash(void);
 /* Block until all work queued by this thread's stream has finished. */
 int jh_synchronize(void);
 
@@ -89,11 +91,16 @@ int jh_gemm_f32_q4(int64_t b_id, int64_t bf_id, const float* a, int aoffset, con
 /* F32 x F32 -> F32.  Replaces gemm_f32 (vector_simd.h:26). */
 int jh_gemm_f32(int64_t b_id, const float* a, int aoffset, const float* b, int boffset, float* r, int roffset,
                 int m, int n0, int n, int k, int lda, int ldb, int ldc);
-/* BF16 x BF16 -> F32 (r) -- replaces gemm_bf16 (vector_simd.h:34) with cr == NULL. */
-int jh_gemm_bf16(int64_t b_id, const uint16_t* a, int aoffset, const uint16_t* b, int boffset, float* r,
+/* BF16 x BF16 -> F32 (r) or BF16 (cr) -- replaces gemm_bf16 (vector_simd.h:34).  Exactly one of cr / r is used, as in
+ * the reference (NativeSimdTensorOperations.java:113-131 passes cr = result when result.dType()==BF16, else NULL;
+ * vector_simd.c:1060-1064): cr != NULL => the results are rounded to BF16 and stored at cr[ldc*i + j - roffset], r is
+ * ignored.  Rounding is FloatConversions.float32ToBFloat16 (RNE, FloatConversions.java:35-60 -- what the Panama provider
+ * writes, PTO:1305-1311); the reference C helper fp32_to_bf16 (vector_simd.c:22-38) truncates its result to `char`
+ * and is not reproduced. */
+int jh_gemm_bf16(int64_t b_id, const uint16_t* a, int aoffset, const uint16_t* b, int boffset, uint16_t* cr, float* r,
                  int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldc);
-/* F32 x BF16 -> F32 -- replaces gemm_f32_bf16 (vector_simd.h:38) with cr == NULL. */
-int jh_gemm_f32_bf16(int64_t b_id, const float* a, int aoffset, const uint16_t* b, int boffset, float* r,
+/* F32 x BF16 -> F32 (r) or BF16 (cr) -- replaces gemm_f32_bf16 (vector_simd.h:38). */
+int jh_gemm_f32_bf16(int64_t b_id, const float* a, int aoffset, const uint16_t* b, int boffset, uint16_t* cr, float* r,
                      int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldc);
 /* `_batch` forms (dotProductBatchChunk, TensorOperations.java:86-99; vector_simd.h:23,31): the same A against
  * batch_num weight tensors, results into batch_num result buffers. */
@@ -104,6 +111,15 @@ int jh_gemm_q8_q4_batch(int batch_num, const int64_t* b_ids, const int64_t* bf_i
 int jh_gemm_f32_q4_batch(int batch_num, const int64_t* b_ids, const int64_t* bf_ids, const float* a, int aoffset,
                          const float* const* bf, const uint8_t* const* b, int boffset, float* const* r, int roffset,
                          int m, int n0, int n, int k, int lda, int ldb, int ldbf, int ldc);
+/* the remaining `_batch` entry points of the reference library (vector_simd.h:27,35,39); b_ids / cr may be NULL */
+int jh_gemm_f32_batch(int batch_num, const int64_t* b_ids, const float* a, int aoffset, const float* const* b, int boffset,
+                      float* const* r, int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldc);
+int jh_gemm_bf16_batch(int batch_num, const int64_t* b_ids, const uint16_t* a, int aoffset, const uint16_t* const* b,
+                       int boffset, uint16_t* const* cr, float* const* r, int roffset, int m, int n0, int n, int k, int lda,
+                       int ldb, int ldc);
+int jh_gemm_f32_bf16_batch(int batch_num, const int64_t* b_ids, const float* a, int aoffset, const uint16_t* const* b,
+                           int boffset, uint16_t* const* cr, float* const* r, int roffset, int m, int n0, int n, int k,
+                           int lda, int ldb, int ldc);
 
 /* accumulate (TensorOperations.java:104): a[i] += b[i], i in [offset, offset+length).  F32 += F32
  * (PanamaTensorOperations.java:2281-2295). */
@@ -144,8 +160,11 @@ int jh_gelu_f32(float* x, int n);
 /* VectorMath.precomputeFreqsCis (VectorMath.java:148-165): out [end*dim/2][2] = (cos, sin). Host-side. */
 int jh_rope_table(int dim, int end, double theta, double scaling, float* out);
 /* RoPE rotation of one q row [n_heads*head_size] and one k row [n_kv_heads*head_size] at `position`
- * (CausalSelfAttention.java:247-286, GQA branch incl. the per-kv-head table offset). rope = jh_rope_table output. */
-int jh_rope_apply_f32(float* q, float* k, const float* rope, int position, int n_heads, int n_kv_heads,
+ * (CausalSelfAttention.java:247-286, GQA branch incl. the per-kv-head table offset: kv head h reads the table row of
+ * position + 2*h).  rope = jh_rope_table output covering `table_positions` positions; a position whose rows would run
+ * past the table (position + 2*(n_kv_heads-1) >= table_positions) is JH_ERR_INVALID -- the reference throws
+ * ArrayIndexOutOfBounds there. */
+int jh_rope_apply_f32(float* q, float* k, const float* rope, int table_positions, int position, int n_heads, int n_kv_heads,
                       int head_size);
 /* KvBufferCache.computePageSize (jlama-core/.../tensor/KvBufferCache.java:224-280). out2 = {layersPerPage, ctxPerPage}. */
 int jh_kv_page_geometry(int64_t max_page_bytes, int n_layers, int context_length, int kv_length, int dtype_size,
@@ -244,6 +263,18 @@ int jh_decode_step(jh_session* s, int32_t token, int pos, int32_t* next_token);
 /* n greedy decode iterations chained on the device (argmax feeds the next embedding lookup without a host
  * round trip; one hipGraph replay per token).  out_tokens: HOST [n].  Timing region of the metric. */
 int jh_decode_n(jh_session* s, int32_t first_token, int start_pos, int n, int32_t* out_tokens);
+/* Stop tokens of the device loop (Config.eosTokens; AbstractModel.java:600-603: generation ends with the step that
+ * samples one).  n_eos == 0 clears the set.  With a non-empty set jh_decode_n stops feeding the GPU once a stop token
+ * was sampled (checked every few steps without draining the queue); the ids up to and including the stop token are
+ * returned and jh_decode_generated() reports how many. */
+int jh_session_set_eos(jh_session* s, const int32_t* eos_ids, int n_eos);
+/* Tokens the last jh_decode_n / jh_decode_wait produced (== n unless a stop token ended the loop early). */
+int jh_decode_generated(jh_session* s, int32_t* out_n);
+/* Verification mode: every float accumulation of the decode path in the reference's Panama-512 order (16-lane
+ * accumulators over ascending K, halving-tree lane reduction, sequential softmax sum, position-ordered saxpy), so that
+ * results are bit-identical to the reference arithmetic instead of equal up to summation order.  Slower (no MFMA
+ * prefill, byte-granular weight reads).  Default from the environment: JH_STRICT_ORDER=1.  JQ4 models only. */
+int jh_session_set_strict(jh_session* s, int on);
 /* Same, but returns after queueing; jh_decode_wait() fetches the tokens.  Lets a caller bracket the loop with
  * its own device events. */
 int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n);

@@ -1,5 +1,6 @@
 """Loader / builder of libjlamahip.so and its ctypes prototypes (include/jlama_hip.h)."""
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
@@ -7,7 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "lib", "libjlamahip.so")
 SRC = os.path.join(HERE, "csrc", "jlama_hip.hip")
-HDRS = [os.path.join(HERE, "csrc", "jh_kernels.h"), os.path.join(ROOT, "include", "jlama_hip.h")]
+HDRS = [os.path.join(HERE, "csrc", "jh_kernels.h"), os.path.join(HERE, "csrc", "jh_strict.h"),
+        os.path.join(ROOT, "include", "jlama_hip.h")]
 
 JH_OK, JH_ERR_NO_DEVICE, JH_ERR_OOM, JH_ERR_UNSUPPORTED, JH_ERR_INVALID, JH_ERR_HIP = 0, -1, -2, -3, -4, -5
 DT_F32, DT_BF16, DT_I8, DT_Q4 = 0, 1, 2, 3
@@ -34,14 +36,36 @@ class Config(C.Structure):
                 ("rope_theta", C.c_float), ("rope_scaling", C.c_float)]
 
 
+def source_hash():
+    """sha256 over the library's sources; compiled into the .so (jh_source_hash) so a stale binary is detectable."""
+    h = hashlib.sha256()
+    for p in [SRC] + HDRS:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:32]
+
+
+def built_hash():
+    """The source hash the existing .so was compiled from, or None (missing / predates the hash).  Read by scanning the
+    file: dlopen-ing a stale library here would pin it in this process."""
+    try:
+        with open(LIB_PATH, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(b"JHSRCHASH:")
+    return blob[i + 10:i + 42].decode(errors="replace") if i >= 0 else None
+
+
 def build(force=False, verbose=False):
-    """Compile libjlamahip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile libjlamahip.so for gfx950 (hipcc cross-compiles without a GPU).  Without `force` the compile is skipped
+    only when the existing binary carries the hash of the current sources (never by timestamps)."""
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    newest = max(os.path.getmtime(p) for p in [SRC] + HDRS)
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+    want = source_hash()
+    if not force and built_hash() == want:
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wno-unused-value", SRC, "-o", LIB_PATH]
+           "-Wno-unused-value", f'-DJH_SRC_HASH="{want}"', SRC, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -63,8 +87,11 @@ _PROTOS = {
     "jh_gemm_q8_q4": (_i, [_l, _l, _p, _p, _i, _p, _p, _i, _p, _i] + [_i] * 9),
     "jh_gemm_f32_q4": (_i, [_l, _l, _p, _i, _p, _p, _i, _p, _i] + [_i] * 8),
     "jh_gemm_f32": (_i, [_l, _p, _i, _p, _i, _p, _i] + [_i] * 7),
-    "jh_gemm_bf16": (_i, [_l, _p, _i, _p, _i, _p, _i] + [_i] * 7),
-    "jh_gemm_f32_bf16": (_i, [_l, _p, _i, _p, _i, _p, _i] + [_i] * 7),
+    "jh_gemm_bf16": (_i, [_l, _p, _i, _p, _i, _p, _p, _i] + [_i] * 7),
+    "jh_gemm_f32_bf16": (_i, [_l, _p, _i, _p, _i, _p, _p, _i] + [_i] * 7),
+    "jh_gemm_f32_batch": (_i, [_i, _p, _p, _i, _p, _i, _p, _i] + [_i] * 7),
+    "jh_gemm_bf16_batch": (_i, [_i, _p, _p, _i, _p, _i, _p, _p, _i] + [_i] * 7),
+    "jh_gemm_f32_bf16_batch": (_i, [_i, _p, _p, _i, _p, _i, _p, _p, _i] + [_i] * 7),
     "jh_gemm_q8_q4_batch": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i] + [_i] * 9),
     "jh_gemm_f32_q4_batch": (_i, [_i, _p, _p, _p, _i, _p, _p, _i, _p, _i] + [_i] * 8),
     "jh_accumulate_f32": (_i, [_p, _p, _i, _i]),
@@ -81,7 +108,7 @@ _PROTOS = {
     "jh_layernorm_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "jh_gelu_f32": (_i, [_p, _i]),
     "jh_rope_table": (_i, [_i, _i, _d, _d, _p]),
-    "jh_rope_apply_f32": (_i, [_p, _p, _p, _i, _i, _i, _i]),
+    "jh_rope_apply_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i]),
     "jh_kv_page_geometry": (_i, [_l, _i, _i, _i, _i, _p]),
     "jh_model_create": (_i, [_p, _p]),
     "jh_model_destroy": (_i, [_p]),
@@ -97,6 +124,10 @@ _PROTOS = {
     "jh_decode_n": (_i, [_p, _i, _i, _i, _p]),
     "jh_decode_n_async": (_i, [_p, _i, _i, _i]),
     "jh_decode_wait": (_i, [_p, _p, _i]),
+    "jh_session_set_eos": (_i, [_p, _p, _i]),
+    "jh_decode_generated": (_i, [_p, _p]),
+    "jh_session_set_strict": (_i, [_p, _i]),
+    "jh_source_hash": (C.c_char_p, []),
     "jh_get_logits": (_i, [_p, _p]),
     "jh_model_set_kv_head_offset": (_i, [_p, _i]),
     "jh_tp_set_row": (_i, [_p, _i, _p, _i]),

@@ -151,7 +151,7 @@ struct DecodeState {
     int pos;     // position of the row being forwarded
     int token;   // its token id
     int step;    // index into out_tokens
-    int pad;
+    int done;    // a stop token was sampled (jh_session_set_eos): later replays of the decode graph change nothing
 };
 
 // ------------------------------------------------------------------------------------------------ GEMV params
@@ -1416,7 +1416,7 @@ __global__ void add_rows_kernel(const float* a, const float* b, float* out, int 
 }
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
-    st->pos = pos; st->token = token; st->step = step;
+    st->pos = pos; st->token = token; st->step = step; st->done = 0;
 }
 
 // EmbedInput for a Q4 / BF16 / F32 table (core/model/llama/LlamaModel.java:67-98): x[j] = (nib-8)*scale
@@ -1448,12 +1448,15 @@ __global__ void embed_kernel(const void* table, const float* scales, int dtype, 
 
 // argmax over the LM head's per-workgroup partials -> next token; advance the decode state and look up the
 // next embedding row, so a greedy decode step needs no host round trip (AbstractModel.java:590-599).
+// Stop tokens (Config.eosTokens, AbstractModel.java:600-603): the step that samples one is the last; st->done freezes
+// the state, so the remaining replays of an already-queued decode loop emit nothing.
 __global__ void finish_token_kernel(const float* partv, const int* parti, int nparts, DecodeState* st,
                                     int* out_tokens, const void* table, const float* scales, int dtype, int E,
-                                    float* x, int do_embed) {
+                                    float* x, int do_embed, const int* eos, int n_eos) {
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ int tok;
+    if (st->done) return;   // uniform: every thread reads the same word
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
@@ -1478,6 +1481,9 @@ __global__ void finish_token_kernel(const float* partv, const int* parti, int np
         st->token = bi;
         st->pos = st->pos + 1;
         st->step = st->step + 1;
+        int stop = 0;
+        for (int i = 0; i < n_eos; i++) stop |= (eos[i] == bi);
+        st->done = stop;
     }
     __syncthreads();
     if (do_embed) embed_row(table, scales, dtype, tok, E, x);
@@ -2303,6 +2309,11 @@ __global__ void widen_bf16_kernel(const uint16_t* in, long long n, float* out) {
 __global__ void quantize_bf16_kernel(const float* x, long long n, uint16_t* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = f32_to_bf16(x[i]);
+}
+// BF16 result tensor of a Tier-1 GEMM: out[i*ld + j] = bf16(in[i*ld + j]) for j < n, one grid row per matrix row
+__global__ void store_bf16_2d_kernel(const float* in, uint16_t* out, int n, int ld) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[(size_t)blockIdx.y * ld + j] = f32_to_bf16(in[(size_t)blockIdx.y * ld + j]);
 }
 // RMSNorm.forward (core/model/RMSNorm.java:33-56), single workgroup per row
 __global__ __launch_bounds__(1024) void rmsnorm_kernel(const float* x, const float* w, float adj, int n, float eps,

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "jh_kernels.h"
+#include "jh_strict.h"
 
 using namespace jh;
 
@@ -295,7 +296,9 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
         case 2: return launch_gemm_q8q4_mfma_mt<2>(g, st);
         case 3: case 4: return launch_gemm_q8q4_mfma_mt<4>(g, st);
         case 5: case 6: return launch_gemm_q8q4_mfma_mt<6>(g, st);
-        default: return launch_gemm_q8q4_mfma_mt<8>(g, st);
+        // M > 192 with K % 256 != 0: the all-of-M-per-wave kernel would need 8 accumulator tiles and spills (156 VGPRs
+        // to scratch when it existed); such shapes take the generic kernel instead
+        default: return set_err(JH_ERR_UNSUPPORTED, "I8xQ4 MFMA GEMM: M > 192 needs K % 256 == 0");
     }
 }
 
@@ -451,6 +454,11 @@ const char* jh_name(void) { return "HIP CDNA4 (gfx950) Operations"; }
 int jh_parallel_split_size(void) { return 1; }
 int jh_preferred_working_qtype(void) { return JH_DT_I8; }
 const char* jh_last_error(void) { return g_err.c_str(); }
+#ifndef JH_SRC_HASH
+#define JH_SRC_HASH "unknown"
+#endif
+static const char g_src_hash_marker[] = "JHSRCHASH:" JH_SRC_HASH;   // the host side finds it by scanning the file (no dlopen)
+const char* jh_source_hash(void) { return g_src_hash_marker + 10; }
 int jh_synchronize(void) {
     JHCHK(ensure_ctx());
     HIPCHK(hipStreamSynchronize(tctx.stream));
@@ -490,8 +498,8 @@ namespace {
 // Shared Tier-1 GEMM driver.  a_es/b_es: element size in bytes of A / B storage rows (Q4: ldb already in bytes).
 int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float* af, int aoffset, const void* b,
                const float* bf, int boffset, float* r, int roffset, int m, int n0, int n, int k, int lda, int ldaf,
-               int ldb, int ldbf, int ldc) {
-    if (m < 0 || n < 0 || k < 0 || !r || !a) return set_err(JH_ERR_INVALID, "gemm: bad argument");
+               int ldb, int ldbf, int ldc, uint16_t* cr = nullptr) {
+    if (m < 0 || n < 0 || k < 0 || (!r && !cr) || !a) return set_err(JH_ERR_INVALID, "gemm: bad argument");
     const bool q4 = (kind == G_Q8Q4 || kind == G_F32Q4);
     if (q4 && (k % QB)) return set_err(JH_ERR_INVALID, "gemm: K must be a multiple of 32 for Q4/Q8 blocks");
     if (m == 0 || n == 0) return JH_OK;
@@ -577,8 +585,9 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         g.a = (const int8_t*)dA + aoffset; g.af = (const float*)dAf + aoffset / QB;
         g.w = dB + boffset; g.ws = dBf + (boffset * 2) / QB; g.c = (float*)dR; g.resid = nullptr;
         g.m = m; g.n0 = n0; g.n = n; g.k = k; g.lda = lda; g.ldaf = ldaf; g.ldb = ldb; g.ldbf = ldbf; g.ldc = ldc; g.roffset = roffset;
-        JHCHK(launch_gemm_q8q4_mfma(g, st));
-        fast = true;
+        const int rcm = launch_gemm_q8q4_mfma(g, st);
+        if (rcm == JH_OK) fast = true;
+        else if (rcm != JH_ERR_UNSUPPORTED) return rcm;
     }
     if (!fast && kind == G_BF16 && m >= 2 && m <= 256 && (k % MG_KS) == 0 && (n % 32) == 0 && (aoffset % 8) == 0 && (boffset % 8) == 0 &&
         (lda % 8) == 0 && (ldb % 8) == 0 && !env_int("JH_TIER1_GENERIC", 0)) {
@@ -606,8 +615,17 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         }
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpy2DAsync(r + cmin, (size_t)ldc * 4, (float*)dR + cmin, (size_t)ldc * 4, (size_t)n * 4, m,
-                            hipMemcpyDeviceToHost, st));
+    if (cr) {   // BF16 result tensor (vector_simd.c:1060-1064): round on the device, ship 2 bytes per element
+        void* dC = nullptr;
+        JHCHK(dev_buf(5, r_elems * 2, &dC));
+        hipLaunchKernelGGL(store_bf16_2d_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, st, (const float*)dR + cmin,
+                           (uint16_t*)dC + cmin, n, ldc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy2DAsync(cr + cmin, (size_t)ldc * 2, (uint16_t*)dC + cmin, (size_t)ldc * 2, (size_t)n * 2, m, hipMemcpyDeviceToHost, st));
+    } else {
+        HIPCHK(hipMemcpy2DAsync(r + cmin, (size_t)ldc * 4, (float*)dR + cmin, (size_t)ldc * 4, (size_t)n * 4, m,
+                                hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipStreamSynchronize(st));
     return JH_OK;
 }
@@ -653,15 +671,40 @@ int jh_gemm_f32(int64_t b_id, const float* a, int aoffset, const float* b, int b
     return tier1_gemm(G_F32, b_id, -1, a, nullptr, aoffset, b, nullptr, boffset, r, roffset, m, n0, n, k, lda, 0, ldb,
                       0, ldc);
 }
-int jh_gemm_bf16(int64_t b_id, const uint16_t* a, int aoffset, const uint16_t* b, int boffset, float* r, int roffset,
-                 int m, int n0, int n, int k, int lda, int ldb, int ldc) {
+int jh_gemm_bf16(int64_t b_id, const uint16_t* a, int aoffset, const uint16_t* b, int boffset, uint16_t* cr, float* r,
+                 int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldc) {
     return tier1_gemm(G_BF16, b_id, -1, a, nullptr, aoffset, b, nullptr, boffset, r, roffset, m, n0, n, k, lda, 0, ldb,
-                      0, ldc);
+                      0, ldc, cr);
 }
-int jh_gemm_f32_bf16(int64_t b_id, const float* a, int aoffset, const uint16_t* b, int boffset, float* r, int roffset,
-                     int m, int n0, int n, int k, int lda, int ldb, int ldc) {
+int jh_gemm_f32_bf16(int64_t b_id, const float* a, int aoffset, const uint16_t* b, int boffset, uint16_t* cr, float* r,
+                     int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldc) {
     return tier1_gemm(G_F32BF16, b_id, -1, a, nullptr, aoffset, b, nullptr, boffset, r, roffset, m, n0, n, k, lda, 0,
-                      ldb, 0, ldc);
+                      ldb, 0, ldc, cr);
+}
+int jh_gemm_f32_batch(int batch_num, const int64_t* b_ids, const float* a, int aoffset, const float* const* b, int boffset,
+                      float* const* r, int roffset, int m, int n0, int n, int k, int lda, int ldb, int ldc) {
+    if (batch_num < 0 || !r) return set_err(JH_ERR_INVALID, "gemm_f32_batch: bad argument");
+    for (int i = 0; i < batch_num; i++)
+        JHCHK(jh_gemm_f32(b_ids ? b_ids[i] : -1, a, aoffset, b ? b[i] : nullptr, boffset, r[i], roffset, m, n0, n, k, lda, ldb, ldc));
+    return JH_OK;
+}
+int jh_gemm_bf16_batch(int batch_num, const int64_t* b_ids, const uint16_t* a, int aoffset, const uint16_t* const* b,
+                       int boffset, uint16_t* const* cr, float* const* r, int roffset, int m, int n0, int n, int k, int lda,
+                       int ldb, int ldc) {
+    if (batch_num < 0 || (!r && !cr)) return set_err(JH_ERR_INVALID, "gemm_bf16_batch: bad argument");
+    for (int i = 0; i < batch_num; i++)   // vector_simd.c:1256-1261
+        JHCHK(jh_gemm_bf16(b_ids ? b_ids[i] : -1, a, aoffset, b ? b[i] : nullptr, boffset, cr ? cr[i] : nullptr, r ? r[i] : nullptr,
+                           roffset, m, n0, n, k, lda, ldb, ldc));
+    return JH_OK;
+}
+int jh_gemm_f32_bf16_batch(int batch_num, const int64_t* b_ids, const float* a, int aoffset, const uint16_t* const* b,
+                           int boffset, uint16_t* const* cr, float* const* r, int roffset, int m, int n0, int n, int k,
+                           int lda, int ldb, int ldc) {
+    if (batch_num < 0 || (!r && !cr)) return set_err(JH_ERR_INVALID, "gemm_f32_bf16_batch: bad argument");
+    for (int i = 0; i < batch_num; i++)   // vector_simd.c:1487-1492
+        JHCHK(jh_gemm_f32_bf16(b_ids ? b_ids[i] : -1, a, aoffset, b ? b[i] : nullptr, boffset, cr ? cr[i] : nullptr,
+                               r ? r[i] : nullptr, roffset, m, n0, n, k, lda, ldb, ldc));
+    return JH_OK;
 }
 int jh_gemm_q8_q4_batch(int batch_num, const int64_t* b_ids, const int64_t* bf_ids, const float* af, const int8_t* a,
                         int aoffset, const float* const* bf, const uint8_t* const* b, int boffset, float* const* r,
@@ -876,9 +919,14 @@ int jh_rope_table(int dim, int end, double theta, double scaling, float* out) {
     }
     return JH_OK;
 }
-int jh_rope_apply_f32(float* q, float* k, const float* rope, int position, int n_heads, int n_kv_heads, int head_size) {
+int jh_rope_apply_f32(float* q, float* k, const float* rope, int table_positions, int position, int n_heads, int n_kv_heads,
+                      int head_size) {
     if (!q || !k || !rope || position < 0 || n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads || (head_size & 1))
         return set_err(JH_ERR_INVALID, "rope_apply: bad argument");
+    // kv head h reads table row position + 2*h (CausalSelfAttention.java:260-283): the reference indexes past its table
+    // (ArrayIndexOutOfBoundsException) for the last 2*(kvHeads-1) positions
+    if ((long long)position + 2LL * (n_kv_heads - 1) >= (long long)table_positions)
+        return set_err(JH_ERR_INVALID, "rope_apply: position + 2*(n_kv_heads-1) is beyond the RoPE table");
     JHCHK(ensure_ctx());
     hipStream_t st = tctx.stream;
     const int half = head_size / 2;
@@ -991,14 +1039,54 @@ struct jh_session {
     std::map<uint64_t, hipGraphExec_t> pb_graphs;   // captured layer loops, key = rows | key-count bucket << 32
     std::vector<hipGraph_t> pb_graph_src;
     int prefill_batch_min = 4;
+    int strict = 0;           // jh_session_set_strict: Panama-order kernels (jh_strict.h)
+    // stop tokens (jh_session_set_eos): device copy for finish_token_kernel + host-side feeding control
+    int* eos_dev = nullptr;
+    int n_eos = 0;
+    DecodeState* st_host = nullptr;   // pinned: state snapshots the host polls between chunks of graph replays
+    hipEvent_t ev_chunk[2] = {nullptr, nullptr};
+    int generated = 0;
 };
 
 static int attn_variant_for(const jh_session* s, int pos);
 static void drop_stale_graphs(jh_session* s);
+constexpr int ROPE_MARGIN = 512;
+// The RoPE row of kv head h at position p is table row p + 2*h (global head index): the reference's table has
+// context_length rows and Java throws ArrayIndexOutOfBoundsException beyond it -- same positions refused here.
+static int check_positions(const jh_session* s, int last_pos) {
+    const jh_model* m = s->m;
+    const long long last_row = (long long)last_pos + 2LL * (m->kv_head_offset + m->c.n_kv_heads - 1);
+    if (last_row >= (long long)m->c.context_length)
+        return set_err(JH_ERR_INVALID, "position " + std::to_string(last_pos) + ": RoPE row position + 2*(kvHeads-1) is beyond the model's context_length (the reference's table ends there)");
+    return JH_OK;
+}
 
 namespace {
 
 bool is_global_slot(int which) { return which == JH_W_EMBED || which == JH_W_LMHEAD || which == JH_W_FINALNORM; }
+
+// ---- strict-order launchers (jh_strict.h): 4 waves x 4 output rows per workgroup
+template <int PRO, int EPI>
+int launch_gemv_i8q4_strict(const GemvParams& p, hipStream_t st) {
+    const size_t lds = lds_bytes_i8(p.K);
+    int grid = (p.nrows + 15) / 16;
+    if (grid < 1) grid = 1;
+    JHCHK(allow_lds((gemv_i8q4_strict_kernel<PRO, EPI>), lds));
+    hipLaunchKernelGGL((gemv_i8q4_strict_kernel<PRO, EPI>), dim3(grid), dim3(256), lds, st, p);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+int launch_gemv_f32q4_strict(const GemvParams& p, int* grid_out, hipStream_t st) {
+    const size_t lds = lds_bytes_f32_strict(p.K);
+    int grid = (p.nrows + 15) / 16;
+    if (grid > 2048) grid = 2048;   // argmax partial buffers hold 4096 entries
+    if (grid < 1) grid = 1;
+    if (grid_out) *grid_out = grid;
+    JHCHK(allow_lds((gemv_f32q4_strict_kernel<PRO_RMS_F32>), lds));
+    hipLaunchKernelGGL((gemv_f32q4_strict_kernel<PRO_RMS_F32>), dim3(grid), dim3(256), lds, st, p);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
 
 int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg = nullptr) {
     jh_model* m = s->m;
@@ -1032,6 +1120,14 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     p.tap_q = tap ? s->tapq : nullptr;
     p.dbg = dbg;
     p.combine_kernel = (s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0;
+    if (s->strict) {
+        const size_t lds_s = lds_bytes_attn_strict(c.head_size, s->max_ctx);
+        if (lds_s > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "strict attention: the score row of max_ctx positions must fit in LDS");
+        JHCHK(allow_lds(attn_strict_kernel, lds_s));
+        hipLaunchKernelGGL(attn_strict_kernel, dim3(c.n_heads), dim3(256), lds_s, st, p);
+        HIPCHK(hipGetLastError());
+        return JH_OK;
+    }
     const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
     const int sc_cap = s->chunk_cap > 2 * s->max_splits ? s->chunk_cap : 2 * s->max_splits;
     const size_t lds = ((size_t)group * hs + 2 * hs + (size_t)(ATT_THREADS * 4) * group + 2 * group + 4 + (size_t)group * sc_cap) * 4;
@@ -1084,11 +1180,15 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         GemvParams p;
         memset(&p, 0, sizeof(p));
         const JWeight& F = m->qkv[(size_t)li];
-        if (!F.data || !W[JH_W_Q].data || !W[JH_W_K].data || !W[JH_W_V].data) return set_err(JH_ERR_INVALID, "layer: q/k/v weights not set");
+        // every slot this half dereferences on the device (a partial checkpoint or a wrong layer range must be an error
+        // code, not a GPU fault)
+        if (!F.data || !W[JH_W_Q].data || !W[JH_W_K].data || !W[JH_W_V].data || !W[JH_W_O].data || !W[JH_W_NORM1].data)
+            return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": q/k/v/o/input_layernorm weights not set");
         p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
         p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st))); }
+        else if (s->strict) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_STORE>(p, st)));
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
         JHCHK(trace_sync("qkv", st));
     }
@@ -1116,6 +1216,9 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
             p.ldb = A * 2;
             if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
             else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
+        } else if (s->strict) {
+            if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
+            else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
         } else if (!resid) {
             JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_STORE>(p, s->cfg_o, st)));
         } else if (s->direct_max > 0) {
@@ -1141,6 +1244,8 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
     const jh_config& c = m->c;
     const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     const int E = c.embedding_length, H = c.hidden_length;
+    if (!W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data || !W[JH_W_NORM2].data)
+        return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": gate/up/down/post_attention_layernorm weights not set");
     {   // gate/up (MLPBlock.java:117-142) with fused preFFNorm + maybeQuantize, SiLU*up + maybeQuantize
         GemvParams p;
         memset(&p, 0, sizeof(p));
@@ -1150,6 +1255,7 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
         p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
         p.out = s->hf;   // silu(gate)*up, F32; the down projection's prologue quantizes it (MLPBlock.java:144)
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, g_cu_count * 4, nullptr, st))); }
+        else if (s->strict) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
         JHCHK(trace_sync("gateup", st));
     }
@@ -1164,6 +1270,9 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
             p.ldb = H * 2;
             if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
             else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
+        } else if (s->strict) {
+            if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
+            else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
         } else if (resid) {
             JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
         } else {
@@ -1192,9 +1301,10 @@ constexpr int PB_MAX_ROWS = 256;   // rows per chunk = the MFMA GEMM's M limit (
 
 bool prefill_batch_ok(jh_session* s) {
     const jh_config& c = s->m->c;
-    if (s->prefill_batch_min <= 0 || s->tap_layer >= 0 || (c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16)) return false;
+    if (s->prefill_batch_min <= 0 || s->tap_layer >= 0 || s->strict || (c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16)) return false;
     const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
     if (c.embedding_length % 64 || c.hidden_length % 64 || A % 64 || (A + 2 * KV) % 32) return false;
+    if (c.weight_dtype == JH_DT_Q4 && (c.embedding_length % 256 || c.hidden_length % 256 || A % 256)) return false;   // tiled MFMA GEMMs only
     if (!((hs == 128 || hs == 64) && (group == 1 || group == 2 || group == 4 || group == 8))) return false;
     return true;
 }
@@ -1388,8 +1498,9 @@ int prefill_layers(jh_session* s, int rows, int nkeys_bound, hipStream_t st) {
         const int rel = li - c.layer_start;
         JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
         JWeight& F = m->qkv[(size_t)li];
-        if (!F.data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data)
-            return set_err(JH_ERR_INVALID, "layer: weights not set");
+        if (!F.data || !W[JH_W_Q].data || !W[JH_W_K].data || !W[JH_W_V].data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data ||
+            !W[JH_W_DOWN].data || !W[JH_W_NORM1].data || !W[JH_W_NORM2].data)
+            return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": weights not set");
         // preAttentionNorm + maybeQuantize, q|k|v projections (CausalSelfAttention.java:161-171)
         JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
         JHCHK(prefill_gemm(s, F, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, st));
@@ -1487,8 +1598,11 @@ int lmhead_launch(jh_session* s, hipStream_t st) {
     if (w->dtype == JH_DT_BF16) {
         p.ldb = p.K * 2;
         JHCHK((launch_gemv_bf16<PROB_RMS_F32, EPI_STORE, true>(p, 4096, &grid, st)));   // F32 x BF16 (GemmerF32BF16)
-    } else
-    JHCHK((launch_gemv_f32q4<PRO_RMS_F32>(p, s->cfg_lm, &grid, st)));
+    } else if (s->strict) {
+        JHCHK(launch_gemv_f32q4_strict(p, &grid, st));
+    } else {
+        JHCHK((launch_gemv_f32q4<PRO_RMS_F32>(p, s->cfg_lm, &grid, st)));
+    }
     s->lm_grid = grid;
     return JH_OK;
 }
@@ -1498,7 +1612,7 @@ int finish_launch(jh_session* s, hipStream_t st, int do_embed) {
     const JWeight& e = m->global_w[JH_W_EMBED];
     hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(256), 0, st, (const float*)s->amax_v, (const int*)s->amax_i, s->lm_grid,
                        s->st, s->out_tokens, (const void*)e.data, (const float*)e.scales, e.dtype, m->c.embedding_length, s->x,
-                       (do_embed && e.data) ? 1 : 0);
+                       (do_embed && e.data) ? 1 : 0, (const int*)s->eos_dev, s->n_eos);
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
@@ -1535,9 +1649,11 @@ int jh_model_create(const jh_config* cfg, jh_model** out) {
     m->qkv.resize((size_t)cfg->n_layers);
     m->gateup.resize((size_t)cfg->n_layers);
     // Config ctor (core/safetensors/Config.java:270-274): table over the whole context
+    // (+ ROPE_MARGIN rows: kv head h reads row position + 2*h, CausalSelfAttention.java:260-283; positions whose rows
+    // would leave the reference's table are refused by check_positions(), the margin only keeps a stray read in bounds)
     const int half = cfg->head_size / 2;
-    std::vector<float> table((size_t)cfg->context_length * half * 2);
-    jh_rope_table(cfg->head_size, cfg->context_length, (double)cfg->rope_theta, (double)cfg->rope_scaling, table.data());
+    std::vector<float> table((size_t)(cfg->context_length + ROPE_MARGIN) * half * 2);
+    jh_rope_table(cfg->head_size, cfg->context_length + ROPE_MARGIN, (double)cfg->rope_theta, (double)cfg->rope_scaling, table.data());
     hipError_t e = hipMalloc(&m->rope, table.size() * 4);
     if (e != hipSuccess) { delete m; return set_err(JH_ERR_OOM, "hipMalloc rope table"); }
     HIPCHK(hipMemcpy(m->rope, table.data(), table.size() * 4, hipMemcpyHostToDevice));
@@ -1665,13 +1781,25 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
 }
 int64_t jh_model_weight_bytes(jh_model* m) { return m ? m->weight_bytes : 0; }
 
+static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_page_bytes);
 int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_session** out) {
     if (!m || !out || max_ctx <= 0) return set_err(JH_ERR_INVALID, "session_create: bad argument");
     HIPCHK(hipSetDevice(m->device));
-    const jh_config& c = m->c;
-    if (max_ctx > c.context_length) max_ctx = c.context_length;
+    if (max_ctx > m->c.context_length) max_ctx = m->c.context_length;
     jh_session* s = new jh_session();
     s->m = m;
+    const int rc = session_init(s, m, max_ctx, max_page_bytes);
+    if (rc != JH_OK) {   // a half-built session must not leak its stream / slabs (the error text survives the destroy)
+        const std::string keep = g_err;
+        jh_session_destroy(s);
+        g_err = keep;
+        return rc;
+    }
+    *out = s;
+    return JH_OK;
+}
+static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_page_bytes) {
+    const jh_config& c = m->c;
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const int nl = c.layer_end - c.layer_start;
     const int KV = c.n_kv_heads * c.head_size, A = c.n_heads * c.head_size, E = c.embedding_length, H = c.hidden_length;
@@ -1692,7 +1820,7 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     const size_t slab_bytes = page_bytes * s->n_layer_pages * s->n_ctx_alloc;
     {
         hipError_t e = hipMalloc(&s->kv_slab, slab_bytes);
-        if (e != hipSuccess) { jh_session_destroy(s); return set_err(JH_ERR_OOM, "hipMalloc KV pages"); }
+        if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc KV pages");
         HIPCHK(hipMemset(s->kv_slab, 0, slab_bytes));
     }
     for (int lp = 0; lp < s->n_layer_pages; lp++)
@@ -1742,12 +1870,49 @@ int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_sessi
     if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
     s->prefill_batch_min = env_int("JH_PREFILL_BATCH_MIN", 4);   // chunks of fewer rows go row by row; 0 disables batching
     s->graphs_version = m->weights_version;
+    HIPCHK(hipHostMalloc((void**)&s->st_host, 2 * sizeof(DecodeState), hipHostMallocDefault));
+    memset(s->st_host, 0, 2 * sizeof(DecodeState));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_chunk[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&s->ev_chunk[1], hipEventDisableTiming));
+    s->strict = env_int("JH_STRICT_ORDER", 0) ? 1 : 0;
+    if (s->strict && c.weight_dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "JH_STRICT_ORDER: strict-order kernels exist for JQ4 models only");
     if (prefill_batch_ok(s)) {
         // the MFMA-ordered weight copies of the prefill GEMM are made here, once per model, not inside the first prompt
         JHCHK(ensure_all_tiled(s, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
     }
-    *out = s;
+    return JH_OK;
+}
+int jh_session_set_strict(jh_session* s, int on) {
+    if (!s) return set_err(JH_ERR_INVALID, "set_strict: null");
+    if (on && s->m->c.weight_dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "set_strict: strict-order kernels exist for JQ4 models only");
+    HIPCHK(hipSetDevice(s->m->device));
+    if ((on ? 1 : 0) != s->strict) {
+        HIPCHK(hipStreamSynchronize(s->stream));
+        s->strict = on ? 1 : 0;
+        s->graphs_version = -1;   // the captured graphs hold the other mode's kernels
+        drop_stale_graphs(s);
+    }
+    return JH_OK;
+}
+int jh_session_set_eos(jh_session* s, const int32_t* eos_ids, int n_eos) {
+    if (!s || n_eos < 0 || (n_eos > 0 && !eos_ids)) return set_err(JH_ERR_INVALID, "set_eos: bad argument");
+    HIPCHK(hipSetDevice(s->m->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->eos_dev) { HIPCHK(hipFree(s->eos_dev)); s->eos_dev = nullptr; }
+    s->n_eos = 0;
+    if (n_eos > 0) {
+        HIPCHK(hipMalloc(&s->eos_dev, (size_t)n_eos * sizeof(int)));
+        HIPCHK(hipMemcpy(s->eos_dev, eos_ids, (size_t)n_eos * sizeof(int), hipMemcpyHostToDevice));
+        s->n_eos = n_eos;
+    }
+    s->graphs_version = -1;       // finish_token_kernel's arguments are baked into the decode graphs
+    drop_stale_graphs(s);
+    return JH_OK;
+}
+int jh_decode_generated(jh_session* s, int32_t* out_n) {
+    if (!s || !out_n) return set_err(JH_ERR_INVALID, "decode_generated: null");
+    *out_n = s->generated;
     return JH_OK;
 }
 int jh_session_destroy(jh_session* s) {
@@ -1770,6 +1935,9 @@ int jh_session_destroy(jh_session* s) {
     for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
+    for (hipEvent_t e : s->ev_chunk) if (e) hipEventDestroy(e);
+    if (s->st_host) hipHostFree(s->st_host);
+    if (s->eos_dev) hipFree(s->eos_dev);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
     return JH_OK;
@@ -1986,6 +2154,7 @@ static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in,
                         float* x_out, bool x_out_dev) {
     if (!s || n <= 0 || start_pos < 0 || (!tokens && !x_in)) return set_err(JH_ERR_INVALID, "forward: bad argument");
     if (start_pos + n > s->max_ctx) return set_err(JH_ERR_INVALID, "forward: position beyond the session's max_ctx");
+    JHCHK(check_positions(s, start_pos + n - 1));
     jh_model* m = s->m;
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = s->stream;
@@ -2051,7 +2220,12 @@ int jh_model_set_kv_head_offset(jh_model* m, int kv_head_offset) {
 }
 int jh_tp_set_row(jh_session* s, int32_t token, const float* x_dev, int pos) {
     if (!s || pos < 0 || pos >= s->max_ctx) return set_err(JH_ERR_INVALID, "tp_set_row: bad argument");
+    JHCHK(check_positions(s, pos));
     jh_model* m = s->m;
+    if (!x_dev) {   // validate before anything is queued
+        if (!m->global_w[JH_W_EMBED].data) return set_err(JH_ERR_INVALID, "tp_set_row: this shard has no embedding table");
+        if (token < 0 || token >= m->c.vocab_size) return set_err(JH_ERR_INVALID, "tp_set_row: token id out of range");
+    }
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = s->stream;
     const int E = m->c.embedding_length;
@@ -2182,6 +2356,7 @@ static int build_graph(jh_session* s, int v) {
 int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) {
     if (!s || n <= 0 || start_pos < 0) return set_err(JH_ERR_INVALID, "decode_n: bad argument");
     if (start_pos + n > s->max_ctx) return set_err(JH_ERR_INVALID, "decode_n: positions beyond the session's max_ctx");
+    JHCHK(check_positions(s, start_pos + n - 1));
     jh_model* m = s->m;
     HIPCHK(hipSetDevice(m->device));
     const JWeight& emb = m->global_w[JH_W_EMBED];
@@ -2199,6 +2374,11 @@ int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) 
                        (const DecodeState*)s->st, m->c.embedding_length, s->x);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev0, st));
+    // Stop tokens: the device freezes its state at the step that samples one (finish_token_kernel); the host keeps two
+    // chunks of replays queued and, before queueing a third, looks at the state snapshot taken after the first -- the GPU
+    // never idles and at most 2*EOS_CHUNK steps are replayed for nothing.
+    constexpr int EOS_CHUNK = 16;
+    int launched = 0, chunk = 0;
     for (int i = 0; i < n; i++) {
         const int v = attn_variant_for(s, start_pos + i);   // the host knows every token's position in advance
         if (use_graph) {
@@ -2214,9 +2394,20 @@ int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) 
             s->tap_layer = saved;
             JHCHK(rc);
         }
+        launched++;
+        if (s->n_eos > 0 && launched % EOS_CHUNK == 0 && i + 1 < n) {
+            const int slot = chunk & 1;
+            if (chunk >= 2) {   // snapshot taken two chunks ago lives in this slot
+                HIPCHK(hipEventSynchronize(s->ev_chunk[slot]));
+                if (s->st_host[slot].done) break;
+            }
+            HIPCHK(hipMemcpyAsync(&s->st_host[slot], s->st, sizeof(DecodeState), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(s->ev_chunk[slot], st));
+            chunk++;
+        }
     }
     HIPCHK(hipEventRecord(s->ev1, st));
-    s->pending_n = n;
+    s->pending_n = launched;
     return JH_OK;
 }
 int jh_decode_wait(jh_session* s, int32_t* out_tokens, int n) {
@@ -2227,10 +2418,13 @@ int jh_decode_wait(jh_session* s, int32_t* out_tokens, int n) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         s->ms_per_token = (double)ms / s->pending_n;
+        DecodeState hs;
+        HIPCHK(hipMemcpy(&hs, s->st, sizeof(hs), hipMemcpyDeviceToHost));
+        s->generated = hs.step < s->pending_n ? hs.step : s->pending_n;   // fewer than queued only after a stop token
     }
     if (out_tokens && n > 0) {
-        if (n > s->pending_n) n = s->pending_n;
-        HIPCHK(hipMemcpy(out_tokens, s->out_tokens, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (n > s->generated) n = s->generated;
+        if (n > 0) HIPCHK(hipMemcpy(out_tokens, s->out_tokens, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     }
     s->pending_n = 0;
     return JH_OK;

@@ -55,9 +55,13 @@ class HipTensorOperations:
         rOffset = -rRowOffset  # NativeSimdTensorOperations.java:105 (dense: no sparse offsets)
         bid, bfid = b.reg_ids if b.reg_ids else (-1, -1)
         L = self._lib
-        if result.dtype != DT_F32:
-            raise N.UnsupportedOperation(N.JH_ERR_UNSUPPORTED, "result must be F32")
-        r = N.ptr(result.data)
+        # BF16 result tensors exist for the BF16-weight GEMMs only (NativeSimdTensorOperations.java:113-131,156-174:
+        # cr = result when result.dType()==BF16, else NULL)
+        bf16_out = result.dtype == DT_BF16 and b.dtype == DT_BF16 and a.dtype in (DT_BF16, DT_F32)
+        if result.dtype != DT_F32 and not bf16_out:
+            raise N.UnsupportedOperation(N.JH_ERR_UNSUPPORTED, "result must be F32 (or BF16 for BF16 weights)")
+        r = None if bf16_out else N.ptr(result.data)
+        cr = N.ptr(result.data) if bf16_out else None
         if a.dtype == DT_I8 and b.dtype == DT_Q4:
             rc = L.jh_gemm_q8_q4(bid, bfid, N.ptr(a.scales), N.ptr(a.data), aOffset, N.ptr(b.scales), N.ptr(b.data),
                                  bOffset // 2, r, rOffset, M, bRowOffset, Nn, K, a.stride, a.scales.shape[1],
@@ -70,10 +74,10 @@ class HipTensorOperations:
             rc = L.jh_gemm_f32(bid, N.ptr(a.data), aOffset, N.ptr(b.data), bOffset, r, rOffset, M, bRowOffset, Nn, K,
                                a.stride, b.stride, result.stride)
         elif a.dtype == DT_BF16 and b.dtype == DT_BF16:
-            rc = L.jh_gemm_bf16(bid, N.ptr(a.data), aOffset, N.ptr(b.data), bOffset, r, rOffset, M, bRowOffset, Nn, K,
+            rc = L.jh_gemm_bf16(bid, N.ptr(a.data), aOffset, N.ptr(b.data), bOffset, cr, r, rOffset, M, bRowOffset, Nn, K,
                                 a.stride, b.stride, result.stride)
         elif a.dtype == DT_F32 and b.dtype == DT_BF16:
-            rc = L.jh_gemm_f32_bf16(bid, N.ptr(a.data), aOffset, N.ptr(b.data), bOffset, r, rOffset, M, bRowOffset, Nn,
+            rc = L.jh_gemm_f32_bf16(bid, N.ptr(a.data), aOffset, N.ptr(b.data), bOffset, cr, r, rOffset, M, bRowOffset, Nn,
                                     K, a.stride, b.stride, result.stride)
         else:
             raise N.UnsupportedOperation(N.JH_ERR_UNSUPPORTED, f"dtype pair {a.dtype} x {b.dtype}")
@@ -84,10 +88,49 @@ class HipTensorOperations:
         self.batchDotProduct(result, a, b, columnOffset, columnOffset, columnLimit, 0, rowOffset, rowChunkSize)
 
     def dotProductBatchChunk(self, results, a, bs, offset, limit, chunkStart, chunkSize):
-        # TensorOperations.java:86-99
-        assert len(results) == len(bs)
-        for r, b in zip(results, bs):
-            self.dotProductChunk(r, a, b, offset, limit, chunkStart, chunkSize)
+        """TensorOperations.java:86-99 through the `_batch` entry points: arrays of weight / result pointers filled like
+        MemorySegmentSupport.setupBatch (jlama-native/.../NativeSimdTensorOperations.java:236-334)."""
+        assert len(results) == len(bs) and len(bs) > 0
+        nb = len(bs)
+        dt_b = bs[0].dtype
+        if any(b.dtype != dt_b or b.stride != bs[0].stride for b in bs) or any(r.stride != results[0].stride for r in results):
+            for r, b in zip(results, bs):   # heterogeneous batch: one call each
+                self.dotProductChunk(r, a, b, offset, limit, chunkStart, chunkSize)
+            return
+        L = self._lib
+        M, K = a.rows, limit
+        arr_p = lambda xs: (C.c_void_p * nb)(*[x.ctypes.data for x in xs])
+        arr_l = lambda xs: (C.c_int64 * nb)(*xs)
+        ids = arr_l([b.reg_ids[0] if b.reg_ids else -1 for b in bs])
+        b_ptr = arr_p([b.data for b in bs])
+        bf16_out = all(r.dtype == DT_BF16 for r in results) and dt_b == DT_BF16
+        if not bf16_out and any(r.dtype != DT_F32 for r in results):
+            raise N.UnsupportedOperation(N.JH_ERR_UNSUPPORTED, "result must be F32 (or BF16 for BF16 weights)")
+        r_ptr = None if bf16_out else arr_p([r.data for r in results])
+        cr_ptr = arr_p([r.data for r in results]) if bf16_out else None
+        ldc = results[0].stride
+        if a.dtype == DT_I8 and dt_b == DT_Q4:
+            sid = arr_l([b.reg_ids[1] if b.reg_ids else -1 for b in bs])
+            rc = L.jh_gemm_q8_q4_batch(nb, ids, sid, N.ptr(a.scales), N.ptr(a.data), offset, arr_p([b.scales for b in bs]), b_ptr,
+                                       offset // 2, r_ptr, 0, M, chunkStart, chunkSize, K, a.stride, a.scales.shape[1],
+                                       bs[0].stride // 2, bs[0].scales.shape[1], ldc)
+        elif a.dtype == DT_F32 and dt_b == DT_Q4:
+            sid = arr_l([b.reg_ids[1] if b.reg_ids else -1 for b in bs])
+            rc = L.jh_gemm_f32_q4_batch(nb, ids, sid, N.ptr(a.data), offset, arr_p([b.scales for b in bs]), b_ptr, offset // 2,
+                                        r_ptr, 0, M, chunkStart, chunkSize, K, a.stride, bs[0].stride // 2,
+                                        bs[0].scales.shape[1], ldc)
+        elif a.dtype == DT_F32 and dt_b == DT_F32:
+            rc = L.jh_gemm_f32_batch(nb, ids, N.ptr(a.data), offset, b_ptr, offset, r_ptr, 0, M, chunkStart, chunkSize, K,
+                                     a.stride, bs[0].stride, ldc)
+        elif a.dtype == DT_BF16 and dt_b == DT_BF16:
+            rc = L.jh_gemm_bf16_batch(nb, ids, N.ptr(a.data), offset, b_ptr, offset, cr_ptr, r_ptr, 0, M, chunkStart, chunkSize,
+                                      K, a.stride, bs[0].stride, ldc)
+        elif a.dtype == DT_F32 and dt_b == DT_BF16:
+            rc = L.jh_gemm_f32_bf16_batch(nb, ids, N.ptr(a.data), offset, b_ptr, offset, cr_ptr, r_ptr, 0, M, chunkStart,
+                                          chunkSize, K, a.stride, bs[0].stride, ldc)
+        else:
+            raise N.UnsupportedOperation(N.JH_ERR_UNSUPPORTED, f"dtype pair {a.dtype} x {dt_b}")
+        N.check(rc)
 
     def dotProduct(self, a, b, aoffset=0, boffset=0, limit=None):
         # TensorOperations.java:41-49
@@ -193,5 +236,6 @@ class HipTensorOperations:
     def rope_apply(self, q, k, rope, position, n_heads, n_kv_heads, head_size):
         q = np.ascontiguousarray(q, dtype=np.float32).copy()
         k = np.ascontiguousarray(k, dtype=np.float32).copy()
-        N.check(self._lib.jh_rope_apply_f32(N.ptr(q), N.ptr(k), N.ptr(rope), position, n_heads, n_kv_heads, head_size))
+        N.check(self._lib.jh_rope_apply_f32(N.ptr(q), N.ptr(k), N.ptr(rope), rope.shape[0] // (head_size // 2), position,
+                                            n_heads, n_kv_heads, head_size))
         return q, k

@@ -148,9 +148,24 @@ class HipSession:
         return tok.value
 
     def decode_n(self, first_token, start_pos, n):
+        """n greedy steps chained on the device; fewer ids come back when a stop token (set_eos) ended the loop."""
         out = np.empty(n, dtype=np.int32)
         N.check(N.lib().jh_decode_n(self.h, int(first_token), int(start_pos), int(n), N.ptr(out)))
-        return out
+        return out[:self.decode_generated()]
+
+    def decode_generated(self):
+        k = C.c_int32()
+        N.check(N.lib().jh_decode_generated(self.h, C.byref(k)))
+        return k.value
+
+    def set_eos(self, eos_tokens):
+        """Config.eosTokens for the device loop (AbstractModel.java:600-603)."""
+        ids = np.ascontiguousarray(list(eos_tokens), dtype=np.int32)
+        N.check(N.lib().jh_session_set_eos(self.h, N.ptr(ids) if ids.size else None, int(ids.size)))
+
+    def set_strict(self, on=True):
+        """Panama-order verification kernels (include/jlama_hip.h: jh_session_set_strict)."""
+        N.check(N.lib().jh_session_set_strict(self.h, 1 if on else 0))
 
     def decode_n_async(self, first_token, start_pos, n):
         N.check(N.lib().jh_decode_n_async(self.h, int(first_token), int(start_pos), int(n)))
@@ -158,7 +173,7 @@ class HipSession:
     def decode_wait(self, n):
         out = np.empty(n, dtype=np.int32)
         N.check(N.lib().jh_decode_wait(self.h, N.ptr(out), n))
-        return out
+        return out[:self.decode_generated()]
 
     def decode_stats(self):
         ms, k = C.c_double(), C.c_int32()
@@ -200,8 +215,12 @@ class HipSession:
         out = [nxt]
         start = prompt_tokens.size
         n_more = ntokens - start
-        if temperature == 0.0 and on_device_loop and n_more > 0 and not eos_tokens:
-            out.extend(int(t) for t in self.decode_n(nxt, start, n_more))
+        if temperature == 0.0 and on_device_loop and n_more > 0:
+            # the device loop honours the stop tokens itself (finish_token_kernel); a prompt whose first sampled token is
+            # already one ends here, as in the reference (the loop body never runs: AbstractModel.java:590)
+            self.set_eos(eos_tokens)
+            if nxt not in eos_tokens:
+                out.extend(int(t) for t in self.decode_n(nxt, start, n_more))
         else:
             for i in range(start, ntokens):
                 if temperature == 0.0:

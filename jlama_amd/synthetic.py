@@ -39,13 +39,13 @@ def layer_shapes(cfg):
     return {W_Q: (A, E), W_K: (KV, E), W_V: (KV, E), W_O: (E, A), W_GATE: (H, E), W_UP: (H, E), W_DOWN: (E, H)}
 
 
-def _q4(rng, rows, cols, sigma):
+def _q4(rng, rows, cols, sigma, quantize=None):
     x = rng.standard_normal((rows, cols), dtype=np.float32) * np.float32(sigma)
-    nib, sc = jq4.quantize_q4(x)
+    nib, sc = (quantize or jq4.quantize_q4)(x)
     return {"dtype": DT_Q4, "data": nib, "scales": sc, "shape": (rows, cols)}
 
 
-def _bf16(rng, rows, cols, sigma):
+def _bf16(rng, rows, cols, sigma, quantize=None):
     x = rng.standard_normal((rows, cols), dtype=np.float32) * np.float32(sigma)
     return {"dtype": DT_BF16, "data": jq4.f32_to_bf16(x), "scales": None, "shape": (rows, cols)}
 
@@ -55,8 +55,10 @@ def _norm(rng, E):
     return {"dtype": DT_BF16, "data": jq4.f32_to_bf16(w).reshape(1, E), "scales": None, "shape": (1, E)}
 
 
-def make_weights(cfg, seed=0, layers=None):
-    """dict {(layer or -1, slot): {dtype, data, scales, shape}} for the given layer range (default: all)."""
+def make_weights(cfg, seed=0, layers=None, quantize=None):
+    """dict {(layer or -1, slot): {dtype, data, scales, shape}} for the given layer range (default: all).
+    quantize: optional F32 [rows, cols] -> (nibbles, scales) callable replacing jq4.quantize_q4 (tests pass a compiled,
+    bit-identical quantizer to build multi-layer real-shape models in seconds)."""
     E, V, L = cfg["embedding_length"], cfg["vocab_size"], cfg["n_layers"]
     ls, le = layers if layers else (0, L)
     out = {}
@@ -65,7 +67,10 @@ def make_weights(cfg, seed=0, layers=None):
     def rng_for(i):
         return np.random.default_rng(BASE_SEED + seed * 100003 + i)
 
-    _q4 = globals()["_q4"] if cfg["weight_dtype"] == DT_Q4 else _bf16   # BF16 models: RNE of the F32 draw
+    _mk = globals()["_q4"] if cfg["weight_dtype"] == DT_Q4 else _bf16   # BF16 models: RNE of the F32 draw
+
+    def _q4(rng, rows, cols, sigma):
+        return _mk(rng, rows, cols, sigma, quantize)
 
     out[(-1, W_EMBED)] = _q4(rng_for(idx), V, E, 0.02); idx += 1
     for li in range(L):

@@ -22,7 +22,7 @@
  * (jlama-tests/.../model/TestCorrectness.java:92-115); exp/sqrt are "parity unpinned"
  * beyond the logit tolerance.
  *
- * Build: see oracle/Makefile (-O2 -ffp-contract=off: Java never contracts a*b+c; every
+ * Build: see oracle/Makefile (-O3 -march=x86-64-v3 -ffp-contract=off: Java never contracts a*b+c; every
  * FMA below is an explicit fmaf() where the reference calls FloatVector.fma()).
  */
 #include <math.h>
@@ -32,6 +32,16 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
+/* Optional x86 SIMD bodies for the two GEMV inner loops that dominate a full-size (8B) oracle run.  They execute the
+ * SAME per-lane operations in the SAME order as the scalar statements next to them (16 float lanes = two 8-lane
+ * registers, one fmadd per lane per step), so results are bit-identical; tests/test_oracle.py asserts that against the
+ * always-scalar jo_gemm_*_scalar entry points.  Without AVX2+FMA the scalar text is what runs. */
+#if defined(__AVX2__) && defined(__FMA__) && !defined(JO_NO_SIMD)
+#include <immintrin.h>
+#define JO_SIMD 1
+#else
+#define JO_SIMD 0
 #endif
 
 #define JO_BLOCK 32
@@ -201,58 +211,144 @@ void jo_bf16_quantize(const float* x, int64_t n, uint16_t* out) {
 /* I8 x Q4 -> F32, GemmerI8Q4_512 1x1 tile PTO:807-850 (1x4 :852-955 and 2x2 :958-1043 do
  * the same per-element arithmetic).  Lane t of 16 accumulates over blocks in ascending K:
  *   acc_t = fma(sa*sb, (float)(short)(lo[t]*a[t] + hi[t]*a[t+16]), acc_t). */
-void jo_gemm_i8q4(const int8_t* a, const float* af, int lda, int ldaf, const uint8_t* b,
-                  const float* bf, int ldb_bytes, int ldbf, float* r, int ldc, int M, int aColOff,
-                  int bColOff, int K, int rRowOff, int bRowOff, int N) {
+static inline float jo_dot_i8q4_scalar(const int8_t* ap, const float* afr, const uint8_t* bp, const float* bfr, int nblk) {
+    float acc[16];
+    for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+    for (int blk = 0; blk < nblk; blk++, ap += JO_BLOCK, bp += JO_HALF) {
+        float scale = afr[blk] * bfr[blk];
+        for (int t = 0; t < 16; t++) {
+            int16_t lo = (int16_t)((bp[t] & 0x0F) - 8);
+            int16_t hi = (int16_t)(((bp[t] >> 4) & 0x0F) - 8);
+            int16_t isum = (int16_t)(lo * ap[t] + hi * ap[t + 16]); /* |.| <= 2032: exact */
+            acc[t] = fmaf(scale, (float)isum, acc[t]);
+        }
+    }
+    return jo_reduce16(acc);
+}
+#if JO_SIMD
+/* same lanes, same order: lanes 0..7 in acc0, 8..15 in acc1 */
+static inline float jo_dot_i8q4_simd(const int8_t* ap, const float* afr, const uint8_t* bp, const float* bfr, int nblk) {
+    __m256 acc0 = _mm256_setzero_ps(), acc1 = _mm256_setzero_ps();
+    const __m128i m4 = _mm_set1_epi8(0x0F), e8 = _mm_set1_epi8(8);
+    for (int blk = 0; blk < nblk; blk++, ap += JO_BLOCK, bp += JO_HALF) {
+        const __m256 sc = _mm256_set1_ps(afr[blk] * bfr[blk]);
+        const __m128i bb = _mm_loadu_si128((const __m128i*)bp);
+        const __m128i lo = _mm_sub_epi8(_mm_and_si128(bb, m4), e8);
+        const __m128i hi = _mm_sub_epi8(_mm_and_si128(_mm_srli_epi16(bb, 4), m4), e8);
+        const __m256i a0 = _mm256_cvtepi8_epi16(_mm_loadu_si128((const __m128i*)ap));
+        const __m256i a1 = _mm256_cvtepi8_epi16(_mm_loadu_si128((const __m128i*)(ap + 16)));
+        const __m256i is = _mm256_add_epi16(_mm256_mullo_epi16(_mm256_cvtepi8_epi16(lo), a0),
+                                            _mm256_mullo_epi16(_mm256_cvtepi8_epi16(hi), a1));
+        const __m256 f0 = _mm256_cvtepi32_ps(_mm256_cvtepi16_epi32(_mm256_castsi256_si128(is)));
+        const __m256 f1 = _mm256_cvtepi32_ps(_mm256_cvtepi16_epi32(_mm256_extracti128_si256(is, 1)));
+        acc0 = _mm256_fmadd_ps(sc, f0, acc0);
+        acc1 = _mm256_fmadd_ps(sc, f1, acc1);
+    }
+    float acc[16];
+    _mm256_storeu_ps(acc, acc0);
+    _mm256_storeu_ps(acc + 8, acc1);
+    return jo_reduce16(acc);
+}
+#endif
+static void jo_gemm_i8q4_impl(int simd, const int8_t* a, const float* af, int lda, int ldaf, const uint8_t* b,
+                              const float* bf, int ldb_bytes, int ldbf, float* r, int ldc, int M, int aColOff,
+                              int bColOff, int K, int rRowOff, int bRowOff, int N) {
+    (void)simd;
 #pragma omp parallel for schedule(static) if (N >= 512)
     for (int j = bRowOff; j < bRowOff + N; j++) {
         for (int i = 0; i < M; i++) {
-            float acc[16];
-            for (int t = 0; t < 16; t++) acc[t] = 0.0f;
-            int ao = aColOff, bo = bColOff;
-            for (int l = 0; l < K; l += JO_BLOCK, ao += JO_BLOCK, bo += JO_BLOCK) {
-                float scale = af[(int64_t)i * ldaf + ao / JO_BLOCK] * bf[(int64_t)j * ldbf + bo / JO_BLOCK];
-                const int8_t* ap = a + (int64_t)i * lda + ao;
-                const uint8_t* bp = b + (int64_t)j * ldb_bytes + bo / 2;
-                for (int t = 0; t < 16; t++) {
-                    int16_t lo = (int16_t)((bp[t] & 0x0F) - 8);
-                    int16_t hi = (int16_t)(((bp[t] >> 4) & 0x0F) - 8);
-                    int16_t isum = (int16_t)(lo * ap[t] + hi * ap[t + 16]); /* |.| <= 2032: exact */
-                    acc[t] = fmaf(scale, (float)isum, acc[t]);
-                }
-            }
-            r[(int64_t)i * ldc + j + rRowOff] = jo_reduce16(acc);
+            const int8_t* ap = a + (int64_t)i * lda + aColOff;
+            const float* afr = af + (int64_t)i * ldaf + aColOff / JO_BLOCK;
+            const uint8_t* bp = b + (int64_t)j * ldb_bytes + bColOff / 2;
+            const float* bfr = bf + (int64_t)j * ldbf + bColOff / JO_BLOCK;
+#if JO_SIMD
+            if (simd) { r[(int64_t)i * ldc + j + rRowOff] = jo_dot_i8q4_simd(ap, afr, bp, bfr, K / JO_BLOCK); continue; }
+#endif
+            r[(int64_t)i * ldc + j + rRowOff] = jo_dot_i8q4_scalar(ap, afr, bp, bfr, K / JO_BLOCK);
         }
     }
 }
+void jo_gemm_i8q4(const int8_t* a, const float* af, int lda, int ldaf, const uint8_t* b,
+                  const float* bf, int ldb_bytes, int ldbf, float* r, int ldc, int M, int aColOff,
+                  int bColOff, int K, int rRowOff, int bRowOff, int N) {
+    jo_gemm_i8q4_impl(1, a, af, lda, ldaf, b, bf, ldb_bytes, ldbf, r, ldc, M, aColOff, bColOff, K, rRowOff, bRowOff, N);
+}
+/* the scalar text only (what the SIMD body is checked against) */
+void jo_gemm_i8q4_scalar(const int8_t* a, const float* af, int lda, int ldaf, const uint8_t* b,
+                         const float* bf, int ldb_bytes, int ldbf, float* r, int ldc, int M, int aColOff,
+                         int bColOff, int K, int rRowOff, int bRowOff, int N) {
+    jo_gemm_i8q4_impl(0, a, af, lda, ldaf, b, bf, ldb_bytes, ldbf, r, ldc, M, aColOff, bColOff, K, rRowOff, bRowOff, N);
+}
+int jo_simd_enabled(void) { return JO_SIMD; }
 
 /* F32 x Q4 -> F32, GemmerF32Q4_512 1x1 PTO:336-374: dequantize first w = float(nib-8)*scale,
  * then acc = fma(a_lo, w_lo, acc); acc = fma(a_hi, w_hi, acc) per block, 16 lanes. */
-void jo_gemm_f32q4(const float* a, int lda, const uint8_t* b, const float* bf, int ldb_bytes,
-                   int ldbf, float* r, int ldc, int M, int aColOff, int bColOff, int K, int rRowOff,
-                   int bRowOff, int N) {
+static inline float jo_dot_f32q4_scalar(const float* ap, const uint8_t* bp, const float* bfr, int nblk) {
+    float acc[16];
+    for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+    for (int blk = 0; blk < nblk; blk++, ap += JO_BLOCK, bp += JO_HALF) {
+        float scale = bfr[blk];
+        for (int t = 0; t < 16; t++) {
+            float low = (float)((bp[t] & 0x0F) - 8) * scale;
+            acc[t] = fmaf(ap[t], low, acc[t]);
+        }
+        for (int t = 0; t < 16; t++) {
+            float high = (float)(((bp[t] >> 4) & 0x0F) - 8) * scale;
+            acc[t] = fmaf(ap[t + 16], high, acc[t]);
+        }
+    }
+    return jo_reduce16(acc);
+}
+#if JO_SIMD
+static inline float jo_dot_f32q4_simd(const float* ap, const uint8_t* bp, const float* bfr, int nblk) {
+    __m256 acc0 = _mm256_setzero_ps(), acc1 = _mm256_setzero_ps();
+    const __m128i m4 = _mm_set1_epi8(0x0F), e8 = _mm_set1_epi8(8);
+    for (int blk = 0; blk < nblk; blk++, ap += JO_BLOCK, bp += JO_HALF) {
+        const __m256 sc = _mm256_set1_ps(bfr[blk]);
+        const __m128i bb = _mm_loadu_si128((const __m128i*)bp);
+        const __m128i lo = _mm_sub_epi8(_mm_and_si128(bb, m4), e8);
+        const __m128i hi = _mm_sub_epi8(_mm_and_si128(_mm_srli_epi16(bb, 4), m4), e8);
+        const __m256 l0 = _mm256_mul_ps(_mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(lo)), sc);
+        const __m256 l1 = _mm256_mul_ps(_mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(_mm_srli_si128(lo, 8))), sc);
+        const __m256 h0 = _mm256_mul_ps(_mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(hi)), sc);
+        const __m256 h1 = _mm256_mul_ps(_mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(_mm_srli_si128(hi, 8))), sc);
+        acc0 = _mm256_fmadd_ps(_mm256_loadu_ps(ap), l0, acc0);
+        acc1 = _mm256_fmadd_ps(_mm256_loadu_ps(ap + 8), l1, acc1);
+        acc0 = _mm256_fmadd_ps(_mm256_loadu_ps(ap + 16), h0, acc0);
+        acc1 = _mm256_fmadd_ps(_mm256_loadu_ps(ap + 24), h1, acc1);
+    }
+    float acc[16];
+    _mm256_storeu_ps(acc, acc0);
+    _mm256_storeu_ps(acc + 8, acc1);
+    return jo_reduce16(acc);
+}
+#endif
+static void jo_gemm_f32q4_impl(int simd, const float* a, int lda, const uint8_t* b, const float* bf, int ldb_bytes,
+                               int ldbf, float* r, int ldc, int M, int aColOff, int bColOff, int K, int rRowOff,
+                               int bRowOff, int N) {
+    (void)simd;
 #pragma omp parallel for schedule(static) if (N >= 512)
     for (int j = bRowOff; j < bRowOff + N; j++) {
         for (int i = 0; i < M; i++) {
-            float acc[16];
-            for (int t = 0; t < 16; t++) acc[t] = 0.0f;
-            int ao = aColOff, bo = bColOff;
-            for (int l = 0; l < K; l += JO_BLOCK, ao += JO_BLOCK, bo += JO_BLOCK) {
-                float scale = bf[(int64_t)j * ldbf + bo / JO_BLOCK];
-                const float* ap = a + (int64_t)i * lda + ao;
-                const uint8_t* bp = b + (int64_t)j * ldb_bytes + bo / 2;
-                for (int t = 0; t < 16; t++) {
-                    float low = (float)((bp[t] & 0x0F) - 8) * scale;
-                    acc[t] = fmaf(ap[t], low, acc[t]);
-                }
-                for (int t = 0; t < 16; t++) {
-                    float high = (float)(((bp[t] >> 4) & 0x0F) - 8) * scale;
-                    acc[t] = fmaf(ap[t + 16], high, acc[t]);
-                }
-            }
-            r[(int64_t)i * ldc + j + rRowOff] = jo_reduce16(acc);
+            const float* ap = a + (int64_t)i * lda + aColOff;
+            const uint8_t* bp = b + (int64_t)j * ldb_bytes + bColOff / 2;
+            const float* bfr = bf + (int64_t)j * ldbf + bColOff / JO_BLOCK;
+#if JO_SIMD
+            if (simd) { r[(int64_t)i * ldc + j + rRowOff] = jo_dot_f32q4_simd(ap, bp, bfr, K / JO_BLOCK); continue; }
+#endif
+            r[(int64_t)i * ldc + j + rRowOff] = jo_dot_f32q4_scalar(ap, bp, bfr, K / JO_BLOCK);
         }
     }
+}
+void jo_gemm_f32q4(const float* a, int lda, const uint8_t* b, const float* bf, int ldb_bytes,
+                   int ldbf, float* r, int ldc, int M, int aColOff, int bColOff, int K, int rRowOff,
+                   int bRowOff, int N) {
+    jo_gemm_f32q4_impl(1, a, lda, b, bf, ldb_bytes, ldbf, r, ldc, M, aColOff, bColOff, K, rRowOff, bRowOff, N);
+}
+void jo_gemm_f32q4_scalar(const float* a, int lda, const uint8_t* b, const float* bf, int ldb_bytes,
+                          int ldbf, float* r, int ldc, int M, int aColOff, int bColOff, int K, int rRowOff,
+                          int bRowOff, int N) {
+    jo_gemm_f32q4_impl(0, a, lda, b, bf, ldb_bytes, ldbf, r, ldc, M, aColOff, bColOff, K, rRowOff, bRowOff, N);
 }
 
 /* F32 x F32 -> F32, GemmerF32 1x1 PTO:1086-1102: 16 lanes, one fma per 16-element step. */

@@ -28,6 +28,16 @@ def test_library_exports_every_declared_symbol():
     assert sorted(N.EXPORTS) == declared
 
 
+def test_library_is_built_from_the_current_sources():
+    """The .so carries the hash of the sources it was compiled from (jh_source_hash): a stale binary -- edited kernels,
+    forgotten rebuild -- must fail here, not silently test old code on the GPU box."""
+    from jlama_amd import _native as N
+    assert N.built_hash() == N.source_hash(), "libjlamahip.so is stale: run __graft_entry__.build()"
+    L = C.CDLL(N.LIB_PATH)
+    L.jh_source_hash.restype = C.c_char_p
+    assert L.jh_source_hash().decode() == N.source_hash()
+
+
 def test_only_c_abi_symbols_are_exported():
     from jlama_amd import _native as N
     out = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True).stdout

@@ -8,10 +8,13 @@ between any two providers (Panama's reduceLanes order is itself unspecified).  M
 (tools/dbg_traj.py): GPU and oracle agree to ~2e-7 until the first I8 code flips, then the difference settles at a
 noise floor of ~1e-2 absolute on O(1) logits (every flip moves a GEMV output by scale/127*|w|, and a perturbed
 activation row flips ~10% of the next quantizer's codes).  So the tests hold:
-  * stage taps of layer 0 (before any flip can matter): 1e-4 relative;
-  * logits: LOGIT_TOL = 4e-2 absolute at every teacher-forced step, mean |diff| <= 5e-3;
+  * stage taps: every layer is fed the GPU's own input rows (per-layer teacher forcing), 1e-4 relative for the taps
+    upstream of the layer's second quantizer; the bit-exact / per-layer checks proper live in tests/test_gpu_parity.py
+    (strict-order mode: zero tolerance at every layer; fast kernels: every layer in isolation);
+  * free-running multi-layer outputs (flips cascade through layers): TRUNK_TOL relative, logits LOGIT_TOL = 4e-2
+    absolute at every teacher-forced step, mean |diff| <= 5e-3;
   * token ids: bit-exact wherever the oracle's own decision margin exceeds LOGIT_TOL (a smaller margin is a coin
-    flip between ANY two correct implementations)."""
+    flip between ANY two correct implementations; in strict-order mode they are simply bit-exact)."""
 import numpy as np
 import pytest
 
@@ -24,7 +27,7 @@ TRUNK_TOL = 4e-2   # relative to the row's max |x|
 def _pair(cfg, seed, oracle, layer_range=None):
     from jlama_amd import synthetic as S
     from jlama_amd.model import HipLlamaModel
-    w = S.make_weights(cfg, seed=seed)
+    w = S.make_weights(cfg, seed=seed, quantize=oracle.q4_quantize)   # compiled quantizer, bit-equal to jq4 (test_oracle.py)
     return HipLlamaModel(cfg, w, layer_range=layer_range), oracle.OracleModel(cfg, w, layer_range=layer_range), w
 
 
@@ -34,28 +37,34 @@ def _rel(got, want):
 
 @pytest.mark.parametrize("cfgname", ["TINY", "SMALL"])
 def test_stage_taps_single_token(gpu, oracle, cfgname):
+    """DebugSupport-named stage taps of EVERY layer at 1e-4: the oracle's layer l is fed the GPU's own input rows of
+    layer l (teacher forcing), so no layer inherits quantizer flips from the ones before it."""
     from jlama_amd import synthetic as S
     cfg = dict(getattr(S, cfgname))
-    hm, om, _ = _pair(cfg, 0, oracle)
-    hs, os_ = hm.session(64), om.session()
+    hm, om, w = _pair(cfg, 0, oracle)
     prompt = S.prompt_tokens(cfg, n=9, seed=5)
     E, A = cfg["embedding_length"], cfg["n_heads"] * cfg["head_size"]
     KV = cfg["n_kv_heads"] * cfg["head_size"]
     for layer in range(cfg["n_layers"]):
-        hs2, os2 = hm.session(64), om.session()
+        hs2 = hm.session(64)
         hs2.set_tap_layer(layer)
+        om_l = oracle.OracleModel(cfg, w, layer_range=(layer, layer + 1))
+        os2 = om_l.session()
         os2.set_tap_layer(layer)
         for i, t in enumerate(prompt):
             hs2.forward([t], i, want_output=False)
-            os2.forward([t], i)
-        for name, n, tol in [("input_emb", E, 1e-4), ("query", A, 1e-4), ("key", KV, 1e-4), ("value", KV, 1e-4),
+            x_in = hs2.tap("input_emb", E)
+            os2.forward(None, i, x=x_in.reshape(1, E))
+        for name, n, tol in [("input_emb", E, 0.0), ("query", A, 1e-4), ("key", KV, 1e-4), ("value", KV, 1e-4),
                              ("query+rope", A, 1e-4), ("key+rope", KV, 1e-4), ("after_attention", A, 1e-4),
-                             ("post_ff_res", E, 1e-4)]:
+                             ("post_ff_res", E, 3e-3)]:   # post_ff_res sits behind three more quantizers of this layer
             got, want = hs2.tap(name, n), os2.tap(name, n)
             if layer == 0 and name == "input_emb":
-                np.testing.assert_array_equal(got, want)  # Q4 embedding row dequantization is exact
-            # later layers inherit Q8 re-quantization flips of earlier stages: tolerance of the Q8 path
-            assert _rel(got, want) <= (tol if layer == 0 else TRUNK_TOL), (layer, name, _rel(got, want))
+                om0 = om.session()
+                om0.set_tap_layer(0)
+                om0.forward([prompt[-1]], 0)
+                np.testing.assert_array_equal(got, om0.tap(name, n))  # Q4 embedding row dequantization is exact
+            assert _rel(got, want) <= tol, (layer, name, _rel(got, want))
 
 
 def test_prefill_logits_and_greedy_tokens(gpu, oracle):

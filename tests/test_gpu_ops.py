@@ -364,3 +364,115 @@ def test_gpt2_family_pieces(ops, oracle):
     g = (rng.standard_normal(4096) * 4).astype(np.float32)
     np.testing.assert_array_equal(ops.gelu(g), oracle.gelu(g))
     assert ops.gelu(np.zeros(3, np.float32)).tolist() == [0.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("pair", ["bf16_bf16", "f32_bf16"])
+@pytest.mark.parametrize("m", [1, 5, 129])
+def test_bf16_result_tensor(ops, oracle, pair, m):
+    """The `cr` output of gemm_bf16 / gemm_f32_bf16 (vector_simd.h:34,38; NativeSimdTensorOperations.java:113-131 passes it
+    when result.dType()==BF16): results rounded with FloatConversions.float32ToBFloat16 (RNE).  The rounding of a value
+    within float-ordering noise of a BF16 tie may differ, so: identical to the rounded F32 result of the SAME kernel, and
+    within one BF16 ulp of the oracle's."""
+    from jlama_amd.jq4 import Tensor
+    from jlama_amd import _native as N
+    rng = np.random.default_rng(31 + m)
+    k, n = 512, 96
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = rng.standard_normal((n, k)).astype(np.float32)
+    A = Tensor.bf16(a) if pair == "bf16_bf16" else Tensor.f32(a)
+    B = Tensor.bf16(w)
+    Rf = Tensor.zeros(m, n)
+    ops.batchDotProduct(Rf, A, B, 0, 0, k)
+    Rb = Tensor(N.DT_BF16, np.zeros((m, n), dtype=np.uint16))
+    ops.batchDotProduct(Rb, A, B, 0, 0, k)
+    np.testing.assert_array_equal(Rb.data, oracle.bf16_quantize(Rf.data))
+    want = oracle.gemm_bf16(A.data, B.data) if pair == "bf16_bf16" else oracle.gemm_f32bf16(a, B.data)
+    assert np.abs(Rb.data.astype(np.int32) - oracle.bf16_quantize(want).astype(np.int32)).max() <= 1
+    # window form: only columns [32, 96) are written, the rest of the BF16 result keeps the caller's bytes
+    Rw = Tensor(N.DT_BF16, np.full((m, n), 0x1234, dtype=np.uint16))
+    ops.batchDotProduct(Rw, A, B, 256, 256, 256, 0, 32, 64)
+    assert (Rw.data[:, :32] == 0x1234).all()
+    ref = np.zeros((m, n), np.float32)
+    Rr = Tensor.f32(ref)
+    ops.batchDotProduct(Rr, A, B, 256, 256, 256, 0, 32, 64)
+    np.testing.assert_array_equal(Rw.data[:, 32:], oracle.bf16_quantize(Rr.data[:, 32:]))
+
+
+@pytest.mark.parametrize("pair", ["i8_q4", "f32_q4", "f32_f32", "bf16_bf16", "f32_bf16"])
+def test_dot_product_batch_chunk_entry_points(ops, oracle, pair):
+    """dotProductBatchChunk (TensorOperations.java:86-99) through every `_batch` entry point of the reference library
+    (vector_simd.h:23,27,31,35,39): one activation against several weight tensors, pointer arrays like
+    MemorySegmentSupport.setupBatch -- each result equals the single call's, bit for bit."""
+    from jlama_amd.jq4 import Tensor
+    rng = np.random.default_rng(41)
+    m, k, n = 3, 512, 64
+    a = _acts(rng, m, k)
+    ws = [_wts(rng, n, k) * s for s in (1.0, -0.5, 2.0)]
+    if pair == "i8_q4":
+        A, Bs = ops.quantize(Tensor.f32(a), 2, 0, k), [Tensor.q4(w) for w in ws]
+    elif pair == "f32_q4":
+        A, Bs = Tensor.f32(a), [Tensor.q4(w) for w in ws]
+    elif pair == "f32_f32":
+        A, Bs = Tensor.f32(a), [Tensor.f32(w) for w in ws]
+    elif pair == "bf16_bf16":
+        A, Bs = Tensor.bf16(a), [Tensor.bf16(w) for w in ws]
+    else:
+        A, Bs = Tensor.f32(a), [Tensor.bf16(w) for w in ws]
+    ops.registerModelTensor(Bs[1])                      # a mix of registered and host-resident weights
+    Rs = [Tensor.zeros(m, n) for _ in ws]
+    ops.dotProductBatchChunk(Rs, A, Bs, 128, 256, 16, 32)
+    for R, B in zip(Rs, Bs):
+        single = Tensor.zeros(m, n)
+        ops.dotProductChunk(single, A, B, 128, 256, 16, 32)
+        np.testing.assert_array_equal(R.data, single.data)
+        assert np.abs(R.data[:, 16:48]).max() > 0 and (R.data[:, :16] == 0).all() and (R.data[:, 48:] == 0).all()
+
+
+def test_tier1_calls_are_reentrant(ops, oracle):
+    """The reference calls batchDotProduct from many pfor workers at once (heads of one attention step,
+    CausalSelfAttention.java:314; VectorMath.pfor): Tier-1 keeps a stream + scratch per calling thread.  8 threads, each
+    issuing the score GEMM of its own heads (F32 x F32, column windows into shared q / K tensors) plus an I8 x Q4 GEMV
+    against a registered weight, many times over; every result must equal the single-threaded one bit for bit."""
+    import threading
+    from jlama_amd.jq4 import Tensor
+    rng = np.random.default_rng(51)
+    heads, hs, ctx = 32, 128, 96
+    q = Tensor.f32(rng.standard_normal((1, heads * hs)).astype(np.float32))
+    kpage = Tensor.f32(rng.standard_normal((ctx, 8 * hs)).astype(np.float32))
+    w = Tensor.q4(_wts(rng, 256, 1024))
+    ops.registerModelTensor(w)
+    aq = ops.quantize(Tensor.f32(_acts(rng, 1, 1024)), 2, 0, 1024)
+
+    def scores(h, out):
+        ops.batchDotProduct(out, q, kpage, h * hs, (h // 4) * hs, hs, 0, 0, ctx)
+
+    want = []
+    for h in range(heads):
+        r = Tensor.zeros(1, ctx)
+        scores(h, r)
+        want.append(r.data.copy())
+    wg = Tensor.zeros(1, 256)
+    ops.batchDotProduct(wg, aq, w, 0, 0, 1024)
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(20):
+                for h in range(t, heads, 8):
+                    r = Tensor.zeros(1, ctx)
+                    scores(h, r)
+                    if not np.array_equal(r.data, want[h]):
+                        errors.append(("scores", t, h, rep))
+                g = Tensor.zeros(1, 256)
+                ops.batchDotProduct(g, aq, w, 0, 0, 1024)
+                if not np.array_equal(g.data, wg.data):
+                    errors.append(("gemv", t, rep))
+        except Exception as e:   # noqa: BLE001
+            errors.append(("exc", t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]

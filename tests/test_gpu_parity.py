@@ -1,0 +1,259 @@
+"""GPU parity, the two instruments that take the Q8 quantizer's step function out of the comparison:
+
+1. STRICT ORDER (jh_session_set_strict): every float accumulation of the decode path in the reference's Panama-512 order
+   (jlama_amd/csrc/jh_strict.h).  With identical summation order there is no noise floor to hide behind: stage taps of
+   EVERY layer, logits and greedy ids must equal the oracle BIT FOR BIT.
+2. PER-LAYER TEACHER FORCING of the fast kernels: layer l of the oracle is fed the GPU's own `input_emb` tap of layer l
+   (all positions), so each layer is compared in isolation -- no cascade from earlier layers.  Within ONE layer the fast
+   kernels can still differ from the oracle by a single I8 code flip downstream of a 1e-7 summation-order difference
+   (o-projection input, down-projection input); such a flip moves the layer output by ~4e-4 of the row scale.  An
+   addressing bug (wrong KV page for rel_layer > 0, RoPE row off by one, wrong head) moves it by O(1).  So: every
+   (layer, row) <= 3e-3 of the row scale, and most of them (no flip) <= 1e-5.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FLIP_TOL = 3e-3      # one I8 code flip inside a layer (see module docstring)
+NOFLIP_TOL = 1e-5    # float summation order only
+
+
+def _pair(cfg, seed, oracle, layer_range=None):
+    from jlama_amd import synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    w = S.make_weights(cfg, seed=seed, quantize=oracle.q4_quantize)   # compiled quantizer, bit-equal to jq4 (test_oracle.py)
+    return HipLlamaModel(cfg, w, layer_range=layer_range), oracle.OracleModel(cfg, w, layer_range=layer_range), w
+
+
+_REAL = {}
+
+
+def _real(name, oracle):
+    """Benchmark-config shapes (E, H, heads, head size) with few layers and a reduced vocabulary; built once per module."""
+    if name not in _REAL:
+        from jlama_amd import synthetic as S
+        cfg = dict(getattr(S, name))
+        cfg.update(n_layers=1 if name == "LLAMA3_70B" else 3, vocab_size=2048, context_length=512, bos_token=1)
+        cfg.pop("tied", None)
+        _REAL[name] = (cfg,) + _pair(cfg, 7, oracle)
+    return _REAL[name]
+
+
+def _rowrel(got, want):
+    """max |diff| per row, relative to the row's max |want|."""
+    return np.abs(got - want).max(axis=-1) / (np.abs(want).max(axis=-1) + 1e-30)
+
+
+def layer_teacher_forced(hm, oracle, cfg, w, prompt, max_ctx, strict=False):
+    """For every layer l: run the GPU over the prompt one position at a time with the taps of layer l armed, collect its
+    input rows and output rows, then run the ORACLE's layer l alone on those input rows.  Returns rel[l, row]."""
+    E, L = cfg["embedding_length"], cfg["n_layers"]
+    rel = np.zeros((L, prompt.size))
+    for layer in range(L):
+        hs = hm.session(max_ctx)
+        if strict:
+            hs.set_strict(True)
+        hs.set_tap_layer(layer)
+        xin, xout = [], []
+        for i, t in enumerate(prompt):
+            hs.forward([t], i, want_output=False)
+            xin.append(hs.tap("input_emb", E))
+            xout.append(hs.tap("post_ff_res", E))
+        hs.close()
+        om_l = oracle.OracleModel(cfg, w, layer_range=(layer, layer + 1))
+        want = om_l.session().forward(None, 0, x=np.stack(xin))
+        got = np.stack(xout)
+        if strict:
+            np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32), err_msg=f"layer {layer}")
+        rel[layer] = _rowrel(got, want)
+    return rel
+
+
+@pytest.mark.parametrize("cfgname", ["TINY", "SMALL"])
+def test_every_layer_teacher_forced(gpu, oracle, cfgname):
+    from jlama_amd import synthetic as S
+    cfg = dict(getattr(S, cfgname))
+    hm, om, w = _pair(cfg, 0, oracle)
+    prompt = S.prompt_tokens(cfg, n=40, seed=5)        # 41 positions: crosses a KV context page (32 rows) for SMALL
+    rel = layer_teacher_forced(hm, oracle, cfg, w, prompt, 64)
+    assert rel.max() <= FLIP_TOL, (rel.max(), np.unravel_index(rel.argmax(), rel.shape))
+    assert (rel <= NOFLIP_TOL).mean() >= 0.5, (rel <= NOFLIP_TOL).mean()
+    for layer in range(cfg["n_layers"]):                # no layer may be systematically worse than the others
+        assert np.median(rel[layer]) <= NOFLIP_TOL, (layer, np.median(rel[layer]))
+
+
+@pytest.mark.parametrize("name", ["LLAMA32_1B", "LLAMA3_8B"])
+def test_every_layer_teacher_forced_real_shapes(gpu, oracle, name):
+    """The kernel instantiations the benchmark configs use (head size 64 / 128, NB = 1 / 2 / 7 blocks per lane), three
+    layers so that rel_layer > 0 pages and the per-layer weight pointers are exercised; reduced vocabulary."""
+    from jlama_amd import synthetic as S
+    cfg, hm, om, w = _real(name, oracle)
+    prompt = S.prompt_tokens(cfg, n=35, seed=8)
+    rel = layer_teacher_forced(hm, oracle, cfg, w, prompt, 64)
+    assert rel.max() <= FLIP_TOL, (rel.max(), np.unravel_index(rel.argmax(), rel.shape))
+    assert (rel <= NOFLIP_TOL).mean() >= 0.5
+    for layer in range(cfg["n_layers"]):
+        assert np.median(rel[layer]) <= NOFLIP_TOL, (layer, np.median(rel[layer]))
+
+
+@pytest.mark.parametrize("cfgname", ["TINY", "SMALL"])
+def test_strict_order_is_bit_identical(gpu, oracle, cfgname):
+    """Strict order: taps of every layer, the forward output of every prompt row, the logits of every decode step and the
+    greedy ids -- all equal to the oracle bit for bit, free-running (no teacher forcing needed: nothing diverges)."""
+    from jlama_amd import synthetic as S
+    cfg = dict(getattr(S, cfgname))
+    hm, om, w = _pair(cfg, 1, oracle)
+    prompt = S.prompt_tokens(cfg, n=40, seed=11)
+    E, A, KV = cfg["embedding_length"], cfg["n_heads"] * cfg["head_size"], cfg["n_kv_heads"] * cfg["head_size"]
+    # stage taps, every layer, positions 0..8
+    for layer in range(cfg["n_layers"]):
+        hs, os_ = hm.session(64), om.session()
+        hs.set_strict(True)
+        hs.set_tap_layer(layer)
+        os_.set_tap_layer(layer)
+        for i, t in enumerate(prompt[:9]):
+            hs.forward([t], i, want_output=False)
+            os_.forward([t], i)
+        for name, n in [("input_emb", E), ("query", A), ("key", KV), ("value", KV), ("query+rope", A), ("key+rope", KV),
+                        ("after_attention", A), ("post_ff_res", E)]:
+            np.testing.assert_array_equal(hs.tap(name, n).view(np.uint32), os_.tap(name, n).view(np.uint32),
+                                          err_msg=f"layer {layer} tap {name}")
+    # prompt (row by row on the GPU, one batch in the oracle: same per-row arithmetic), then free-running greedy decode
+    hs, os_ = hm.session(200), om.session()
+    hs.set_strict(True)
+    out_h, out_o = hs.batch_forward(prompt, 0), os_.forward(prompt, 0)
+    np.testing.assert_array_equal(out_h.view(np.uint32), out_o.view(np.uint32))
+    tok_h, lh = hs.sample(0.0, 0.5, want_logits=True)
+    tok_o, lo = om.sample(out_o[-1])
+    np.testing.assert_array_equal(lh.view(np.uint32), lo.view(np.uint32))
+    assert tok_h == tok_o
+    n_gen = 100
+    ids_h = hs.decode_n(tok_h, prompt.size, n_gen)                 # hipGraph replay of the strict kernels
+    lh_last = hs.logits()
+    ids_o, tok = [], tok_o
+    for i in range(n_gen):
+        xo = os_.forward([tok], prompt.size + i)
+        tok, lo = om.sample(xo[-1])
+        ids_o.append(tok)
+    np.testing.assert_array_equal(ids_h, np.array(ids_o, dtype=np.int32))
+    np.testing.assert_array_equal(lh_last.view(np.uint32), lo.view(np.uint32))
+    # the fast kernels on the same session (mode switch re-captures the graphs): same ids wherever the decision margin
+    # is above the Q8 noise floor -- i.e. summation order is the ONLY difference between the two modes
+    hs.set_strict(False)
+    hs.batch_forward(prompt, 0)
+    fast_first = hs.sample()
+    ids_f = hs.decode_n(fast_first, prompt.size, 20)
+    agree = int((np.concatenate([[fast_first], ids_f]) == np.concatenate([[tok_o], ids_o[:20]])).cumprod().sum())
+    assert agree >= 8, agree
+
+
+@pytest.mark.parametrize("name", ["LLAMA32_1B", "LLAMA3_8B", "LLAMA3_70B"])
+def test_strict_order_real_shapes(gpu, oracle, name):
+    """Strict order at the benchmark configs' shapes (reduced vocabulary): bit-identical prompt rows, logits and 24 greedy
+    ids; and every layer teacher-forced in strict mode is bit-identical too."""
+    from jlama_amd import synthetic as S
+    cfg, hm, om, w = _real(name, oracle)
+    prompt = S.prompt_tokens(cfg, n=36, seed=8)      # 37 rows: crosses a 32-row KV context page
+    hs, os_ = hm.session(96), om.session()
+    hs.set_strict(True)
+    got, want = hs.batch_forward(prompt, 0), os_.forward(prompt, 0)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+    th, lh = hs.sample(0.0, 0.5, want_logits=True)
+    to, lo = om.sample(want[-1])
+    np.testing.assert_array_equal(lh.view(np.uint32), lo.view(np.uint32))
+    assert th == to
+    ids = hs.decode_n(th, prompt.size, 24)
+    tok = to
+    for i, g in enumerate(ids):
+        xo = os_.forward([tok], prompt.size + i)
+        tok, lo = om.sample(xo[-1])
+        assert g == tok, (i, g, tok)
+    np.testing.assert_array_equal(hs.logits().view(np.uint32), lo.view(np.uint32))
+    if name != "LLAMA3_70B":
+        layer_teacher_forced(hm, oracle, cfg, w, prompt[:12], 64, strict=True)
+
+
+def test_strict_mode_rejects_bf16_models(gpu):
+    from jlama_amd import _native as N, synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    cfg = dict(S.TINY)
+    cfg["weight_dtype"] = N.DT_BF16
+    hs = HipLlamaModel(cfg, S.make_weights(cfg, seed=0)).session(16)
+    with pytest.raises(N.UnsupportedOperation):
+        hs.set_strict(True)
+
+
+def test_device_loop_stops_at_eos(gpu, oracle):
+    """AbstractModel.java:600-603: the step that samples a stop token is the last one.  The device loop freezes its state
+    there (finish_token_kernel) and the host stops feeding; the ids up to and including the stop token come back."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.TINY)
+    hm, om, _ = _pair(cfg, 2, oracle)
+    prompt = S.prompt_tokens(cfg, n=20, seed=2)
+    s = hm.session(250)
+    s.batch_forward(prompt, 0)
+    first = s.sample()
+    free = s.decode_n(first, prompt.size, 200)
+    assert free.size == 200 and s.decode_generated() == 200
+    for k in (3, 37, 150):                      # inside the first chunk, after two chunks, deep into the loop
+        stop = int(free[k])
+        kfirst = int(np.nonzero(free == stop)[0][0])      # the id may occur earlier than step k
+        s2 = hm.session(250)
+        s2.set_eos([stop, cfg["vocab_size"] - 1])
+        s2.batch_forward(prompt, 0)
+        assert s2.sample() == first
+        got = s2.decode_n(first, prompt.size, 200)
+        assert got.size == kfirst + 1 and s2.decode_generated() == kfirst + 1, (k, kfirst, got.size)
+        np.testing.assert_array_equal(got, free[:kfirst + 1])
+        # the session is reusable afterwards and the set can be cleared
+        s2.set_eos([])
+        again = s2.decode_n(first, prompt.size, 50)
+        np.testing.assert_array_equal(again, free[:50])
+    # generate(): same contract at the host mirror's level
+    res = hm.session(250).generate(prompt, prompt.size + 200, eos_tokens=(int(free[37]),))
+    kf = int(np.nonzero(free == free[37])[0][0])
+    if first != int(free[37]):
+        np.testing.assert_array_equal(res["tokens"], np.concatenate([[first], free[:kf + 1]]))
+
+
+def test_positions_at_the_context_tail_are_refused(gpu):
+    """kv head h reads RoPE table row position + 2*h (CausalSelfAttention.java:260-283); the reference's table has
+    context_length rows and Java throws ArrayIndexOutOfBounds for the last 2*(kvHeads-1) positions.  Same positions are
+    an error code here (never an out-of-bounds read of the device table)."""
+    from jlama_amd import _native as N, synthetic as S
+    from jlama_amd.hip_tensor_operations import HipTensorOperations
+    from jlama_amd.model import HipLlamaModel
+    cfg = dict(S.TINY)                               # context 256, 2 kv heads => last usable position 253
+    hm = HipLlamaModel(cfg, S.make_weights(cfg, seed=0))
+    s = hm.session(cfg["context_length"])
+    last_ok = cfg["context_length"] - 1 - 2 * (cfg["n_kv_heads"] - 1)
+    s.forward([3], last_ok, want_output=False)
+    with pytest.raises(N.JhError) as e:
+        s.forward([3], last_ok + 1, want_output=False)
+    assert e.value.code == N.JH_ERR_INVALID
+    with pytest.raises(N.JhError) as e:
+        s.decode_n(3, last_ok - 3, 6)              # within max_ctx, but the last positions' RoPE rows leave the table
+    assert e.value.code == N.JH_ERR_INVALID
+    ops = HipTensorOperations()
+    table = ops.rope_table(64, 16, 10000.0)
+    q = np.ones(4 * 64, np.float32); k = np.ones(2 * 64, np.float32)
+    ops.rope_apply(q, k, table, 13, 4, 2, 64)
+    with pytest.raises(N.JhError):
+        ops.rope_apply(q, k, table, 14, 4, 2, 64)
+
+
+def test_missing_weights_are_an_error_code_not_a_gpu_fault(gpu):
+    from jlama_amd import _native as N, synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    cfg = dict(S.TINY)
+    w = S.make_weights(cfg, seed=0)
+    for drop in [(1, S.W_DOWN), (0, S.W_NORM2), (1, S.W_O), (0, S.W_NORM1)]:
+        part = {k: v for k, v in w.items() if k != drop}
+        s = HipLlamaModel(cfg, part).session(32)
+        with pytest.raises(N.JhError) as e:
+            s.forward([1, 2, 3, 4, 5, 6], 0)       # batched prefill path
+        assert e.value.code == N.JH_ERR_INVALID
+        with pytest.raises(N.JhError) as e:
+            s.forward([1], 0)                      # decode path
+        assert e.value.code == N.JH_ERR_INVALID

@@ -260,3 +260,30 @@ def test_layernorm_and_gelu_restatements(oracle):
     v = g.astype(np.float64)
     want = (0.5 * v * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (v + 0.044715 * v ** 3)))).astype(np.float32)
     assert np.abs(oracle.gelu(g) - want).max() <= 1e-6
+
+
+def test_simd_bodies_equal_the_scalar_text(oracle):
+    """The oracle's optional AVX2 bodies of the two big GEMV loops (what makes a full-size 8B oracle run affordable) must
+    reproduce the scalar restatement bit for bit: same lanes, same order, same roundings."""
+    O = oracle
+    L = O.lib()
+    rng = np.random.default_rng(77)
+    for (M, N, K) in [(1, 96, 4096), (3, 40, 1024), (2, 33, 14336)]:
+        x = (rng.standard_normal((M, K)) * rng.uniform(0.01, 30)).astype(np.float32)
+        w = rng.standard_normal((N, K)).astype(np.float32)
+        bn, bs = O.q4_quantize(w)
+        aq, ad = O.q8_quantize(x)
+        p = O._p
+        a = np.zeros((M, N), np.float32); b = np.zeros((M, N), np.float32)
+        L.jo_gemm_i8q4(p(aq), p(ad), K, K // 32, p(bn), p(bs), K // 2, K // 32, p(a), N, M, 0, 0, K, 0, 0, N)
+        L.jo_gemm_i8q4_scalar(p(aq), p(ad), K, K // 32, p(bn), p(bs), K // 2, K // 32, p(b), N, M, 0, 0, K, 0, 0, N)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        a[:] = 0; b[:] = 0
+        L.jo_gemm_f32q4(p(x), K, p(bn), p(bs), K // 2, K // 32, p(a), N, M, 0, 0, K, 0, 0, N)
+        L.jo_gemm_f32q4_scalar(p(x), K, p(bn), p(bs), K // 2, K // 32, p(b), N, M, 0, 0, K, 0, 0, N)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        # windows: column offsets and a row offset, as the attention / sharded callers use them
+        a[:] = 0; b[:] = 0
+        L.jo_gemm_i8q4(p(aq), p(ad), K, K // 32, p(bn), p(bs), K // 2, K // 32, p(a), N, M, 512, 512, 256, 0, 8, 16)
+        L.jo_gemm_i8q4_scalar(p(aq), p(ad), K, K // 32, p(bn), p(bs), K // 2, K // 32, p(b), N, M, 512, 512, 256, 0, 8, 16)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
