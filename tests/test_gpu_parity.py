@@ -6,16 +6,17 @@
 2. PER-LAYER TEACHER FORCING of the fast kernels: layer l of the oracle is fed the GPU's own `input_emb` tap of layer l
    (all positions), so each layer is compared in isolation -- no cascade from earlier layers.  Within ONE layer the fast
    kernels can still differ from the oracle by a single I8 code flip downstream of a 1e-7 summation-order difference
-   (o-projection input, down-projection input); such a flip moves the layer output by ~4e-4 of the row scale.  An
-   addressing bug (wrong KV page for rel_layer > 0, RoPE row off by one, wrong head) moves it by O(1).  So: every
-   (layer, row) <= 3e-3 of the row scale, and most of them (no flip) <= 1e-5.
+   (o-projection input, down-projection input); such a flip moves the layer output by (max|a|/127)*|w| -- measured
+   2e-4 .. 6e-3 of the row scale on these models, and two flips in one layer add.  An addressing bug (wrong KV page for
+   rel_layer > 0, RoPE row off by one, wrong head) moves it by O(1).  So: every (layer, row) <= 1.5e-2 of the row scale,
+   and most of them (no flip) <= 1e-5, with every layer's median <= 1e-5.
 """
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-FLIP_TOL = 3e-3      # one I8 code flip inside a layer (see module docstring)
+FLIP_TOL = 1.5e-2    # one or two I8 code flips inside a layer (see module docstring)
 NOFLIP_TOL = 1e-5    # float summation order only
 
 
