@@ -9,8 +9,13 @@ token, AbstractModel.java:589), bracketed by barrier + device synchronize; rank 
 
 N=1: the whole model on one GPU.  N>1: DistributedContext layer split (DistributedContext.java:75-77) -- rank r owns
 layers [r*L/N,(r+1)*L/N) and its KV pages; [1,E] F32 activations hop rank->rank with RCCL send/recv and the sampled
-token returns to rank 0; N sessions are kept in flight (one per pipeline stage) so every GPU streams its weights on
-every tick; value = tokens completed by all sessions / time.  Total work (K tokens) is fixed => "strong" scaling.
+token returns to rank 0 (jlama_amd/distributed.py).
+
+`--config` selects the other BASELINE.json configs (LLAMA32_1B, MISTRAL_7B: parity-test cases and profile lines, not the
+driver's bench line).  The line carries `roofline` (dominant kernel, HIP events on the session's stream),
+`cpu_baseline` (the reference's C SIMD GEMM driving the restated decode loop on the host cores) and
+`parity_full_size` (same weights on GPU and CPU: strict-order ids/logits bit-for-bit, and the pairwise logit distances
+GPU <-> Panama-order oracle <-> reference C GEMM).
 """
 import argparse
 import json
@@ -23,18 +28,27 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense BF16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
+MFMA_I8_PEAK_TOPS = 5000.0       # dense I8 MFMA ~ 2x the BF16 rate (MI355X_MICROARCH.md: >= 3944 TOPS measured)
 
 
-def _measured_traffic(config):
-    """HBM bytes per gate/up launch from the committed rocprofv3 PMC passes (profiles/), gfx950-corrected; counters
-    cannot be collected from inside this process, so the figure is the last profiled one for this workload."""
-    if config != "LLAMA3_8B":
-        return None
+def _profiled(config):
+    """Counter / trace figures of the dominant kernel from the committed rocprofv3 passes (profiles/): HBM bytes per
+    launch (FETCH_SIZE / WRITE_SIZE, gfx950-corrected) and the kernel-trace average duration.  Counters cannot be
+    collected from inside this process, so they are reported ONLY when the profile was taken on a binary built from the
+    sources this run uses (source hash recorded by tools/profile_round.sh); otherwise `traffic` is null and the stale
+    figure is named as such."""
+    from jlama_amd import _native as N
+    path = os.path.join(ROOT, "profiles", f"r02_{config}_dominant_kernel.json")
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r01_gateup_traffic.json")))["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None, None
+    fresh = d.get("source_hash") == N.source_hash()
+    return (d.get("traffic_bytes_per_launch") if fresh else None), (d.get("us_per_launch_rocprof") if fresh else None), \
+        {"file": os.path.relpath(path, ROOT), "source_hash": d.get("source_hash"), "matches_this_build": fresh,
+         "traffic_bytes_per_launch": d.get("traffic_bytes_per_launch"), "us_per_launch_rocprof": d.get("us_per_launch_rocprof")}
 
 
 def parse():
@@ -45,7 +59,9 @@ def parse():
     ap.add_argument("--config", default="LLAMA3_8B")
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=256)   # ~12 s of CPU work at the reference path's ~21 tok/s
+    ap.add_argument("--parity-steps", type=int, default=256)   # free-running strict-order ids compared with the oracle
     ap.add_argument("--probe-iters", type=int, default=3)
     return ap.parse_args()
 
@@ -58,37 +74,123 @@ def cpu_baseline(cfg, host_w, n_prompt, n_decode):
     reference: T = max(2, availableProcessors/2) (PhysicalCoreExecutor.java:27), where availableProcessors honours the
     container's CPU quota as the JVM does.  Bounded sample of the same workload."""
     from oracle import oracle as O
+    from jlama_amd import synthetic as S
     avail = O.available_cpus()
     T = max(2, avail // 2)
     m = O.OracleModel(cfg, host_w)
     kind = "port"
-    if O.ref_lib() is not None:
+    if O.ref_lib() is not None and cfg["weight_dtype"] == O.DT_Q4:
         m.use_reference_gemm(T)
         kind = "reference"
-    from jlama_amd import synthetic as S
     prompt = S.prompt_tokens(cfg, n=n_prompt - 1, seed=1234)
     sess = m.session()
     # prompt rows one at a time (batchForwardSlow, AbstractModel.java:282-290): the reference's C tiler leaves
     # output corners uncomputed for M > 5 (tests/test_oracle.py::test_reference_library_tiler_...), M = 1 is exact
     for i, t in enumerate(prompt):
         x = sess.forward([t], i)
-    first, logits0 = m.sample(x[-1])
+    tok, _ = m.sample(x[-1])
     t0 = time.perf_counter()
-    toks, tok = [first], first
-    step_logits = [logits0]                      # logits of the first TF_STEPS steps, for the teacher-forced parity check
     for i in range(n_decode):
         x = sess.forward([tok], prompt.size + i)
-        tok, lg = m.sample(x[-1])
-        toks.append(tok)
-        if len(step_logits) < TF_STEPS:
-            step_logits.append(lg)
+        tok, _ = m.sample(x[-1])
     dt = time.perf_counter() - t0
-    tps = n_decode / dt
-    return {"value": round(tps, 3), "unit": "tokens/s", "cores": T, "kind": kind,
+    return {"value": round(n_decode / dt, 3), "unit": "tokens/s", "cores": T, "kind": kind,
             "sample": f"{n_decode} greedy decode steps after a {n_prompt}-row prompt, full {cfg['n_layers']}-layer model; "
                       f"{'reference C SIMD GEMM (vector_simd.c, AVX-512 VNNI kernels) + ' if kind == 'reference' else ''}restated "
-                      f"Java ops; T={T} threads = max(2, available/2), {avail} CPUs available to the container of {os.cpu_count()} on the host"}, \
-        np.array(toks, dtype=np.int32), prompt, step_logits
+                      f"Java ops; T={T} threads = max(2, available/2), {avail} CPUs available to the container of {os.cpu_count()} on the host"}
+
+
+def _dist(a, b):
+    """max and mean-over-steps of max |a - b| for two lists of logit vectors."""
+    d = [float(np.abs(x - y).max()) for x, y in zip(a, b)]
+    return {"max": round(max(d), 6), "mean_of_max": round(float(np.mean(d)), 6)}
+
+
+def full_size_parity(cfg, model, host_w, n_prompt=8, n_free=256, n_tf=TF_STEPS):
+    """End-to-end parity at FULL size on identical weights (GPU resident copy vs host copy).
+
+    A. Panama-order oracle (the restated reference provider) runs the prompt and n_free greedy steps free.
+    B. The GPU in STRICT ORDER does the same: ids must be IDENTICAL and logits equal to ~0 -- this is the measurement
+       that the fast kernels' residual is summation order only.
+    C. Teacher-forced on A's ids for n_tf steps, three logit streams are compared pairwise: the GPU's fast kernels, the
+       Panama-order oracle, and the oracle driven by the reference's own compiled C GEMM (oracle/_ref) -- i.e. the
+       reference's two CPU providers.  Their mutual distance is the noise floor any second implementation sits on."""
+    from oracle import oracle as O
+    from jlama_amd import synthetic as S
+    prompt = S.prompt_tokens(cfg, n=n_prompt - 1, seed=1234)
+    out = {"prompt_rows": int(prompt.size), "free_steps": n_free, "teacher_forced_steps": n_tf}
+    # ---- A: Panama-order oracle, free-running
+    om = O.OracleModel(cfg, host_w)
+    osess = om.session()
+    t0 = time.perf_counter()
+    x = osess.forward(prompt, 0)
+    tok, lg = om.sample(x[-1])
+    ids_o, logits_o = [tok], [lg]
+    for i in range(n_free):
+        x = osess.forward([tok], prompt.size + i)
+        tok, lg = om.sample(x[-1])
+        ids_o.append(tok)
+        if len(logits_o) <= n_tf:
+            logits_o.append(lg)
+    last_logits_o = lg
+    out["oracle_panama_order_s"] = round(time.perf_counter() - t0, 1)
+    ids_o = np.array(ids_o, dtype=np.int32)
+    # ---- B: GPU strict order, free-running
+    ss = model.session(prompt.size + n_free + 8)
+    ss.set_strict(True)
+    ss.batch_forward(prompt, 0)
+    tok_s, lg_s = ss.sample(0.0, 0.5, want_logits=True)
+    logits_s, ids_s = [lg_s], [tok_s]
+    tok = tok_s
+    for i in range(min(n_tf, n_free)):                    # host loop while logits are being collected ...
+        tok = ss.decode_step(tok, prompt.size + i)
+        ids_s.append(tok)
+        logits_s.append(ss.logits())
+    if n_free > n_tf:                                     # ... then the on-device loop
+        ids_s.extend(int(t) for t in ss.decode_n(tok, prompt.size + n_tf, n_free - n_tf))
+    last_logits_s = ss.logits()
+    ids_s = np.array(ids_s, dtype=np.int32)
+    ss.close()
+    out["strict_order"] = {"ids_equal": int((ids_s == ids_o).cumprod().sum()), "n_ids": int(ids_o.size),
+                           "logits_vs_panama_oracle": _dist(logits_s, logits_o[:len(logits_s)]),
+                           "last_step_logits_max_abs_diff": float(np.abs(last_logits_s - last_logits_o).max())}
+    # ---- C: teacher-forced on A's ids: GPU fast kernels, and the oracle on the reference's compiled C GEMM
+    fs = model.session(prompt.size + n_tf + 8)
+    fs.batch_forward(prompt, 0)
+    tok_f, lg_f = fs.sample(0.0, 0.5, want_logits=True)
+    logits_f, ids_f = [lg_f], [tok_f]
+    for i in range(n_tf):
+        ids_f.append(fs.decode_step(int(ids_o[i]), prompt.size + i))
+        logits_f.append(fs.logits())
+    fs.close()
+    logits_o_tf = logits_o[:n_tf + 1]
+    pair = {"gpu_fast__panama_oracle": _dist(logits_f, logits_o_tf)}
+    if O.ref_lib() is not None and cfg["weight_dtype"] == O.DT_Q4:
+        rm = O.OracleModel(cfg, host_w)
+        rm.use_reference_gemm(max(2, O.available_cpus() // 2))
+        rs = rm.session()
+        for i, t in enumerate(prompt):
+            x = rs.forward([t], i)
+        _, lg = rm.sample(x[-1])
+        logits_r = [lg]
+        for i in range(n_tf):
+            x = rs.forward([int(ids_o[i])], prompt.size + i)
+            _, lg = rm.sample(x[-1])
+            logits_r.append(lg)
+        pair["gpu_fast__reference_c_gemm"] = _dist(logits_f, logits_r)
+        pair["panama_oracle__reference_c_gemm"] = _dist(logits_o_tf, logits_r)
+    out["teacher_forced_pairwise_logit_distance"] = pair
+    out["logit_scale"] = float(np.abs(logits_o[0]).max())
+    # argmax agreement of the fast kernels against a FIXED margin: steps whose oracle top-2 margin exceeds 0.25
+    # (~3% of the logit scale, above every pairwise distance measured so far)
+    decided = agree = 0
+    for i, want in enumerate(logits_o_tf):
+        top2 = np.partition(want, -2)[-2:]
+        if top2[1] - top2[0] > 0.25:
+            decided += 1
+            agree += int(ids_f[i] == int(np.argmax(want)))
+    out["fast_argmax_vs_oracle_at_margin_0.25"] = {"decided_steps": decided, "agree": agree, "of": len(logits_o_tf)}
+    return out, ids_o
 
 
 def run_single(args, cfg):
@@ -128,6 +230,7 @@ def run_single(args, cfg):
     toks = s.decode_wait(args.steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    assert toks.size == args.steps
     ev_ms, kernels = s.decode_stats()
     tps = args.steps / dt
     # roofline of the dominant kernel (gate/up GEMV: 54% of the weight bytes), HIP events on the session's stream
@@ -143,6 +246,14 @@ def run_single(args, cfg):
     kvb = S.kv_bytes_per_position(cfg)
     mean_pos = prompt.size + (args.steps - 1) / 2.0
     bytes_per_token = wbytes + kvb * (mean_pos + 1) + kvb
+    traffic, us_rocprof, prof = _profiled(args.config)
+    # prefill as a GEMM workload: 2 * rows * (projection weights) flops; against the dense MFMA peak of the dtype this is
+    # the "MFMA utilisation" of BASELINE configs[3] (BF16); SURVEY 8d: at M = 129 the HBM roofline caps it at ~41 %
+    per_layer = sum(r * c for r, c in S.layer_shapes(cfg).values())
+    prefill_flops = 2.0 * prompt.size * cfg["n_layers"] * per_layer
+    prefill_tflops = prefill_flops / (prompt_ms * 1e-3) / 1e12
+    mfma_peak = MFMA_I8_PEAK_TOPS if is_q4 else MFMA_BF16_PEAK_TFLOPS
+    bytes_per_weight = 0.625 if is_q4 else 2.0
     out = {
         "metric": "decode tokens/sec Llama-3-8B JQ4, 128-tok prompt" if args.config == "LLAMA3_8B" else f"decode tokens/sec {args.config}",
         "value": round(tps, 2), "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -154,47 +265,40 @@ def run_single(args, cfg):
                    "prefill_tokens_per_s": round(prompt.size / prompt_ms * 1e3, 1)},
         "roofline": ({"bound": "hbm", "kernel": "gemv_i8q4_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV, fused RMSNorm+Q8 prologue, SiLU*up epilogue)",
                       "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": _measured_traffic(args.config),
-                      "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"]} if is_q4 else
+                      "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                      "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"], "us_per_launch_rocprof": us_rocprof,
+                      "profile": prof} if is_q4 else
                      {"bound": "hbm", "kernel": "whole decode step (per-kernel probe is JQ4-only)",
                       "achieved": round(bytes_per_token * tps / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(bytes_per_token * tps / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}),
         "token_roofline": {"bytes_per_token": int(bytes_per_token), "achieved_GBps": round(bytes_per_token * tps / 1e9, 1),
                            "frac_of_8TBps": round(bytes_per_token * tps / 1e9 / HBM_PEAK_GBS, 4),
                            "event_ms_per_token": round(ev_ms, 4)},
+        "prefill_mfma": {"rows": int(prompt.size), "flops": prefill_flops, "achieved_TFLOPs": round(prefill_tflops, 1),
+                         "peak_TFLOPs": mfma_peak, "frac": round(prefill_tflops / mfma_peak, 4),
+                         "hbm_bound_frac": round(min(1.0, 2.0 * prompt.size * HBM_PEAK_GBS * 1e9 / (bytes_per_weight * mfma_peak * 1e12)), 3),
+                         "note": "projection GEMMs of the prefill (2*rows*weights flops; attention excluded) over the whole prefill "
+                                 "time, against the dense " + ("BF16" if not is_q4 else "I8") + " MFMA peak; hbm_bound_frac = the share "
+                                 "of that peak the weight stream allows at this row count (SURVEY.md 8d)"},
         "kernels": probe,
         "weights_gen_s": round(gen_s, 1),
     }
+    host_w = None
     if not args.no_cpu_baseline:
         host_w = ST.to_host(w)
-        cb, cpu_toks, cpu_prompt, cpu_logits = cpu_baseline(cfg, host_w, 8, args.cpu_steps)
-        out["cpu_baseline"] = cb
-        # end-to-end parity at FULL size on the same weights.  (1) free-running greedy ids (diverge at the first near-tie,
-        # as any two float summation orders do on random weights); (2) TEACHER-FORCED on the CPU path's tokens: the logits
-        # of every step compared, and the argmax wherever the CPU path's own top-2 margin exceeds the logit difference
-        ps = model.session(cpu_prompt.size + args.cpu_steps + 8)
-        ps.batch_forward(cpu_prompt, 0)
-        gfirst, glogits = ps.sample(0.0, 0.5, want_logits=True)
-        gtoks = np.concatenate([[gfirst], ps.decode_n(gfirst, cpu_prompt.size, args.cpu_steps)])
-        tf = model.session(cpu_prompt.size + len(cpu_logits) + 8)
-        tf.batch_forward(cpu_prompt, 0)
-        diffs, agree, decided = [], 0, 0
-        for i, want in enumerate(cpu_logits):
-            if i > 0:
-                tf.forward([int(cpu_toks[i - 1])], cpu_prompt.size + i - 1, want_output=False)
-            gt, gl = tf.sample(0.0, 0.5, want_logits=True)
-            d = float(np.abs(gl - want).max())
-            diffs.append(d)
-            top2 = np.partition(want, -2)[-2:]
-            if top2[1] - top2[0] > 2 * d:          # the CPU path's decision is not within the numerical noise
-                decided += 1
-                agree += int(gt == int(np.argmax(want)))
-        out["parity_full_size"] = {"max_abs_logit_diff": float(np.abs(glogits - cpu_logits[0]).max()),
-                                   "logit_scale": float(np.abs(cpu_logits[0]).max()),
-                                   "leading_tokens_equal": int((gtoks == cpu_toks).cumprod().sum()), "n": int(cpu_toks.size),
-                                   "teacher_forced": {"steps": len(cpu_logits), "max_abs_logit_diff": round(max(diffs), 4),
-                                                      "mean_abs_max_diff": round(float(np.mean(diffs)), 4),
-                                                      "decided_steps": decided, "argmax_agree": agree}}
+        out["cpu_baseline"] = cpu_baseline(cfg, host_w, 8, args.cpu_steps)
+    if not args.no_parity and is_q4:
+        host_w = host_w or ST.to_host(w)
+        par, ids_o = full_size_parity(cfg, model, host_w, 8, args.parity_steps, TF_STEPS)
+        # free-running ids of the FAST kernels vs the oracle's (diverge at the first near-tie, as any two float summation
+        # orders do on random weights; the strict-order run above does not)
+        pp = S.prompt_tokens(cfg, n=7, seed=1234)
+        ps = model.session(pp.size + args.parity_steps + 8)
+        ps.batch_forward(pp, 0)
+        gfirst = ps.sample()
+        ids_fast = np.concatenate([[gfirst], ps.decode_n(gfirst, pp.size, args.parity_steps)])
+        par["fast_free_running_ids_equal_prefix"] = int((ids_fast == ids_o).cumprod().sum())
+        out["parity_full_size"] = par
     return out, toks
 
 

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_round.sh run into the record bench.py reads: the dominant kernel's rocprofv3 average duration,
+its HBM traffic from the FETCH_SIZE / WRITE_SIZE passes (gfx950 correction of MI355X_MICROARCH.md HBM section: FETCH_SIZE
+counts 1/2 of a wide coalesced streaming read), and the source hash of the binary that was profiled.
+Usage: dominant_kernel_json.py <prefix of the *_kernel_trace_stats.md / *_pmc_*.md files> <CONFIG>"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from jlama_amd import _native as N, synthetic as S  # noqa: E402
+
+prefix, cfgname = sys.argv[1], sys.argv[2]
+cfg = getattr(S, cfgname)
+
+
+def rows(path):
+    out = []
+    for line in open(path):
+        cells = [c.strip() for c in line.strip().strip("|").split("|")]
+        if len(cells) >= 4 and cells[0] and not set(cells[0]) <= set("-") and cells[0] != "kernel":
+            out.append(cells)
+    return out
+
+
+def is_gateup(name):   # gemv_i8q4_kernel<PRO_RMS_Q8=1, EPI_SILU_MUL=2, ...> or the persistent layer kernel
+    return re.match(r"gemv_i8q4_kernel<1, 2,", name) is not None
+
+
+trace = [r for r in rows(prefix + "_kernel_trace_stats.md") if is_gateup(r[0])]
+fetch = [r for r in rows(prefix + "_pmc_fetch_size.md") if is_gateup(r[0])]
+write = [r for r in rows(prefix + "_pmc_write_size.md") if is_gateup(r[0])]
+E, H = cfg["embedding_length"], cfg["hidden_length"]
+algo = int(2 * H * E * 0.625)
+rec = {"config": cfgname, "source_hash": N.built_hash(), "kernel": trace[0][0] if trace else None,
+       "us_per_launch_rocprof": float(trace[0][2]) if trace else None,
+       "FETCH_SIZE_KB_per_dispatch": float(fetch[0][3]) if fetch else None,
+       "WRITE_SIZE_KB_per_dispatch": float(write[0][3]) if write else None,
+       "algorithmic_bytes_per_launch": algo,
+       "correction": "gfx950: FETCH_SIZE reports 1/2 of a wide coalesced (16 B/lane) streaming read; traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+if fetch:
+    rec["traffic_bytes_per_launch"] = (2 * rec["FETCH_SIZE_KB_per_dispatch"] + (rec["WRITE_SIZE_KB_per_dispatch"] or 0.0)) * 1024
+    rec["ratio_to_algorithmic"] = rec["traffic_bytes_per_launch"] / algo
+print(json.dumps(rec, indent=1))

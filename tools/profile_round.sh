@@ -1,14 +1,26 @@
+#!/bin/bash
+# Round profile of one bench config on the GPU box:  tools/profile_round.sh <round tag, e.g. r02> <CONFIG> [extra bench args]
+#   1. un-profiled bench line                         -> gpurun_out/<tag>_<CONFIG>_bench.json
+#   2. rocprofv3 --kernel-trace --stats               -> gpurun_out/<tag>_<CONFIG>_kernel_trace_stats.md (+ the traced run's bench line)
+#   3. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE  -> gpurun_out/<tag>_<CONFIG>_pmc_{fetch,write}_size.md  (separate passes, counters only)
+#   4. the dominant kernel's figures + the source hash of the profiled binary -> gpurun_out/<tag>_<CONFIG>_dominant_kernel.json
+# Copy what should be judged into profiles/ (bench.py reports `traffic` only from a profile whose hash matches its build).
 set -x
-cd /root/repo
-JH_BENCH_FORCE_PIPELINE=1 timeout 300 python bench.py --steps 64 --warmup 8 2>/dev/null | tail -1 | cut -c1-400 > gpurun_out/pipeline_w1.json
+TAG=${1:-r02}; CFG=${2:-LLAMA3_8B}; shift; shift
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
 export TMPDIR=/tmp
-REPO=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python $REPO/bench.py --steps 256 --warmup 16 --no-cpu-baseline > /tmp/bench_prof.log 2>&1
-tail -1 /tmp/bench_prof.log | cut -c1-3000 > $REPO/gpurun_out/r01b_bench_under_rocprof.json
-DB=$(find /tmp/prof_kt -name "*.db" | head -1)
-python $REPO/tools/rocpd_stats.py $DB > $REPO/gpurun_out/r01b_kernel_trace_stats.md 2>&1
-rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -- python $REPO/bench.py --steps 32 --warmup 4 --no-cpu-baseline > /tmp/bench_f.log 2>&1
-DBF=$(find /tmp/prof_f -name "*.db" | head -1)
-python $REPO/tools/rocpd_pmc.py $DBF > $REPO/gpurun_out/r01b_pmc_fetch_size.md 2>&1
-ls -la $REPO/gpurun_out/
+EXTRA="$@"
+python $REPO/bench.py --config $CFG --steps 256 --warmup 16 $EXTRA > $OUT/${TAG}_${CFG}_bench.json 2> $OUT/${TAG}_${CFG}_bench.err
+rm -rf /tmp/prof_kt /tmp/prof_f /tmp/prof_w
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python $REPO/bench.py --config $CFG --steps 128 --warmup 8 --no-cpu-baseline --no-parity > /tmp/bench_prof.log 2>&1
+tail -1 /tmp/bench_prof.log | cut -c1-4000 > $OUT/${TAG}_${CFG}_bench_under_rocprof.json
+python $REPO/tools/rocpd_stats.py $(find /tmp/prof_kt -name "*.db" | head -1) > $OUT/${TAG}_${CFG}_kernel_trace_stats.md 2>&1
+rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -- python $REPO/bench.py --config $CFG --steps 16 --warmup 0 --no-cpu-baseline --no-parity --probe-iters 1 > /tmp/bench_f.log 2>&1
+python $REPO/tools/rocpd_pmc.py $(find /tmp/prof_f -name "*.db" | head -1) > $OUT/${TAG}_${CFG}_pmc_fetch_size.md 2>&1
+rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -- python $REPO/bench.py --config $CFG --steps 16 --warmup 0 --no-cpu-baseline --no-parity --probe-iters 1 > /tmp/bench_w.log 2>&1
+python $REPO/tools/rocpd_pmc.py $(find /tmp/prof_w -name "*.db" | head -1) > $OUT/${TAG}_${CFG}_pmc_write_size.md 2>&1
+python $REPO/tools/dominant_kernel_json.py $OUT/${TAG}_${CFG} $CFG > $OUT/${TAG}_${CFG}_dominant_kernel.json
+ls -la $OUT
