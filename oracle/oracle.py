@@ -251,6 +251,31 @@ def ref_gemm_f32(a, b, aColOff=0, bColOff=0, K=None, rRowOff=0, bRowOff=0, N=Non
     return out
 
 
+def ref_gemm_bf16(a, b, aColOff=0, bColOff=0, K=None, rRowOff=0, bRowOff=0, N=None):
+    """gemm_bf16 of the reference C library with F32 output (rs = NULL), M = 1 ONLY: gemm_bf16_512 indexes A with the
+    COLUMN tile index (`params.lda * (jj + ni)`, vector_simd.c:1189) -- a reference bug that is harmless exactly when
+    the A row stride passed is 0, which is legitimate for a single row."""
+    r = ref_lib()
+    assert a.shape[0] == 1, "reference gemm_bf16 is only usable for M = 1 (vector_simd.c:1189)"
+    K = a.shape[1] if K is None else K
+    N = b.shape[0] if N is None else N
+    out = np.zeros((1, rRowOff + bRowOff + N), dtype=np.float32)
+    r.gemm_bf16(REF_FLAGS, _p(a), aColOff, _p(b), bColOff, None, _p(out), -rRowOff, 1, bRowOff, N, K, 0, b.shape[1],
+                out.shape[1])
+    return out
+
+
+def ref_gemm_f32_bf16(a, b, aColOff=0, bColOff=0, K=None, rRowOff=0, bRowOff=0, N=None):
+    r = ref_lib()
+    M = a.shape[0]
+    K = a.shape[1] if K is None else K
+    N = b.shape[0] if N is None else N
+    out = np.zeros((M, rRowOff + bRowOff + N), dtype=np.float32)
+    r.gemm_f32_bf16(REF_FLAGS, _p(a), aColOff, _p(b), bColOff, None, _p(out), -rRowOff, M, bRowOff, N, K, a.shape[1],
+                    b.shape[1], out.shape[1])
+    return out
+
+
 # ----------------------------------------------------------------------------- small ops
 def rmsnorm(x, w, eps, weight_adj=0.0):
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -35,5 +35,13 @@ kpage = rng.standard_normal((48, 256), dtype=np.float32)
 q = rng.standard_normal((1, 256), dtype=np.float32)
 out["f32_q"], out["f32_kpage"] = q, kpage
 out["f32_scores"] = O.ref_gemm_f32(q, kpage, aColOff=128, bColOff=128, K=128)
+# BF16 weights (config 4 family): BF16 x BF16 and F32 x BF16, M = 1, F32 output (gemm_bf16 / gemm_f32_bf16,
+# vector_simd.c:1226-1263,1457-1492; the BF16-activation kernel only with a zero A row stride, see oracle.ref_gemm_bf16)
+wb = O.bf16_quantize(w)
+xb = O.bf16_quantize(x)
+out["w_bf16"], out["x_bf16"] = wb, xb
+out["bf16_full"] = O.ref_gemm_bf16(xb, wb)
+out["f32bf16_full"] = O.ref_gemm_f32_bf16(x, wb)
+out["bf16_window"] = O.ref_gemm_bf16(xb, wb, aColOff=512, bColOff=512, K=512, bRowOff=32, N=64)
 np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_gemm_vectors.npz"), **out)
 print({k: v.shape for k, v in out.items()})

@@ -343,6 +343,20 @@ def test_against_vectors_from_the_reference_library(ops):
     R = Tensor.zeros(1, 48)
     ops.batchDotProduct(R, Q, KP, 128, 128, 128)
     _close(R.data, g["f32_scores"], 1e-4)
+    # BF16 weights (config 4): gemm_bf16 / gemm_f32_bf16 of the reference library, M = 1, F32 output; the device BF16
+    # quantizer must reproduce the activation codes the reference consumed
+    WB = Tensor(N.DT_BF16, np.ascontiguousarray(g["w_bf16"]))
+    XB = ops.quantize(X, N.DT_BF16, 0, X.cols)
+    np.testing.assert_array_equal(XB.data, g["x_bf16"])
+    R = Tensor.zeros(1, n)
+    ops.batchDotProduct(R, XB, WB, 0, 0, k)
+    _close(R.data, g["bf16_full"], 1e-4)
+    R = Tensor.zeros(1, n)
+    ops.batchDotProduct(R, X, WB, 0, 0, k)
+    _close(R.data, g["f32bf16_full"], 1e-4)
+    R = Tensor.zeros(1, 96)
+    ops.batchDotProduct(R, XB, WB, 512, 512, 512, 0, 32, 64)
+    _close(R.data[:, 32:96], g["bf16_window"][:, 32:96], 1e-4)
 
 
 def test_gpt2_family_pieces(ops, oracle):

@@ -237,6 +237,13 @@ def test_oracle_matches_committed_reference_vectors(oracle):
                             out=np.zeros((1, 96), np.float32))
     np.testing.assert_array_equal(got[:, 32:96], g["f32q4_window"][:, 32:96])
     np.testing.assert_array_equal(oracle.gemm_f32(g["f32_q"], g["f32_kpage"], aColOff=128, bColOff=128, K=128), g["f32_scores"])
+    # BF16 legs (GemmerBF16 / GemmerF32BF16 restatements) against the reference library's gemm_bf16 / gemm_f32_bf16, M = 1:
+    # bit-exact (elements t then t+16 into 16 lanes, halving-tree reduce); activations' BF16 codes = RNE of the F32 row
+    np.testing.assert_array_equal(oracle.bf16_quantize(g["x"]), g["x_bf16"])
+    np.testing.assert_array_equal(oracle.gemm_bf16(g["x_bf16"], g["w_bf16"]), g["bf16_full"])
+    np.testing.assert_array_equal(oracle.gemm_f32bf16(g["x"], g["w_bf16"]), g["f32bf16_full"])
+    got = oracle.gemm_bf16(g["x_bf16"], g["w_bf16"], aColOff=512, bColOff=512, K=512, bRowOff=32, N=64, out=np.zeros((1, 96), np.float32))
+    np.testing.assert_array_equal(got[:, 32:96], g["bf16_window"][:, 32:96])
 
 
 def test_layernorm_and_gelu_restatements(oracle):
