@@ -578,8 +578,14 @@ typedef struct {
     float rope_scaling;
 } jo_config;
 
+/* slots 0..11 mirror include/jlama_hip.h (Llama family); 12.. are the extra tensors of the GPT-2 family
+ * (core/model/gpt2/GPT2Model.java:53-129): attention / MLP biases, LayerNorm biases, learned position embeddings.
+ * For GPT-2, GATE = mlp.c_fc (no UP projection), DOWN = mlp.c_proj, EMBED = wte (also the LM head, :112-127). */
 enum { JO_W_Q = 0, JO_W_K, JO_W_V, JO_W_O, JO_W_GATE, JO_W_UP, JO_W_DOWN, JO_W_NORM1, JO_W_NORM2,
-       JO_W_EMBED, JO_W_LMHEAD, JO_W_FINALNORM, JO_W_COUNT };
+       JO_W_EMBED, JO_W_LMHEAD, JO_W_FINALNORM,
+       JO_W_QB, JO_W_KB, JO_W_VB, JO_W_OB, JO_W_GATEB, JO_W_DOWNB, JO_W_NORM1B, JO_W_NORM2B, JO_W_WPE, JO_W_FINALNORMB,
+       JO_W_COUNT };
+enum { JO_ARCH_LLAMA = 0, JO_ARCH_GPT2 = 1 };
 
 typedef struct { int dtype; const void* data; const float* scales; int rows, cols; } jo_weight;
 
@@ -601,6 +607,7 @@ typedef struct jo_model {
     int ref_flags;
     int nthreads;       /* pchunk split for ref GEMMs (core/math/VectorMath.java:38-67) */
     int kv_head_offset; /* tensor-parallel shard: global index of local kv head 0 (DistributedContext.groupHeadStart) */
+    int arch;           /* JO_ARCH_LLAMA: RMSNorm, RoPE, SiLU(gate)*up;  JO_ARCH_GPT2: LayerNorm+bias, wte+wpe, biases, GELU, no RoPE */
 } jo_model;
 
 typedef struct jo_session {
@@ -641,6 +648,7 @@ int jo_model_set_weight(jo_model* m, int layer, int which, int dtype, const void
     return 0;
 }
 void jo_model_set_kv_head_offset(jo_model* m, int off) { m->kv_head_offset = off; }
+void jo_model_set_arch(jo_model* m, int arch) { m->arch = arch; }
 void jo_model_set_ref_gemm(jo_model* m, void* q8q4, void* f32q4, int flags, int nthreads) {
     m->ref_q8q4 = (jo_ref_q8q4_fn)q8q4;
     m->ref_f32q4 = (jo_ref_f32q4_fn)f32q4;
@@ -773,11 +781,37 @@ static void jo_load_norm(const jo_weight* w, int E, float* out) {
         out[j] = w->dtype == JO_DT_BF16 ? jo_bf16_to_f32(((const uint16_t*)w->data)[j]) : ((const float*)w->data)[j];
 }
 
+/* preAttentionNorm / preFFNorm / output norm of one row: RMSNorm (Llama family, core/model/RMSNorm.java:33-56) or
+ * LayerNorm with bias (GPT-2, core/model/LayerNorm.java:41-67) */
+static void jo_norm_row(jo_model* m, const float* x, const jo_weight* w, const jo_weight* b, float* nw, float* nb, float* out) {
+    int E = m->c.embedding_length;
+    jo_load_norm(w, E, nw);
+    if (m->arch == JO_ARCH_GPT2) {
+        jo_load_norm(b, E, nb);
+        jo_layernorm(x, nw, nb, 0, E, E, m->c.rms_eps, out);
+    } else {
+        jo_rmsnorm(x, nw, 0.0f, E, m->c.rms_eps, out);
+    }
+}
+/* accumulate(result, bias, 0, n) per batch row (TensorOperations.accumulate with a one-row bias, PTO:2150-2218) */
+static void jo_add_bias(const jo_weight* b, float* r, int B, int n, float* tmp) {
+    if (!b->data) return;
+    jo_load_norm(b, n, tmp);
+    for (int i = 0; i < B; i++) jo_accumulate_f32(r + (size_t)i * n, tmp, 0, n);
+}
+
 /* EmbedInput: LlamaModel.loadInputWeights core/model/llama/LlamaModel.java:67-98.  For a Q4
  * table the row stays Q4 and every consumer reads (nib-8)*scale; BF16 widens by <<16. */
-static void jo_embed(jo_model* m, int token, float* out) {
+static void jo_embed(jo_model* m, int token, int position, float* out) {
     const jo_weight* w = &m->global_w[JO_W_EMBED];
     int E = m->c.embedding_length;
+    if (m->arch == JO_ARCH_GPT2) {
+        /* GPT2Model.loadInputWeights core/model/gpt2/GPT2Model.java:53-68: v = wte.get(token, i) + wpe.get(position, i) */
+        const float* wte = (const float*)w->data + (size_t)token * E;
+        const float* wpe = (const float*)m->global_w[JO_W_WPE].data + (size_t)position * E;
+        for (int j = 0; j < E; j++) out[j] = wte[j] + wpe[j];
+        return;
+    }
     if (w->dtype == JO_DT_Q4) {
         const uint8_t* nr = (const uint8_t*)w->data + (size_t)token * (E / 2);
         const float* sr = w->scales + (size_t)token * (E / JO_BLOCK);
@@ -808,14 +842,14 @@ static void jo_layer_attn(jo_session* s, int li, const float* x, int B, int star
     float* k = (float*)malloc(sizeof(float) * (size_t)B * KV);
     float* v = (float*)malloc(sizeof(float) * (size_t)B * KV);
     float* val = (float*)malloc(sizeof(float) * (size_t)B * A);
-    float* nw = (float*)malloc(sizeof(float) * (size_t)E);
+    float* nw = (float*)malloc(sizeof(float) * (size_t)(A > E ? A : E));
+    float* nb = (float*)malloc(sizeof(float) * (size_t)E);
     int max_ctx_alloc = ((start_pos + B) / s->ctx_per_page + 1) * s->ctx_per_page;
     float* attn_all = (float*)malloc(sizeof(float) * (size_t)max_ctx_alloc * (size_t)jo_num_threads());
 
     jo_tap(s, li, JO_TAP_INPUT_EMB, x, B * E);
     /* preAttentionNorm TransformerBlock.java:167 */
-    jo_load_norm(&W[JO_W_NORM1], E, nw);
-    for (int b = 0; b < B; b++) jo_rmsnorm(x + (size_t)b * E, nw, 0.0f, E, c->rms_eps, ln + (size_t)b * E);
+    for (int b = 0; b < B; b++) jo_norm_row(m, x + (size_t)b * E, &W[JO_W_NORM1], &W[JO_W_NORM1B], nw, nb, ln + (size_t)b * E);
     jo_tap(s, li, JO_TAP_LN_EMB, ln, B * E);
     jo_act qa;
     jo_maybe_quantize(m, ln, B, E, &qa); /* :172 */
@@ -824,6 +858,10 @@ static void jo_layer_attn(jo_session* s, int li, const float* x, int B, int star
     jo_weight_gemm(m, &qa, B, &W[JO_W_K], 0, E, k, KV);
     jo_weight_gemm(m, &qa, B, &W[JO_W_V], 0, E, v, KV);
     jo_act_free(&qa);
+    /* queryAttnBias / keyAttnBias / valueAttnBias (CausalSelfAttention.java:183-191; present for GPT-2) */
+    jo_add_bias(&W[JO_W_QB], q, B, A, nw);
+    jo_add_bias(&W[JO_W_KB], k, B, KV, nw);
+    jo_add_bias(&W[JO_W_VB], v, B, KV, nw);
     jo_tap(s, li, JO_TAP_QUERY, q, B * A);
     jo_tap(s, li, JO_TAP_KEY, k, B * KV);
     jo_tap(s, li, JO_TAP_VALUE, v, B * KV);
@@ -839,7 +877,8 @@ static void jo_layer_attn(jo_session* s, int li, const float* x, int B, int star
         /* RoPE :247-286 (GQA branch). table index poffset + g, g over kvHead*hs + [0,half) with the GLOBAL kv head
          * index (dctx.groupHeadStart.. :275) => effective position pos + 2*kvHead (quirk kept). */
         int poffset = position * half + m->kv_head_offset * hs;
-        for (int h = 0; h < c->n_heads; h++) {
+        /* c.ropeFreqs.ifPresent(...) :247: GPT-2 has no RoPE (learned position embeddings) */
+        for (int h = 0; m->arch != JO_ARCH_GPT2 && h < c->n_heads; h++) {
             int offset = h * hs, goffset = (h / group) * hs; /* Config.maybeMapToGroupHead */
             for (int i = offset, gg = goffset; i < offset + half; i++, gg++) {
                 float q0 = query[i], q1 = query[i + half];
@@ -848,7 +887,7 @@ static void jo_layer_attn(jo_session* s, int li, const float* x, int B, int star
                 query[i + half] = q0 * fci + q1 * fcr;
             }
         }
-        for (int h = 0; h < c->n_kv_heads; h++) {
+        for (int h = 0; m->arch != JO_ARCH_GPT2 && h < c->n_kv_heads; h++) {
             int offset = h * hs;
             for (int i = offset; i < offset + half; i++) {
                 float k0 = key[i], k1 = key[i + half];
@@ -893,8 +932,9 @@ static void jo_layer_attn(jo_session* s, int li, const float* x, int B, int star
     jo_maybe_quantize(m, val, B, A, &va);
     jo_weight_gemm(m, &va, B, &W[JO_W_O], 0, A, att_out, E);
     jo_act_free(&va);
+    jo_add_bias(&W[JO_W_OB], att_out, B, E, nw);   /* outputProjectionBias :378-380 (after the reducer) */
     jo_tap(s, li, JO_TAP_POST_ATTN, att_out, B * E);
-    free(ln); free(q); free(k); free(v); free(val); free(nw); free(attn_all);
+    free(ln); free(q); free(k); free(v); free(val); free(nw); free(nb); free(attn_all);
 }
 
 /* feed-forward half: preFFNorm -> gate, up -> SiLU*up -> down over this shard's hidden segment.
@@ -907,25 +947,28 @@ static void jo_layer_ffn(jo_session* s, int li, const float* att_res, int B, flo
     float* ln = (float*)malloc(sizeof(float) * (size_t)B * E);
     float* g = (float*)malloc(sizeof(float) * (size_t)B * H);
     float* u = (float*)malloc(sizeof(float) * (size_t)B * H);
-    float* nw = (float*)malloc(sizeof(float) * (size_t)E);
+    float* nw = (float*)malloc(sizeof(float) * (size_t)(H > E ? H : E));
+    float* nb = (float*)malloc(sizeof(float) * (size_t)E);
     /* preFFNorm :187 */
-    jo_load_norm(&W[JO_W_NORM2], E, nw);
-    for (int b = 0; b < B; b++) jo_rmsnorm(att_res + (size_t)b * E, nw, 0.0f, E, c->rms_eps, ln + (size_t)b * E);
+    for (int b = 0; b < B; b++) jo_norm_row(m, att_res + (size_t)b * E, &W[JO_W_NORM2], &W[JO_W_NORM2B], nw, nb, ln + (size_t)b * E);
     jo_tap(s, li, JO_TAP_PRE_FF_NORM, ln, B * E);
     jo_act fa;
     jo_maybe_quantize(m, ln, B, E, &fa); /* :192 */
     /* MLPBlock.forward MLPBlock.java:117-142 */
     jo_weight_gemm(m, &fa, B, &W[JO_W_GATE], 0, E, g, H);
-    jo_weight_gemm(m, &fa, B, &W[JO_W_UP], 0, E, u, H);
+    if (W[JO_W_UP].data) jo_weight_gemm(m, &fa, B, &W[JO_W_UP], 0, E, u, H);   /* upProjectionWeights != null :119-126 */
     jo_act_free(&fa);
-    for (size_t t = 0; t < (size_t)B * H; t++) g[t] = jo_silu(g[t]);
-    jo_maccumulate_f32(g, u, 0, B * H);
+    jo_add_bias(&W[JO_W_GATEB], g, B, H, nw);                                  /* fullyConnectedBias :128-130 */
+    if (m->arch == JO_ARCH_GPT2) { for (size_t t = 0; t < (size_t)B * H; t++) g[t] = jo_gelu(g[t]); }   /* c.activationFunction = GELU (GPT2Config.java:49) */
+    else { for (size_t t = 0; t < (size_t)B * H; t++) g[t] = jo_silu(g[t]); }
+    if (W[JO_W_UP].data) jo_maccumulate_f32(g, u, 0, B * H);
     jo_act ha;
     jo_maybe_quantize(m, g, B, H, &ha); /* :144 */
     jo_weight_gemm(m, &ha, B, &W[JO_W_DOWN], 0, H, ff, E);
     jo_act_free(&ha);
+    jo_add_bias(&W[JO_W_DOWNB], ff, B, E, nw);                                 /* projectionBias :163 */
     jo_tap(s, li, JO_TAP_POST_FF, ff, B * E);
-    free(ln); free(g); free(u); free(nw);
+    free(ln); free(g); free(u); free(nw); free(nb);
 }
 
 /* forward a batch of B rows through layers [layer_start, layer_end).  x: [B,E] in/out.
@@ -935,7 +978,7 @@ int jo_forward(jo_session* s, const int32_t* tokens, float* x, int B, int start_
     const jo_config* c = &m->c;
     int E = c->embedding_length;
     if (tokens)
-        for (int b = 0; b < B; b++) jo_embed(m, tokens[b], x + (size_t)b * E);
+        for (int b = 0; b < B; b++) jo_embed(m, tokens[b], start_pos + b, x + (size_t)b * E);
     float* att_out = (float*)malloc(sizeof(float) * (size_t)B * E);
     float* ff = (float*)malloc(sizeof(float) * (size_t)B * E);
     for (int li = c->layer_start; li < c->layer_end; li++) {
@@ -965,7 +1008,7 @@ int jo_tp_ffn(jo_session* s, int layer, const float* att_res, int B, float* part
     return 0;
 }
 void jo_embed_rows(jo_model* m, const int32_t* tokens, int B, float* x) {
-    for (int b = 0; b < B; b++) jo_embed(m, tokens[b], x + (size_t)b * m->c.embedding_length);
+    for (int b = 0; b < B; b++) jo_embed(m, tokens[b], b, x + (size_t)b * m->c.embedding_length);
 }
 
 /* All model shards in one process, in lock step (head split, DistributedContext.java:79-98): shard r holds heads
@@ -1002,14 +1045,14 @@ int jo_sample(jo_model* m, const float* last_row, float temperature, float unifo
     const jo_config* c = &m->c;
     int E = c->embedding_length, V = c->vocab_size;
     float* nw = (float*)malloc(sizeof(float) * E);
+    float* nb = (float*)malloc(sizeof(float) * E);
     float* emb = (float*)malloc(sizeof(float) * E);
-    jo_load_norm(&m->global_w[JO_W_FINALNORM], E, nw);
-    jo_rmsnorm(last_row, nw, 0.0f, E, c->rms_eps, emb);
+    jo_norm_row(m, last_row, &m->global_w[JO_W_FINALNORM], &m->global_w[JO_W_FINALNORMB], nw, nb, emb);   /* getOutputLayerNorm */
     /* LM head: the F32 normed row is NOT re-quantized (:443-449) => F32xQ4 / F32xBF16 / F32xF32 */
     jo_act a = { NULL, NULL, NULL, emb, E };
     const jo_weight* w = m->global_w[JO_W_LMHEAD].data ? &m->global_w[JO_W_LMHEAD] : &m->global_w[JO_W_EMBED];
     jo_weight_gemm(m, &a, 1, w, 0, E, logits, V);
-    free(nw); free(emb);
+    free(nw); free(nb); free(emb);
     int maxi = INT32_MIN;
     double maxv = -INFINITY;
     for (int i = 0; i < V; i++) {

@@ -17,6 +17,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DT_F32, DT_BF16, DT_I8, DT_Q4 = 0, 1, 2, 3
 (W_Q, W_K, W_V, W_O, W_GATE, W_UP, W_DOWN, W_NORM1, W_NORM2, W_EMBED, W_LMHEAD, W_FINALNORM) = range(12)
+# GPT-2 family extras (core/model/gpt2/GPT2Model.java:53-129): biases, LayerNorm biases, learned position embeddings
+(W_QB, W_KB, W_VB, W_OB, W_GATEB, W_DOWNB, W_NORM1B, W_NORM2B, W_WPE, W_FINALNORMB) = range(12, 22)
+ARCH_LLAMA, ARCH_GPT2 = 0, 1
 TAPS = ["input_emb", "ln_emb", "query", "key", "value", "query+rope", "key+rope", "after_attention",
         "post_attn", "pre_ff_norm", "post_ff", "post_ff_res"]
 
@@ -337,9 +340,11 @@ def kv_page_geometry(max_page_bytes, n_layers, context_length, kv_length, dtype_
 class OracleModel:
     """CPU restatement of AbstractModel.generate()/forward() for Llama-family models."""
 
-    def __init__(self, cfg: dict, weights: dict, layer_range=None, kv_head_offset=0):
+    def __init__(self, cfg: dict, weights: dict, layer_range=None, kv_head_offset=0, arch=ARCH_LLAMA):
         """kv_head_offset: for a tensor-parallel shard (cfg carries the LOCAL head counts / hidden length), the global
-        index of its first kv head (DistributedContext.groupHeadStart) -- RoPE table rows are indexed globally."""
+        index of its first kv head (DistributedContext.groupHeadStart) -- RoPE table rows are indexed globally.
+        arch=ARCH_GPT2: LayerNorm + biases, wte + wpe embeddings, GELU MLP without up-projection, no RoPE, LM head = wte
+        (BASELINE.json configs[0], the reference's CPU plumbing case)."""
         L = cfg["n_layers"]
         ls, le = layer_range if layer_range else (0, L)
         self.cfg = cfg
@@ -355,6 +360,8 @@ class OracleModel:
             assert rc == 0
         if kv_head_offset:
             lib().jo_model_set_kv_head_offset(self.m, int(kv_head_offset))
+        if arch:
+            lib().jo_model_set_arch(self.m, int(arch))
 
     def embed_rows(self, tokens):
         tokens = np.ascontiguousarray(tokens, dtype=np.int32)
