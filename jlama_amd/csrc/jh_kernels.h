@@ -2194,6 +2194,188 @@ __global__ __launch_bounds__(PF_THREADS) void attn_prefill_kernel(PrefillAttnPar
     }
 }
 
+// ---- blockwise causal prefill attention on the matrix cores (reference loop CausalSelfAttention.java:199-357).
+// attn_prefill_kernel above re-reads every K/V row once per query row (O(n^2) traffic: 1.5 s of an 8100-row prompt).  Here a
+// workgroup owns a tile of 32 query rows of ONE kv head -- its GROUP waves are the GROUP query heads sharing that kv head, so a
+// K/V tile staged in LDS is read from HBM/L2 once per 32 x GROUP query rows -- and walks the causal key range in tiles of 32:
+//   S = Q K^T   v_mfma_f32_32x32x2_f32 (F32 in, F32 accumulate: exact products, a different summation order only), HS/2 per tile;
+//   online softmax per row in the reference's float/double recipe ((float)exp((double)(s - max)), running max / sum, rescale);
+//   O += P V    the same MFMA, HS/32 output tiles x 16 per key tile.
+// MFMA operand layout (32x32x2): A lane l = A[m = l&31][k = l>>5], B lane l = B[k = l>>5][n = l&31]; D reg r of lane l =
+// D[m = (r&3) + 8*(r>>2) + 4*(l>>5)][n = l&31].  The k index of an instruction is OURS to assign as long as A and B agree:
+// instruction j of QK^T multiplies dims (j, HS/2 + j) so that a lane's Q operands are HS/2 CONTIGUOUS floats, instruction j of
+// PV multiplies keys (j, 16 + j).  P goes from the D layout (lane = key column) to the A layout (lane = query row) through a
+// wave-private LDS transpose.  Long contexts: `nsplit` workgroups share the key range of a query tile (each a contiguous run of
+// key tiles), partial (O, max, sum) go to a workspace and attn_prefill_combine_kernel merges them in split order.
+struct PrefillMfmaExtra {
+    int nsplit;          // key-range splits per query tile
+    float* ws_o;         // [rows][n_heads][nsplit][HS] unnormalised partial outputs (nsplit > 1)
+    float* ws_ml;        // [rows][n_heads][nsplit][2]  (running max, running sum)
+};
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+
+template <int HS, int GROUP>
+__global__ __launch_bounds__(GROUP * 64) void attn_prefill_mfma_kernel(PrefillAttnParams p, PrefillMfmaExtra e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HS + 4;            // K tile row stride (floats): 16 consecutive lanes' ds_read_b128 hit distinct banks
+    constexpr int SS = 33;                // per-wave transpose buffer row stride
+    constexpr int NT = GROUP * 64;
+    float* Kt = (float*)smem;             // [32][KS]
+    float* Vt = Kt + 32 * KS;             // [32][HS]
+    float* Sx = Vt + 32 * HS;             // [GROUP][32][SS]
+    float* Cb = Sx + GROUP * 32 * SS;     // [GROUP][32]  per-row factors handed from the A layout to the D layout
+    const int tid = threadIdx.x, lane = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ml = lane & 31, kh = lane >> 5;
+    const int qt = blockIdx.x / e.nsplit, split = blockIdx.x - qt * e.nsplit;
+    const int kvh = blockIdx.y, head = kvh * GROUP + g;
+    const int start = p.start_pos[0];
+    const int KV = p.n_kv_heads * HS;
+    const int row0 = qt * 32;
+    int qrow = row0 + ml;
+    qrow = qrow < p.rows ? qrow : p.rows - 1;          // rows beyond the chunk replicate the last row (never stored)
+    const int qpos = start + qrow;
+    // key tiles this query tile needs: keys 0 .. start + min(row0 + 31, rows - 1)
+    const int last_row = (row0 + 31 < p.rows ? row0 + 31 : p.rows - 1);
+    const int ntiles = (start + last_row) / 32 + 1;
+    const int t_begin = (int)((long long)ntiles * split / e.nsplit), t_end = (int)((long long)ntiles * (split + 1) / e.nsplit);
+    // Q operands: lane (m, kh) holds Q[row m][head][kh*HS/2 + j], j < HS/2 (roped in place by rows_rope_kv_kernel)
+    float qa[HS / 2];
+    {
+        const float4* qp = (const float4*)(p.qkv + (size_t)qrow * p.ldqkv + (size_t)head * HS + kh * (HS / 2));
+#pragma unroll
+        for (int j = 0; j < HS / 8; j++) {
+            const float4 v = qp[j];
+            qa[4 * j] = v.x; qa[4 * j + 1] = v.y; qa[4 * j + 2] = v.z; qa[4 * j + 3] = v.w;
+        }
+    }
+    f32x16v oacc[HS / 32];
+#pragma unroll
+    for (int dt = 0; dt < HS / 32; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[dt][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    float* sx = Sx + g * 32 * SS;
+    float* cb = Cb + g * 32;
+    for (int kt = t_begin; kt < t_end; kt++) {
+        __syncthreads();                                 // every wave is done reading the previous tile
+        // ---- stage K and V rows kt*32 .. kt*32+31 of this kv head (positions beyond the newest row are clamped: masked below)
+#pragma unroll 4
+        for (int i = tid; i < 32 * (HS / 4); i += NT) {
+            const int k = i / (HS / 4), d4 = i - k * (HS / 4);
+            int t = kt * 32 + k;
+            const int tmax = start + p.rows - 1;
+            t = t < tmax ? t : tmax;
+            const float4 kv4 = ((const float4*)(kv_row(p, 0, t, KV) + (size_t)kvh * HS))[d4];
+            const float4 vv4 = ((const float4*)(kv_row(p, 1, t, KV) + (size_t)kvh * HS))[d4];
+            *(float4*)(Kt + k * KS + 4 * d4) = kv4;
+            *(float4*)(Vt + k * HS + 4 * d4) = vv4;
+        }
+        __syncthreads();
+        // ---- S = Q K^T over this key tile: lane (n = key, kh) feeds K[key n][kh*HS/2 + j]
+        f32x16v sacc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+        {
+            const float* kr = Kt + ml * KS + kh * (HS / 2);
+#pragma unroll
+            for (int j4 = 0; j4 < HS / 8; j4++) {
+                const float4 b = *(const float4*)(kr + 4 * j4);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[4 * j4 + 0], b.x, sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[4 * j4 + 1], b.y, sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[4 * j4 + 2], b.z, sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[4 * j4 + 3], b.w, sacc, 0, 0, 0);
+            }
+        }
+        // ---- D layout (lane = key column ml, regs = rows) -> wave-private LDS, scaled (ops.scale after the dot, :332)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sx[((r & 3) + 8 * (r >> 2) + 4 * kh) * SS + ml] = sacc[r] * p.scale;
+        // ---- A layout: lane (m = ml, kh) owns row m, keys kh*16 .. kh*16+15 of the tile; causal mask; online softmax
+        float sv[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int key = kt * 32 + kh * 16 + j;
+            float v = sx[ml * SS + kh * 16 + j];
+            v = key <= qpos ? v : -INFINITY;
+            sv[j] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));                // the other half of the row's keys
+        const float m_new = fmaxf(m_run, mx);
+        float ls = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float pj = sv[j] == -INFINITY ? 0.0f : (float)exp((double)(sv[j] - m_new));
+            sv[j] = pj;
+            ls += pj;
+        }
+        ls += __shfl_xor(ls, 32);
+        const float corr = m_run == -INFINITY ? 0.0f : (float)exp((double)(m_run - m_new));
+        l_run = l_run * corr + ls;
+        m_run = m_new;
+        if (kh == 0) cb[ml] = corr;
+        // ---- rescale O (D layout: reg r of lane (n, kh) is row (r&3) + 8*(r>>2) + 4*kh), then O += P V
+        float cr[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) cr[r] = cb[(r & 3) + 8 * (r >> 2) + 4 * kh];
+#pragma unroll
+        for (int dt = 0; dt < HS / 32; dt++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[dt][r] *= cr[r];
+            const float* vr = Vt + (kh * 16) * HS + dt * 32 + ml;     // V[key kh*16 + j][dim dt*32 + ml]
+#pragma unroll
+            for (int j = 0; j < 16; j++) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[j], vr[j * HS], oacc[dt], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: rows of the D layout need their (max, sum): hand them over through the per-wave buffer
+    __syncthreads();
+    if (kh == 0) { cb[ml] = l_run; sx[ml] = m_run; }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int row = row0 + m;
+        if (row >= p.rows) continue;
+        const float l = cb[m];
+        if (e.nsplit == 1) {
+            float* orow = p.out + (size_t)row * p.ldo + (size_t)head * HS;
+#pragma unroll
+            for (int dt = 0; dt < HS / 32; dt++) orow[dt * 32 + ml] = oacc[dt][r] / l;
+        } else {
+            float* orow = e.ws_o + (((size_t)row * p.n_heads + head) * e.nsplit + split) * HS;
+#pragma unroll
+            for (int dt = 0; dt < HS / 32; dt++) orow[dt * 32 + ml] = oacc[dt][r];
+            if (ml == 0) {
+                float* mlp = e.ws_ml + (((size_t)row * p.n_heads + head) * e.nsplit + split) * 2;
+                mlp[0] = sx[m];
+                mlp[1] = l;
+            }
+        }
+    }
+}
+static inline size_t prefill_mfma_lds(int hs, int group) { return ((size_t)32 * (hs + 4) + 32 * hs + (size_t)group * 32 * 33 + group * 32) * 4; }
+
+// merge the key-range splits of attn_prefill_mfma_kernel: w_s = exp(m_s - M), out = sum_s w_s O_s / sum_s w_s l_s (split order)
+__global__ __launch_bounds__(128) void attn_prefill_combine_kernel(PrefillAttnParams p, PrefillMfmaExtra e) {
+    const int row = blockIdx.x, head = blockIdx.y, HS = p.head_size;
+    const float* ml = e.ws_ml + ((size_t)row * p.n_heads + head) * e.nsplit * 2;
+    float M = -INFINITY;
+    for (int s = 0; s < e.nsplit; s++) M = fmaxf(M, ml[2 * s]);
+    float L = 0.0f;
+    for (int s = 0; s < e.nsplit; s++) {
+        const float w = ml[2 * s] == -INFINITY ? 0.0f : (float)exp((double)(ml[2 * s] - M));
+        L += ml[2 * s + 1] * w;
+    }
+    const float* ob = e.ws_o + ((size_t)row * p.n_heads + head) * e.nsplit * HS;
+    for (int d = threadIdx.x; d < HS; d += blockDim.x) {
+        float o = 0.0f;
+        for (int s = 0; s < e.nsplit; s++) {
+            const float w = ml[2 * s] == -INFINITY ? 0.0f : (float)exp((double)(ml[2 * s] - M));
+            o = fmaf(ob[(size_t)s * HS + d], w, o);
+        }
+        p.out[(size_t)row * p.ldo + (size_t)head * HS + d] = o / L;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Tier-1 generic kernels
 // One wave per output element C[i, j]; lanes stride over K.  Correct for every offset/stride combination the
 // reference's C entry points accept (nc/simd/vector_simd.h:22-38); used for M>1, windows, F32/BF16 operands.

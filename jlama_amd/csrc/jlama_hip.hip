@@ -1034,6 +1034,8 @@ struct jh_session {
     float *pb_x = nullptr, *pb_x1 = nullptr, *pb_qkv = nullptr, *pb_att = nullptr, *pb_g = nullptr, *pb_u = nullptr, *pb_ad = nullptr;
     int8_t* pb_aq = nullptr;
     float* pb_ws = nullptr;   // split-K workspace of the BF16 prefill GEMM
+    float *pb_att_o = nullptr, *pb_att_ml = nullptr;   // key-range split partials of the MFMA prefill attention
+    int prefill_attn_mfma_min = 384;   // chunks whose newest position reaches this many keys take attn_prefill_mfma_kernel
     int* pb_tok = nullptr;
     int* pb_start = nullptr;  // device word: start position of the chunk being prefilled
     std::map<uint64_t, hipGraphExec_t> pb_graphs;   // captured layer loops, key = rows | key-count bucket << 32
@@ -1298,6 +1300,7 @@ int layers_launch(jh_session* s, hipStream_t st, int pos_for_tap) {
 
 // ---- batched prefill -----------------------------------------------------------------------------------------------
 constexpr int PB_MAX_ROWS = 256;   // rows per chunk = the MFMA GEMM's M limit (8 tiles of 32)
+constexpr int PF_MAX_SPLIT = 8;    // key-range splits of the MFMA prefill attention
 
 bool prefill_batch_ok(jh_session* s) {
     const jh_config& c = s->m->c;
@@ -1313,8 +1316,11 @@ size_t prefill_attn_lds(const jh_config& c, int n_keys) {
     const int rps = PF_THREADS / (hs / 4);
     return ((size_t)rps * group * hs + (size_t)group * n_keys) * 4;
 }
-bool prefill_chunk_fits(jh_session* s, int start_pos, int rows) {   // the score rows of the last position must fit in LDS
-    return prefill_attn_lds(s->m->c, start_pos + rows) <= 150 * 1024;
+bool prefill_attn_mfma(const jh_session* s, int start_pos, int rows) {   // blockwise MFMA kernel for this chunk?
+    return s->prefill_attn_mfma_min >= 0 && start_pos + rows >= s->prefill_attn_mfma_min && rows >= 2;
+}
+bool prefill_chunk_fits(jh_session* s, int start_pos, int rows) {   // per-row kernel: the score rows of the last position must fit in LDS
+    return prefill_attn_mfma(s, start_pos, rows) || prefill_attn_lds(s->m->c, start_pos + rows) <= 150 * 1024;
 }
 int prefill_alloc(jh_session* s) {
     if (s->pb_rows) return JH_OK;
@@ -1334,6 +1340,8 @@ int prefill_alloc(jh_session* s) {
     HIPCHK(hipMalloc(&s->pb_tok, R * 4));
     HIPCHK(hipMalloc(&s->pb_start, 64));
     if (c.weight_dtype == JH_DT_BF16) HIPCHK(hipMalloc(&s->pb_ws, BF16_SPLITK_WS_BYTES));
+    HIPCHK(hipMalloc(&s->pb_att_o, R * c.n_heads * PF_MAX_SPLIT * c.head_size * 4));
+    HIPCHK(hipMalloc(&s->pb_att_ml, R * c.n_heads * PF_MAX_SPLIT * 2 * 4));
     s->pb_rows = PB_MAX_ROWS;
     return JH_OK;
 }
@@ -1455,7 +1463,7 @@ int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, 
     return launch_gemm_q8q4_mfma(g, st);
 }
 // nkeys_bound >= start_pos + rows sizes the score rows in LDS (the position itself is read from s->pb_start)
-int prefill_attn_launch(jh_session* s, int rel, int nkeys_bound, int rows, hipStream_t st) {
+int prefill_attn_launch(jh_session* s, int rel, int nkeys_bound, int rows, bool mfma, hipStream_t st) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
     const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
@@ -1475,6 +1483,29 @@ int prefill_attn_launch(jh_session* s, int rel, int nkeys_bound, int rows, hipSt
     p.out = s->pb_att; p.ldo = A;
     hipLaunchKernelGGL(rows_rope_kv_kernel, dim3(rows, 4), dim3(256), 0, st, p);   // 4 workgroups per row: the pair loop is latency-bound
     HIPCHK(hipGetLastError());
+    if (mfma) {
+        // blockwise causal attention on the matrix cores: (query tile of 32 rows) x (kv head) x (key-range split)
+        const int qtiles = (rows + 31) / 32, tiles_bound = (nkeys_bound + 31) / 32;
+        int S = 1;
+        while (S < PF_MAX_SPLIT && qtiles * c.n_kv_heads * S < g_cu_count && tiles_bound / (2 * S) >= 8) S *= 2;
+        PrefillMfmaExtra e{S, s->pb_att_o, s->pb_att_ml};
+        const size_t lds_m = prefill_mfma_lds(hs, group);
+        dim3 grid_m(qtiles * S, c.n_kv_heads), block_m(group * 64);
+#define JH_PMFMA(HSV, GV)                                                                         \
+    if (hs == HSV && group == GV) {                                                               \
+        JHCHK(allow_lds((attn_prefill_mfma_kernel<HSV, GV>), lds_m));                             \
+        hipLaunchKernelGGL((attn_prefill_mfma_kernel<HSV, GV>), grid_m, block_m, lds_m, st, p, e);  \
+        HIPCHK(hipGetLastError());                                                                \
+        if (S > 1) {                                                                              \
+            hipLaunchKernelGGL(attn_prefill_combine_kernel, dim3(rows, c.n_heads), dim3(128), 0, st, p, e); \
+            HIPCHK(hipGetLastError());                                                            \
+        }                                                                                         \
+        return JH_OK;                                                                             \
+    }
+        JH_PMFMA(128, 4) JH_PMFMA(128, 8) JH_PMFMA(64, 4) JH_PMFMA(128, 1) JH_PMFMA(128, 2) JH_PMFMA(64, 1) JH_PMFMA(64, 2) JH_PMFMA(64, 8)
+#undef JH_PMFMA
+        return set_err(JH_ERR_UNSUPPORTED, "prefill attention: unsupported head geometry");
+    }
     const size_t lds = prefill_attn_lds(c, nkeys_bound);
     dim3 grid(c.n_kv_heads, rows), block(PF_THREADS);
 #define JH_PATTN(HSV, GV)                                                                  \
@@ -1489,7 +1520,7 @@ int prefill_attn_launch(jh_session* s, int rel, int nkeys_bound, int rows, hipSt
     return set_err(JH_ERR_UNSUPPORTED, "prefill attention: unsupported head geometry");
 }
 // the layer loop of one chunk (also what the prefill graphs capture)
-int prefill_layers(jh_session* s, int rows, int nkeys_bound, hipStream_t st) {
+int prefill_layers(jh_session* s, int rows, int nkeys_bound, bool attn_mfma, hipStream_t st) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
     const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
@@ -1504,7 +1535,7 @@ int prefill_layers(jh_session* s, int rows, int nkeys_bound, hipStream_t st) {
         // preAttentionNorm + maybeQuantize, q|k|v projections (CausalSelfAttention.java:161-171)
         JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
         JHCHK(prefill_gemm(s, F, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, st));
-        JHCHK(prefill_attn_launch(s, rel, nkeys_bound, rows, st));
+        JHCHK(prefill_attn_launch(s, rel, nkeys_bound, rows, attn_mfma, st));
         // maybeQuantize(valueBatch) + output projection + residual (:364-376, TransformerBlock.java:185)
         JHCHK((rows_quant_launch<ROWS_QUANT>(s, s->pb_att, A, nullptr, 0, nullptr, 0.f, A, rows, st)));
         JHCHK(prefill_gemm(s, W[JH_W_O], E, A, rows, s->pb_x1, E, s->pb_x, st));
@@ -1547,15 +1578,16 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     // of a long prompt replays the same graph
     int bound = 1024;
     while (bound < start_pos + rows) bound *= 2;
-    if (!prefill_chunk_fits(s, 0, bound)) bound = start_pos + rows;
+    const bool attn_mfma = prefill_attn_mfma(s, start_pos, rows);
+    if (!attn_mfma && !prefill_chunk_fits(s, 0, bound)) bound = start_pos + rows;
     static const int use_graph = env_int("JH_PREFILL_GRAPH", 1);
     if (use_graph && !env_int("JH_TRACE", 0)) {
         drop_stale_graphs(s);
-        const uint64_t key = (uint64_t)rows | ((uint64_t)bound << 32);
+        const uint64_t key = (uint64_t)rows | ((uint64_t)(attn_mfma ? 1 : 0) << 16) | ((uint64_t)bound << 32);
         auto it = s->pb_graphs.find(key);
         if (it == s->pb_graphs.end()) {
             HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const int rc = prefill_layers(s, rows, bound, st);
+            const int rc = prefill_layers(s, rows, bound, attn_mfma, st);
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(st, &g);
             if (rc != JH_OK) { if (g) hipGraphDestroy(g); return rc; }
@@ -1567,7 +1599,7 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
         }
         HIPCHK(hipGraphLaunch(it->second, st));
     } else {
-        JHCHK(prefill_layers(s, rows, bound, st));
+        JHCHK(prefill_layers(s, rows, bound, attn_mfma, st));
     }
     // the chunk's last row is the session's current row (what sample() / the next shard's hand-off reads)
     HIPCHK(hipMemcpyAsync(s->x, s->pb_x + (size_t)(rows - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
@@ -1869,6 +1901,7 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 2), env_int("JH_LM_WAVES", 8), cu * env_int("JH_LM_GRIDX", 2), 1};   // tools/sweep_lm.py
     if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
     s->prefill_batch_min = env_int("JH_PREFILL_BATCH_MIN", 4);   // chunks of fewer rows go row by row; 0 disables batching
+    s->prefill_attn_mfma_min = env_int("JH_PREFILL_ATTN_MFMA_MIN", 384);   // -1: always the per-row kernel; 0: always the MFMA kernel
     s->graphs_version = m->weights_version;
     HIPCHK(hipHostMalloc((void**)&s->st_host, 2 * sizeof(DecodeState), hipHostMallocDefault));
     memset(s->st_host, 0, 2 * sizeof(DecodeState));
@@ -1930,7 +1963,7 @@ int jh_session_destroy(jh_session* s) {
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
-    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start}) if (b) hipFree(b);
+    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start, (void*)s->pb_att_o, (void*)s->pb_att_ml}) if (b) hipFree(b);
     for (auto& kv : s->pb_graphs) hipGraphExecDestroy(kv.second);
     for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
     if (s->ev0) hipEventDestroy(s->ev0);

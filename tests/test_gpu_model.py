@@ -509,3 +509,62 @@ def test_decode_attention_long_slices(gpu, oracle):
                 toks.append(ref_toks[i])
         finally:
             del os.environ["JH_ATTN_SPLITS"]
+
+
+@pytest.mark.parametrize("cfgname,mfma_min", [("SMALL", "0"), ("TINY", "0"), ("SMALL", "100")])
+def test_blockwise_mfma_prefill_attention(gpu, oracle, monkeypatch, cfgname, mfma_min):
+    """f4: attn_prefill_mfma_kernel (32-row query tiles x K/V tiles on v_mfma_f32_32x32x2_f32, online softmax, key-range
+    splits + combine) against the one-position-at-a-time decode path and the oracle: a 300-row prompt in two chunks (the
+    second starts at position 256: query tiles not aligned with... key tiles are absolute), a continuation at an odd
+    start position, head sizes 128 (SMALL, 4 heads per kv head) and 64 (TINY, 2 per kv head)."""
+    from jlama_amd import synthetic as S
+    cfg = dict(getattr(S, cfgname))
+    cfg["context_length"] = 1024
+    hm, om, _ = _pair(cfg, 23, oracle)
+    prompt = S.prompt_tokens(cfg, n=300, seed=24)
+    want = om.session().forward(prompt, 0)
+    monkeypatch.setenv("JH_PREFILL_BATCH_MIN", "0")
+    rows = hm.session(512).forward(prompt, 0)                 # decode kernels, one position at a time
+    monkeypatch.delenv("JH_PREFILL_BATCH_MIN")
+    monkeypatch.setenv("JH_PREFILL_ATTN_MFMA_MIN", mfma_min)
+    s = hm.session(512)
+    bat = s.forward(prompt, 0)
+    assert _rel(bat, want) <= TRUNK_TOL and _rel(bat, rows) <= TRUNK_TOL
+    assert np.abs(bat - rows)[:4].max() <= 1e-5               # before any I8 code flips: float-ordering noise only
+    # odd split: [0,37) then [37,300): the second call's query tiles start at position 37, key tiles at multiples of 32
+    s2 = hm.session(512)
+    a = s2.forward(prompt[:37], 0)
+    b = s2.forward(prompt[37:], 37)
+    assert _rel(np.concatenate([a, b]), want) <= TRUNK_TOL
+    # the KV pages / current row are what the decode path expects
+    th, lh = s.sample(0.0, 0.5, want_logits=True)
+    to, lo = om.sample(want[-1])
+    assert np.abs(lh - lo).max() <= LOGIT_TOL
+    ob = om.session()
+    ob.forward(prompt, 0)
+    tok = th
+    for i, g in enumerate(s.decode_n(th, prompt.size, 8)):
+        xo = ob.forward([tok], prompt.size + i)
+        no, lo = om.sample(xo[-1])
+        assert g == no or lo.max() - lo[g] <= LOGIT_TOL, (i, g, no)
+        tok = int(g)
+
+
+def test_blockwise_prefill_attention_is_exact_in_isolation(gpu, oracle, monkeypatch):
+    """The attention block alone, one layer, no quantizer downstream of it in the comparison: the `after_attention`
+    rows of the MFMA kernel against the per-row kernel on IDENTICAL q/k/v (same session weights, same prompt) must agree
+    to float-ordering level (1e-5 of the row scale) for every row of a 700-row prompt (3 chunks, key-range splits)."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.SMALL)
+    cfg.update(n_layers=1, context_length=1024)
+    hm, om, _ = _pair(cfg, 29, oracle)
+    prompt = S.prompt_tokens(cfg, n=699, seed=30)
+    monkeypatch.setenv("JH_PREFILL_ATTN_MFMA_MIN", "-1")
+    ref = hm.session(800).forward(prompt, 0)
+    monkeypatch.setenv("JH_PREFILL_ATTN_MFMA_MIN", "0")
+    got = hm.session(800).forward(prompt, 0)
+    # one layer: the outputs differ only through the attention rows (then one Q8 step); most rows see no code flip
+    rel = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    assert rel.max() <= 1.5e-2 and np.median(rel) <= 1e-5, (rel.max(), np.median(rel))
+    want = om.session().forward(prompt, 0)
+    assert _rel(got, want) <= TRUNK_TOL
