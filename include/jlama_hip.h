@@ -247,6 +247,21 @@ int jh_tp_ffn(jh_session* s, int layer, const float* reduced_attn_dev, float* pa
 int jh_tp_finish_layer(jh_session* s, const float* reduced_ffn_dev);  /* x = x1 + reduced */
 int jh_session_get_row(jh_session* s, float* out, int to_device);   /* the session's current row x [E] */
 
+/* ---- One-process layer-sharded pipeline (BASELINE north_star: "one-process layer sharding across the GPUs of
+ * a single node"): stage k is a session of a model created with its own [layer_start, layer_end) on the device that was
+ * current (jh_init) at creation; the first stage's model holds the embedding table, the last one final norm + LM head.
+ * One host thread queues every stage; a hop is a hipMemcpyPeerAsync of the [n, E] F32 activation (16 KiB per decode token)
+ * over xGMI ordered by events -- the PassRecord hand-off of jlama-net/.../Worker.java:193-248 without a host round trip --
+ * and the sampled token id travels back to stage 0 the same way (Coordinator.java:184).  Stages may share a device (loopback). */
+typedef struct jh_pipeline jh_pipeline;
+int jh_pipeline_create(jh_session* const* stages, int n_stages, jh_pipeline** out);
+int jh_pipeline_destroy(jh_pipeline* p);
+/* batchForward of n prompt rows at [start_pos, start_pos+n) through all stages, then sample (temperature 0) on the last. */
+int jh_pipeline_prefill(jh_pipeline* p, const int32_t* tokens, int n, int start_pos, int32_t* first_token);
+/* n greedy decode steps; returns after queueing (every stage's work is stream-ordered), _wait fetches the ids. */
+int jh_pipeline_decode_n_async(jh_pipeline* p, int32_t first_token, int start_pos, int n);
+int jh_pipeline_decode_wait(jh_pipeline* p, int32_t* out_tokens, int n);
+
 /* batchForward (AbstractModel.java:295-312): run rows through this shard's layers at positions
  * [start_pos, start_pos+n).  tokens != NULL: rows come from the embedding table (first shard);
  * else x_in (HOST, [n,E] F32) is the previous shard's output.  x_out (HOST [n,E], may be NULL) receives the

@@ -1415,6 +1415,7 @@ __global__ void add_rows_kernel(const float* a, const float* b, float* out, int 
     if (i < n) out[i] = a[i] + b[i];
 }
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
+__global__ void set_pos_kernel(DecodeState* st, int pos) { st->pos = pos; }   // pipeline stages: the token / step words stay
 __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
     st->pos = pos; st->token = token; st->step = step; st->done = 0;
 }

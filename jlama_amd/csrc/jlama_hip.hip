@@ -2466,6 +2466,171 @@ int jh_decode_n(jh_session* s, int32_t first_token, int start_pos, int n, int32_
     JHCHK(jh_decode_n_async(s, first_token, start_pos, n));
     return jh_decode_wait(s, out_tokens, n);
 }
+// ---- one-process layer-sharded pipeline ------------------------------------------------------------------------------
+struct jh_pipeline {
+    std::vector<jh_session*> st;          // stages in order
+    std::vector<float*> hop;              // per stage: [PB_MAX_ROWS, E] F32 on the stage's device (prefill hand-off landing zone)
+    std::vector<hipEvent_t> done;         // per stage: its part of the current row / chunk is complete
+    int pending_n = 0;
+};
+int jh_pipeline_create(jh_session* const* stages, int n_stages, jh_pipeline** out) {
+    if (!stages || n_stages <= 0 || !out) return set_err(JH_ERR_INVALID, "pipeline_create: bad argument");
+    for (int k = 0; k < n_stages; k++) {
+        if (!stages[k]) return set_err(JH_ERR_INVALID, "pipeline_create: null stage");
+        const jh_config& c = stages[k]->m->c;
+        const jh_config& c0 = stages[0]->m->c;
+        if (c.embedding_length != c0.embedding_length || c.n_layers != c0.n_layers)
+            return set_err(JH_ERR_INVALID, "pipeline_create: stages belong to different models");
+        if (k > 0 && c.layer_start != stages[k - 1]->m->c.layer_end)
+            return set_err(JH_ERR_INVALID, "pipeline_create: stage layer ranges must be contiguous and in order");
+    }
+    if (stages[0]->m->c.layer_start != 0 || stages[n_stages - 1]->m->c.layer_end != stages[0]->m->c.n_layers)
+        return set_err(JH_ERR_INVALID, "pipeline_create: stages must cover layers [0, n_layers)");
+    if (!stages[0]->m->global_w[JH_W_EMBED].data) return set_err(JH_ERR_INVALID, "pipeline_create: the first stage needs the embedding table");
+    jh_model* ml = stages[n_stages - 1]->m;
+    if (!lm_head_weight(ml)->data || !ml->global_w[JH_W_FINALNORM].data)
+        return set_err(JH_ERR_INVALID, "pipeline_create: the last stage needs final norm and LM head");
+    jh_pipeline* p = new jh_pipeline();
+    const size_t E = (size_t)stages[0]->m->c.embedding_length;
+    for (int k = 0; k < n_stages; k++) {
+        jh_session* s = stages[k];
+        p->st.push_back(s);
+        hipSetDevice(s->m->device);
+        float* h = nullptr;
+        hipEvent_t ev = nullptr;
+        if (hipMalloc(&h, (size_t)PB_MAX_ROWS * E * 4) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            p->hop.push_back(h); p->done.push_back(ev);
+            jh_pipeline_destroy(p);
+            return set_err(JH_ERR_OOM, "pipeline_create: hop buffers");
+        }
+        p->hop.push_back(h);
+        p->done.push_back(ev);
+        // direct xGMI copies between neighbouring stages (ignored when already enabled / same device)
+        if (k > 0 && stages[k - 1]->m->device != s->m->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, s->m->device, stages[k - 1]->m->device) == hipSuccess && can)
+                (void)hipDeviceEnablePeerAccess(stages[k - 1]->m->device, 0);
+            (void)hipGetLastError();
+        }
+    }
+    if (n_stages > 1 && stages[0]->m->device != stages[n_stages - 1]->m->device) {   // the token id's way back
+        hipSetDevice(stages[0]->m->device);
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, stages[0]->m->device, stages[n_stages - 1]->m->device) == hipSuccess && can)
+            (void)hipDeviceEnablePeerAccess(stages[n_stages - 1]->m->device, 0);
+        (void)hipGetLastError();
+    }
+    *out = p;
+    return JH_OK;
+}
+int jh_pipeline_destroy(jh_pipeline* p) {
+    if (!p) return JH_OK;
+    for (size_t k = 0; k < p->st.size(); k++) {
+        hipSetDevice(p->st[k]->m->device);
+        hipStreamSynchronize(p->st[k]->stream);
+        if (k < p->hop.size() && p->hop[k]) hipFree(p->hop[k]);
+        if (k < p->done.size() && p->done[k]) hipEventDestroy(p->done[k]);
+    }
+    delete p;
+    return JH_OK;
+}
+int jh_pipeline_prefill(jh_pipeline* p, const int32_t* tokens, int n, int start_pos, int32_t* first_token) {
+    if (!p || !tokens || n <= 0 || !first_token) return set_err(JH_ERR_INVALID, "pipeline_prefill: bad argument");
+    const int N = (int)p->st.size();
+    const size_t E = (size_t)p->st[0]->m->c.embedding_length;
+    for (int done = 0; done < n; done += PB_MAX_ROWS) {
+        const int rows = n - done < PB_MAX_ROWS ? n - done : PB_MAX_ROWS;
+        for (int k = 0; k < N; k++) {
+            jh_session* s = p->st[k];
+            HIPCHK(hipSetDevice(s->m->device));
+            // a stage may overwrite its hop buffer only after the next stage has pulled the previous chunk out of it
+            if (done > 0 && k + 1 < N) HIPCHK(hipStreamWaitEvent(s->stream, p->done[k + 1], 0));
+            if (k > 0) {
+                jh_session* prev = p->st[k - 1];
+                HIPCHK(hipStreamWaitEvent(s->stream, p->done[k - 1], 0));
+                // the previous stage left its [rows, E] output in ITS hop buffer; pull it across
+                HIPCHK(hipMemcpyPeerAsync(p->hop[k], s->m->device, p->hop[k - 1], prev->m->device, (size_t)rows * E * 4, s->stream));
+            }
+            // in place on the stage's own hop buffer: input rows -> output rows (stream-ordered inside jh_forward_device)
+            JHCHK(jh_forward_device(s, k == 0 ? tokens + done : nullptr, k == 0 ? nullptr : p->hop[k], rows, start_pos + done, p->hop[k]));
+            HIPCHK(hipEventRecord(p->done[k], s->stream));
+        }
+    }
+    jh_session* last = p->st[N - 1];
+    HIPCHK(hipSetDevice(last->m->device));
+    return jh_sample(last, 0.0f, 0.5f, first_token, nullptr);
+}
+int jh_pipeline_decode_n_async(jh_pipeline* p, int32_t first_token, int start_pos, int n) {
+    if (!p || n <= 0 || start_pos < 0) return set_err(JH_ERR_INVALID, "pipeline_decode_n: bad argument");
+    const int N = (int)p->st.size();
+    jh_session* s0 = p->st[0];
+    jh_session* sl = p->st[N - 1];
+    for (int k = 0; k < N; k++) {
+        if (start_pos + n > p->st[k]->max_ctx) return set_err(JH_ERR_INVALID, "pipeline_decode_n: positions beyond a stage's max_ctx");
+        JHCHK(check_positions(p->st[k], start_pos + n - 1));
+    }
+    if (first_token < 0 || first_token >= s0->m->c.vocab_size) return set_err(JH_ERR_INVALID, "pipeline_decode_n: token id out of range");
+    if (N == 1) { p->pending_n = n; return jh_decode_n_async(s0, first_token, start_pos, n); }
+    const size_t E = (size_t)s0->m->c.embedding_length;
+    const JWeight& emb = s0->m->global_w[JH_W_EMBED];
+    HIPCHK(hipSetDevice(sl->m->device));
+    JHCHK(ensure_out_tokens(sl, n));
+    // graphs first (a capture costs milliseconds and must not sit inside the queued loop)
+    for (int k = 0; k < N; k++) {
+        jh_session* s = p->st[k];
+        HIPCHK(hipSetDevice(s->m->device));
+        for (int v = 0; v < 2; v++) {
+            if (attn_variant_for(s, start_pos) != v && attn_variant_for(s, start_pos + n - 1) != v) continue;
+            if (k == N - 1) JHCHK(build_graph(s, v)); else JHCHK(build_row_graph(s, v));
+        }
+    }
+    HIPCHK(hipSetDevice(s0->m->device));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s0->stream, s0->st, start_pos, first_token, 0);
+    HIPCHK(hipSetDevice(sl->m->device));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, sl->stream, sl->st, start_pos, first_token, 0);
+    HIPCHK(hipEventRecord(sl->ev0, sl->stream));
+    for (int i = 0; i < n; i++) {
+        const int pos = start_pos + i;
+        for (int k = 0; k < N; k++) {
+            jh_session* s = p->st[k];
+            HIPCHK(hipSetDevice(s->m->device));
+            hipStream_t st = s->stream;
+            const int v = attn_variant_for(s, pos);
+            if (k == 0) {
+                if (i > 0) {   // the id sampled by the last stage for the previous position
+                    HIPCHK(hipStreamWaitEvent(st, p->done[N - 1], 0));
+                    HIPCHK(hipMemcpyPeerAsync(&s->st->token, s->m->device, &sl->st->token, sl->m->device, sizeof(int), st));
+                }
+                hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, s->st, pos);
+                hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                                   (const DecodeState*)s->st, (int)E, s->x);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipGraphLaunch(s->row_exec[v], st));
+            } else {
+                HIPCHK(hipStreamWaitEvent(st, p->done[k - 1], 0));
+                HIPCHK(hipMemcpyPeerAsync(s->x, s->m->device, p->st[k - 1]->x, p->st[k - 1]->m->device, E * 4, st));
+                hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, s->st, pos);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipGraphLaunch(k == N - 1 ? s->exec[v] : s->row_exec[v], st));   // last stage: layers + LM head + argmax
+            }
+            HIPCHK(hipEventRecord(p->done[k], st));
+        }
+    }
+    HIPCHK(hipSetDevice(sl->m->device));
+    HIPCHK(hipEventRecord(sl->ev1, sl->stream));
+    sl->pending_n = n;
+    p->pending_n = n;
+    return JH_OK;
+}
+int jh_pipeline_decode_wait(jh_pipeline* p, int32_t* out_tokens, int n) {
+    if (!p) return set_err(JH_ERR_INVALID, "pipeline_decode_wait: null");
+    jh_session* sl = p->st.back();
+    for (jh_session* s : p->st) { HIPCHK(hipSetDevice(s->m->device)); HIPCHK(hipStreamSynchronize(s->stream)); }
+    HIPCHK(hipSetDevice(sl->m->device));
+    p->pending_n = 0;
+    return jh_decode_wait(sl, out_tokens, n);
+}
+
 int jh_decode_stats(jh_session* s, double* ms_per_token, int32_t* kernels_per_token) {
     if (!s) return set_err(JH_ERR_INVALID, "decode_stats: null");
     if (ms_per_token) *ms_per_token = s->ms_per_token;

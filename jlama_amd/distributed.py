@@ -91,14 +91,16 @@ def pipeline_prefill(dist, engine, rank, world, session, prompt, E, device, dtyp
     return int(tok.item())
 
 
-def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_per_session, E, device, dtype):
-    """Greedy-decode ``steps_per_session`` tokens for each of ``world`` sessions with the sessions staggered across the
-    pipeline.  Work item q = (session q % N, step q // N); rank r handles item q at tick q + r.
+def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_per_session, E, device, dtype, n_sessions=None):
+    """Greedy-decode ``steps_per_session`` tokens for each of ``n_sessions`` (default: ``world``) sessions with the sessions
+    staggered across the pipeline.  Work item q = (session q % S, step q // S); every rank handles the items in that
+    order, so with S = world every GPU is busy on every tick and with S = 1 the run is the single-stream (batch-1) case.
     Returns the tokens the LAST rank sampled, as an int array [sessions, steps] (zeros on other ranks)."""
     import torch
     N = world
-    n_items = N * steps_per_session
-    out = np.zeros((N, steps_per_session), dtype=np.int32)
+    S = n_sessions if n_sessions else world
+    n_items = S * steps_per_session
+    out = np.zeros((S, steps_per_session), dtype=np.int32)
     x_in = torch.empty((1, E), dtype=dtype, device=device)
     x_out = [torch.empty((1, E), dtype=dtype, device=device) for _ in range(2)]
     tok_in = torch.zeros(1, dtype=torch.int32, device=device)
@@ -108,7 +110,7 @@ def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_pe
         q = tick - rank
         if q < 0 or q >= n_items:
             continue
-        j, k = q % N, q // N
+        j, k = q % S, q // S
         buf = tick & 1
         if rank == 0:
             if k == 0:
@@ -290,8 +292,56 @@ def tp_generate(dist, engine, rank, prompt, n_gen, cfg, device, dtype):
     return np.asarray(out, dtype=np.int32)
 
 
+def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=None):
+    """The one-process N-device host (jh_pipeline_*, BASELINE north_star): stage k on HIP device k, hops are stream-ordered
+    peer copies.  Measures the single-stream (batch-1) decode rate and the aggregate rate of N sessions in flight over the
+    same stage models.  Returns a dict (also printed as JSON by `python -m jlama_amd.distributed --one-process ...`)."""
+    import torch
+    from . import _native as N, synthetic as S, synthetic_torch as ST
+    from .model import HipPipeline, build_stage_models
+    cfg = dict(getattr(S, config))
+    devices = list(devices) if devices is not None else list(range(n_gpus))
+    n = len(devices)
+    prompt = S.prompt_tokens(cfg, n=prompt_n, seed=1234)
+    per_session = max(1, steps // n)
+    max_ctx = prompt.size + max(steps, warmup) + 8
+
+    def weights_for_stage(k, rng, dev):
+        torch.cuda.set_device(dev)
+        w = ST.make_weights(cfg, seed=0, layers=rng, device=f"cuda:{dev}", need_embed=(k == 0 or cfg.get("tied", False)), need_head=(k == n - 1))
+        torch.cuda.synchronize()
+        return w
+
+    models = build_stage_models(cfg, weights_for_stage, devices)
+    pipes = [HipPipeline(models, max_ctx) for _ in range(n)]
+    firsts = [p.prefill(prompt) for p in pipes]
+    if warmup > 0:
+        pipes[0].decode_n(firsts[0], prompt.size, warmup)
+    # single stream: one session, `steps` tokens
+    t0 = time.perf_counter()
+    toks = pipes[0].decode_n(firsts[0], prompt.size, steps)
+    dt_single = time.perf_counter() - t0
+    # N sessions in flight: every pipeline queued before any is awaited
+    t0 = time.perf_counter()
+    for p, f in zip(pipes, firsts):
+        p.decode_n_async(f, prompt.size, per_session)
+    outs = [p.decode_wait(per_session) for p in pipes]
+    dt_agg = time.perf_counter() - t0
+    same = all(np.array_equal(o, outs[0]) for o in outs) and np.array_equal(outs[0], toks[:per_session])
+    return {"mode": "one process, %d devices, hipMemcpyPeerAsync hops ordered by events" % n, "devices": devices,
+            "single_stream_tokens_per_s": round(steps / dt_single, 2), "single_stream_ms_per_token": round(dt_single / steps * 1e3, 4),
+            "aggregate_tokens_per_s": round(per_session * n / dt_agg, 2), "sessions": n, "steps_per_session": per_session,
+            "sessions_agree": bool(same)}
+
+
 def bench_pipeline(args, cfg):
-    """bench.py's N>1 leg (one rank per GPU under torch.distributed.run).  Returns the JSON dict on rank 0."""
+    """bench.py's N>1 leg (one rank per GPU under torch.distributed.run).  Returns the JSON dict on rank 0.
+    Three measurements: N sessions in flight through the rank-per-GPU RCCL pipeline (the timed K tokens of the contract),
+    the same pipeline with ONE session (single-stream, batch-1: bounded by a single GPU's rate by construction), and --
+    from rank 0 in a child process -- the one-process N-device host over the same GPUs."""
+    import json
+    import subprocess
+    import sys
     import torch
     import torch.distributed as dist
     from . import synthetic as S, synthetic_torch as ST
@@ -305,24 +355,44 @@ def bench_pipeline(args, cfg):
     dist.init_process_group(backend="nccl", device_id=device)
     L, E = cfg["n_layers"], cfg["embedding_length"]
     ls, le = layer_range(rank, world, L)
-    w = ST.make_weights(cfg, seed=0, layers=(ls, le), device=device, need_embed=(rank == 0), need_head=(rank == world - 1))
+    w = ST.make_weights(cfg, seed=0, layers=(ls, le), device=device, need_embed=(rank == 0 or cfg.get("tied", False)),
+                        need_head=(rank == world - 1))
     prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
     steps_per_session = max(1, args.steps // world)
-    max_ctx = prompt.size + max(steps_per_session, args.warmup) + 8
+    single_steps = max(8, min(64, args.steps))
+    max_ctx = prompt.size + max(steps_per_session, args.warmup, single_steps) + 8
     engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=world, max_ctx=max_ctx)
     firsts = [pipeline_prefill(dist, engine, rank, world, j, prompt, E, device, torch.float32) for j in range(world)]
     if args.warmup > 0:  # untimed decode ticks on the same sessions' KV tail (positions beyond the timed range are rewritten)
         pipeline_decode(dist, engine, rank, world, firsts, prompt.size, max(1, args.warmup // world), E, device, torch.float32)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    toks = pipeline_decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
+
+    def timed(fn):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return r, float(dt.item())
+
+    toks, dt = timed(lambda: pipeline_decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32))
+    _, dt1 = timed(lambda: pipeline_decode(dist, engine, rank, world, firsts[:1], prompt.size, single_steps, E, device, torch.float32,
+                                           n_sessions=1))
     total = steps_per_session * world
+    one_proc = None
+    if rank == 0 and world > 1 and not os.environ.get("JH_BENCH_NO_ONE_PROCESS"):
+        # the one-process host drives the same GPUs from a child process (its own HIP contexts); the ranks wait at the barrier
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+            r = subprocess.run([sys.executable, "-m", "jlama_amd.distributed", "--one-process", "--config", args.config, "--gpus", str(world),
+                                "--steps", str(args.steps), "--warmup", str(args.warmup), "--prompt", str(args.prompt)],
+                               capture_output=True, text=True, timeout=420, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            one_proc = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or "")[-400:]}
+        except Exception as e:   # noqa: BLE001 -- the contract line must be printed whatever this optional leg does
+            one_proc = {"error": repr(e)[:400]}
+    dist.barrier()
     out = None
     if rank == 0:
         tps = total / dt
@@ -333,9 +403,32 @@ def bench_pipeline(args, cfg):
                "ms_per_step": round(dt / total * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "i8xq4->f32", "data": "synthetic",
                "config": {"workload": f"{args.config} JQ4, {prompt.size}-row prefill + {steps_per_session} greedy decode steps x {world} "
-                                      f"sessions in flight", "parallelism": f"layer-sharded pp{world} ({L // world} layers/GPU), RCCL send/recv of [1,E] F32"},
-               "roofline": {"bound": "hbm", "achieved": round(bytes_per_token * tps / 1e9 / world, 1), "peak": 8000.0, "unit": "GB/s",
+                                      f"sessions in flight", "parallelism": f"layer-sharded pp{world} ({L // world} layers/GPU), RCCL send/recv of [1,E] F32",
+                          "sessions_in_flight": world, "aggregate_tokens_per_s": round(tps, 2),
+                          "per_session_tokens_per_s": round(tps / world, 2),
+                          "single_stream_tokens_per_s": round(single_steps / dt1, 2), "single_stream_steps": single_steps,
+                          "note": "value = aggregate of the sessions in flight; a single stream passes through all GPUs in sequence and "
+                                  "cannot exceed the 1-GPU rate (SURVEY.md 8d multi-GPU accounting)"},
+               "roofline": {"bound": "hbm", "kernel": "whole pipeline (per-kernel roofline is the 1-GPU run's: same kernels per stage)",
+                            "achieved": round(bytes_per_token * tps / 1e9 / world, 1), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(bytes_per_token * tps / 1e9 / world / 8000.0, 4), "traffic": None,
-                            "note": "per-GPU average: algorithmic bytes of all sessions / time / GPUs (kernel-level roofline is reported by the 1-GPU run)"}}
+                            "note": "per-GPU average: algorithmic bytes of all sessions / time / GPUs"},
+               "cpu_baseline": None, "one_process_pipeline": one_proc}
     dist.destroy_process_group()
     return out
+
+
+if __name__ == "__main__":
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--one-process", action="store_true")
+    ap.add_argument("--config", default="LLAMA3_8B")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--devices", default="")
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--prompt", type=int, default=128)
+    a = ap.parse_args()
+    devs = [int(d) for d in a.devices.split(",")] if a.devices else None
+    print(json.dumps(one_process_pipeline_bench(a.config, a.gpus, a.steps, a.warmup, a.prompt, devs)), flush=True)

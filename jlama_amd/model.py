@@ -245,3 +245,61 @@ class HipSession:
             self.close()
         except Exception:
             pass
+
+
+def build_stage_models(cfg, weights_for_stage, devices):
+    """Shard models of a one-process pipeline: stage k holds layers [k*L/N, (k+1)*L/N) (DistributedContext.java:75-77) on
+    HIP device devices[k].  weights_for_stage(k, (layer_start, layer_end), device) -> weight dict of stage k (the first
+    stage's with the embedding table, the last one's with final norm / LM head)."""
+    n = len(devices)
+    L = cfg["n_layers"]
+    if L % n:
+        raise ValueError(f"{L} layers do not split evenly over {n} stages")
+    per = L // n
+    return [HipLlamaModel(cfg, weights_for_stage(k, (k * per, (k + 1) * per), dev), layer_range=(k * per, (k + 1) * per), device=dev)
+            for k, dev in enumerate(devices)]
+
+
+class HipPipeline:
+    """One-process layer-sharded pipeline over the GPUs of one node (include/jlama_hip.h: jh_pipeline_*): one session per
+    stage model; activations hop device to device with stream-ordered peer copies, no host round trip per token.  Several
+    pipelines over the same stage models = several sessions in flight."""
+
+    def __init__(self, models, max_ctx):
+        self.models = list(models)
+        self.sessions = [m.session(max_ctx) for m in self.models]
+        n = len(self.sessions)
+        arr = (C.c_void_p * n)(*[s.h for s in self.sessions])
+        self.h = C.c_void_p()
+        N.check(N.lib().jh_pipeline_create(arr, n, C.byref(self.h)))
+
+    def prefill(self, tokens, start_pos=0):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        tok = C.c_int32()
+        N.check(N.lib().jh_pipeline_prefill(self.h, N.ptr(tokens), tokens.size, start_pos, C.byref(tok)))
+        return tok.value
+
+    def decode_n_async(self, first_token, start_pos, n):
+        N.check(N.lib().jh_pipeline_decode_n_async(self.h, int(first_token), int(start_pos), int(n)))
+
+    def decode_wait(self, n):
+        out = np.empty(n, dtype=np.int32)
+        N.check(N.lib().jh_pipeline_decode_wait(self.h, N.ptr(out), n))
+        return out[:self.sessions[-1].decode_generated()]
+
+    def decode_n(self, first_token, start_pos, n):
+        self.decode_n_async(first_token, start_pos, n)
+        return self.decode_wait(n)
+
+    def close(self):
+        if self.h:
+            N.lib().jh_pipeline_destroy(self.h)
+            self.h = C.c_void_p()
+        for s in self.sessions:
+            s.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -52,8 +52,10 @@ def _worker(rank, world, port, cfg, n_prompt, steps, q):
     prompts = [S.prompt_tokens(cfg, n=n_prompt, seed=100 + j) for j in range(world)]
     firsts = [D.pipeline_prefill(dist, eng, rank, world, j, prompts[j], E, "cpu", torch.float32) for j in range(world)]
     toks = D.pipeline_decode(dist, eng, rank, world, firsts, prompts[0].size, steps, E, "cpu", torch.float32)
+    # single-stream form (bench.py's batch-1 leg): ONE session through all stages; session 0 decodes the same positions again
+    single = D.pipeline_decode(dist, eng, rank, world, firsts[:1], prompts[0].size, steps, E, "cpu", torch.float32, n_sessions=1)
     if rank == world - 1:
-        q.put((firsts, toks.tolist()))
+        q.put((firsts, toks.tolist(), single.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,7 +74,7 @@ def test_layer_sharded_pipeline_matches_single_process(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, n_prompt, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    firsts, toks = q.get(timeout=240)
+    firsts, toks, single = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -84,6 +86,8 @@ def test_layer_sharded_pipeline_matches_single_process(world):
         want, _, _ = om.session().generate(prompt, steps + 1)
         assert firsts[j] == want[0]
         np.testing.assert_array_equal(np.array(toks[j]), want[1:])
+        if j == 0:
+            np.testing.assert_array_equal(np.array(single[0]), want[1:])
 
 
 def test_layer_range_matches_distributed_context():

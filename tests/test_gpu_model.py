@@ -568,3 +568,128 @@ def test_blockwise_prefill_attention_is_exact_in_isolation(gpu, oracle, monkeypa
     assert rel.max() <= 1.5e-2 and np.median(rel) <= 1e-5, (rel.max(), np.median(rel))
     want = om.session().forward(prompt, 0)
     assert _rel(got, want) <= TRUNK_TOL
+
+
+@pytest.mark.parametrize("stages", [2, 4])
+def test_one_process_pipeline_loopback_is_bit_identical(gpu, oracle, stages):
+    """jh_pipeline_*: the one-process layer-sharded host (BASELINE north_star) with every stage on device 0 -- peer copies
+    degenerate to device-to-device copies, the event choreography, per-stage position words, token feedback and hop-buffer
+    reuse are the multi-GPU ones.  Prompt longer than one 256-row chunk, then 40 greedy steps crossing the attention-variant
+    switch: ids and logits identical to the un-sharded model (same kernels, same order)."""
+    from jlama_amd import synthetic as S
+    from jlama_amd.model import HipLlamaModel, HipPipeline, build_stage_models
+    cfg = dict(S.SMALL)
+    cfg.update(n_layers=4, context_length=1024)
+    w = S.make_weights(cfg, seed=6, quantize=oracle.q4_quantize)
+    prompt = S.prompt_tokens(cfg, n=299, seed=4)
+    full = HipLlamaModel(cfg, w).session(600)
+    full.batch_forward(prompt, 0)
+    first = full.sample()
+    want = full.decode_n(first, prompt.size, 240)
+    models = build_stage_models(cfg, lambda k, rng, dev: w, [0] * stages)
+    pipe = HipPipeline(models, 600)
+    assert pipe.prefill(prompt) == first
+    got = pipe.decode_n(first, prompt.size, 240)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(pipe.sessions[-1].logits(), full.logits())
+    # a second prompt on the same pipeline (hop buffers and events are reused)
+    p2 = S.prompt_tokens(cfg, n=40, seed=5)
+    full2 = HipLlamaModel(cfg, w).session(600)
+    full2.batch_forward(p2, 0)
+    f2 = full2.sample()
+    assert pipe.prefill(p2) == f2
+    np.testing.assert_array_equal(pipe.decode_n(f2, p2.size, 16), full2.decode_n(f2, p2.size, 16))
+    # two pipelines over the same stage models, both queued before either is awaited (two sessions in flight)
+    pa, pb = HipPipeline(models, 600), HipPipeline(models, 600)
+    fa, fb = pa.prefill(prompt), pb.prefill(p2)
+    pa.decode_n_async(fa, prompt.size, 32)
+    pb.decode_n_async(fb, p2.size, 32)
+    np.testing.assert_array_equal(pa.decode_wait(32), want[:32])
+    np.testing.assert_array_equal(pb.decode_wait(32), full2.decode_n(f2, p2.size, 32))
+    for q in (pipe, pa, pb):
+        q.close()
+
+
+class _LoopbackDist:
+    """torch.distributed's send / recv / isend / broadcast between THREADS of one process (one per pipeline rank), so the
+    rank-per-GPU pipeline code (jlama_amd.distributed.pipeline_prefill / pipeline_decode + HipShardEngine) can run with
+    every shard on the one GPU of the test box.  Messages are device tensors cloned at send time."""
+
+    def __init__(self, rank, world, queues, torch):
+        self.rank, self.world, self.q, self.torch = rank, world, queues, torch
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def send(self, t, dst):
+        self.torch.cuda.synchronize()
+        self.q[(self.rank, dst)].put(t.clone())
+
+    def isend(self, t, dst):
+        self.send(t, dst)
+        return self._Done()
+
+    def recv(self, t, src):
+        t.copy_(self.q[(src, self.rank)].get(timeout=120))
+        self.torch.cuda.synchronize()
+
+    def broadcast(self, t, src):
+        if self.rank == src:
+            for d in range(self.world):
+                if d != src:
+                    self.send(t, d)
+        else:
+            self.recv(t, src)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rank_per_gpu_pipeline_engine_loopback(gpu, oracle, world):
+    """The code bench.py runs for --gpus N (HipShardEngine + pipeline_prefill / pipeline_decode) with N shards on ONE
+    device and an in-process transport: N sessions in flight and the single-stream form both reproduce the un-sharded
+    model's ids exactly."""
+    import queue
+    import threading
+    import torch
+    from jlama_amd import distributed as D, synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    cfg = dict(S.SMALL)
+    cfg["n_layers"] = 4
+    w = S.make_weights(cfg, seed=6, quantize=oracle.q4_quantize)
+    E, steps = cfg["embedding_length"], 12
+    prompts = [S.prompt_tokens(cfg, n=20, seed=100 + j) for j in range(world)]
+    want = []
+    full = HipLlamaModel(cfg, w)
+    for j in range(world):
+        s = full.session(64)
+        s.batch_forward(prompts[j], 0)
+        f = s.sample()
+        want.append((f, s.decode_n(f, prompts[j].size, steps)))
+    queues = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    results, errors = {}, []
+    dev = torch.device("cuda", 0)
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            dist = _LoopbackDist(rank, world, queues, torch)
+            eng = D.HipShardEngine(cfg, w, rank, world, 0, n_sessions=world, max_ctx=64)
+            firsts = [D.pipeline_prefill(dist, eng, rank, world, j, prompts[j], E, dev, torch.float32) for j in range(world)]
+            toks = D.pipeline_decode(dist, eng, rank, world, firsts, prompts[0].size, steps, E, dev, torch.float32)
+            single = D.pipeline_decode(dist, eng, rank, world, firsts[:1], prompts[0].size, steps, E, dev, torch.float32, n_sessions=1)
+            results[rank] = (firsts, toks, single)
+        except Exception as e:   # noqa: BLE001
+            import traceback
+            errors.append((rank, traceback.format_exc()))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[0][1]
+    firsts, toks, single = results[world - 1]
+    for j in range(world):
+        assert firsts[j] == want[j][0]
+        np.testing.assert_array_equal(toks[j], want[j][1])
+    np.testing.assert_array_equal(single[0], want[0][1])
