@@ -350,6 +350,14 @@ def bench_pipeline(args, cfg):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if world == 1:   # JH_BENCH_FORCE_PIPELINE=1 without a launcher: a one-rank group over the same code path
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port))):
+            os.environ.setdefault(k, v)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist.init_process_group(backend="nccl", device_id=device)
