@@ -247,6 +247,22 @@ int jh_tp_ffn(jh_session* s, int layer, const float* reduced_attn_dev, float* pa
 int jh_tp_finish_layer(jh_session* s, const float* reduced_ffn_dev);  /* x = x1 + reduced */
 int jh_session_get_row(jh_session* s, float* out, int to_device);   /* the session's current row x [E] */
 
+/* ---- One-process tensor-parallel group: N head-split shard sessions (one per device; loopback on one device allowed)
+ * driven by one host thread with no host synchronisation inside a layer.  The two reductions of a layer
+ * (tensorReducer, CausalSelfAttention.java:378 / MLPBlock.java:160; combine of JlamaService.java:300-376) are one-shot:
+ * every shard writes its [E] partial straight into a slot of every peer's buffer (peer stores over xGMI), an event orders
+ * the write against the readers, and each shard sums the N slots locally in SHARD ORDER 0..N-1 -- the order of the
+ * oracle's lock-step restatement, so results do not depend on arrival order. */
+typedef struct jh_tp_group jh_tp_group;
+int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** out);
+int jh_tp_group_destroy(jh_tp_group* g);
+/* rows of token ids at positions [start_pos, start_pos+n), one position at a time through all layers on every shard */
+int jh_tp_group_forward(jh_tp_group* g, const int32_t* tokens, int n, int start_pos);
+/* greedy sample on shard 0 (every shard holds the same residual stream) */
+int jh_tp_group_sample(jh_tp_group* g, int32_t* next_token);
+/* n greedy decode steps, everything queued without a host round trip; out_tokens: HOST [n] */
+int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int n, int32_t* out_tokens);
+
 /* ---- One-process layer-sharded pipeline (BASELINE north_star: "one-process layer sharding across the GPUs of
  * a single node"): stage k is a session of a model created with its own [layer_start, layer_end) on the device that was
  * current (jh_init) at creation; the first stage's model holds the embedding table, the last one final norm + LM head.

@@ -117,6 +117,11 @@ _PROTOS = {
     "jh_session_create": (_i, [_p, _i, _l, _p]),
     "jh_session_destroy": (_i, [_p]),
     "jh_session_page_info": (_i, [_p, _p]),
+    "jh_tp_group_create": (_i, [_p, _i, _p]),
+    "jh_tp_group_destroy": (_i, [_p]),
+    "jh_tp_group_forward": (_i, [_p, _p, _i, _i]),
+    "jh_tp_group_sample": (_i, [_p, _p]),
+    "jh_tp_group_decode_n": (_i, [_p, _i, _i, _i, _p]),
     "jh_pipeline_create": (_i, [_p, _i, _p]),
     "jh_pipeline_destroy": (_i, [_p]),
     "jh_pipeline_prefill": (_i, [_p, _p, _i, _i, _p]),

@@ -1415,6 +1415,23 @@ __global__ void add_rows_kernel(const float* a, const float* b, float* out, int 
     if (i < n) out[i] = a[i] + b[i];
 }
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
+// tensor-parallel one-shot reduction: a shard's partial [E] goes straight into its slot of EVERY shard's
+// slot buffer (peer stores over xGMI when the destination lives on another device) ...
+__global__ void tp_scatter_kernel(const float* part, float* const* dst, int n_dst, int E) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const float v = part[i];
+    for (int j = 0; j < n_dst; j++) dst[j][i] = v;
+}
+// ... and every shard sums the N slots locally, in shard order 0..N-1 (the lock-step order: results never depend on which
+// peer arrived first)
+__global__ void tp_sum_kernel(const float* slots, int n, int E, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    float v = slots[i];
+    for (int k = 1; k < n; k++) v = v + slots[(size_t)k * E + i];
+    out[i] = v;
+}
 __global__ void set_pos_kernel(DecodeState* st, int pos) { st->pos = pos; }   // pipeline stages: the token / step words stay
 __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
     st->pos = pos; st->token = token; st->step = step; st->done = 0;

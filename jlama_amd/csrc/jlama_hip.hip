@@ -2466,6 +2466,190 @@ int jh_decode_n(jh_session* s, int32_t first_token, int start_pos, int n, int32_
     JHCHK(jh_decode_n_async(s, first_token, start_pos, n));
     return jh_decode_wait(s, out_tokens, n);
 }
+// ---- one-process tensor-parallel group ---------------------------------------------------------------------------------
+struct jh_tp_group {
+    std::vector<jh_session*> sh;
+    std::vector<float*> part, red, slots;      // per shard, on its device: [E], [E], [2 rounds][N][E]
+    std::vector<float**> peers;                // per shard, on its device: [2 rounds][N] destination pointers of ITS slot on every shard
+    std::vector<hipEvent_t> evA, evB, evTok;
+};
+int jh_tp_group_destroy(jh_tp_group* g) {
+    if (!g) return JH_OK;
+    for (size_t k = 0; k < g->sh.size(); k++) {
+        hipSetDevice(g->sh[k]->m->device);
+        hipStreamSynchronize(g->sh[k]->stream);
+        if (k < g->part.size() && g->part[k]) hipFree(g->part[k]);
+        if (k < g->red.size() && g->red[k]) hipFree(g->red[k]);
+        if (k < g->slots.size() && g->slots[k]) hipFree(g->slots[k]);
+        if (k < g->peers.size() && g->peers[k]) hipFree(g->peers[k]);
+        if (k < g->evA.size() && g->evA[k]) hipEventDestroy(g->evA[k]);
+        if (k < g->evB.size() && g->evB[k]) hipEventDestroy(g->evB[k]);
+        if (k < g->evTok.size() && g->evTok[k]) hipEventDestroy(g->evTok[k]);
+    }
+    delete g;
+    return JH_OK;
+}
+int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** out) {
+    if (!shards || n_shards <= 0 || n_shards > 64 || !out) return set_err(JH_ERR_INVALID, "tp_group_create: bad argument");
+    for (int k = 0; k < n_shards; k++) {
+        if (!shards[k]) return set_err(JH_ERR_INVALID, "tp_group_create: null shard");
+        const jh_config &c = shards[k]->m->c, &c0 = shards[0]->m->c;
+        if (c.embedding_length != c0.embedding_length || c.n_layers != c0.n_layers || c.layer_start != 0 || c.layer_end != c.n_layers)
+            return set_err(JH_ERR_INVALID, "tp_group_create: shards must be head-split shards of ONE model holding all layers");
+        if (!shards[k]->m->global_w[JH_W_EMBED].data) return set_err(JH_ERR_INVALID, "tp_group_create: every shard needs the embedding table");
+    }
+    jh_tp_group* g = new jh_tp_group();
+    const int N = n_shards;
+    const size_t E = (size_t)shards[0]->m->c.embedding_length;
+    bool ok = true;
+    for (int k = 0; k < N && ok; k++) {
+        g->sh.push_back(shards[k]);
+        hipSetDevice(shards[k]->m->device);
+        float *p = nullptr, *r = nullptr, *sl = nullptr;
+        float** pe = nullptr;
+        hipEvent_t a = nullptr, b = nullptr, t = nullptr;
+        ok = hipMalloc(&p, E * 4) == hipSuccess && hipMalloc(&r, E * 4) == hipSuccess && hipMalloc(&sl, 2 * (size_t)N * E * 4) == hipSuccess &&
+             hipMalloc(&pe, 2 * (size_t)N * sizeof(float*)) == hipSuccess && hipEventCreateWithFlags(&a, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&t, hipEventDisableTiming) == hipSuccess;
+        g->part.push_back(p); g->red.push_back(r); g->slots.push_back(sl); g->peers.push_back(pe);
+        g->evA.push_back(a); g->evB.push_back(b); g->evTok.push_back(t);
+        for (int j = 0; j < k; j++)   // direct peer stores both ways
+            if (shards[j]->m->device != shards[k]->m->device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, shards[k]->m->device, shards[j]->m->device) == hipSuccess && can) {
+                    hipSetDevice(shards[k]->m->device); (void)hipDeviceEnablePeerAccess(shards[j]->m->device, 0);
+                    hipSetDevice(shards[j]->m->device); (void)hipDeviceEnablePeerAccess(shards[k]->m->device, 0);
+                }
+                (void)hipGetLastError();
+            }
+    }
+    if (!ok) { jh_tp_group_destroy(g); return set_err(JH_ERR_OOM, "tp_group_create: buffers"); }
+    for (int k = 0; k < N; k++) {   // shard k's slot on shard j, round r:  slots[j] + (r*N + k)*E
+        std::vector<float*> h(2 * (size_t)N);
+        for (int r = 0; r < 2; r++)
+            for (int j = 0; j < N; j++) h[(size_t)r * N + j] = g->slots[j] + ((size_t)r * N + k) * E;
+        hipSetDevice(shards[k]->m->device);
+        if (hipMemcpy(g->peers[k], h.data(), h.size() * sizeof(float*), hipMemcpyHostToDevice) != hipSuccess) {
+            jh_tp_group_destroy(g);
+            return set_err(JH_ERR_HIP, "tp_group_create: peer table upload");
+        }
+    }
+    *out = g;
+    return JH_OK;
+}
+namespace {
+// all layers of the row every shard currently holds in s->x at position `pos` (state words already set)
+int tp_group_layers(jh_tp_group* g, int pos) {
+    const int N = (int)g->sh.size();
+    const int E = g->sh[0]->m->c.embedding_length, L = g->sh[0]->m->c.n_layers;
+    const dim3 eg((E + 255) / 256), eb(256);
+    for (int li = 0; li < L; li++) {
+        for (int k = 0; k < N; k++) {
+            jh_session* s = g->sh[k];
+            HIPCHK(hipSetDevice(s->m->device));
+            s->attn_variant = attn_variant_for(s, pos);
+            JHCHK(layer_attn_launch(s, li, s->stream, false, 0, g->part[k], nullptr));
+            hipLaunchKernelGGL(tp_scatter_kernel, eg, eb, 0, s->stream, (const float*)g->part[k], (float* const*)g->peers[k], N, E);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(g->evA[k], s->stream));
+        }
+        for (int j = 0; j < N; j++) {
+            jh_session* s = g->sh[j];
+            HIPCHK(hipSetDevice(s->m->device));
+            for (int k = 0; k < N; k++) if (k != j) HIPCHK(hipStreamWaitEvent(s->stream, g->evA[k], 0));
+            hipLaunchKernelGGL(tp_sum_kernel, eg, eb, 0, s->stream, (const float*)g->slots[j], N, E, g->red[j]);
+            hipLaunchKernelGGL(add_rows_kernel, eg, eb, 0, s->stream, (const float*)s->x, (const float*)g->red[j], s->x1, E);   // TransformerBlock.java:185
+            HIPCHK(hipGetLastError());
+            JHCHK(layer_ffn_launch(s, li, s->stream, false, g->part[j], nullptr));
+            hipLaunchKernelGGL(tp_scatter_kernel, eg, eb, 0, s->stream, (const float*)g->part[j], (float* const*)(g->peers[j] + N), N, E);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(g->evB[j], s->stream));
+        }
+        for (int j = 0; j < N; j++) {
+            jh_session* s = g->sh[j];
+            HIPCHK(hipSetDevice(s->m->device));
+            for (int k = 0; k < N; k++) if (k != j) HIPCHK(hipStreamWaitEvent(s->stream, g->evB[k], 0));
+            hipLaunchKernelGGL(tp_sum_kernel, eg, eb, 0, s->stream, (const float*)(g->slots[j] + (size_t)N * E), N, E, g->red[j]);
+            hipLaunchKernelGGL(add_rows_kernel, eg, eb, 0, s->stream, (const float*)s->x1, (const float*)g->red[j], s->x, E);   // :203
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return JH_OK;
+}
+}  // namespace
+int jh_tp_group_forward(jh_tp_group* g, const int32_t* tokens, int n, int start_pos) {
+    if (!g || !tokens || n <= 0 || start_pos < 0) return set_err(JH_ERR_INVALID, "tp_group_forward: bad argument");
+    for (jh_session* s : g->sh) {
+        if (start_pos + n > s->max_ctx) return set_err(JH_ERR_INVALID, "tp_group_forward: position beyond a shard's max_ctx");
+        JHCHK(check_positions(s, start_pos + n - 1));
+    }
+    for (int i = 0; i < n; i++) {
+        if (tokens[i] < 0 || tokens[i] >= g->sh[0]->m->c.vocab_size) return set_err(JH_ERR_INVALID, "tp_group_forward: token id out of range");
+        for (jh_session* s : g->sh) JHCHK(jh_tp_set_row(s, tokens[i], nullptr, start_pos + i));
+        JHCHK(tp_group_layers(g, start_pos + i));
+    }
+    for (jh_session* s : g->sh) { HIPCHK(hipSetDevice(s->m->device)); HIPCHK(hipStreamSynchronize(s->stream)); }
+    return JH_OK;
+}
+int jh_tp_group_sample(jh_tp_group* g, int32_t* next_token) {
+    if (!g || !next_token) return set_err(JH_ERR_INVALID, "tp_group_sample: null");
+    return jh_sample(g->sh[0], 0.0f, 0.5f, next_token, nullptr);
+}
+int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int n, int32_t* out_tokens) {
+    if (!g || n <= 0 || start_pos < 0 || !out_tokens) return set_err(JH_ERR_INVALID, "tp_group_decode_n: bad argument");
+    const int N = (int)g->sh.size();
+    jh_session* s0 = g->sh[0];
+    for (jh_session* s : g->sh) {
+        if (start_pos + n > s->max_ctx) return set_err(JH_ERR_INVALID, "tp_group_decode_n: positions beyond a shard's max_ctx");
+        JHCHK(check_positions(s, start_pos + n - 1));
+    }
+    if (first_token < 0 || first_token >= s0->m->c.vocab_size) return set_err(JH_ERR_INVALID, "tp_group_decode_n: token id out of range");
+    if (!lm_head_weight(s0->m)->data || !s0->m->global_w[JH_W_FINALNORM].data) return set_err(JH_ERR_INVALID, "tp_group_decode_n: shard 0 needs the output weights");
+    HIPCHK(hipSetDevice(s0->m->device));
+    JHCHK(ensure_out_tokens(s0, n));
+    const int E = s0->m->c.embedding_length;
+    for (int k = 0; k < N; k++) {   // row of the first token on every shard; shard 0's step counter starts at 0
+        jh_session* s = g->sh[k];
+        const JWeight& emb = s->m->global_w[JH_W_EMBED];
+        HIPCHK(hipSetDevice(s->m->device));
+        hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s->stream, s->st, start_pos, first_token, 0);
+        hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, s->stream, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                           (const DecodeState*)s->st, E, s->x);
+        HIPCHK(hipGetLastError());
+    }
+    for (int i = 0; i < n; i++) {
+        const int pos = start_pos + i;
+        JHCHK(tp_group_layers(g, pos));
+        // shard 0 samples (Coordinator.java:184): final norm -> LM head -> argmax; finish_token_kernel advances its state
+        // and embeds the next row; the id then travels to the other shards, which embed it themselves
+        HIPCHK(hipSetDevice(s0->m->device));
+        JHCHK(lmhead_launch(s0, s0->stream));
+        JHCHK(finish_launch(s0, s0->stream, 1));
+        HIPCHK(hipEventRecord(g->evTok[0], s0->stream));
+        for (int k = 1; k < N && i + 1 < n; k++) {
+            jh_session* s = g->sh[k];
+            const JWeight& emb = s->m->global_w[JH_W_EMBED];
+            HIPCHK(hipSetDevice(s->m->device));
+            HIPCHK(hipStreamWaitEvent(s->stream, g->evTok[0], 0));
+            HIPCHK(hipMemcpyPeerAsync(&s->st->token, s->m->device, &s0->st->token, s0->m->device, sizeof(int), s->stream));
+            hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s->stream, s->st, pos + 1);
+            hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, s->stream, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                               (const DecodeState*)s->st, E, s->x);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(g->evTok[k], s->stream));
+        }
+        // shard 0 must not overwrite its token word (next finish) before the peers copied it: it waits for their copies
+        if (i + 1 < n) {
+            HIPCHK(hipSetDevice(s0->m->device));
+            for (int k = 1; k < N; k++) HIPCHK(hipStreamWaitEvent(s0->stream, g->evTok[k], 0));
+        }
+    }
+    for (jh_session* s : g->sh) { HIPCHK(hipSetDevice(s->m->device)); HIPCHK(hipStreamSynchronize(s->stream)); }
+    HIPCHK(hipSetDevice(s0->m->device));
+    HIPCHK(hipMemcpy(out_tokens, s0->out_tokens, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return JH_OK;
+}
+
 // ---- one-process layer-sharded pipeline ------------------------------------------------------------------------------
 struct jh_pipeline {
     std::vector<jh_session*> st;          // stages in order

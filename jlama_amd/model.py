@@ -303,3 +303,44 @@ class HipPipeline:
             self.close()
         except Exception:
             pass
+
+
+class HipTPGroup:
+    """One-process tensor-parallel group (include/jlama_hip.h: jh_tp_group_*): head-split shard models
+    (distributed.tp_shard_config / tp_shard_weights), one session each, reductions as one-shot peer writes + local sums in
+    shard order -- no host synchronisation inside a layer."""
+
+    def __init__(self, shard_models, max_ctx):
+        self.models = list(shard_models)
+        self.sessions = [m.session(max_ctx) for m in self.models]
+        n = len(self.sessions)
+        arr = (C.c_void_p * n)(*[s.h for s in self.sessions])
+        self.h = C.c_void_p()
+        N.check(N.lib().jh_tp_group_create(arr, n, C.byref(self.h)))
+
+    def forward(self, tokens, start_pos=0):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        N.check(N.lib().jh_tp_group_forward(self.h, N.ptr(tokens), tokens.size, start_pos))
+
+    def sample(self):
+        tok = C.c_int32()
+        N.check(N.lib().jh_tp_group_sample(self.h, C.byref(tok)))
+        return tok.value
+
+    def decode_n(self, first_token, start_pos, n):
+        out = np.empty(n, dtype=np.int32)
+        N.check(N.lib().jh_tp_group_decode_n(self.h, int(first_token), int(start_pos), int(n), N.ptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            N.lib().jh_tp_group_destroy(self.h)
+            self.h = C.c_void_p()
+        for s in self.sessions:
+            s.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

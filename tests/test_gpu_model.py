@@ -695,3 +695,67 @@ def test_rank_per_gpu_pipeline_engine_loopback(gpu, oracle, world):
         assert firsts[j] == want[j][0]
         np.testing.assert_array_equal(toks[j], want[j][1])
     np.testing.assert_array_equal(single[0], want[0][1])
+
+
+@pytest.mark.parametrize("size", [2, 4])
+def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, size):
+    """f2: jh_tp_group_* -- all head-split shards in one process (here on one device), the two reductions of a layer as
+    one-shot slot writes + local sums in shard order, nothing synchronised on the host inside a layer.  Bit-identical to
+    the same shards driven by hand with the partials summed in shard order (the path test_tensor_parallel_shards_loopback
+    checks against the oracle's lock-step restatement), and greedy decode through the group equals decode by hand."""
+    import torch
+    from jlama_amd import distributed as D, synthetic as S
+    from jlama_amd.model import HipLlamaModel, HipTPGroup
+    cfg = dict(S.SMALL)
+    cfg["n_kv_heads"] = 4 if size == 4 else cfg["n_kv_heads"]      # 4 shards need >= 4 kv heads (JlamaService.java:65-68)
+    w = S.make_weights(cfg, seed=41, quantize=oracle.q4_quantize)
+    prompt = S.prompt_tokens(cfg, n=12, seed=7)
+    E, L = cfg["embedding_length"], cfg["n_layers"]
+    models, osess = [], []
+    for r in range(size):
+        lc, off = D.tp_shard_config(cfg, r, size)
+        sw = D.tp_shard_weights(cfg, w, r, size)
+        models.append(HipLlamaModel(lc, sw, kv_head_offset=off))
+        osess.append(oracle.OracleModel(lc, sw, kv_head_offset=off).session())
+    # by hand: partials summed in shard order on the host side of the ABI
+    hand = [m.session(64) for m in models]
+    dev = torch.device("cuda", 0)
+    part = [torch.empty(E, dtype=torch.float32, device=dev) for _ in range(size)]
+
+    def hand_row(tok, pos):
+        for s in hand:
+            s.tp_set_row(int(tok), pos)
+        for li in range(L):
+            for s, p in zip(hand, part):
+                s.tp_attn(li, p.data_ptr()); s.synchronize()
+            red = part[0].clone()
+            for p in part[1:]:
+                red = red + p
+            torch.cuda.synchronize()
+            for s, p in zip(hand, part):
+                s.tp_ffn(li, red.data_ptr(), p.data_ptr()); s.synchronize()
+            red2 = part[0].clone()
+            for p in part[1:]:
+                red2 = red2 + p
+            torch.cuda.synchronize()
+            for s in hand:
+                s.tp_finish_layer(red2.data_ptr()); s.synchronize()
+        return hand[0].current_row()
+
+    rows = [hand_row(t, i) for i, t in enumerate(prompt)]
+    grp = HipTPGroup(models, 64)
+    grp.forward(prompt, 0)
+    for s in grp.sessions:
+        np.testing.assert_array_equal(s.current_row(), rows[-1])          # every shard: the same residual stream, same bits
+    want_tp = oracle.forward_tp(osess, prompt, 0)
+    assert _rel(rows[-1], want_tp[-1]) <= TRUNK_TOL
+    first = grp.sample()
+    assert first == hand[0].sample()
+    got = grp.decode_n(first, prompt.size, 10)
+    tok, want_ids = first, []
+    for i in range(10):
+        hand_row(tok, prompt.size + i)
+        tok = hand[0].sample()
+        want_ids.append(tok)
+    np.testing.assert_array_equal(got, np.array(want_ids, dtype=np.int32))
+    grp.close()
