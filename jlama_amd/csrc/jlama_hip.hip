@@ -110,6 +110,7 @@ int allow_lds(K kernel, size_t bytes) {
     return JH_OK;
 }
 
+std::mutex g_capture_mu;   // one hipGraph capture at a time per process (captures are rare; concurrent ones from different host threads are fragile)
 int g_trace = -1;
 int trace_sync(const char* what, hipStream_t st) {
     if (g_trace < 0) g_trace = env_int("JH_TRACE", 0);
@@ -1586,6 +1587,7 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
         const uint64_t key = (uint64_t)rows | ((uint64_t)(attn_mfma ? 1 : 0) << 16) | ((uint64_t)bound << 32);
         auto it = s->pb_graphs.find(key);
         if (it == s->pb_graphs.end()) {
+            std::lock_guard<std::mutex> cap(g_capture_mu);
             HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             const int rc = prefill_layers(s, rows, bound, attn_mfma, st);
             hipGraph_t g = nullptr;
@@ -2173,6 +2175,7 @@ static int build_row_graph(jh_session* s, int v) {
     if (s->row_exec[v]) return JH_OK;
     s->attn_variant = v;
     hipStream_t st = s->stream;
+    std::lock_guard<std::mutex> cap(g_capture_mu);
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     const int rc = layers_launch(s, st, 0);
     hipGraph_t g = nullptr;
@@ -2369,6 +2372,7 @@ static int build_graph(jh_session* s, int v) {
     const jh_config& c = s->m->c;
     const int saved_tap = s->tap_layer;
     s->tap_layer = -1;
+    std::lock_guard<std::mutex> cap(g_capture_mu);
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc = layers_launch(s, st, 0);
     const bool has_out = lm_head_weight(s->m)->data && s->m->global_w[JH_W_FINALNORM].data;

@@ -617,24 +617,29 @@ class _LoopbackDist:
     rank-per-GPU pipeline code (jlama_amd.distributed.pipeline_prefill / pipeline_decode + HipShardEngine) can run with
     every shard on the one GPU of the test box.  Messages are device tensors cloned at send time."""
 
-    def __init__(self, rank, world, queues, torch):
-        self.rank, self.world, self.q, self.torch = rank, world, queues, torch
+    def __init__(self, rank, world, queues, torch, lock):
+        self.rank, self.world, self.q, self.torch, self.lock = rank, world, queues, torch, lock
 
     class _Done:
         def wait(self):
             return None
 
     def send(self, t, dst):
-        self.torch.cuda.synchronize()
-        self.q[(self.rank, dst)].put(t.clone())
+        with self.lock:
+            self.torch.cuda.synchronize()
+            c = t.clone()
+            self.torch.cuda.synchronize()
+        self.q[(self.rank, dst)].put(c)
 
     def isend(self, t, dst):
         self.send(t, dst)
         return self._Done()
 
     def recv(self, t, src):
-        t.copy_(self.q[(src, self.rank)].get(timeout=120))
-        self.torch.cuda.synchronize()
+        m = self.q[(src, self.rank)].get(timeout=120)
+        with self.lock:
+            t.copy_(m)
+            self.torch.cuda.synchronize()
 
     def broadcast(self, t, src):
         if self.rank == src:
@@ -670,12 +675,31 @@ def test_rank_per_gpu_pipeline_engine_loopback(gpu, oracle, world):
     queues = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
     results, errors = {}, []
     dev = torch.device("cuda", 0)
+    gpu_lock = threading.Lock()
+
+    class LockedEngine(D.HipShardEngine):
+        """In the real launch every rank is its own process; here the ranks are threads of one process sharing one HIP
+        runtime, so device work of different ranks is serialised (hipGraph capture is not robust against other threads'
+        runtime calls).  The transport and the pipeline schedule are unaffected."""
+
+        def forward_tokens(self, *a):
+            with gpu_lock:
+                return super().forward_tokens(*a)
+
+        def forward_x(self, *a):
+            with gpu_lock:
+                return super().forward_x(*a)
+
+        def sample(self, *a):
+            with gpu_lock:
+                return super().sample(*a)
 
     def rank_main(rank):
         try:
             torch.cuda.set_device(0)
-            dist = _LoopbackDist(rank, world, queues, torch)
-            eng = D.HipShardEngine(cfg, w, rank, world, 0, n_sessions=world, max_ctx=64)
+            dist = _LoopbackDist(rank, world, queues, torch, gpu_lock)
+            with gpu_lock:
+                eng = LockedEngine(cfg, w, rank, world, 0, n_sessions=world, max_ctx=64)
             firsts = [D.pipeline_prefill(dist, eng, rank, world, j, prompts[j], E, dev, torch.float32) for j in range(world)]
             toks = D.pipeline_decode(dist, eng, rank, world, firsts, prompts[0].size, steps, E, dev, torch.float32)
             single = D.pipeline_decode(dist, eng, rank, world, firsts[:1], prompts[0].size, steps, E, dev, torch.float32, n_sessions=1)
