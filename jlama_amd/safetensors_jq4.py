@@ -199,12 +199,21 @@ def llama_config(model_dir):
     rs = c.get("rope_scaling")
     scaling = float(rs["factor"]) if rs and rs.get("rope_type") == "linear" else 1.0   # only "linear" is honoured (:56)
     eos = c.get("eos_token_id")
+    if eos is None:                       # LlamaConfig requires eos_token_id (an int or a list, LlamaConfig.java:36-40)
+        eos_tokens = []
+    else:
+        eos_tokens = [int(t) for t in eos] if isinstance(eos, list) else [int(eos)]
+    # headSize = embeddingLength / numberOfHeads for Llama models (LlamaConfig passes no headSize, Config.java:95): a `head_dim` key
+    # in config.json is not read by LlamaConfig.java:29-41, so a checkpoint where the two differ is not loadable there either
+    if "head_dim" in c and int(c["head_dim"]) != E // heads:
+        raise ValueError(f"config.json head_dim={c['head_dim']} != hidden_size/num_attention_heads={E // heads}: the reference derives "
+                         "headSize from the latter (Config.java:95) and cannot represent this model")
     return dict(embedding_length=E, hidden_length=int(c["intermediate_size"]), n_heads=heads,
-                n_kv_heads=int(c.get("num_key_value_heads", heads)), head_size=int(c.get("head_dim", E // heads)),
+                n_kv_heads=int(c.get("num_key_value_heads", heads)), head_size=E // heads,
                 n_layers=int(c["num_hidden_layers"]), vocab_size=int(c["vocab_size"]),
                 context_length=int(c["max_position_embeddings"]), rms_eps=float(c["rms_norm_eps"]),
                 rope_theta=float(c.get("rope_theta") or 10000.0), rope_scaling=scaling,
-                bos_token=int(c.get("bos_token_id", 1)), eos_tokens=list(eos) if isinstance(eos, list) else [eos],
+                bos_token=int(c.get("bos_token_id", 1)), eos_tokens=eos_tokens,
                 tied=bool(c.get("tie_word_embeddings", False)))
 
 
@@ -229,7 +238,15 @@ def load_llama_weights(model_dir, layer_range=None):
     ck = Checkpoint(model_dir)
     L = cfg["n_layers"]
     ls, le = layer_range if layer_range else (0, L)
-    cfg["weight_dtype"] = ck.info(tensor_name(ls, S.W_Q)).dtype == "Q4" and N.DT_Q4 or N.DT_BF16
+    qd = ck.info(tensor_name(ls, S.W_Q)).dtype
+    if qd not in ("Q4", "BF16"):          # resident models are JQ4 (I8 activations) or BF16 (include/jlama_hip.h: jh_model_create)
+        raise ValueError(f"{tensor_name(ls, S.W_Q)} is {qd}: this loader handles JQ4 ('Q4' + '.qb' scales) and BF16 checkpoints; "
+                         "quantize F32/F16 checkpoints with the reference's `jlama quantize` first")
+    cfg["weight_dtype"] = N.DT_Q4 if qd == "Q4" else N.DT_BF16
+    for slot in (S.W_NORM1, S.W_NORM2):
+        nd = ck.info(tensor_name(ls, slot)).dtype
+        if nd not in ("BF16", "F32"):
+            raise ValueError(f"{tensor_name(ls, slot)} is {nd}: norm weights must be BF16 or F32")
     w = {}
     tied = "lm_head.weight" not in ck.where
     cfg["tied"] = tied
