@@ -161,9 +161,7 @@ enum { PRO_Q8 = 0,       // already I8 + scales in global memory (Tier-1 jh_gemm
        PRO_QUANT_Q8 = 2, // Q8 quantize an F32 row (LlamaModel.maybeQuantize, core/model/llama/LlamaModel.java:176-184)
        PRO_F32 = 3,      // F32 row as is (F32xQ4)
        PRO_RMS_F32 = 4,  // RMSNorm, keep F32 (LM head: AbstractModel.java:443-449)
-       PRO_ATTN_Q8 = 5,  // combine the attention slices (softmax-weighted sum) then Q8 quantize: o-projection input
-       PRO_RMSH_Q8 = 6 };// PRO_RMS_Q8 with the norm weights read as BF16 (what checkpoints hold; widening is exact): half the
-                         // norm-weight bytes through the per-CU miss path, which is what bounds these kernels
+       PRO_ATTN_Q8 = 5 };// combine the attention slices (softmax-weighted sum) then Q8 quantize: o-projection input
 enum { EPI_STORE = 0,    // out[j] = dot
        EPI_RESID = 1,    // out[j] = dot + resid[j]            (TransformerBlock.java:185,203)
        EPI_SILU_MUL = 2 };// out[j] = silu(dot_gate[j]) * dot_up[j] (MLPBlock.java:132-142)
@@ -182,7 +180,6 @@ struct GemvParams {
     int ldbf;              // floats per scale row
     const float* x;        // F32 activation row (PRO_RMS_*, PRO_QUANT_Q8, PRO_F32)
     const float* nw;       // norm weights, F32 (BF16 on disk is widened at upload)
-    const uint16_t* nwh;   // PRO_RMSH_Q8: the same weights as BF16 (kept when the upload was BF16)
     float eps;
     const int8_t* aq;      // PRO_Q8: pre-quantized activation
     const float* ad;
@@ -254,14 +251,6 @@ __device__ __forceinline__ void load8_norm(const float* nw, int e0, float (&w)[8
     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
 }
 
-__device__ __forceinline__ void load8_norm_h(const uint16_t* nwh, int e0, float (&w)[8]) {   // 8 BF16 = one 16-byte load
-    const i32x4 v = *(const i32x4*)(nwh + e0);
-    w[0] = __int_as_float(v.x << 16); w[1] = __int_as_float(v.x & 0xffff0000);
-    w[2] = __int_as_float(v.y << 16); w[3] = __int_as_float(v.y & 0xffff0000);
-    w[4] = __int_as_float(v.z << 16); w[5] = __int_as_float(v.z & 0xffff0000);
-    w[6] = __int_as_float(v.w << 16); w[7] = __int_as_float(v.w & 0xffff0000);
-}
-
 // Quantize 8 consecutive values held by one lane; the 4 lanes of a quad cover one block of 32.
 // Panama quantizeQ8_512 (PTO:1684-1723): d = max/127, id = 127/max (0 if max==0), q = (byte)(x*id + 0.5f).
 __device__ __forceinline__ void quad_quantize_store(const float (&y)[8], int unit, const ActI8& a) {
@@ -311,22 +300,11 @@ struct ActRegsT {
     float po[UMAX][4][8];   // PRO_ATTN_Q8: this thread's 8 output elements of up to 4 slices
     float m, l;             // PRO_ATTN_Q8: (max, sum) of slice (tid&3) of head (tid>>2)
     int n;                  // context length pos+1
-    i32x4 ql, qh;           // PRO_Q8: block min(tid, nblk-1) of the pre-quantized row, requested BEFORE the weight stream
-    float qd;
 };
 template <int PRO>
 __device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegsT<UMaxFor<PRO>::v>& r) {
     constexpr int UMAX = UMaxFor<PRO>::v;
-    if (PRO == PRO_Q8) {
-        // vmcnt retires oldest-first: the codes must be requested before the weights or this prologue waits for every weight byte
-        const int nblk = p.K / QB;
-        const int b = (int)threadIdx.x < nblk ? (int)threadIdx.x : nblk - 1;
-        const i32x4* src = (const i32x4*)(p.aq + (size_t)b * QB);
-        r.ql = src[0];
-        r.qh = src[1];
-        r.qd = p.ad[b];
-        return;
-    }
+    if (PRO == PRO_Q8) return;
     const int units = p.K / 8, T = blockDim.x;
     // branch-free (clamped) addresses: a guarded load would make hipcc wait for it at the end of its basic block,
     // serialising this round trip with the weight stream that is issued next
@@ -346,7 +324,6 @@ __device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegsT<UMaxFo
         r.xv[u][0] = xa.x; r.xv[u][1] = xa.y; r.xv[u][2] = xa.z; r.xv[u][3] = xa.w;
         r.xv[u][4] = xb.x; r.xv[u][5] = xb.y; r.xv[u][6] = xb.z; r.xv[u][7] = xb.w;
         if (PRO == PRO_RMS_Q8) load8_norm(p.nw, unit * 8, r.wv[u]);
-        if (PRO == PRO_RMSH_Q8) load8_norm_h(p.nwh, unit * 8, r.wv[u]);
         if (PRO == PRO_ATTN_Q8) {
             const int e0 = unit * 8, h = e0 / p.head_size, d0 = e0 - h * p.head_size;
 #pragma unroll
@@ -364,21 +341,18 @@ __device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a
     constexpr int UMAX = UMaxFor<PRO>::v;
     const int K = p.K, nblk = K / QB;
     if (PRO == PRO_Q8) {
-        auto put = [&](int blk, const i32x4& l, const i32x4& h, float d) {
+        for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
+            const i32x4* src = (const i32x4*)(p.aq + (size_t)blk * QB);
+            i32x4 l = src[0], h = src[1];
             a.lo[blk] = l;
             a.hi[blk] = h;
-            a.d[blk] = d;
+            a.d[blk] = p.ad[blk];
             int s = 0;
             s = sdot4(l.x, 0x01010101, s); s = sdot4(l.y, 0x01010101, s);
             s = sdot4(l.z, 0x01010101, s); s = sdot4(l.w, 0x01010101, s);
             s = sdot4(h.x, 0x01010101, s); s = sdot4(h.y, 0x01010101, s);
             s = sdot4(h.z, 0x01010101, s); s = sdot4(h.w, 0x01010101, s);
             a.asum[blk] = s;
-        };
-        if ((int)threadIdx.x < nblk) put(threadIdx.x, r.ql, r.qh, r.qd);          // fetched by stage_issue, ahead of the weights
-        for (int blk = threadIdx.x + blockDim.x; blk < nblk; blk += blockDim.x) {   // rows longer than the workgroup
-            const i32x4* src = (const i32x4*)(p.aq + (size_t)blk * QB);
-            put(blk, src[0], src[1], p.ad[blk]);
         }
     } else {
         const int units = K / 8, T = blockDim.x;
@@ -402,7 +376,7 @@ __device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a
             }
             lds_barrier();
         }
-        if (PRO == PRO_RMS_Q8 || PRO == PRO_RMSH_Q8) {
+        if (PRO == PRO_RMS_Q8) {
             // RMSNorm (core/model/RMSNorm.java:41-49): float squares, double sum, /E, +eps, 1/sqrt in double
             double ss = 0.0;
 #pragma unroll
@@ -427,7 +401,7 @@ __device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a
             if (unit < units) {
                 float y[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) y[i] = (PRO == PRO_RMS_Q8 || PRO == PRO_RMSH_Q8) ? r.wv[u][i] * (fs * r.xv[u][i]) : r.xv[u][i];  // (0 + w) * ((float)ss * x)
+                for (int i = 0; i < 8; i++) y[i] = (PRO == PRO_RMS_Q8) ? r.wv[u][i] * (fs * r.xv[u][i]) : r.xv[u][i];  // (0 + w) * ((float)ss * x)
                 if (PRO == PRO_ATTN_Q8 && direct) {
                     const int h = (unit * 8) / p.head_size;
 #pragma unroll
@@ -450,9 +424,9 @@ __device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a
         for (int unit = threadIdx.x + UMAX * T; unit < units; unit += T) {
             const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
             float y[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-            if (PRO == PRO_RMS_Q8 || PRO == PRO_RMSH_Q8) {
+            if (PRO == PRO_RMS_Q8) {
                 float w[8];
-                if (PRO == PRO_RMSH_Q8) load8_norm_h(p.nwh, unit * 8, w); else load8_norm(p.nw, unit * 8, w);
+                load8_norm(p.nw, unit * 8, w);
 #pragma unroll
                 for (int i = 0; i < 8; i++) y[i] = w[i] * (fs * y[i]);
             }
@@ -1561,8 +1535,6 @@ struct AttnParams {
     int direct_max;        // contexts up to this length use "direct" mode: <= 4 slices of direct_chunk rows, combined by
     int direct_chunk;      //   the o-projection's prologue (PRO_ATTN_Q8); 0 disables
     float* outf;           // [A] attention output, ticket mode only (the o-projection then quantizes it)
-    int8_t* out_q;         // optional: the same output already Q8-quantized (Panama rule, blocks of 32 along A) for the
-    float* out_d;          //   o-projection's PRO_Q8 prologue: 4.6 KB instead of 16 KB through every CU
     float* tap_q;          // roped q [A] (tap), may be null
     long long* dbg;        // optional phase timestamps (wall_clock64, 100 MHz) of workgroups with kvh == 0: [split][16]
     int combine_kernel;    // 1: slices only publish (plain stores); attn_combine_kernel merges them after the kernel edge
@@ -1923,35 +1895,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
     }
     JH_ATT_STAMP(9);   // combined
     for (int i = tid; i < GROUP * HS; i += NT) p.outf[(size_t)kvh * GROUP * HS + i] = oloc[i];
-    if (p.out_q) {
-        // maybeQuantize(valueBatch) (CausalSelfAttention.java:364) done here for the kv head's GROUP*HS outputs: 8 values
-        // per thread, a quad of lanes = one Q8 block (same expressions as quad_quantize_store)
-        for (int unit = tid; unit < GROUP * HS / 8; unit += NT) {   // GROUP*HS/8 is a multiple of 4: quads stay together
-            float y[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) y[i] = oloc[unit * 8 + i];
-            float amax = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(y[i]));
-            amax = fmaxf(amax, dpp_f<0xB1>(amax));
-            amax = fmaxf(amax, dpp_f<0x4E>(amax));
-            const float d = amax / 127.0f;
-            const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
-            int q[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                float v = y[i] * id;
-                v = v + 0.5f;
-                q[i] = f2b(v);
-            }
-            i32x2 packed;
-            packed.x = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-            packed.y = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
-            const size_t e0 = (size_t)kvh * GROUP * HS + (size_t)unit * 8;
-            *(i32x2*)(p.out_q + e0) = packed;
-            if ((unit & 3) == 0) p.out_d[e0 / QB] = d;
-        }
-    }
 }
 
 // Merge the slices of attn_decode_kernel (combine_kernel mode): w_s = l_s*exp(m_s - M) / sum_s(l_s*exp(m_s - M)),

@@ -980,7 +980,6 @@ struct JWeight {
     int rows = 0, cols = 0;
     uint8_t* tiled = nullptr;        // Q4 only: resident copy in MFMA order for the prefill GEMM (made at first use)
     float* tiled_scales = nullptr;
-    uint16_t* bf16 = nullptr;        // norm weights uploaded as BF16: the original 2-byte values (decode prologues read these)
 };
 struct jh_model {
     jh_config c;
@@ -1044,10 +1043,6 @@ struct jh_session {
     std::vector<hipGraph_t> pb_graph_src;
     int prefill_batch_min = 4;
     int strict = 0;           // jh_session_set_strict: Panama-order kernels (jh_strict.h)
-    int norm_bf16 = 1;        // decode prologues read BF16 norm weights where the checkpoint had BF16 (JH_NORM_BF16=0 disables)
-    int attn_q8 = 1;          // the attention kernel also emits its output Q8-quantized for the o-projection (JH_ATTN_Q8=0 disables)
-    int8_t* att_q = nullptr;  // [A] codes, [A/32] scales
-    float* att_d = nullptr;
     // stop tokens (jh_session_set_eos): device copy for finish_token_kernel + host-side feeding control
     int* eos_dev = nullptr;
     int n_eos = 0;
@@ -1073,10 +1068,6 @@ namespace {
 
 bool is_global_slot(int which) { return which == JH_W_EMBED || which == JH_W_LMHEAD || which == JH_W_FINALNORM; }
 
-// the decode attention kernel quantizes its own output for the o-projection (ticket mode of a JQ4 model only)
-bool attn_emits_q8(const jh_session* s) {
-    return s->attn_q8 && !s->strict && s->m->c.weight_dtype == JH_DT_Q4 && s->direct_max == 0 && !s->attn_combine;
-}
 // ---- strict-order launchers (jh_strict.h): 4 waves x 4 output rows per workgroup
 template <int PRO, int EPI>
 int launch_gemv_i8q4_strict(const GemvParams& p, hipStream_t st) {
@@ -1132,7 +1123,6 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     p.tap_q = tap ? s->tapq : nullptr;
     p.dbg = dbg;
     p.combine_kernel = (s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0;
-    if (attn_emits_q8(s)) { p.out_q = s->att_q; p.out_d = s->att_d; }
     if (s->strict) {
         const size_t lds_s = lds_bytes_attn_strict(c.head_size, s->max_ctx);
         if (lds_s > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "strict attention: the score row of max_ctx positions must fit in LDS");
@@ -1202,7 +1192,6 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st))); }
         else if (s->strict) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_STORE>(p, st)));
-        else if (W[JH_W_NORM1].bf16 && s->norm_bf16) { p.nwh = W[JH_W_NORM1].bf16; JHCHK((launch_gemv_i8q4<PRO_RMSH_Q8, EPI_STORE>(p, s->cfg_qkv, st))); }
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
         JHCHK(trace_sync("qkv", st));
     }
@@ -1233,10 +1222,6 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         } else if (s->strict) {
             if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
             else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
-        } else if (attn_emits_q8(s)) {
-            p.aq = s->att_q; p.ad = s->att_d;   // maybeQuantize(valueBatch) (:364) already done by the attention kernel
-            if (resid) JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_o, st)));
-            else JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_STORE>(p, s->cfg_o, st)));
         } else if (!resid) {
             JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_STORE>(p, s->cfg_o, st)));
         } else if (s->direct_max > 0) {
@@ -1274,7 +1259,6 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
         p.out = s->hf;   // silu(gate)*up, F32; the down projection's prologue quantizes it (MLPBlock.java:144)
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, g_cu_count * 4, nullptr, st))); }
         else if (s->strict) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
-        else if (W[JH_W_NORM2].bf16 && s->norm_bf16) { p.nwh = W[JH_W_NORM2].bf16; JHCHK((launch_gemv_i8q4<PRO_RMSH_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st))); }
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
         JHCHK(trace_sync("gateup", st));
     }
@@ -1722,11 +1706,10 @@ int jh_model_destroy(jh_model* m) {
         if (w.scales) hipFree(w.scales);
         if (w.tiled) hipFree(w.tiled);
         if (w.tiled_scales) hipFree(w.tiled_scales);
-        if (w.bf16) hipFree(w.bf16);
     }
     for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); }
     for (auto& w : m->gateup) { if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); }
-    for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.bf16) hipFree(w.bf16); }
+    for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
     if (m->rope) hipFree(m->rope);
     delete m;
     return JH_OK;
@@ -1756,12 +1739,6 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
         return set_err(JH_ERR_UNSUPPORTED, "set_weight: matmul weights must have the model's weight_dtype (Q4 or BF16)");
     std::vector<float> widened;
     void* widened_dev = nullptr;
-    uint16_t* keep_bf16 = nullptr;
-    if (is_norm && dtype == JH_DT_BF16) {
-        const size_t nb16 = (size_t)rows * cols * 2;
-        HIPCHK(hipMalloc((void**)&keep_bf16, nb16 + 64));
-        HIPCHK(hipMemcpy(keep_bf16, data, nb16, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    }
     if (is_norm && dtype == JH_DT_BF16) {
         // 1-D norm weights (BF16 on disk, never quantized: AbstractTensor.java:284) are widened to F32 once; exact.
         const size_t n = (size_t)rows * cols;
@@ -1816,8 +1793,6 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     }
     if (w->data) hipFree(w->data);
     if (w->scales) hipFree(w->scales);
-    if (w->bf16) hipFree(w->bf16);
-    w->bf16 = keep_bf16;
     if (w->tiled) { hipFree(w->tiled); hipFree(w->tiled_scales); w->tiled = nullptr; w->tiled_scales = nullptr; }
     if (layer >= 0 && (which == JH_W_GATE || which == JH_W_UP)) {
         JWeight& gu = m->gateup[(size_t)layer];
@@ -1899,10 +1874,6 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     HIPCHK(hipMalloc(&s->qkv, (size_t)(A + 2 * KV) * 4));
     HIPCHK(hipMalloc(&s->attf, (size_t)A * 4));
     HIPCHK(hipMalloc(&s->tapq, (size_t)A * 4));
-    HIPCHK(hipMalloc(&s->att_q, (size_t)A + 64));
-    HIPCHK(hipMalloc(&s->att_d, (size_t)(A / QB) * 4 + 64));
-    s->norm_bf16 = env_int("JH_NORM_BF16", 1);
-    s->attn_q8 = env_int("JH_ATTN_Q8", 1);
     HIPCHK(hipMalloc(&s->hf, (size_t)H * 4));
     HIPCHK(hipMalloc(&s->logits, (size_t)c.vocab_size * 4));
     HIPCHK(hipMalloc(&s->amax_v, 4096 * 4));
@@ -1990,7 +1961,7 @@ int jh_session_destroy(jh_session* s) {
         if (s->row_graph[v]) hipGraphDestroy(s->row_graph[v]);
     }
     if (s->kv_slab) hipFree(s->kv_slab);
-    void* bufs[] = {s->pages_dev, s->x, s->x1, s->qkv, s->attf, s->tapq, s->hf, s->logits, s->att_q, s->att_d,
+    void* bufs[] = {s->pages_dev, s->x, s->x1, s->qkv, s->attf, s->tapq, s->hf, s->logits,
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
@@ -2106,17 +2077,13 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                 p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
                 p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
                 p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
-                if (W[JH_W_NORM1].bf16 && s->norm_bf16) { p.nwh = W[JH_W_NORM1].bf16; JHCHK((launch_gemv_i8q4<PRO_RMSH_Q8, EPI_STORE>(p, s->cfg_qkv, st))); }
-                else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
+                JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
             } else if (which == 1) {
                 JHCHK(attn_launch(s, li - c.layer_start, st, false));
             } else if (which == 2) {
                 p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = s->x1;
                 p.K = A; p.ldb = A / 2; p.ldbf = A / QB; p.x = s->attf; p.resid = s->x;
-                if (attn_emits_q8(s)) {
-                    p.aq = s->att_q; p.ad = s->att_d;
-                    JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_o, st)));
-                } else if (s->direct_max > 0) {
+                if (s->direct_max > 0) {
                     p.part_o = s->part_o; p.part_ml = s->part_ml; p.st = s->st; p.direct_max = s->direct_max;
                     p.direct_chunk = s->direct_chunk; p.part_stride = s->part_stride; p.head_size = hs; p.n_heads = c.n_heads;
                     JHCHK((launch_gemv_i8q4<PRO_ATTN_Q8, EPI_RESID>(p, s->cfg_o, st)));
@@ -2129,8 +2096,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                 p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
                 p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
                 p.out = s->hf;
-                if (W[JH_W_NORM2].bf16 && s->norm_bf16) { p.nwh = W[JH_W_NORM2].bf16; JHCHK((launch_gemv_i8q4<PRO_RMSH_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st))); }
-                else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
+                JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
             } else if (which == 4) {
                 p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x1;
                 p.K = H; p.ldb = H / 2; p.ldbf = H / QB; p.x = s->hf; p.resid = s->x;
