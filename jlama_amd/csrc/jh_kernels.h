@@ -300,11 +300,22 @@ struct ActRegsT {
     float po[UMAX][4][8];   // PRO_ATTN_Q8: this thread's 8 output elements of up to 4 slices
     float m, l;             // PRO_ATTN_Q8: (max, sum) of slice (tid&3) of head (tid>>2)
     int n;                  // context length pos+1
+    i32x4 ql, qh;           // PRO_Q8: block min(tid, nblk-1) of the pre-quantized row, requested BEFORE the weight stream
+    float qd;
 };
 template <int PRO>
 __device__ __forceinline__ void stage_issue(const GemvParams& p, ActRegsT<UMaxFor<PRO>::v>& r) {
     constexpr int UMAX = UMaxFor<PRO>::v;
-    if (PRO == PRO_Q8) return;
+    if (PRO == PRO_Q8) {
+        // vmcnt retires oldest-first: the codes must be requested before the weights or this prologue waits for every weight byte
+        const int nblk = p.K / QB;
+        const int b = (int)threadIdx.x < nblk ? (int)threadIdx.x : nblk - 1;
+        const i32x4* src = (const i32x4*)(p.aq + (size_t)b * QB);
+        r.ql = src[0];
+        r.qh = src[1];
+        r.qd = p.ad[b];
+        return;
+    }
     const int units = p.K / 8, T = blockDim.x;
     // branch-free (clamped) addresses: a guarded load would make hipcc wait for it at the end of its basic block,
     // serialising this round trip with the weight stream that is issued next
@@ -341,18 +352,21 @@ __device__ __forceinline__ void stage_finish(const GemvParams& p, const ActI8& a
     constexpr int UMAX = UMaxFor<PRO>::v;
     const int K = p.K, nblk = K / QB;
     if (PRO == PRO_Q8) {
-        for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
-            const i32x4* src = (const i32x4*)(p.aq + (size_t)blk * QB);
-            i32x4 l = src[0], h = src[1];
+        auto put = [&](int blk, const i32x4& l, const i32x4& h, float d) {
             a.lo[blk] = l;
             a.hi[blk] = h;
-            a.d[blk] = p.ad[blk];
+            a.d[blk] = d;
             int s = 0;
             s = sdot4(l.x, 0x01010101, s); s = sdot4(l.y, 0x01010101, s);
             s = sdot4(l.z, 0x01010101, s); s = sdot4(l.w, 0x01010101, s);
             s = sdot4(h.x, 0x01010101, s); s = sdot4(h.y, 0x01010101, s);
             s = sdot4(h.z, 0x01010101, s); s = sdot4(h.w, 0x01010101, s);
             a.asum[blk] = s;
+        };
+        if ((int)threadIdx.x < nblk) put(threadIdx.x, r.ql, r.qh, r.qd);          // fetched by stage_issue, ahead of the weights
+        for (int blk = threadIdx.x + blockDim.x; blk < nblk; blk += blockDim.x) {   // rows longer than the workgroup
+            const i32x4* src = (const i32x4*)(p.aq + (size_t)blk * QB);
+            put(blk, src[0], src[1], p.ad[blk]);
         }
     } else {
         const int units = K / 8, T = blockDim.x;

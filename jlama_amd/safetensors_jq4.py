@@ -203,13 +203,12 @@ def llama_config(model_dir):
         eos_tokens = []
     else:
         eos_tokens = [int(t) for t in eos] if isinstance(eos, list) else [int(eos)]
-    # headSize = embeddingLength / numberOfHeads for Llama models (LlamaConfig passes no headSize, Config.java:95): a `head_dim` key
-    # in config.json is not read by LlamaConfig.java:29-41, so a checkpoint where the two differ is not loadable there either
-    if "head_dim" in c and int(c["head_dim"]) != E // heads:
-        raise ValueError(f"config.json head_dim={c['head_dim']} != hidden_size/num_attention_heads={E // heads}: the reference derives "
-                         "headSize from the latter (Config.java:95) and cannot represent this model")
+    # headSize: the reference derives it as embeddingLength / numberOfHeads for Llama models (LlamaConfig passes no headSize,
+    # Config.java:95) and does not read a `head_dim` key.  EXTENSION (documented in DESIGN.md): an explicit `head_dim` is
+    # honoured, as HF does -- checkpoints where the two agree (every published Llama-3 / Mistral one) load identically
+    head_size = int(c["head_dim"]) if "head_dim" in c else E // heads
     return dict(embedding_length=E, hidden_length=int(c["intermediate_size"]), n_heads=heads,
-                n_kv_heads=int(c.get("num_key_value_heads", heads)), head_size=E // heads,
+                n_kv_heads=int(c.get("num_key_value_heads", heads)), head_size=head_size,
                 n_layers=int(c["num_hidden_layers"]), vocab_size=int(c["vocab_size"]),
                 context_length=int(c["max_position_embeddings"]), rms_eps=float(c["rms_norm_eps"]),
                 rope_theta=float(c.get("rope_theta") or 10000.0), rope_scaling=scaling,
