@@ -7,6 +7,7 @@
 # Copy what should be judged into profiles/ (bench.py reports `traffic` only from a profile whose hash matches its build).
 set -x
 TAG=${1:-r02}; CFG=${2:-LLAMA3_8B}; shift; shift
+PMC=${PMC:-1}     # PMC=0: bench line + kernel trace only (the secondary configs)
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -18,6 +19,7 @@ rm -rf /tmp/prof_kt /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python $REPO/bench.py --config $CFG --steps 128 --warmup 8 --no-cpu-baseline --no-parity > /tmp/bench_prof.log 2>&1
 tail -1 /tmp/bench_prof.log | cut -c1-4000 > $OUT/${TAG}_${CFG}_bench_under_rocprof.json
 python $REPO/tools/rocpd_stats.py $(find /tmp/prof_kt -name "*.db" | head -1) > $OUT/${TAG}_${CFG}_kernel_trace_stats.md 2>&1
+if [ "$PMC" = "0" ]; then ls -la $OUT; exit 0; fi
 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_f -- python $REPO/bench.py --config $CFG --steps 16 --warmup 0 --no-cpu-baseline --no-parity --probe-iters 1 > /tmp/bench_f.log 2>&1
 python $REPO/tools/rocpd_pmc.py $(find /tmp/prof_f -name "*.db" | head -1) > $OUT/${TAG}_${CFG}_pmc_fetch_size.md 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_w -- python $REPO/bench.py --config $CFG --steps 16 --warmup 0 --no-cpu-baseline --no-parity --probe-iters 1 > /tmp/bench_w.log 2>&1
