@@ -21,6 +21,8 @@ struct DmaParams {
     int slots;                             // ring depth
     int depth;                             // slots the loader keeps in flight before it waits for the oldest
     int nt;
+    int nload;                             // loader waves per workgroup (loader w fills slots s = w mod nload)
+    int interleave;                        // 1: workgroup b takes global slots b, b+grid, ... (the chip sweeps memory together)
 };
 
 template <int NT>
@@ -54,7 +56,7 @@ __device__ __forceinline__ void wait_vm_rt(int n) {   // counted wait with a run
 
 // NB = Q blocks per lane per row (K = NB*64*32); NCONS consumer waves + 1 loader wave per workgroup
 template <int NB, int NCONS, int NT>
-__global__ __launch_bounds__((NCONS + 1) * 64) void gemv_dma_kernel(DmaParams p) {
+__global__ __launch_bounds__(512) void gemv_dma_kernel(DmaParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int nblk = NB * 64;
     const int slot_w = p.wloads * 1024, slot_s = p.sloads * 1024, slot_bytes = slot_w + slot_s;
@@ -69,10 +71,14 @@ __global__ __launch_bounds__((NCONS + 1) * 64) void gemv_dma_kernel(DmaParams p)
     // rows of this workgroup: contiguous, a whole number of slots
     const int slots_total = p.nrows / p.rows_per_slot;
     const int per = (slots_total + gridDim.x - 1) / gridDim.x;
-    const int s0 = blockIdx.x * per;
+    int s0 = blockIdx.x * per, sstep = 1;
     int s1 = s0 + per;
     if (s1 > slots_total) s1 = slots_total;
-    const int nslots = s1 > s0 ? s1 - s0 : 0;
+    int nslots = s1 > s0 ? s1 - s0 : 0;
+    if (p.interleave) {   // global slot of local slot s = blockIdx + s*grid
+        s0 = blockIdx.x; sstep = gridDim.x;
+        nslots = ((int)blockIdx.x < slots_total) ? (slots_total - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    }
     if (tid < 16) { ready[tid] = 0; freed[tid] = 0; }
     // activation (pre-quantized) -> LDS, by everyone
     for (int b = tid; b < nblk; b += blockDim.x) {
@@ -85,33 +91,36 @@ __global__ __launch_bounds__((NCONS + 1) * 64) void gemv_dma_kernel(DmaParams p)
         asum[b] = s;
     }
     __syncthreads();
-    if (wave == 0) {
-        // ---------------- loader: keep `depth` slots in flight, publish a slot when its loads have landed
+    if (wave < p.nload) {
+        // ---------------- loaders: loader w owns local slots w, w+nload, ...; each keeps `depth` of ITS slots in flight
         const size_t row_bytes = (size_t)nblk * 16, srow_bytes = (size_t)nblk * 4;
         const int loads_per_slot = p.wloads + p.sloads;
-        for (int s = 0; s < nslots + p.depth; s++) {
-            if (s < nslots) {
+        const int mine = (nslots - wave + p.nload - 1) / p.nload;      // number of slots of this loader
+        for (int k = 0; k < mine + p.depth; k++) {
+            const int s = wave + k * p.nload;
+            if (k < mine) {
                 const int slot = s % p.slots;
                 if (s >= p.slots) {   // wait until the consumers released this slot's previous content
                     while (flag_read(&freed[slot]) != s - p.slots + 1) __builtin_amdgcn_s_sleep(1);
                 }
                 char* dst = ring + (size_t)slot * slot_bytes;
-                const size_t r0 = (size_t)(s0 + s) * p.rows_per_slot;
+                const size_t r0 = (size_t)(s0 + (size_t)s * sstep) * p.rows_per_slot;
                 const char* gw = (const char*)p.w + r0 * row_bytes + lane * 16;
                 const char* gs = (const char*)p.ws + r0 * srow_bytes + lane * 16;
                 for (int i = 0; i < p.wloads; i++) glds16<NT>(gw + (size_t)i * 1024, dst + i * 1024);
                 for (int i = 0; i < p.sloads; i++) glds16<NT>(gs + (size_t)i * 1024, dst + slot_w + i * 1024);
             }
-            const int done = s - p.depth;   // the slot issued `depth` iterations ago has landed once at most depth*loads are pending
-            if (done >= 0 && done < nslots) {
-                const int newer = (s < nslots ? s : nslots - 1) - done;   // slots issued after `done`
+            const int kd = k - p.depth;     // my slot issued `depth` iterations ago has landed once at most depth*loads are pending
+            if (kd >= 0 && kd < mine) {
+                const int newer = (k < mine ? k : mine - 1) - kd;   // my slots issued after it
                 wait_vm_rt(newer * loads_per_slot);
+                const int done = wave + kd * p.nload;
                 if (lane == 0) flag_write(&ready[done % p.slots], done + 1);
             }
         }
     } else {
         // ---------------- consumers: slot s -> consumer (s % NCONS)
-        const int c = wave - 1;
+        const int c = wave - p.nload;
         i32x4 rlo[NB], rhi[NB];
         float rd[NB];
         int rs8[NB];
@@ -139,7 +148,7 @@ __global__ __launch_bounds__((NCONS + 1) * 64) void gemv_dma_kernel(DmaParams p)
                 if (lane == r) res = acc;
             }
             if (lane == 0) flag_write(&freed[slot], s + 1);      // every lane's ds_reads of this slot were consumed above
-            if (lane < p.rows_per_slot) p.out[(size_t)(s0 + s) * p.rows_per_slot + lane] = res;
+            if (lane < p.rows_per_slot) p.out[(size_t)(s0 + (size_t)s * sstep) * p.rows_per_slot + lane] = res;
         }
     }
 }
@@ -156,7 +165,7 @@ float run_dma(DmaParams p, int grid, int copies, size_t wstride, size_t sstride,
         if (it == 0) CK(hipEventRecord(e0, st));
         for (int c = 0; c < copies; c++) {
             p.w = w0 + c * wstride; p.ws = (const float*)((const char*)s0 + c * sstride);
-            hipLaunchKernelGGL((gemv_dma_kernel<NB, NCONS, NT>), dim3(grid), dim3((NCONS + 1) * 64), lds, st, p);
+            hipLaunchKernelGGL((gemv_dma_kernel<NB, NCONS, NT>), dim3(grid), dim3((NCONS + p.nload) * 64), lds, st, p);
             if (check_only) break;
         }
         if (check_only) break;
@@ -231,28 +240,24 @@ void shape(const char* name, int nrows, int K, int copies, hipStream_t st) {
     d.rows_per_slot = NB == 2 ? 8 : 2;
     d.wloads = d.rows_per_slot * nblk * 16 / 1024;
     d.sloads = (d.rows_per_slot * nblk * 4 + 1023) / 1024;
-    const int grids[] = {256, 512};
-    const int slots_opt[] = {4, 6};
-    const int depth_opt[] = {1, 2, 3};
-    for (int grid : grids)
-        for (int slots : slots_opt)
-            for (int depth : depth_opt)
-                for (int nt = 1; nt >= 0; nt--) {
-                    d.slots = slots; d.depth = depth; d.nt = nt;
-                    if ((d.wloads + d.sloads) * depth > 63) continue;
-                    if ((size_t)slots * (d.wloads + d.sloads) * 1024 * (grid / 256) > 150 * 1024) continue;
-                    CK(hipMemset(o_dma, 0xff, nrows * 4));
-                    d.w = dw; d.ws = ds;
-                    if (nt) run_dma<NB, 3, 1>(d, grid, 1, wstride, sstride, 1, st, true);
-                    else run_dma<NB, 3, 0>(d, grid, 1, wstride, sstride, 1, st, true);
-                    CK(hipMemcpy(hdma.data(), o_dma, nrows * 4, hipMemcpyDeviceToHost));
-                    int bad = 0;
-                    for (int i = 0; i < nrows; i++) bad += memcmp(&href[i], &hdma[i], 4) != 0;
-                    const float t3 = nt ? run_dma<NB, 3, 1>(d, grid, copies, wstride, sstride, 4, st) : run_dma<NB, 3, 0>(d, grid, copies, wstride, sstride, 4, st);
-                    const float t7 = nt ? run_dma<NB, 7, 1>(d, grid, copies, wstride, sstride, 4, st) : run_dma<NB, 7, 0>(d, grid, copies, wstride, sstride, 4, st);
-                    printf("   dma grid=%d slots=%d depth=%d nt=%d  mismatches=%d   3 consumers: %.2f us %.2f TB/s   7 consumers: %.2f us %.2f TB/s\n", grid, slots,
-                           depth, nt, bad, t3, mb / t3, t7, mb / t7);
-                }
+    struct V { int grid, slots, depth, nload, inter; };
+    const V vs[] = {{256, 6, 2, 1, 0}, {256, 6, 2, 1, 1}, {256, 6, 1, 2, 0}, {256, 6, 1, 2, 1}, {256, 6, 2, 2, 1}, {512, 3, 1, 1, 0}, {512, 3, 1, 1, 1},
+                    {256, 7, 3, 1, 1}, {256, 4, 1, 2, 1}};
+    for (const V& v : vs) {
+        d.slots = v.slots; d.depth = v.depth; d.nt = 1; d.nload = v.nload; d.interleave = v.inter;
+        if ((d.wloads + d.sloads) * v.depth > 63) continue;
+        if ((size_t)v.slots * (d.wloads + d.sloads) * 1024 * (v.grid / 256) + (size_t)nblk * 40 * (v.grid / 256) > 158 * 1024) continue;
+        CK(hipMemset(o_dma, 0xff, nrows * 4));
+        d.w = dw; d.ws = ds;
+        run_dma<NB, 3, 1>(d, v.grid, 1, wstride, sstride, 1, st, true);
+        CK(hipMemcpy(hdma.data(), o_dma, nrows * 4, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < nrows; i++) bad += memcmp(&href[i], &hdma[i], 4) != 0;
+        const float t3 = run_dma<NB, 3, 1>(d, v.grid, copies, wstride, sstride, 4, st);
+        const float t6 = run_dma<NB, 6, 1>(d, v.grid, copies, wstride, sstride, 4, st);
+        printf("   dma grid=%d slots=%d depth=%d loaders=%d interleave=%d  mismatches=%d   3 consumers: %.2f us %.2f TB/s   6 consumers: %.2f us %.2f TB/s\n",
+               v.grid, v.slots, v.depth, v.nload, v.inter, bad, t3, mb / t3, t6, mb / t6);
+    }
     hipFree(dw); hipFree(ds); hipFree(daq); hipFree(dad); hipFree(o_ref); hipFree(o_dma);
 }
 
@@ -260,8 +265,7 @@ int main() {
     hipStream_t st;
     CK(hipStreamCreate(&st));
     shape<2>("gate/up", 28672, 4096, 24, st);
+    shape<2>("gate/up x4 rows (steady state)", 114688, 4096, 8, st);
     shape<7>("down", 4096, 14336, 24, st);
-    shape<2>("qkv", 6144, 4096, 32, st);
-    shape<2>("o-proj", 4096, 4096, 32, st);
     return 0;
 }
