@@ -278,6 +278,16 @@ int jh_pipeline_prefill(jh_pipeline* p, const int32_t* tokens, int n, int start_
 int jh_pipeline_decode_n_async(jh_pipeline* p, int32_t first_token, int start_pos, int n);
 int jh_pipeline_decode_wait(jh_pipeline* p, int32_t* out_tokens, int n);
 
+/* One pipeline stage per PROCESS (rank-per-GPU hosts, the shape of the reference's cluster: one Worker per layer range,
+ * jlama-net/.../Worker.java:193-248; the coordinator samples and feeds the id back, Coordinator.java:184).
+ * jh_stage_decode_async queues ONE decode row of this shard on the session's stream and returns: a first stage
+ * (layer_start == 0) reads the token id from DEVICE memory (token_dev) and embeds it, later stages take the previous stage's
+ * [E] F32 row (x_in_dev); the last stage (layer_end == n_layers) runs final norm + LM head + greedy argmax and stores the id
+ * to token_out_dev, the others store their output row to x_out_dev.  No host synchronisation: the caller's transport (RCCL
+ * send/recv enqueued on jh_session_stream) orders the hops, so a rank queues ticks ahead of its GPU.  */
+int jh_stage_decode_async(jh_session* s, const int32_t* token_dev, const float* x_in_dev, int pos, float* x_out_dev,
+                          int32_t* token_out_dev);
+
 /* batchForward (AbstractModel.java:295-312): run rows through this shard's layers at positions
  * [start_pos, start_pos+n).  tokens != NULL: rows come from the embedding table (first shard);
  * else x_in (HOST, [n,E] F32) is the previous shard's output.  x_out (HOST [n,E], may be NULL) receives the

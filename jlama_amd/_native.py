@@ -127,6 +127,7 @@ _PROTOS = {
     "jh_pipeline_prefill": (_i, [_p, _p, _i, _i, _p]),
     "jh_pipeline_decode_n_async": (_i, [_p, _i, _i, _i]),
     "jh_pipeline_decode_wait": (_i, [_p, _p, _i]),
+    "jh_stage_decode_async": (_i, [_p, _p, _p, _i, _p, _p]),
     "jh_forward": (_i, [_p, _p, _p, _i, _i, _p]),
     "jh_forward_device": (_i, [_p, _p, _p, _i, _i, _p]),
     "jh_sample": (_i, [_p, _f, _f, _p, _p]),

@@ -1447,6 +1447,12 @@ __global__ void tp_sum_kernel(const float* slots, int n, int E, float* out) {
     out[i] = v;
 }
 __global__ void set_pos_kernel(DecodeState* st, int pos) { st->pos = pos; }   // pipeline stages: the token / step words stay
+// one pipeline stage per process: the token id arrives in device memory (shipped by the last stage), never through the host
+__global__ void set_state_dev_kernel(DecodeState* st, int pos, const int* token_dev) {
+    st->pos = pos; st->step = 0; st->done = 0;
+    if (token_dev) st->token = *token_dev;
+}
+__global__ void store_token_kernel(const DecodeState* st, int* out) { *out = st->token; }
 __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
     st->pos = pos; st->token = token; st->step = step; st->done = 0;
 }

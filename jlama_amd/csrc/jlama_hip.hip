@@ -2819,6 +2819,45 @@ int jh_pipeline_decode_wait(jh_pipeline* p, int32_t* out_tokens, int n) {
     return jh_decode_wait(sl, out_tokens, n);
 }
 
+// ---- one pipeline stage per process (rank-per-GPU hosts): one decode row of THIS shard, stream-ordered end to end ----------
+// The caller's transport (RCCL send/recv issued on the session's stream, jh_session_stream) delivers x_in_dev / token_dev and
+// ships x_out_dev / token_out_dev; nothing here touches the host, so a rank can queue its ticks ahead of the GPU.
+int jh_stage_decode_async(jh_session* s, const int32_t* token_dev, const float* x_in_dev, int pos, float* x_out_dev, int32_t* token_out_dev) {
+    if (!s || pos < 0) return set_err(JH_ERR_INVALID, "stage_decode: bad argument");
+    if (pos + 1 > s->max_ctx) return set_err(JH_ERR_INVALID, "stage_decode: position beyond the session's max_ctx");
+    JHCHK(check_positions(s, pos));
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const bool first = c.layer_start == 0, last = c.layer_end == c.n_layers;
+    const JWeight& emb = m->global_w[JH_W_EMBED];
+    if (first && (!token_dev || !emb.data)) return set_err(JH_ERR_INVALID, "stage_decode: the first stage needs a token word and the embedding table");
+    if (!first && !x_in_dev) return set_err(JH_ERR_INVALID, "stage_decode: a later stage needs the previous stage's row");
+    if (last && (!token_out_dev || !lm_head_weight(m)->data || !m->global_w[JH_W_FINALNORM].data))
+        return set_err(JH_ERR_INVALID, "stage_decode: the last stage needs final norm, LM head and a token destination");
+    if (!last && !x_out_dev) return set_err(JH_ERR_INVALID, "stage_decode: this stage needs a destination for its row");
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = s->stream;
+    const size_t E = (size_t)c.embedding_length;
+    const int v = attn_variant_for(s, pos);
+    if (last) { JHCHK(ensure_out_tokens(s, 1)); JHCHK(build_graph(s, v)); }
+    else JHCHK(build_row_graph(s, v));
+    hipLaunchKernelGGL(set_state_dev_kernel, dim3(1), dim3(1), 0, st, s->st, pos, first ? token_dev : nullptr);
+    if (first)
+        hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                           (const DecodeState*)s->st, (int)E, s->x);
+    else
+        HIPCHK(hipMemcpyAsync(s->x, x_in_dev, E * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipGraphLaunch(last ? s->exec[v] : s->row_exec[v], st));   // last stage: layers + LM head + argmax -> st->token
+    if (last) {
+        hipLaunchKernelGGL(store_token_kernel, dim3(1), dim3(1), 0, st, (const DecodeState*)s->st, token_out_dev);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemcpyAsync(x_out_dev, s->x, E * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return JH_OK;
+}
+
 int jh_decode_stats(jh_session* s, double* ms_per_token, int32_t* kernels_per_token) {
     if (!s) return set_err(JH_ERR_INVALID, "decode_stats: null");
     if (ms_per_token) *ms_per_token = s->ms_per_token;

@@ -69,6 +69,19 @@ class HipShardEngine(ShardEngine):
     def sample(self, session):
         return self.sessions[session].sample(0.0, 0.5)
 
+    # -- stream-ordered stage (pipeline_decode_streamed): nothing below touches the host
+    def stream(self, session):
+        """torch view of the session's own HIP stream: RCCL send/recv issued under it are ordered with the kernels."""
+        if not hasattr(self, "_ext"):
+            self._ext = {}
+        if session not in self._ext:
+            self._ext[session] = self.torch.cuda.ExternalStream(self.sessions[session].stream())
+        return self._ext[session]
+
+    def stage_step(self, session, token, x_in, pos, x_out, token_out):
+        p = lambda t: t.data_ptr() if t is not None else 0
+        self.sessions[session].stage_decode_async(p(token), p(x_in), pos, p(x_out), p(token_out))
+
 
 def pipeline_prefill(dist, engine, rank, world, session, prompt, E, device, dtype):
     """Prefill one session through all shards (batchForward, AbstractModel.java:295-312); returns the first sampled
@@ -138,6 +151,55 @@ def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_pe
     if pending is not None:
         pending.wait()
     return out
+
+
+def pipeline_decode_streamed(dist, engine, rank, world, first_tokens, start_pos, steps_per_session, E, device, dtype, n_sessions=None):
+    """pipeline_decode without a single host round trip inside the loop.  Same schedule (work item q = (session q % S, step
+    q // S) in that order on every rank), but every hop is issued under the session's own HIP stream (``engine.stream``):
+    ``dist.recv`` makes that stream wait for the RCCL transfer, ``engine.stage_step`` queues the shard's graph behind it,
+    ``dist.isend`` ships the row (or, from the last rank, the sampled id -- a device word, read by rank 0's embedding kernel)
+    when the graph is done.  The host only enqueues; sessions overlap on the GPU because each has its own stream.  Buffers are
+    per session: a row buffer is rewritten only after the stream has waited for the send that read it.
+    Returns the ids sampled by the LAST rank, [sessions, steps] (zeros elsewhere)."""
+    import torch
+    N = world
+    S = n_sessions if n_sessions else world
+    steps = steps_per_session
+    first, last = rank == 0, rank == N - 1
+    x_in = [torch.empty((1, E), dtype=dtype, device=device) for _ in range(S)] if not first else None
+    x_out = [torch.empty((1, E), dtype=dtype, device=device) for _ in range(S)] if not last else None
+    tok_in = torch.zeros((S, 1), dtype=torch.int32, device=device) if first else None
+    out_dev = torch.zeros((S, steps), dtype=torch.int32, device=device) if last else None
+    on_gpu = torch.device(device).type == "cuda"
+    sync = (lambda: torch.cuda.synchronize(device)) if on_gpu else (lambda: None)   # CPU engines (tests over gloo) are synchronous
+    if first:
+        tok_in.copy_(torch.as_tensor(np.asarray(first_tokens[:S], dtype=np.int32).reshape(S, 1)))
+    sync()
+    sent = [None] * S          # the last isend that read x_out[j]
+    keep = []                  # token sends in flight (each reads its own element of out_dev)
+    for q in range(S * steps):
+        j, k = q % S, q // S
+        with torch.cuda.stream(engine.stream(j) if on_gpu else None):
+            if first:
+                if k > 0 and N > 1:
+                    dist.recv(tok_in[j], src=N - 1)            # id sampled for step k-1 of this session
+                elif k > 0:
+                    tok_in[j].copy_(out_dev[j, k - 1:k])       # one rank: first and last stage are the same session
+            else:
+                dist.recv(x_in[j], src=rank - 1)
+            if sent[j] is not None:
+                sent[j].wait()                                 # stream-level: x_out[j] is free again
+                sent[j] = None
+            engine.stage_step(j, tok_in[j] if first else None, None if first else x_in[j], start_pos + k,
+                              None if last else x_out[j], out_dev[j, k:k + 1] if last else None)
+            if not last:
+                sent[j] = dist.isend(x_out[j], dst=rank + 1)
+            elif N > 1 and k + 1 < steps:
+                keep.append(dist.isend(out_dev[j, k:k + 1], dst=0))
+    for w in keep + [w for w in sent if w is not None]:
+        w.wait()
+    sync()
+    return out_dev.cpu().numpy() if last else np.zeros((S, steps), dtype=np.int32)
 
 
 # ------------------------------------------------------------------------------------------------ tensor parallel (f2)
@@ -371,8 +433,22 @@ def bench_pipeline(args, cfg):
     max_ctx = prompt.size + max(steps_per_session, args.warmup, single_steps) + 8
     engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=world, max_ctx=max_ctx)
     firsts = [pipeline_prefill(dist, engine, rank, world, j, prompt, E, device, torch.float32) for j in range(world)]
+    # The decode loop: stream-ordered hops (pipeline_decode_streamed: RCCL send/recv on the sessions' streams, token id as a
+    # device word) unless JH_PIPELINE_HOST_SYNC=1 asks for the host-synchronised reference loop.  The first ids of both are
+    # compared before anything is timed; a mismatch falls back to the reference loop and is reported.
+    streamed = not os.environ.get("JH_PIPELINE_HOST_SYNC")
+    check_steps = max(1, min(4, steps_per_session))
+    ref_ids = pipeline_decode(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32)
+    streamed_ok = None
+    if streamed:
+        got = pipeline_decode_streamed(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32)
+        flag = torch.tensor([1 if (rank != world - 1 or np.array_equal(got, ref_ids)) else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        streamed_ok = bool(int(flag.item()))
+        streamed = streamed_ok
+    decode = pipeline_decode_streamed if streamed else pipeline_decode
     if args.warmup > 0:  # untimed decode ticks on the same sessions' KV tail (positions beyond the timed range are rewritten)
-        pipeline_decode(dist, engine, rank, world, firsts, prompt.size, max(1, args.warmup // world), E, device, torch.float32)
+        decode(dist, engine, rank, world, firsts, prompt.size, max(1, args.warmup // world), E, device, torch.float32)
 
     def timed(fn):
         dist.barrier()
@@ -385,9 +461,12 @@ def bench_pipeline(args, cfg):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return r, float(dt.item())
 
-    toks, dt = timed(lambda: pipeline_decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32))
-    _, dt1 = timed(lambda: pipeline_decode(dist, engine, rank, world, firsts[:1], prompt.size, single_steps, E, device, torch.float32,
-                                           n_sessions=1))
+    toks, dt = timed(lambda: decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32))
+    _, dt1 = timed(lambda: decode(dist, engine, rank, world, firsts[:1], prompt.size, single_steps, E, device, torch.float32, n_sessions=1))
+    host_sync = None
+    if streamed:   # the reference loop beside it (what the hops cost when the host sits in them)
+        _, dth = timed(lambda: pipeline_decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32))
+        host_sync = round(steps_per_session * world / dth, 2)
     total = steps_per_session * world
     one_proc = None
     if rank == 0 and world > 1 and not os.environ.get("JH_BENCH_NO_ONE_PROCESS"):
@@ -415,6 +494,9 @@ def bench_pipeline(args, cfg):
                           "sessions_in_flight": world, "aggregate_tokens_per_s": round(tps, 2),
                           "per_session_tokens_per_s": round(tps / world, 2),
                           "single_stream_tokens_per_s": round(single_steps / dt1, 2), "single_stream_steps": single_steps,
+                          "hops": "stream-ordered (RCCL send/recv on the session streams, token id fed back as a device word)" if streamed
+                                  else "host-synchronised", "streamed_ids_equal_host_synchronised": streamed_ok,
+                          "host_synchronised_aggregate_tokens_per_s": host_sync,
                           "note": "value = aggregate of the sessions in flight; a single stream passes through all GPUs in sequence and "
                                   "cannot exceed the 1-GPU rate (SURVEY.md 8d multi-GPU accounting)"},
                "roofline": {"bound": "hbm", "kernel": "whole pipeline (per-kernel roofline is the 1-GPU run's: same kernels per stage)",

@@ -104,6 +104,11 @@ class HipSession:
                                           C.c_void_p(x_in_ptr) if x_in_ptr else None, n, start_pos,
                                           C.c_void_p(x_out_ptr) if x_out_ptr else None))
 
+    def stage_decode_async(self, token_ptr, x_in_ptr, pos, x_out_ptr, token_out_ptr):
+        """One decode row of this layer shard, queued on the session's stream (token id and rows in device memory)."""
+        v = lambda q: C.c_void_p(q) if q else None
+        N.check(N.lib().jh_stage_decode_async(self.h, v(token_ptr), v(x_in_ptr), pos, v(x_out_ptr), v(token_out_ptr)))
+
     def batch_forward(self, tokens, start_pos=0):
         """Chunks of jlama.max_batch_size rows (AbstractModel.java:304); returns the last chunk's output."""
         tokens = np.ascontiguousarray(tokens, dtype=np.int32)

@@ -46,6 +46,20 @@ def _worker(rank, world, port, cfg, n_prompt, steps, q):
         def sample(self, session):
             return self.m.sample(self.last[session])[0]
 
+        # the stage form pipeline_decode_streamed drives (HipShardEngine: jh_stage_decode_async on the session's stream)
+        def stream(self, session):
+            return None
+
+        def stage_step(self, session, token, x_in, pos, x_out, token_out):
+            if token is not None:
+                x = self.s[session].forward(np.array([int(token[0])], dtype=np.int32), pos)
+            else:
+                x = self.s[session].forward(None, pos, x=x_in.numpy()[:1])
+            if x_out is not None:
+                x_out.copy_(torch.from_numpy(x))
+            if token_out is not None:
+                token_out[0] = int(self.m.sample(x[-1])[0])
+
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     eng = OracleShardEngine()
     E = cfg["embedding_length"]
@@ -54,7 +68,11 @@ def _worker(rank, world, port, cfg, n_prompt, steps, q):
     toks = D.pipeline_decode(dist, eng, rank, world, firsts, prompts[0].size, steps, E, "cpu", torch.float32)
     # single-stream form (bench.py's batch-1 leg): ONE session through all stages; session 0 decodes the same positions again
     single = D.pipeline_decode(dist, eng, rank, world, firsts[:1], prompts[0].size, steps, E, "cpu", torch.float32, n_sessions=1)
+    # the stream-ordered schedule (what bench.py --gpus N runs over RCCL): same ids, sessions in flight and single stream
+    streamed = D.pipeline_decode_streamed(dist, eng, rank, world, firsts, prompts[0].size, steps, E, "cpu", torch.float32)
+    streamed1 = D.pipeline_decode_streamed(dist, eng, rank, world, firsts[:1], prompts[0].size, steps, E, "cpu", torch.float32, n_sessions=1)
     if rank == world - 1:
+        assert streamed.tolist() == toks.tolist() and streamed1.tolist() == single.tolist()
         q.put((firsts, toks.tolist(), single.tolist()))
     dist.barrier()
     dist.destroy_process_group()

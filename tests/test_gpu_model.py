@@ -721,6 +721,169 @@ def test_rank_per_gpu_pipeline_engine_loopback(gpu, oracle, world):
     np.testing.assert_array_equal(single[0], want[0][1])
 
 
+class _StreamLoopbackDist:
+    """The stream-ordered half of torch.distributed's NCCL semantics between THREADS of one process: ``isend`` snapshots
+    the tensor on the CURRENT stream and records an event; ``recv`` blocks the host only until the peer has *enqueued* its
+    send, then makes the current stream wait for that event and copies -- nothing waits for the GPU.  That is how RCCL
+    send/recv behave under ``torch.cuda.stream(session stream)`` in pipeline_decode_streamed."""
+
+    def __init__(self, rank, world, queues, torch, lock):
+        self.rank, self.world, self.q, self.torch, self.lock = rank, world, queues, torch, lock
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def isend(self, t, dst):
+        with self.lock:
+            c = t.clone()
+            ev = self.torch.cuda.Event()
+            ev.record(self.torch.cuda.current_stream())
+        self.q[(self.rank, dst)].put((c, ev))
+        return self._Done()
+
+    def recv(self, t, src):
+        c, ev = self.q[(src, self.rank)].get(timeout=120)
+        with self.lock:
+            cur = self.torch.cuda.current_stream()
+            cur.wait_event(ev)
+            t.copy_(c)
+            c.record_stream(cur)   # the snapshot was allocated on the sender's stream
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rank_per_gpu_pipeline_stream_ordered_loopback(gpu, oracle, world):
+    """pipeline_decode_streamed + jh_stage_decode_async: the rank-per-GPU decode loop with every hop ordered on the sessions'
+    own streams (token id fed back as a device word, no host synchronisation inside the loop).  N shards on ONE device,
+    in-process transport with NCCL's stream semantics: ids equal the un-sharded model's, sessions in flight and single stream."""
+    import queue
+    import threading
+    import torch
+    from jlama_amd import distributed as D, synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    cfg = dict(S.SMALL)
+    cfg["n_layers"] = 4
+    w = S.make_weights(cfg, seed=16, quantize=oracle.q4_quantize)
+    E, steps = cfg["embedding_length"], 12
+    prompts = [S.prompt_tokens(cfg, n=20, seed=300 + j) for j in range(world)]
+    want = []
+    full = HipLlamaModel(cfg, w)
+    for j in range(world):
+        s = full.session(64)
+        s.batch_forward(prompts[j], 0)
+        f = s.sample()
+        want.append((f, s.decode_n(f, prompts[j].size, steps)))
+    queues = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    results, errors = {}, []
+    dev = torch.device("cuda", 0)
+    gpu_lock = threading.Lock()
+    ready = threading.Barrier(world)
+
+    class LockedEngine(D.HipShardEngine):
+        """Ranks are threads here (one HIP runtime): runtime calls of different ranks are serialised, the GPU work is not."""
+
+        def forward_tokens(self, *a):
+            with gpu_lock:
+                return super().forward_tokens(*a)
+
+        def forward_x(self, *a):
+            with gpu_lock:
+                return super().forward_x(*a)
+
+        def sample(self, *a):
+            with gpu_lock:
+                return super().sample(*a)
+
+        def stage_step(self, *a):
+            with gpu_lock:
+                return super().stage_step(*a)
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            host = _LoopbackDist(rank, world, queues, torch, gpu_lock)        # prefill uses the host-synchronised hops
+            dist = _StreamLoopbackDist(rank, world, queues, torch, gpu_lock)
+            with gpu_lock:
+                eng = LockedEngine(cfg, w, rank, world, 0, n_sessions=world, max_ctx=64)
+            firsts = [D.pipeline_prefill(host, eng, rank, world, j, prompts[j], E, dev, torch.float32) for j in range(world)]
+            # one throw-away row per session captures the stage graphs before the ranks run concurrently (a capture must
+            # not overlap other threads' runtime calls in a shared process; separate processes do not have that problem)
+            tok = torch.zeros(1, dtype=torch.int32, device=dev)
+            xa, xb = (torch.zeros((1, E), dtype=torch.float32, device=dev) for _ in range(2))
+            for j in range(world):
+                eng.stage_step(j, tok if rank == 0 else None, None if rank == 0 else xa, prompts[0].size,
+                               None if rank == world - 1 else xb, tok if rank == world - 1 else None)
+            with gpu_lock:
+                torch.cuda.synchronize()
+            ready.wait(timeout=120)
+            toks = D.pipeline_decode_streamed(dist, eng, rank, world, firsts, prompts[0].size, steps, E, dev, torch.float32)
+            ready.wait(timeout=120)
+            single = D.pipeline_decode_streamed(dist, eng, rank, world, firsts[:1], prompts[0].size, steps, E, dev, torch.float32, n_sessions=1)
+            results[rank] = (firsts, toks, single)
+        except Exception:   # noqa: BLE001
+            import traceback
+            errors.append((rank, traceback.format_exc()))
+            ready.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[0][1]
+    firsts, toks, single = results[world - 1]
+    for j in range(world):
+        assert firsts[j] == want[j][0]
+        np.testing.assert_array_equal(toks[j], want[j][1])
+    np.testing.assert_array_equal(single[0], want[0][1])
+
+
+def test_stage_decode_rejects_incomplete_calls(gpu, oracle):
+    """jh_stage_decode_async validates what each kind of stage needs (token word / input row / destinations)."""
+    import torch
+    from jlama_amd import synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    from jlama_amd._native import JhError
+    cfg = dict(S.SMALL)
+    cfg["n_layers"] = 4
+    w = S.make_weights(cfg, seed=2, quantize=oracle.q4_quantize)
+    dev = torch.device("cuda", 0)
+    E = cfg["embedding_length"]
+    tok = torch.zeros(1, dtype=torch.int32, device=dev)
+    x = torch.zeros((1, E), dtype=torch.float32, device=dev)
+    first = HipLlamaModel(cfg, w, layer_range=(0, 2)).session(32)
+    lastm = HipLlamaModel(cfg, w, layer_range=(2, 4)).session(32)
+    with pytest.raises(JhError):
+        first.stage_decode_async(0, 0, 0, x.data_ptr(), 0)               # first stage without a token word
+    with pytest.raises(JhError):
+        first.stage_decode_async(tok.data_ptr(), 0, 0, 0, 0)              # ... without a destination row
+    with pytest.raises(JhError):
+        lastm.stage_decode_async(0, 0, 0, 0, tok.data_ptr())              # later stage without the input row
+    with pytest.raises(JhError):
+        lastm.stage_decode_async(0, x.data_ptr(), 0, 0, 0)                # last stage without a token destination
+    with pytest.raises(JhError):
+        first.stage_decode_async(tok.data_ptr(), 0, 32, x.data_ptr(), 0)  # beyond max_ctx
+    # the complete two-stage hand-off equals the un-sharded greedy step
+    full = HipLlamaModel(cfg, w).session(32)
+    prompt = S.prompt_tokens(cfg, n=9, seed=5)
+    full.batch_forward(prompt, 0)
+    f = full.sample()
+    want = full.decode_n(f, prompt.size, 1)[0]
+    xs = torch.zeros((prompt.size, E), dtype=torch.float32, device=dev)
+    first.forward_device(prompt, 0, prompt.size, 0, xs.data_ptr())
+    first.synchronize()
+    lastm.forward_device(None, xs.data_ptr(), prompt.size, 0, xs.data_ptr())
+    lastm.synchronize()
+    tok[0] = int(f)
+    out = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    first.stage_decode_async(tok.data_ptr(), 0, prompt.size, x.data_ptr(), 0)
+    first.synchronize()
+    lastm.stage_decode_async(0, x.data_ptr(), prompt.size, 0, out.data_ptr())
+    lastm.synchronize()
+    assert int(out.item()) == int(want)
+
+
 @pytest.mark.parametrize("size", [2, 4])
 def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, size):
     """f2: jh_tp_group_* -- all head-split shards in one process (here on one device), the two reductions of a layer as
