@@ -667,24 +667,41 @@ __device__ __forceinline__ ActF32 carve_f32(char* smem, int nblk) {
 }
 static inline size_t lds_bytes_f32(int K) { return (size_t)K * 4 + 32 * 8 + 16 * 4 + 16 * 4; }
 
-__device__ __forceinline__ float q4_block_dot_f32(const i32x4& w, float scale, const float4 (&y)[8], float acc) {
-    const float m8 = -8.0f * scale;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Per weight: v_cvt_f32_ubyteN + fma (dequantize) + fma (accumulate) -- at 525 M weights the LM head was VALU-bound (69 us
+// against 54 us of HBM time).  Two weights per v_pk_fma_f32: even elements accumulate in .x, odd ones in .y (each an
+// ascending-k fma chain with the reference's per-element operations); the halves are added once per row.
+// byte N of a dword as float in ONE instruction.  Written as asm because hipcc folds `(x & 0x0F0F0F0F) >> 8 & 0xff` back into
+// per-nibble shift + and + cvt_ubyte0 (3 VALU ops per weight instead of 1 + 3/8).
+template <int N>
+__device__ __forceinline__ float cvt_ubyte(int x) {
+    float f;
+    if constexpr (N == 0) asm("v_cvt_f32_ubyte0_e32 %0, %1" : "=v"(f) : "v"(x));
+    else if constexpr (N == 1) asm("v_cvt_f32_ubyte1_e32 %0, %1" : "=v"(f) : "v"(x));
+    else if constexpr (N == 2) asm("v_cvt_f32_ubyte2_e32 %0, %1" : "=v"(f) : "v"(x));
+    else asm("v_cvt_f32_ubyte3_e32 %0, %1" : "=v"(f) : "v"(x));
+    return f;
+}
+__device__ __forceinline__ f32x2 q4_block_dot_f32(const i32x4& w, float scale, const float4 (&y)[8], f32x2 acc) {
+    const f32x2 sc = {scale, scale};
+    const float m8s = -8.0f * scale;
+    const f32x2 m8 = {m8s, m8s};
     const int wl[4] = {w.x & 0x0F0F0F0F, w.y & 0x0F0F0F0F, w.z & 0x0F0F0F0F, w.w & 0x0F0F0F0F};
     const int wh[4] = {(w.x >> 4) & 0x0F0F0F0F, (w.y >> 4) & 0x0F0F0F0F, (w.z >> 4) & 0x0F0F0F0F,
                        (w.w >> 4) & 0x0F0F0F0F};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        acc = fmaf(y[c].x, fmaf(scale, (float)(wl[c] & 0xff), m8), acc);
-        acc = fmaf(y[c].y, fmaf(scale, (float)((wl[c] >> 8) & 0xff), m8), acc);
-        acc = fmaf(y[c].z, fmaf(scale, (float)((wl[c] >> 16) & 0xff), m8), acc);
-        acc = fmaf(y[c].w, fmaf(scale, (float)((wl[c] >> 24) & 0xff), m8), acc);
+        const f32x2 f01 = {cvt_ubyte<0>(wl[c]), cvt_ubyte<1>(wl[c])};
+        const f32x2 f23 = {cvt_ubyte<2>(wl[c]), cvt_ubyte<3>(wl[c])};
+        acc = __builtin_elementwise_fma(f32x2{y[c].x, y[c].y}, __builtin_elementwise_fma(sc, f01, m8), acc);
+        acc = __builtin_elementwise_fma(f32x2{y[c].z, y[c].w}, __builtin_elementwise_fma(sc, f23, m8), acc);
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        acc = fmaf(y[4 + c].x, fmaf(scale, (float)(wh[c] & 0xff), m8), acc);
-        acc = fmaf(y[4 + c].y, fmaf(scale, (float)((wh[c] >> 8) & 0xff), m8), acc);
-        acc = fmaf(y[4 + c].z, fmaf(scale, (float)((wh[c] >> 16) & 0xff), m8), acc);
-        acc = fmaf(y[4 + c].w, fmaf(scale, (float)((wh[c] >> 24) & 0xff), m8), acc);
+        const f32x2 f01 = {cvt_ubyte<0>(wh[c]), cvt_ubyte<1>(wh[c])};
+        const f32x2 f23 = {cvt_ubyte<2>(wh[c]), cvt_ubyte<3>(wh[c])};
+        acc = __builtin_elementwise_fma(f32x2{y[4 + c].x, y[4 + c].y}, __builtin_elementwise_fma(sc, f01, m8), acc);
+        acc = __builtin_elementwise_fma(f32x2{y[4 + c].z, y[4 + c].w}, __builtin_elementwise_fma(sc, f23, m8), acc);
     }
     return acc;
 }
@@ -734,16 +751,17 @@ __global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
             for (int c = 0; c < 8; c++) yr[i][c] = a.y[(size_t)c * nblk + lane + 64 * i];
         for (int g = g0; g < g1; g++) {
             if (g + 1 < g1) load_group<EPI_STORE, R, NB>(p, g + 1, lane, nxt);
+            f32x2 acc2[R];
             float acc[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = 0.0f;
+            for (int r = 0; r < R; r++) acc2[r] = f32x2{0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < NB; i++)
 #pragma unroll
-                for (int r = 0; r < R; r++) acc[r] = q4_block_dot_f32(cur.w[r][i], cur.s[r][i], yr[i], acc[r]);
+                for (int r = 0; r < R; r++) acc2[r] = q4_block_dot_f32(cur.w[r][i], cur.s[r][i], yr[i], acc2[r]);
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                acc[r] = wave_sum(acc[r]);
+                acc[r] = wave_sum(acc2[r].x + acc2[r].y);
                 if (acc[r] > bestv) { bestv = acc[r]; besti = g * R + r; }  // rows ascend: strict > keeps the first
             }
             store_group<EPI_STORE, R>(p, g, lane, acc);
@@ -753,9 +771,10 @@ __global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
         for (int g = g0; g < g1; g++) {
             const uint8_t* wbase = p.w + (size_t)g * R * p.ldb;
             const float* sbase = p.ws + (size_t)g * R * p.ldbf;
+            f32x2 acc2[R];
             float acc[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = 0.0f;
+            for (int r = 0; r < R; r++) acc2[r] = f32x2{0.0f, 0.0f};
             for (int blk = lane; blk < nblk; blk += 64) {
                 float4 yb[8];
 #pragma unroll
@@ -763,12 +782,12 @@ __global__ __launch_bounds__(512) void gemv_f32q4_kernel(GemvParams p) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const i32x4 wv = __builtin_nontemporal_load((const i32x4*)(wbase + (size_t)r * p.ldb) + blk);
-                    acc[r] = q4_block_dot_f32(wv, sbase[(size_t)r * p.ldbf + blk], yb, acc[r]);
+                    acc2[r] = q4_block_dot_f32(wv, sbase[(size_t)r * p.ldbf + blk], yb, acc2[r]);
                 }
             }
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                acc[r] = wave_sum(acc[r]);
+                acc[r] = wave_sum(acc2[r].x + acc2[r].y);
                 if (acc[r] > bestv) { bestv = acc[r]; besti = g * R + r; }
             }
             store_group<EPI_STORE, R>(p, g, lane, acc);
@@ -1157,7 +1176,6 @@ __global__ void retile_bf16_kernel(const uint16_t* w, int N, int K, uint16_t* wt
 // rows and all of M (weights read once from HBM); the A slice [M,128] (4 blocks) goes through LDS with its block
 // scales and 8*sum(a) per (row, block).
 typedef int i32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct MfmaQ4Params {
     const int8_t* a; const float* af; const uint8_t* w; const float* ws; float* c;
     const float* resid;    // optional: C += resid (same layout as C), e.g. the residual stream in prefill

@@ -285,6 +285,10 @@ class TPEngine:
     def sample(self):                               # rank 0: greedy token of the current row
         raise NotImplementedError
 
+    def stream_context(self):                       # the stream the halves AND the all-reduces are ordered on
+        import contextlib
+        return contextlib.nullcontext()
+
 
 class HipTPEngine(TPEngine):
     """One head-split shard resident on one MI355X (Tier-2 C ABI); one session (batch 1)."""
@@ -297,38 +301,39 @@ class HipTPEngine(TPEngine):
         self.model = HipLlamaModel(lcfg, tp_shard_weights(cfg, weights, rank, size), device=device_index, kv_head_offset=off)
         self.s = self.model.session(max_ctx)
 
-    def _after_torch(self):
-        self.torch.cuda.current_stream().synchronize()   # the all-reduce ran on torch's stream
+    def stream_context(self):
+        """Everything of a row -- the halves (jh_tp_attn / jh_tp_ffn / jh_tp_finish_layer) and the RCCL all-reduces between
+        them -- is ordered on the session's own HIP stream: no host synchronisation inside a row."""
+        if not hasattr(self, "_ext"):
+            self._ext = self.torch.cuda.ExternalStream(self.s.stream())
+        return self.torch.cuda.stream(self._ext)
 
     def set_row(self, token, pos):
         self.s.tp_set_row(token, pos)
 
     def attn(self, layer, partial):
         self.s.tp_attn(layer, partial.data_ptr())
-        self.s.synchronize()
 
     def ffn(self, layer, reduced, partial):
-        self._after_torch()
         self.s.tp_ffn(layer, reduced.data_ptr(), partial.data_ptr())
-        self.s.synchronize()
 
     def finish_layer(self, reduced):
-        self._after_torch()
         self.s.tp_finish_layer(reduced.data_ptr())
 
     def sample(self):
-        return self.s.sample(0.0, 0.5)
+        return self.s.sample(0.0, 0.5)   # synchronises the session stream (the row, incl. its last all-reduce, is complete)
 
 
 def tp_forward_row(dist, engine, token, pos, layers, buf):
     """One row through all layers on every shard: 2 all-reduces (sum) per layer.  buf: [E] float32 on the engine's device."""
-    engine.set_row(token, pos)
-    for li in range(*layers):
-        engine.attn(li, buf)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        engine.ffn(li, buf, buf)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        engine.finish_layer(buf)
+    with engine.stream_context():
+        engine.set_row(token, pos)
+        for li in range(*layers):
+            engine.attn(li, buf)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            engine.ffn(li, buf, buf)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            engine.finish_layer(buf)
 
 
 def tp_generate(dist, engine, rank, prompt, n_gen, cfg, device, dtype):
@@ -344,10 +349,11 @@ def tp_generate(dist, engine, rank, prompt, n_gen, cfg, device, dtype):
         tp_forward_row(dist, engine, int(t), pos, layers, buf)
         pos += 1
     for _ in range(n_gen):
-        if rank == 0:
-            tok[0] = engine.sample()
-        dist.broadcast(tok, src=0)
-        nxt = int(tok.item())
+        with engine.stream_context():
+            if rank == 0:
+                tok[0] = engine.sample()
+            dist.broadcast(tok, src=0)
+            nxt = int(tok.item())
         out.append(nxt)
         tp_forward_row(dist, engine, nxt, pos, layers, buf)
         pos += 1

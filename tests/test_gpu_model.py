@@ -15,6 +15,8 @@ activation row flips ~10% of the next quantizer's codes).  So the tests hold:
     absolute at every teacher-forced step, mean |diff| <= 5e-3;
   * token ids: bit-exact wherever the oracle's own decision margin exceeds LOGIT_TOL (a smaller margin is a coin
     flip between ANY two correct implementations; in strict-order mode they are simply bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -882,6 +884,46 @@ def test_stage_decode_rejects_incomplete_calls(gpu, oracle):
     lastm.stage_decode_async(0, x.data_ptr(), prompt.size, 0, out.data_ptr())
     lastm.synchronize()
     assert int(out.item()) == int(want)
+
+
+def test_rccl_world1_stream_ordered_hosts(gpu, oracle):
+    """The two rank-per-GPU hosts under the REAL backend (nccl = RCCL) with a one-rank group on the test box's GPU: RCCL
+    collectives issued under torch.cuda.ExternalStream(session stream) are ordered with the library's kernels.
+    (a) HipTPEngine + tp_generate: a 1-shard "split" with its two all-reduces per layer equals the resident model's ids;
+    (b) HipShardEngine + pipeline_decode_streamed (one stage: token word fed back on device) equals them too."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from jlama_amd import distributed as D, synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg = dict(S.SMALL)
+        w = S.make_weights(cfg, seed=23, quantize=oracle.q4_quantize)
+        prompt = S.prompt_tokens(cfg, n=10, seed=8)
+        n_gen = 8
+        full = HipLlamaModel(cfg, w).session(64)
+        full.batch_forward(prompt, 0)
+        first = full.sample()
+        want = np.concatenate([[first], full.decode_n(first, prompt.size, n_gen - 1)])
+        eng = D.HipTPEngine(cfg, w, 0, 1, 0, 64)
+        got = D.tp_generate(dist, eng, 0, prompt, n_gen, cfg, dev, torch.float32)
+        np.testing.assert_array_equal(got, want)
+        E = cfg["embedding_length"]
+        sh = D.HipShardEngine(cfg, w, 0, 1, 0, n_sessions=1, max_ctx=64)
+        f = D.pipeline_prefill(dist, sh, 0, 1, 0, prompt, E, dev, torch.float32)
+        assert f == first
+        toks = D.pipeline_decode_streamed(dist, sh, 0, 1, [f], prompt.size, n_gen - 1, E, dev, torch.float32)
+        np.testing.assert_array_equal(toks[0], want[1:])
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("size", [2, 4])
