@@ -475,16 +475,27 @@ def bench_pipeline(args, cfg):
         host_sync = round(steps_per_session * world / dth, 2)
     total = steps_per_session * world
     one_proc = None
-    if rank == 0 and world > 1 and not os.environ.get("JH_BENCH_NO_ONE_PROCESS"):
-        # the one-process host drives the same GPUs from a child process (its own HIP contexts); the ranks wait at the barrier
-        try:
-            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-            r = subprocess.run([sys.executable, "-m", "jlama_amd.distributed", "--one-process", "--config", args.config, "--gpus", str(world),
-                                "--steps", str(args.steps), "--warmup", str(args.warmup), "--prompt", str(args.prompt)],
-                               capture_output=True, text=True, timeout=420, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-            one_proc = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or "")[-400:]}
-        except Exception as e:   # noqa: BLE001 -- the contract line must be printed whatever this optional leg does
-            one_proc = {"error": repr(e)[:400]}
+    if world > 1 and not os.environ.get("JH_BENCH_NO_ONE_PROCESS"):
+        # The one-process host drives the same GPUs from a child of rank 0 (its own HIP contexts).  The other ranks wait on the
+        # rendezvous store -- on the HOST: an RCCL barrier would park a spinning kernel on every GPU the child is measuring.
+        from datetime import timedelta
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = _get_default_store()
+        if rank == 0:
+            try:
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+                r = subprocess.run([sys.executable, "-m", "jlama_amd.distributed", "--one-process", "--config", args.config, "--gpus", str(world),
+                                    "--steps", str(args.steps), "--warmup", str(args.warmup), "--prompt", str(args.prompt)],
+                                   capture_output=True, text=True, timeout=240, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                one_proc = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or "")[-400:]}
+            except Exception as e:   # noqa: BLE001 -- the contract line must be printed whatever this optional leg does
+                one_proc = {"error": repr(e)[:400]}
+            store.set("jh_one_process_leg_done", "1")
+        else:
+            try:
+                store.wait(["jh_one_process_leg_done"], timedelta(seconds=300))
+            except Exception:   # noqa: BLE001 -- fall through to the collective barrier below
+                pass
     dist.barrier()
     out = None
     if rank == 0:
