@@ -1332,6 +1332,10 @@ __global__ __launch_bounds__(KSPLIT * 64) void gemm_q8q4_mfma_kernel(MfmaQ4Param
 // CW: column tiles per workgroup.  The CW*S waves of a workgroup share the row tile: the A tile of a block is fetched
 // once into the CU's L1 and hit by the other CW-1 waves (the kernel is bound by the per-CU L1 miss path, A is 2/3 of
 // its traffic), and the activation-scale slices in LDS are shared too.  The host guarantees n % (32*CW) == 0.
+// single-instruction f32 ops hipcc cannot re-pack into v_pk_*_f32
+__device__ __forceinline__ float mul1(float a, float b) { float r; asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float fma1(float a, float b, float c) { asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(c) : "v"(a), "v"(b)); return c; }
+
 template <int S, bool TILED, int CW>
 __global__ __launch_bounds__(S * CW * 64) __attribute__((amdgpu_waves_per_eu(3))) void gemm_q8q4_tile_kernel(MfmaQ4Params p, int mtiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1377,9 +1381,9 @@ __global__ __launch_bounds__(S * CW * 64) __attribute__((amdgpu_waves_per_eu(3))
         }
     };
     const int sh = h ? 0 : 4;
-    f32x2 acc2[8];
+    float acc[16];
 #pragma unroll
-    for (int r = 0; r < 8; r++) acc2[r] = f32x2{0.0f, 0.0f};
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
     auto compute_chunk = [&](const i32x4 (&av)[4], const i32x4 (&wv)[4], const float (&sv)[4], int blk0) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -1392,15 +1396,16 @@ __global__ __launch_bounds__(S * CW * 64) __attribute__((amdgpu_waves_per_eu(3))
 #pragma unroll
             for (int j = 0; j < 4; j++) {   // rows 4h + 8j + (0..3)
                 const float4 da4 = *(const float4*)(dr + 8 * j);
-                const f32x2 p01 = f32x2{da4.x, da4.y} * s16, p23 = f32x2{da4.z, da4.w} * s16;
-                const f32x2 d01 = f32x2{(float)d[4 * j + 0], (float)d[4 * j + 1]};
-                const f32x2 d23 = f32x2{(float)d[4 * j + 2], (float)d[4 * j + 3]};
-                acc2[2 * j + 0] = __builtin_elementwise_fma(p01, d01, acc2[2 * j + 0]);
-                acc2[2 * j + 1] = __builtin_elementwise_fma(p23, d23, acc2[2 * j + 1]);
+                // single f32 instructions (mul1 / fma1): the packed forms cost more than two scalar ones beside MFMAs on this chip
+                acc[4 * j + 0] = fma1(mul1(da4.x, s16), (float)d[4 * j + 0], acc[4 * j + 0]);
+                acc[4 * j + 1] = fma1(mul1(da4.y, s16), (float)d[4 * j + 1], acc[4 * j + 1]);
+                acc[4 * j + 2] = fma1(mul1(da4.z, s16), (float)d[4 * j + 2], acc[4 * j + 2]);
+                acc[4 * j + 3] = fma1(mul1(da4.w, s16), (float)d[4 * j + 3], acc[4 * j + 3]);
             }
             // pin this block's scaling here (the optimizer otherwise sinks all four blocks' VALU work below the fourth
             // MFMA and keeps four result tiles live): the accumulators pass through an opaque asm
-            asm volatile("" : "+v"(acc2[0]), "+v"(acc2[1]), "+v"(acc2[2]), "+v"(acc2[3]), "+v"(acc2[4]), "+v"(acc2[5]), "+v"(acc2[6]), "+v"(acc2[7]));
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                         "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
         }
     };
     load_chunk(a0, w0, s0, 0);
@@ -1410,9 +1415,6 @@ __global__ __launch_bounds__(S * CW * 64) __attribute__((amdgpu_waves_per_eu(3))
         load_chunk(a0, w0, s0, c + 8);
         compute_chunk(a1, w1, s1, c + 4);
     }
-    float acc[16];
-#pragma unroll
-    for (int r = 0; r < 8; r++) { acc[2 * r] = acc2[r].x; acc[2 * r + 1] = acc2[r].y; }
     // ---- split-K partials meet in LDS (after every wave is done with its scale slice); wave ks finishes registers
     // r = ks*(16/S) ..., summing the K ranges in ascending order
     float* red = (float*)smem + (size_t)cw * S * 16 * 64;   // one reduction region per column tile of the workgroup
@@ -1438,6 +1440,175 @@ __global__ __launch_bounds__(S * CW * 64) __attribute__((amdgpu_waves_per_eu(3))
         if (mrow < p.m) {
             const size_t idx = (size_t)p.ldc * mrow + ncol - p.roffset;
             p.c[idx] = p.resid ? v + p.resid[idx] : v;
+        }
+    }
+}
+
+// ---- I8 x Q4 GEMM, MFMA-ordered operands, A through LDS ------------------------------------------------------------------
+// gemm_q8q4_tile_kernel fetches the activation tile once per WAVE (1 KB per Q block and 32x32 output tile, L1 hits for the
+// other waves of the workgroup): with the weights that is 1.5 KB through the CU's texture path per MFMA, and the knock-out runs
+// show the path, not the VALU scaling, as the bound.  Here a workgroup = ONE row tile x (CW waves x CT column tiles each):
+// the A blocks of a 4-block chunk are fetched once per workgroup (each wave one block, registers -> LDS, double buffered, one
+// barrier per chunk) and read back by every wave with one ds_read_b128 per block that serves its CT MFMAs; per MFMA the
+// texture path now carries 512 B of weights + 128 B of scales + 1 KB / (CW*CT) of A.
+// VALU per (block, tile): 8 (nibble unpack) + 16 v_cvt_f32_i32 + 16 v_mul_f32 + 16 v_fma_f32 + 1, all SINGLE f32 instructions
+// written as asm helpers: on this chip a wave64 f32 VALU op issues in 2 cycles while the packed forms (v_pk_mul/fma_f32,
+// which hipcc's SLP vectoriser produces by itself from adjacent scalar ops) cost more than two scalar ones beside MFMAs
+// (MI355X_MICROARCH.md, "price of one filler beside MFMAs").  Arithmetic per output and block: acc = fma(da*sb, (float)isum, acc).
+// A wave issues at most one instruction per 4 cycles while a SIMD retires a VALU op in 2, so the chip only fills with >= 4
+// resident waves per SIMD: S waves of a workgroup split the K range of each column tile (own A ring per slice, partial tiles
+// meet in LDS, ascending order) -- at M = 129 one wave per output tile is 2.2 waves per SIMD for the whole launch.
+// grid.y = further K slices across workgroups (small N): partials go to a workspace [slice][m][n], splitk_reduce_kernel adds them.
+template <int CW, int CT, int S, bool PK = false>
+__global__ __launch_bounds__(CW * S * 64) void gemm_q8q4_lds_kernel(MfmaQ4Params p, int mtiles, int nbz, float* part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wv % CW, ks = wv / CW;                    // column-tile slot and K slice of this wave
+    const int nl = lane & 31, h = lane >> 5;
+    // blockIdx.x = g_lo + 8*(rt + mtiles*g_hi): the row tiles of a column group run on ONE XCD and share its L2 copy of the weights
+    const int g_lo = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int rt = rest % mtiles, cg = (rest / mtiles) * 8 + g_lo;
+    if (cg * CW * CT * 32 >= p.n) return;                    // whole workgroups only (n % (32*CW*CT) == 0)
+    const int ct0 = (cg * CW + cw) * CT;
+    const int nblk = p.k / QB, z = blockIdx.y, nbs = nbz / S, b0 = z * nbz + ks * nbs;   // this wave's blocks: [b0, b0 + nbs)
+    float* dA = (float*)smem;                                // [nbz][32 rows] activation block scales of the workgroup's K range
+    i32x4* ring = (i32x4*)(smem + (size_t)nbz * 128) + (size_t)ks * 2 * 4 * 64;   // per K slice: [2 chunks][4 blocks][64 lanes] x 16 B
+    {
+        const float4* src = (const float4*)(p.af + ((size_t)rt * nblk + z * nbz) * 32);
+        for (int i4 = tid; i4 < nbz * 8; i4 += CW * S * 64) ((float4*)dA)[i4] = src[i4];
+    }
+    const float* dAs = dA + (size_t)ks * nbs * 32;
+    const i32x4* ap = (const i32x4*)p.a + ((size_t)rt * nblk + b0) * 64 + lane;            // + blk * 64
+    const i32x4* wp[CT];
+    const float* sp[CT];
+#pragma unroll
+    for (int t = 0; t < CT; t++) {
+        wp[t] = (const i32x4*)p.w + ((size_t)(p.n0 / 32 + ct0 + t) * nblk + b0) * 32 + nl;   // + blk * 32
+        sp[t] = p.ws + ((size_t)(p.n0 / 32 + ct0 + t) * nblk + b0) * 32 + nl;                // + blk * 32
+    }
+    constexpr int APW = (4 + CW - 1) / CW;                   // A blocks of a chunk fetched by one wave of the K slice
+    const int last = nbs - 1;
+    i32x4 ast[APW], w0[4][CT], w1[4][CT];
+    float s0[4][CT], s1[4][CT];
+    auto load_a = [&](int blk0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < APW; i++) {
+            int blk = blk0 + cw + i * CW;
+            blk = blk < last ? blk : last;
+            ast[i] = ap[(size_t)blk * 64];
+        }
+    };
+    auto store_a = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < APW; i++)
+            if (cw + i * CW < 4) ring[(buf * 4 + cw + i * CW) * 64 + lane] = ast[i];
+    };
+    auto load_w = [&](i32x4 (&wv_)[4][CT], float (&sv)[4][CT], int blk0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int blk = blk0 + q;
+            blk = blk < last ? blk : last;
+#pragma unroll
+            for (int t = 0; t < CT; t++) {
+                wv_[q][t] = __builtin_nontemporal_load(wp[t] + (size_t)blk * 32);
+                sv[q][t] = sp[t][(size_t)blk * 32];
+            }
+        }
+    };
+    const int sh = h ? 0 : 4;
+    float acc[CT][16];
+#pragma unroll
+    for (int t = 0; t < CT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    auto compute_chunk = [&](int buf, const i32x4 (&wv_)[4][CT], const float (&sv)[4][CT], int blk0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const i32x4 av = ring[(buf * 4 + q) * 64 + lane];
+            const float* dr = dAs + (blk0 + q) * 32 + 4 * h;
+            float da[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {   // rows 4h + 8j + (0..3)
+                const float4 v = *(const float4*)(dr + 8 * j);
+                da[4 * j + 0] = v.x; da[4 * j + 1] = v.y; da[4 * j + 2] = v.z; da[4 * j + 3] = v.w;
+            }
+#pragma unroll
+            for (int t = 0; t < CT; t++) {
+                i32x4 bw = wv_[q][t] << sh;
+                bw = (bw & (int)0xF0F0F0F0) ^ (int)0x80808080;                   // int8 16*(nib-8): low nibbles for h=0, high for h=1
+                const i32x16 z16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                const i32x16 d = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bw, z16, 0, 0, 0);
+                const float s16 = sv[q][t] * 0.0625f;
+                if constexpr (PK) {   // experiment: the packed forms
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 pp = f32x2{da[r], da[r + 1]} * s16;
+                        const f32x2 dd = f32x2{(float)d[r], (float)d[r + 1]};
+                        const f32x2 aa = __builtin_elementwise_fma(pp, dd, f32x2{acc[t][r], acc[t][r + 1]});
+                        acc[t][r] = aa.x; acc[t][r + 1] = aa.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[t][r] = fma1(mul1(da[r], s16), (float)d[r], acc[t][r]);   // the conversion stays visible to hipcc: it owns the MFMA -> VALU hazard
+                }
+                // pin this tile's scaling here (the optimizer otherwise sinks all the VALU work below the chunk's last MFMA and
+                // keeps eight result tiles live): the accumulators pass through an opaque asm
+                asm volatile("" : "+v"(acc[t][0]), "+v"(acc[t][1]), "+v"(acc[t][2]), "+v"(acc[t][3]), "+v"(acc[t][4]), "+v"(acc[t][5]),
+                             "+v"(acc[t][6]), "+v"(acc[t][7]), "+v"(acc[t][8]), "+v"(acc[t][9]), "+v"(acc[t][10]), "+v"(acc[t][11]),
+                             "+v"(acc[t][12]), "+v"(acc[t][13]), "+v"(acc[t][14]), "+v"(acc[t][15]));
+            }
+        }
+    };
+    load_a(0);
+    load_w(w0, s0, 0);
+    store_a(0);
+    lds_barrier();
+    for (int c = 0; c < nbs; c += 8) {   // host guarantees nbs % 8 == 0
+        load_a(c + 4);
+        load_w(w1, s1, c + 4);
+        compute_chunk(0, w0, s0, c);
+        store_a(1);
+        lds_barrier();
+        load_a(c + 8);
+        load_w(w0, s0, c + 8);
+        compute_chunk(1, w1, s1, c + 4);
+        store_a(0);
+        lds_barrier();
+    }
+    // ---- K slices of the workgroup meet in LDS (the scale / ring regions are dead now); wave ks finishes registers
+    // r = ks*(16/S) ..., summing the slices in ascending K order
+    float* red = (float*)smem + (size_t)cw * S * CT * 16 * 64;
+    if (S > 1) {
+#pragma unroll
+        for (int t = 0; t < CT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) red[((ks * CT + t) * 16 + r) * 64 + lane] = acc[t][r];
+        lds_barrier();
+    }
+    constexpr int RP = 16 / S;
+#pragma unroll
+    for (int t = 0; t < CT; t++) {
+        const int col = (ct0 + t) * 32 + nl;
+#pragma unroll
+        for (int i = 0; i < RP; i++) {
+            const int r = S > 1 ? ks * RP + i : i;
+            float v;
+            if (S > 1) {
+                v = 0.0f;
+#pragma unroll
+                for (int q = 0; q < S; q++) v += red[((q * CT + t) * 16 + r) * 64 + lane];
+            } else {
+                v = acc[t][i];
+            }
+            const int mrow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mrow < p.m) {
+                if (part) {
+                    part[((size_t)z * p.m + mrow) * p.n + col] = v;
+                } else {
+                    const size_t idx = (size_t)p.ldc * mrow + p.n0 + col - p.roffset;
+                    p.c[idx] = p.resid ? v + p.resid[idx] : v;
+                }
+            }
         }
     }
 }

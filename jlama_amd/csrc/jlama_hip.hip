@@ -268,13 +268,57 @@ int launch_gemm_q8q4_tile(const MfmaQ4Params& g, int mtiles, hipStream_t st) {
     return JH_OK;
 }
 
+// gemm_q8q4_lds_kernel: one row tile x CW*CT column tiles per workgroup, A staged through LDS; K split over grid.y when the
+// output alone does not fill the chip (partials in ws, summed in ascending K order by splitk_reduce_kernel)
+template <int CW, int CT, int S, bool PK = false>
+int launch_gemm_q8q4_lds(const MfmaQ4Params& g, int mtiles, float* ws, size_t ws_bytes, hipStream_t st) {
+    const int nblk = g.k / QB;
+    const int cgroups = g.n / (32 * CW * CT), gg = (cgroups + 7) / 8;
+    int Z = 1;
+    static const int z_env = env_int("JH_GEMM_Z", 0);
+    while (Z < 8 && (long long)mtiles * cgroups * Z < (long long)g_cu_count * 2 && nblk % (16 * S * Z) == 0 &&
+           ws && (size_t)(2 * Z) * g.m * g.n * 4 <= ws_bytes) Z *= 2;
+    if (z_env > 0 && nblk % (8 * S * z_env) == 0 && (z_env == 1 || (ws && (size_t)z_env * g.m * g.n * 4 <= ws_bytes))) Z = z_env;
+    const int nbz = nblk / Z;
+    size_t lds = (size_t)nbz * 128 + (size_t)S * 2 * 4 * 1024;
+    const size_t red = S > 1 ? (size_t)CW * S * CT * 16 * 64 * 4 : 0;
+    if (red > lds) lds = red;
+    JHCHK(allow_lds((gemm_q8q4_lds_kernel<CW, CT, S, PK>), lds));
+    hipLaunchKernelGGL((gemm_q8q4_lds_kernel<CW, CT, S, PK>), dim3(8 * mtiles * gg, Z), dim3(CW * S * 64), lds, st, g, mtiles, nbz, Z > 1 ? ws : nullptr);
+    HIPCHK(hipGetLastError());
+    if (Z > 1) {
+        const size_t tot = (size_t)g.m * g.n;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)ws, Z, g.m, g.n, g.n0, g.c, g.ldc,
+                           g.roffset, g.resid);
+        HIPCHK(hipGetLastError());
+    }
+    return JH_OK;
+}
+
 // tiled = both operands already in MFMA order (see gemm_q8q4_tile_kernel)
-int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = false) {
+int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = false, float* ws = nullptr, size_t ws_bytes = 0) {
     const int mt = (g.m + 31) / 32;
     const int nblk = g.k / QB;
     if (nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024 && (tiled || (g.lda % 16) == 0) && (tiled || !env_int("JH_GEMM_FAT", 0))) {
         // one 32x32 output tile per wave; split K over S waves until the chip has >= ~8 waves per CU; CW column tiles per
         // workgroup share the A tile through L1 (S*CW <= 8 waves: several workgroups per CU keep the CUs evenly loaded)
+        // gemm_q8q4_lds_kernel (A through LDS, K split over the waves of a workgroup) for the GEMMs with enough work per column
+        // group -- gate|up and down: 71 vs 78 us and 45 vs 56 us at M = 129, 96 vs 102 and 54 vs 67 at M = 256 -- the tile kernel
+        // below for q|k|v and the o-projection (21 vs 30 us).  JH_GEMM_LDS = 0 / 1 forces one of them.
+        static const int lds_env = env_int("JH_GEMM_LDS", -1);
+        const bool lds_auto = (long long)(g.n / 32) * nblk >= (long long)896 * 64;
+        if (tiled && (lds_env > 0 || (lds_env < 0 && lds_auto))) {
+            static const int cw_l = env_int("JH_GEMM_LDS_CW", 4), ct_l = env_int("JH_GEMM_LDS_CT", 1), s_l = env_int("JH_GEMM_LDS_S", 2);
+            int CWL = cw_l, CTL = ct_l > 2 ? 2 : ct_l, SL = s_l;
+            while (CTL > 1 && g.n % (32 * CWL * CTL)) CTL >>= 1;
+            while (CWL > 1 && g.n % (32 * CWL * CTL)) CWL >>= 1;
+            while (SL > 1 && nblk % (8 * SL)) SL >>= 1;
+            if (CWL == 4 && CTL == 1 && SL == 2 && env_int("JH_GEMM_LDS_PK", 0)) return launch_gemm_q8q4_lds<4, 1, 2, true>(g, mt, ws, ws_bytes, st);
+#define JH_LDS(CV, TV, SV) if (CWL == CV && CTL == TV && SL == SV) return launch_gemm_q8q4_lds<CV, TV, SV>(g, mt, ws, ws_bytes, st);
+            JH_LDS(4, 1, 1) JH_LDS(4, 1, 2) JH_LDS(4, 1, 4) JH_LDS(2, 1, 2) JH_LDS(2, 1, 4) JH_LDS(2, 1, 8) JH_LDS(4, 2, 1) JH_LDS(4, 2, 2) JH_LDS(2, 2, 2)
+            JH_LDS(1, 1, 4) JH_LDS(1, 1, 8) JH_LDS(2, 1, 1) JH_LDS(1, 1, 1) JH_LDS(1, 1, 2)
+#undef JH_LDS
+        }
         const long long tiles = (long long)mt * (g.n / 32);
         int S = 1;
         while (S < 8 && tiles * S < (long long)g_cu_count * 8 && nblk % (16 * S) == 0) S *= 2;   // nblk/S stays a multiple of 8
@@ -1340,7 +1384,7 @@ int prefill_alloc(jh_session* s) {
     HIPCHK(hipMalloc(&s->pb_ad, R * (kmax / QB) * 4));
     HIPCHK(hipMalloc(&s->pb_tok, R * 4));
     HIPCHK(hipMalloc(&s->pb_start, 64));
-    if (c.weight_dtype == JH_DT_BF16) HIPCHK(hipMalloc(&s->pb_ws, BF16_SPLITK_WS_BYTES));
+    HIPCHK(hipMalloc(&s->pb_ws, BF16_SPLITK_WS_BYTES));   // split-K partials (BF16 tile GEMM, I8xQ4 LDS GEMM)
     HIPCHK(hipMalloc(&s->pb_att_o, R * c.n_heads * PF_MAX_SPLIT * c.head_size * 4));
     HIPCHK(hipMalloc(&s->pb_att_ml, R * c.n_heads * PF_MAX_SPLIT * 2 * 4));
     s->pb_rows = PB_MAX_ROWS;
@@ -1442,7 +1486,7 @@ int prefill_gemm_tiled(jh_session* s, const JWeight& W, int N, int K, int rows, 
         return launch_gemm_bf16_tile(g, st);
     }
     MfmaQ4Params g{s->pb_aq, s->pb_ad, W.tiled, W.tiled_scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
-    return launch_gemm_q8q4_mfma(g, st, true);
+    return launch_gemm_q8q4_mfma(g, st, true, s->pb_ws, BF16_SPLITK_WS_BYTES);
 }
 // out[rows, N] = act[rows, K] x W[N, K]^T (+ resid): I8 x Q4 (exact integer MFMA) or BF16 x BF16 (MFMA), by model dtype
 int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
@@ -1458,7 +1502,7 @@ int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, 
     if (prefill_tiled(s, K)) {
         JHCHK(ensure_tiled(W, st));
         MfmaQ4Params g{s->pb_aq, s->pb_ad, W.tiled, W.tiled_scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
-        return launch_gemm_q8q4_mfma(g, st, true);
+        return launch_gemm_q8q4_mfma(g, st, true, s->pb_ws, BF16_SPLITK_WS_BYTES);
     }
     MfmaQ4Params g{s->pb_aq, s->pb_ad, (const uint8_t*)W.data, W.scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
     return launch_gemm_q8q4_mfma(g, st);
@@ -2018,7 +2062,7 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
     HIPCHK(hipMalloc(&af, (size_t)(m + 32) * (k / QB) * 4)); HIPCHK(hipMemset(af, 0, (size_t)(m + 32) * (k / QB) * 4));
     HIPCHK(hipMalloc(&c, (size_t)m * n * 4));
     float* bf16_ws = nullptr;
-    if (kind == 1 || kind == 3) HIPCHK(hipMalloc(&bf16_ws, BF16_SPLITK_WS_BYTES));   // kind 3 = BF16 with MFMA-ordered operands
+    HIPCHK(hipMalloc(&bf16_ws, BF16_SPLITK_WS_BYTES));   // split-K workspace; kind 3 = BF16 with MFMA-ordered operands
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     int rc = JH_OK;
     for (int it = -1; it < iters && rc == JH_OK; it++) {
@@ -2026,7 +2070,7 @@ int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* 
         for (int l = 0; l < copies && rc == JH_OK; l++) {
             if (q4) {
                 MfmaQ4Params g{(const int8_t*)a, af, w + l * wbytes, ws + l * (sbytes / 4), c, nullptr, m, 0, n, k, k, k / QB, k / 2, k / QB, n, 0};
-                rc = launch_gemm_q8q4_mfma(g, st, kind == 2);
+                rc = launch_gemm_q8q4_mfma(g, st, kind == 2, bf16_ws, BF16_SPLITK_WS_BYTES);
             } else if (kind == 3) {
                 MfmaBf16TileParams g{(const uint16_t*)a, (const uint16_t*)(w + l * wbytes), c, nullptr, m, n, k, n, bf16_ws, 1};
                 rc = launch_gemm_bf16_tile(g, st);

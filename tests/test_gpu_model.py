@@ -700,8 +700,7 @@ def test_rank_per_gpu_pipeline_engine_loopback(gpu, oracle, world):
         try:
             torch.cuda.set_device(0)
             dist = _LoopbackDist(rank, world, queues, torch, gpu_lock)
-            with gpu_lock:
-                eng = LockedEngine(cfg, w, rank, world, 0, n_sessions=world, max_ctx=64)
+            eng = engines[rank]
             firsts = [D.pipeline_prefill(dist, eng, rank, world, j, prompts[j], E, dev, torch.float32) for j in range(world)]
             toks = D.pipeline_decode(dist, eng, rank, world, firsts, prompts[0].size, steps, E, dev, torch.float32)
             single = D.pipeline_decode(dist, eng, rank, world, firsts[:1], prompts[0].size, steps, E, dev, torch.float32, n_sessions=1)
@@ -710,6 +709,10 @@ def test_rank_per_gpu_pipeline_engine_loopback(gpu, oracle, world):
             import traceback
             errors.append((rank, traceback.format_exc()))
 
+    # shard engines are built here, one after the other: device / context initialisation racing with other threads' allocations
+    # is a property of threads-as-ranks (one HIP runtime), not of the rank-per-process launch
+    engines = [LockedEngine(cfg, w, r, world, 0, n_sessions=world, max_ctx=64) for r in range(world)]
+    torch.cuda.synchronize()
     threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in threads:
         t.start()
@@ -805,8 +808,7 @@ def test_rank_per_gpu_pipeline_stream_ordered_loopback(gpu, oracle, world):
             torch.cuda.set_device(0)
             host = _LoopbackDist(rank, world, queues, torch, gpu_lock)        # prefill uses the host-synchronised hops
             dist = _StreamLoopbackDist(rank, world, queues, torch, gpu_lock)
-            with gpu_lock:
-                eng = LockedEngine(cfg, w, rank, world, 0, n_sessions=world, max_ctx=64)
+            eng = engines[rank]
             firsts = [D.pipeline_prefill(host, eng, rank, world, j, prompts[j], E, dev, torch.float32) for j in range(world)]
             # one throw-away row per session captures the stage graphs before the ranks run concurrently (a capture must
             # not overlap other threads' runtime calls in a shared process; separate processes do not have that problem)
@@ -827,6 +829,10 @@ def test_rank_per_gpu_pipeline_stream_ordered_loopback(gpu, oracle, world):
             errors.append((rank, traceback.format_exc()))
             ready.abort()
 
+    # shard engines are built here, one after the other: device / context initialisation racing with other threads' allocations
+    # is a property of threads-as-ranks (one HIP runtime), not of the rank-per-process launch
+    engines = [LockedEngine(cfg, w, r, world, 0, n_sessions=world, max_ctx=64) for r in range(world)]
+    torch.cuda.synchronize()
     threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in threads:
         t.start()

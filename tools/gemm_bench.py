@@ -6,6 +6,8 @@ for kind, name, bpw in ((2, "I8xQ4t", 0.625), (3, "BF16t", 2.0), (0, "I8xQ4", 0.
     shapes = ((129, 4096, 4096), (129, 28672, 4096), (129, 4096, 14336), (256, 28672, 4096), (32, 28672, 4096))
     if os.environ.get("GB_MODEL_SHAPES"):
         shapes = ((129, 6144, 4096), (129, 4096, 4096), (129, 14336, 4096), (129, 4096, 14336), (256, 14336, 4096))
+    if os.environ.get("GB_PREFILL_SHAPES"):   # the four GEMMs of a Llama-3-8B prefill layer at 129 and 256 rows
+        shapes = tuple((m, n, k) for m in (129, 256) for (n, k) in ((6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)))
     if os.environ.get("GB_KINDS") and str(kind) not in os.environ["GB_KINDS"].split(","):
         continue
     for (m, n, k) in shapes:
