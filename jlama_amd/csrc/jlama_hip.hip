@@ -275,7 +275,7 @@ int launch_gemm_q8q4_lds(const MfmaQ4Params& g, int mtiles, float* ws, size_t ws
     const int nblk = g.k / QB;
     const int cgroups = g.n / (32 * CW * CT), gg = (cgroups + 7) / 8;
     int Z = 1;
-    static const int z_env = env_int("JH_GEMM_Z", 0);
+    const int z_env = env_int("JH_GEMM_Z", 0);
     while (Z < 8 && (long long)mtiles * cgroups * Z < (long long)g_cu_count * 2 && nblk % (16 * S * Z) == 0 &&
            ws && (size_t)(2 * Z) * g.m * g.n * 4 <= ws_bytes) Z *= 2;
     if (z_env > 0 && nblk % (8 * S * z_env) == 0 && (z_env == 1 || (ws && (size_t)z_env * g.m * g.n * 4 <= ws_bytes))) Z = z_env;
@@ -305,10 +305,11 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
         // gemm_q8q4_lds_kernel (A through LDS, K split over the waves of a workgroup) for the GEMMs with enough work per column
         // group -- gate|up and down: 71 vs 78 us and 45 vs 56 us at M = 129, 96 vs 102 and 54 vs 67 at M = 256 -- the tile kernel
         // below for q|k|v and the o-projection (21 vs 30 us).  JH_GEMM_LDS = 0 / 1 forces one of them.
-        static const int lds_env = env_int("JH_GEMM_LDS", -1);
+        const int lds_env = env_int("JH_GEMM_LDS", -1);   // read per call: the tests flip it within one process
         const bool lds_auto = (long long)(g.n / 32) * nblk >= (long long)896 * 64;
-        if (tiled && (lds_env > 0 || (lds_env < 0 && lds_auto))) {
-            static const int cw_l = env_int("JH_GEMM_LDS_CW", 4), ct_l = env_int("JH_GEMM_LDS_CT", 1), s_l = env_int("JH_GEMM_LDS_S", 2);
+        const bool lds_fits = (size_t)nblk * 128 + 4 * 8192 <= 150 * 1024;   // scale slice + the A rings of up to 4 K slices
+        if (tiled && lds_fits && (lds_env > 0 || (lds_env < 0 && lds_auto))) {
+            const int cw_l = env_int("JH_GEMM_LDS_CW", 4), ct_l = env_int("JH_GEMM_LDS_CT", 1), s_l = env_int("JH_GEMM_LDS_S", 2);
             int CWL = cw_l, CTL = ct_l > 2 ? 2 : ct_l, SL = s_l;
             while (CTL > 1 && g.n % (32 * CWL * CTL)) CTL >>= 1;
             while (CWL > 1 && g.n % (32 * CWL * CTL)) CWL >>= 1;

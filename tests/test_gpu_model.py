@@ -513,6 +513,38 @@ def test_decode_attention_long_slices(gpu, oracle):
             del os.environ["JH_ATTN_SPLITS"]
 
 
+@pytest.mark.parametrize("shape", ["4,1,2", "2,1,4", "4,1,1", "4,2,2"])
+def test_prefill_gemm_lds_kernel_equals_tile_kernel(gpu, oracle, monkeypatch, shape):
+    """gemm_q8q4_lds_kernel (A through LDS, K split over the waves of a workgroup; the default for gate|up and down at model
+    size) against gemm_q8q4_tile_kernel on the same 300-row prompt: the integer block sums are exact in both and the per-block
+    scaling is the same expression, so rows agree to float-ordering noise where the K split differs (bar the rare Q8 code
+    that the noise tips over its rounding edge) and the batched prefill keeps its distance to the oracle.  JH_GEMM_Z = 2 adds the cross-workgroup K split (workspace + splitk_reduce_kernel)."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.SMALL)
+    # 32 / 64 Q blocks per row: every K split divides.  ONE layer: a tipped Q8 code then stays in its own row (with more layers
+    # it reaches every later row through the K/V it changes)
+    cfg["embedding_length"], cfg["hidden_length"], cfg["n_layers"] = 1024, 2048, 1
+    hm, om, _ = _pair(cfg, 27, oracle)
+    prompt = S.prompt_tokens(cfg, n=300, seed=28)
+    want = om.session().forward(prompt, 0)
+    monkeypatch.setenv("JH_GEMM_LDS", "0")
+    tile = hm.session(512).forward(prompt, 0)
+    cw, ct, sk = shape.split(",")
+    monkeypatch.setenv("JH_GEMM_LDS", "1")
+    monkeypatch.setenv("JH_GEMM_LDS_CW", cw)
+    monkeypatch.setenv("JH_GEMM_LDS_CT", ct)
+    monkeypatch.setenv("JH_GEMM_LDS_S", sk)
+    lds = hm.session(512).forward(prompt, 0)
+    monkeypatch.setenv("JH_GEMM_Z", "2")
+    ldz = hm.session(512).forward(prompt, 0)
+    for got in (lds, ldz):
+        assert _rel(got, want) <= TRUNK_TOL and _rel(got, tile) <= TRUNK_TOL
+        # summation-order noise only (1e-7) unless it tips a Q8 code of a later quantization over its rounding edge: such rows
+        # differ by one code step (1e-2 of the row scale); they are a small minority
+        per_row = np.abs(got - tile).max(axis=1)
+        assert np.mean(per_row <= 1e-5) >= 0.8, np.sort(per_row)[-8:]
+
+
 @pytest.mark.parametrize("cfgname,mfma_min", [("SMALL", "0"), ("TINY", "0"), ("SMALL", "100")])
 def test_blockwise_mfma_prefill_attention(gpu, oracle, monkeypatch, cfgname, mfma_min):
     """f4: attn_prefill_mfma_kernel (32-row query tiles x K/V tiles on v_mfma_f32_32x32x2_f32, online softmax, key-range
