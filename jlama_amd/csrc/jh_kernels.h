@@ -1740,6 +1740,7 @@ struct AttnParams {
     float* part_ml;        // [n_heads][part_stride][2]    slice (max, sum)
     unsigned* counters;    // [n_kv_heads], zero between launches
     int max_splits;        // slices in "ticket" mode (long contexts)
+    int mid_splits, mid_max;   // contexts of <= mid_max rows use at most mid_splits slices (0 = no such tier)
     int part_stride;       // >= max(max_splits, 4)
     int direct_max;        // contexts up to this length use "direct" mode: <= 4 slices of direct_chunk rows, combined by
     int direct_chunk;      //   the o-projection's prologue (PRO_ATTN_Q8); 0 disables
@@ -1780,7 +1781,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
     constexpr int RPS = NT / LPR;        // rows per workgroup step (scores and PV use the same row->thread map)
     constexpr int half = HS / 2;
     constexpr int NQ = (GROUP * half + NT - 1) / NT;   // q-rotation pairs per thread
-    constexpr int CS = 16;               // slices combined per batch of in-flight loads (ticket mode)
+    constexpr int CS = GROUP * HS <= NT ? 32 : 16;   // slices combined per batch of in-flight loads (ticket mode)
     JH_ATT_STAMP(0);
     const int pos = p.st->pos;
     const int kvh = blockIdx.y, split = blockIdx.x;
@@ -1790,7 +1791,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
     if (direct) S = (n + p.direct_chunk - 1) / p.direct_chunk;
     else {
         S = (n + 31) / 32;
-        if (S > p.max_splits) S = p.max_splits;
+        int cap = p.max_splits;
+        if (p.mid_max && n <= p.mid_max && p.mid_splits < cap) cap = p.mid_splits;
+        if (S > cap) S = cap;
     }
     if (split >= S) return;
     const int chunk = direct ? p.direct_chunk : (n + S - 1) / S;
@@ -2114,8 +2117,9 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
     __shared__ float wts[GROUP * 64];
     const int kvh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.st->pos + 1;
-    int S = (n + 31) / 32;
-    if (S > p.max_splits) S = p.max_splits;
+    int S = (n + 31) / 32, cap = p.max_splits;
+    if (p.mid_max && n <= p.mid_max && p.mid_splits < cap) cap = p.mid_splits;
+    if (S > cap) S = cap;
     for (int gi = wave; gi < GROUP; gi += 4) {
         const float* pr = p.part_ml + ((size_t)(kvh * GROUP + gi) * p.part_stride) * 2;
         float m = -INFINITY;

@@ -1040,6 +1040,7 @@ struct jh_model {
     int weights_version = 0;  // bumped by jh_model_set_weight: sessions drop graphs that captured the old device pointers
 };
 enum { TAP_SLOTS = 12 };
+constexpr int N_ATTN_VARIANTS = 3;
 struct jh_session {
     jh_model* m;
     hipStream_t stream = nullptr;
@@ -1049,6 +1050,7 @@ struct jh_session {
     float* kv_slab = nullptr;
     size_t page_elems = 0;
     int max_ctx = 0, max_splits = 32, chunk_cap = 32;
+    int long_splits = 32, long_min = 2048, mid_splits = 24, mid_max = 6144;   // attention variant 2: more slices for long contexts
     // activations
     float *x = nullptr, *x1 = nullptr, *qkv = nullptr, *attf = nullptr, *hf = nullptr;
     float *logits = nullptr, *amax_v = nullptr, *part_o = nullptr, *part_ml = nullptr, *tapq = nullptr;
@@ -1059,14 +1061,14 @@ struct jh_session {
     int* out_tokens = nullptr;
     int out_cap = 0;
     int lm_grid = 0;
-    // graphs exist per attention variant (0: PRE=8 rows steps prefetched, 1: PRE=2 for short contexts)
+    // graphs exist per attention variant (0: PRE=8 row steps prefetched, 1: PRE=2 for short contexts, 2: long contexts -- more slices)
     int attn_variant = 0;
     int graphs_version = 0;   // jh_model::weights_version the cached graphs were captured against
     int attn_combine = 0;   // 1: slices merged by attn_combine_kernel after the kernel edge (0: in-kernel ticket + last arriver)
-    hipGraph_t graph[2] = {nullptr, nullptr};
-    hipGraphExec_t exec[2] = {nullptr, nullptr};
-    hipGraph_t row_graph[2] = {nullptr, nullptr};   // this shard's layers only: single-row forward (pipeline stages)
-    hipGraphExec_t row_exec[2] = {nullptr, nullptr};
+    hipGraph_t graph[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t exec[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
+    hipGraph_t row_graph[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};   // this shard's layers only: single-row forward (pipeline stages)
+    hipGraphExec_t row_exec[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
     int pending_n = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms_per_token = 0;
@@ -1163,11 +1165,14 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     p.direct_max = s->direct_max;
     p.direct_chunk = s->direct_chunk;
     p.counters = s->counters;
-    p.max_splits = s->max_splits;
+    const bool long_v = s->attn_variant == 2;
+    p.max_splits = long_v ? s->long_splits : s->max_splits;
+    p.mid_splits = long_v ? s->mid_splits : 0;
+    p.mid_max = long_v ? s->mid_max : 0;
     p.outf = s->attf;
     p.tap_q = tap ? s->tapq : nullptr;
     p.dbg = dbg;
-    p.combine_kernel = (s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0;
+    p.combine_kernel = (s->attn_combine && s->direct_max == 0 && p.max_splits <= 64) ? 1 : 0;
     if (s->strict) {
         const size_t lds_s = lds_bytes_attn_strict(c.head_size, s->max_ctx);
         if (lds_s > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "strict attention: the score row of max_ctx positions must fit in LDS");
@@ -1177,9 +1182,10 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
         return JH_OK;
     }
     const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
-    const int sc_cap = s->chunk_cap > 2 * s->max_splits ? s->chunk_cap : 2 * s->max_splits;
+    const int most = s->long_splits > s->max_splits ? s->long_splits : s->max_splits;
+    const int sc_cap = s->chunk_cap > 2 * most ? s->chunk_cap : 2 * most;
     const size_t lds = ((size_t)group * hs + 2 * hs + (size_t)(ATT_THREADS * 4) * group + 2 * group + 4 + (size_t)group * sc_cap) * 4;
-    const int gx = s->max_splits > 4 ? s->max_splits : 4;
+    const int gx = p.max_splits > 4 ? p.max_splits : 4;
     dim3 grid(gx, c.n_kv_heads), block(ATT_THREADS);
 #define JH_ATTN(HSV, GV)                                                                   \
     if (hs == HSV && group == GV) {                                                        \
@@ -1701,7 +1707,7 @@ int ensure_out_tokens(jh_session* s, int n) {
     if (s->out_tokens) HIPCHK(hipFree(s->out_tokens));
     HIPCHK(hipMalloc(&s->out_tokens, (size_t)n * sizeof(int)));
     s->out_cap = n;
-    for (int v = 0; v < 2; v++) if (s->exec[v]) {  // out_tokens pointer is baked into the captured graphs
+    for (int v = 0; v < N_ATTN_VARIANTS; v++) if (s->exec[v]) {  // out_tokens pointer is baked into the captured graphs
         hipGraphExecDestroy(s->exec[v]); s->exec[v] = nullptr;
         hipGraphDestroy(s->graph[v]); s->graph[v] = nullptr;
     }
@@ -1923,10 +1929,20 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     HIPCHK(hipMalloc(&s->logits, (size_t)c.vocab_size * 4));
     HIPCHK(hipMalloc(&s->amax_v, 4096 * 4));
     HIPCHK(hipMalloc(&s->amax_i, 4096 * 4));
+    // long contexts (> long_min rows) are bandwidth-bound and want the whole chip: up to long_splits slices (mid_splits up to
+    // mid_max rows) -- 8100 rows: 518 vs 464 tok/s with 32 instead of 16, 4096 rows: 560 vs 537 with 24; <= 1024 rows lose with more than 16
+    s->long_splits = env_int("JH_ATTN_LONG_SPLITS", 32);
+    s->long_min = env_int("JH_ATTN_LONG_MIN", 2048);
+    s->mid_splits = env_int("JH_ATTN_MID_SPLITS", 24);
+    s->mid_max = env_int("JH_ATTN_MID_MAX", 6144);
+    if (s->long_splits > 64) s->long_splits = 64;
+    if (s->long_splits <= s->max_splits) s->long_splits = 0;   // no separate tier
     s->part_stride = s->max_splits > 4 ? s->max_splits : 4;
+    if (s->long_splits > s->part_stride) s->part_stride = s->long_splits;
     // "direct" attention: contexts of up to 4 slices x 128 rows are combined by the o-projection's prologue
     s->direct_chunk = env_int("JH_ATTN_DIRECT_CHUNK", 128);
     s->direct_max = env_int("JH_ATTN_DIRECT", 0) ? 4 * s->direct_chunk : 0;   // measured slower on MI355X: off by default
+    if (s->direct_max) s->long_splits = 0;
     if (c.n_heads * 4 > 512 || (A / 8) > 2 * 512) s->direct_max = 0;   // prologue limits (PRO_ATTN_Q8)
     HIPCHK(hipMalloc(&s->part_o, (size_t)c.n_heads * s->part_stride * c.head_size * 4));
     HIPCHK(hipMalloc(&s->part_ml, (size_t)c.n_heads * s->part_stride * 2 * 4));
@@ -1999,7 +2015,7 @@ int jh_session_destroy(jh_session* s) {
     if (!s) return JH_OK;
     hipSetDevice(s->m->device);
     if (s->stream) hipStreamSynchronize(s->stream);
-    for (int v = 0; v < 2; v++) {
+    for (int v = 0; v < N_ATTN_VARIANTS; v++) {
         if (s->exec[v]) hipGraphExecDestroy(s->exec[v]);
         if (s->graph[v]) hipGraphDestroy(s->graph[v]);
         if (s->row_exec[v]) hipGraphExecDestroy(s->row_exec[v]);
@@ -2199,7 +2215,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
 // captured graphs hold raw device pointers of the weights: drop them all if a weight was replaced since the capture
 static void drop_stale_graphs(jh_session* s) {
     if (s->graphs_version == s->m->weights_version) return;
-    for (int v = 0; v < 2; v++) {
+    for (int v = 0; v < N_ATTN_VARIANTS; v++) {
         if (s->exec[v]) { hipGraphExecDestroy(s->exec[v]); s->exec[v] = nullptr; }
         if (s->graph[v]) { hipGraphDestroy(s->graph[v]); s->graph[v] = nullptr; }
         if (s->row_exec[v]) { hipGraphExecDestroy(s->row_exec[v]); s->row_exec[v] = nullptr; }
@@ -2213,7 +2229,19 @@ static void drop_stale_graphs(jh_session* s) {
 }
 // which attention variant serves position pos: slices of <= 32 rows need only 2 prefetched row steps
 static int attn_variant_for(const jh_session* s, int pos) {
-    return (s->direct_max == 0 && pos + 1 <= s->max_splits * 32) ? 1 : 0;
+    if (s->direct_max == 0 && pos + 1 <= s->max_splits * 32) return 1;
+    if (s->long_splits > 0 && pos + 1 > s->long_min) return 2;
+    return 0;
+}
+// does any position of [first, last] use attention variant v?  (variants change at most twice along the context)
+static bool attn_variant_in_range(const jh_session* s, int v, int first, int last) {
+    const int edges[4] = {first, last, s->max_splits * 32, s->long_min};   // positions next to the two thresholds
+    for (int e : edges)
+        for (int d = -1; d <= 1; d++) {
+            const int pos = e + d;
+            if (pos >= first && pos <= last && attn_variant_for(s, pos) == v) return true;
+        }
+    return false;
 }
 static int build_row_graph(jh_session* s, int v) {
     drop_stale_graphs(s);
@@ -2448,8 +2476,8 @@ int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) 
     hipStream_t st = s->stream;
     const bool use_graph = !env_int("JH_NO_GRAPH", 0);
     if (use_graph) {   // capture the graph variants this call needs before the timed region (a capture costs milliseconds)
-        JHCHK(build_graph(s, attn_variant_for(s, start_pos)));
-        JHCHK(build_graph(s, attn_variant_for(s, start_pos + n - 1)));
+        for (int v = 0; v < N_ATTN_VARIANTS; v++)
+            if (attn_variant_in_range(s, v, start_pos, start_pos + n - 1)) JHCHK(build_graph(s, v));
     }
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, start_pos, first_token, 0);
     hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
@@ -2812,8 +2840,8 @@ int jh_pipeline_decode_n_async(jh_pipeline* p, int32_t first_token, int start_po
     for (int k = 0; k < N; k++) {
         jh_session* s = p->st[k];
         HIPCHK(hipSetDevice(s->m->device));
-        for (int v = 0; v < 2; v++) {
-            if (attn_variant_for(s, start_pos) != v && attn_variant_for(s, start_pos + n - 1) != v) continue;
+        for (int v = 0; v < N_ATTN_VARIANTS; v++) {
+            if (!attn_variant_in_range(s, v, start_pos, start_pos + n - 1)) continue;
             if (k == N - 1) JHCHK(build_graph(s, v)); else JHCHK(build_row_graph(s, v));
         }
     }
