@@ -223,7 +223,11 @@ def run_single(args, cfg):
     s.batch_forward(prompt, 0)                                # same rows again (rewrites the same KV rows): steady state
     first = s.sample()
     prompt_ms = (time.perf_counter() - tp0) * 1e3
-    s.decode_n(first, prompt.size, 1)                         # untimed: captures this session's decode graph (the timed run rewrites the row)
+    # untimed: capture every decode-graph variant the timed positions will replay (short / medium / long context attention);
+    # the timed run rewrites these rows
+    last_pos = prompt.size + args.steps - 1
+    for p0 in sorted({prompt.size, last_pos} | {b for b in (512, 513, 2048, 2049) if prompt.size <= b <= last_pos}):
+        s.decode_n(first, p0, 1)
     torch.cuda.synchronize(); s.synchronize()
     t0 = time.perf_counter()
     s.decode_n_async(first, prompt.size, args.steps)
