@@ -1153,6 +1153,102 @@ __global__ __launch_bounds__(CWB * 64) void gemm_bf16_tile_kernel(MfmaBf16TilePa
             }
         }
 }
+// The same GEMM with the A fragments through LDS.  In gemm_bf16_tile_kernel every wave fetches its own MT A fragments per k
+// slice ((1 + MT) KB through the CU's texture path per wave and slice, L1 hits for all but the first wave): 5.5 MB per CU for the
+// gate|up GEMM at M = 129 = 39 us at 64 B/clk, the bound of that kernel.  Here the CWB waves of a workgroup fetch a chunk of
+// SLC k slices of A once (MT*SLC 1-KB pieces, spread over the waves, registers -> LDS, double buffered, one barrier per chunk)
+// and read the fragments back with ds_read_b128; only the weight fragment (1 KB per wave and slice, used MT times) still comes
+// through the texture path.  Same MFMA order, same results.
+template <int MT, int CWB>
+__global__ __launch_bounds__(CWB * 64) void gemm_bf16_lds_kernel(MfmaBf16TileParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLC = 4;                                   // k slices per chunk
+    constexpr int PIECES = MT * SLC, APW = (PIECES + CWB - 1) / CWB;
+    i32x4* ring = (i32x4*)smem;                              // [2][MT][SLC][64] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nl = lane & 31, h = lane >> 5;
+    const int ct = blockIdx.x * CWB + wv;                    // host: n % (32*CWB) == 0
+    const int nks = p.k / 16, nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    const int per = nks / nsplit, s0 = blockIdx.y * per;     // host: per % (2*SLC) == 0
+    const i32x4* wp = (const i32x4*)p.w + ((size_t)ct * nks + s0) * 64 + lane;
+    const i32x4* ap = (const i32x4*)p.a + (size_t)s0 * 64 + lane;          // + (rt*nks + s)*64
+    const size_t a_rt = (size_t)nks * 64;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    i32x4 ast[APW], w0[SLC], w1[SLC];
+    const int last = per - 1;
+    auto load_a = [&](int sl0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < APW; i++) {
+            int pc = wv + i * CWB;
+            pc = pc < PIECES ? pc : PIECES - 1;
+            const int t = pc / SLC, q = pc - t * SLC;
+            int sl = sl0 + q;
+            sl = sl < last ? sl : last;
+            ast[i] = ap[(size_t)t * a_rt + (size_t)sl * 64];
+        }
+    };
+    auto store_a = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < APW; i++) {
+            const int pc = wv + i * CWB;
+            if (pc < PIECES) ring[((size_t)buf * PIECES + pc) * 64 + lane] = ast[i];
+        }
+    };
+    auto load_w = [&](i32x4 (&wr)[SLC], int sl0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < SLC; q++) {
+            int sl = sl0 + q;
+            sl = sl < last ? sl : last;
+            wr[q] = __builtin_nontemporal_load(wp + (size_t)sl * 64);
+        }
+    };
+    auto mma_chunk = [&](int buf, const i32x4 (&wr)[SLC]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < SLC; q++) {
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, wr[q]);
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                const i32x4 av = ring[((size_t)buf * PIECES + t * SLC + q) * 64 + lane];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bfrag, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    load_a(0);
+    load_w(w0, 0);
+    store_a(0);
+    lds_barrier();
+    for (int s = 0; s < per; s += 2 * SLC) {
+        load_a(s + SLC);
+        load_w(w1, s + SLC);
+        mma_chunk(0, w0);
+        store_a(1);
+        lds_barrier();
+        load_a(s + 2 * SLC);
+        load_w(w0, s + 2 * SLC);
+        mma_chunk(1, w1);
+        store_a(0);
+        lds_barrier();
+    }
+    const int ncol = ct * 32 + nl;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mrow < p.m) {
+                if (nsplit > 1) {
+                    p.ws[((size_t)blockIdx.y * p.m + mrow) * p.n + ncol] = acc[t][r];
+                } else {
+                    const size_t idx = (size_t)p.ldc * mrow + ncol;
+                    p.c[idx] = p.resid ? acc[t][r] + p.resid[idx] : acc[t][r];
+                }
+            }
+        }
+}
 // row-major BF16 weight [N][K] -> MFMA order [N/32][K/16][h][n][8]; one thread per 16-byte chunk
 __global__ void retile_bf16_kernel(const uint16_t* w, int N, int K, uint16_t* wt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -394,7 +394,15 @@ template <int MT, int CWB>
 int launch_gemm_bf16_tile_mc(MfmaBf16TileParams g, int S, hipStream_t st) {
     const int tiles = g.n / 32, grid = (tiles + CWB - 1) / CWB;
     g.nsplit = S;
-    hipLaunchKernelGGL((gemm_bf16_tile_kernel<MT, CWB>), dim3(grid, S), dim3(CWB * 64), 0, st, g);
+    // A through LDS (gemm_bf16_lds_kernel) when the K range of a workgroup row divides into double chunks of 4 slices
+    const int lds_env = env_int("JH_BF16_LDS", 1);
+    if (lds_env && (tiles % CWB) == 0 && ((g.k / 16 / S) % 8) == 0) {
+        const size_t lds = (size_t)2 * MT * 4 * 1024;
+        JHCHK(allow_lds((gemm_bf16_lds_kernel<MT, CWB>), lds));
+        hipLaunchKernelGGL((gemm_bf16_lds_kernel<MT, CWB>), dim3(grid, S), dim3(CWB * 64), lds, st, g);
+    } else {
+        hipLaunchKernelGGL((gemm_bf16_tile_kernel<MT, CWB>), dim3(grid, S), dim3(CWB * 64), 0, st, g);
+    }
     HIPCHK(hipGetLastError());
     if (S > 1) {
         const size_t tot = (size_t)g.m * g.n;
@@ -416,9 +424,26 @@ int launch_gemm_bf16_tile(const MfmaBf16TileParams& g, hipStream_t st) {
     if (cwb < 2 && tiles % 2 == 0) cwb = 2;
     if (cwb_env > 0 && tiles % cwb_env == 0) cwb = cwb_env;
     int S = 1;
-    if (g.ws)
+    const bool lds_kernel = env_int("JH_BF16_LDS", 1) != 0 && nks % 8 == 0;
+    if (lds_kernel && cwb_env <= 0) {
+        // gemm_bf16_lds_kernel (tools/bf16_exp.sh sweeps, profiles/r02i_*): the waves of a workgroup share the staged A chunk, so
+        // 4 column tiles per workgroup (8 when the A chunk is 7-8 row tiles); K split until the launch has a workgroup per CU and
+        // either 1.5 per CU or <= 64 k slices per workgroup
+        cwb = (mt >= 7 && tiles % 8 == 0) ? 8 : (tiles % 4 == 0 ? 4 : (tiles % 2 == 0 ? 2 : 1));
+        if (g.ws) {
+            auto fits = [&](int s2) {
+                return nks % (8 * s2) == 0 && (size_t)s2 * g.n <= (size_t)8 * 16384 && (g.n <= 8192 || s2 * g.m <= 512);
+            };
+            while (S < 16 && fits(2 * S)) {
+                const int wgs = (tiles / cwb) * S;
+                if (wgs >= g_cu_count && (2 * wgs >= 3 * g_cu_count || nks / S <= 64)) break;
+                S *= 2;
+            }
+        }
+    } else if (g.ws) {
         while (S < 16 && (tiles / cwb) * S < g_cu_count * 2 && nks % (4 * S) == 0 && nks / (2 * S) >= 8 &&   // nks/S stays even
                (size_t)(2 * S) * g.n <= (size_t)8 * 16384 && (g.n <= 8192 || 2 * S * g.m <= 640)) S *= 2;
+    }
     if (s_env > 0 && g.ws && nks % (2 * s_env) == 0 && (size_t)s_env * g.n <= (size_t)8 * 16384) S = s_env;
     if ((nks / S) % 2) return set_err(JH_ERR_UNSUPPORTED, "tiled BF16 GEMM needs K % 32 == 0");
 #define JH_BT(MV) { if (cwb == 8) return launch_gemm_bf16_tile_mc<MV, 8>(g, S, st); if (cwb == 4) return launch_gemm_bf16_tile_mc<MV, 4>(g, S, st); \
