@@ -21,6 +21,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+FLIP_ROW = 5e-2   # one tipped Q8 code moves a row of a single-layer model by about one code step of its scale
 
 LOGIT_TOL = 4e-2
 TRUNK_TOL = 4e-2   # relative to the row's max |x|
@@ -511,6 +512,31 @@ def test_decode_attention_long_slices(gpu, oracle):
                 toks.append(ref_toks[i])
         finally:
             del os.environ["JH_ATTN_SPLITS"]
+
+
+@pytest.mark.parametrize("rows", [129, 37, 264])
+def test_prefill_ragged_last_row_tile(gpu, oracle, monkeypatch, rows):
+    """Prompts whose last 32-row tile is nearly empty (the metric's 129 = 4*32 + 1; 37; 264): rows past M are computed on
+    replicated / clamped operands and never stored.  Batched prefill (default dispatch and each I8xQ4 GEMM kernel forced)
+    against the one-position-at-a-time path and the oracle, single layer so that a tipped Q8 code stays in its row."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.SMALL)
+    cfg["embedding_length"], cfg["hidden_length"], cfg["n_layers"] = 1024, 2048, 1
+    hm, om, _ = _pair(cfg, 37, oracle)
+    prompt = S.prompt_tokens(cfg, n=rows, seed=38)
+    want = om.session().forward(prompt, 0)
+    monkeypatch.setenv("JH_PREFILL_BATCH_MIN", "0")
+    row = hm.session(512).forward(prompt, 0)
+    monkeypatch.delenv("JH_PREFILL_BATCH_MIN")
+    got = [hm.session(512).forward(prompt, 0)]
+    monkeypatch.setenv("JH_GEMM_LDS", "1")
+    got.append(hm.session(512).forward(prompt, 0))
+    monkeypatch.setenv("JH_GEMM_LDS", "0")
+    got.append(hm.session(512).forward(prompt, 0))
+    for g in got:
+        assert g.shape == want.shape and _rel(g, want) <= TRUNK_TOL and _rel(g, row) <= TRUNK_TOL
+        per_row = np.abs(g - row).max(axis=1)
+        assert np.mean(per_row <= 1e-5) >= 0.8 and per_row[-1] <= FLIP_ROW, (np.sort(per_row)[-6:], per_row[-1])
 
 
 def test_decode_attention_slice_tiers(gpu, oracle, monkeypatch):
