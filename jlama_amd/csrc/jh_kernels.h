@@ -1877,7 +1877,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
     constexpr int RPS = NT / LPR;        // rows per workgroup step (scores and PV use the same row->thread map)
     constexpr int half = HS / 2;
     constexpr int NQ = (GROUP * half + NT - 1) / NT;   // q-rotation pairs per thread
-    constexpr int CS = GROUP * HS <= NT ? 32 : 16;   // slices combined per batch of in-flight loads (ticket mode)
+    constexpr int CS = 16;               // slices combined per batch of in-flight loads (ticket mode); a second batch for the long-context tier
     JH_ATT_STAMP(0);
     const int pos = p.st->pos;
     const int kvh = blockIdx.y, split = blockIdx.x;
