@@ -402,17 +402,20 @@ def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=
             "sessions_agree": bool(same)}
 
 
-def bench_pipeline(args, cfg):
+def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
     """bench.py's N>1 leg (one rank per GPU under torch.distributed.run).  Returns the JSON dict on rank 0.
     Three measurements: N sessions in flight through the rank-per-GPU RCCL pipeline (the timed K tokens of the contract),
     the same pipeline with ONE session (single-stream, batch-1: bounded by a single GPU's rate by construction), and --
-    from rank 0 in a child process -- the one-process N-device host over the same GPUs."""
+    from rank 0 in a child process -- the one-process N-device host over the same GPUs.
+    ``backend="gloo"`` + ``engine_factory(rank, world, n_sessions, max_ctx) -> ShardEngine`` run the same control flow on CPU
+    (tests/test_distributed.py drives every branch of the N>1 line that way; the product path is nccl + HipShardEngine)."""
     import json
     import subprocess
     import sys
     import torch
     import torch.distributed as dist
-    from . import synthetic as S, synthetic_torch as ST
+    from . import synthetic as S
+    on_gpu = backend == "nccl"
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -426,18 +429,28 @@ def bench_pipeline(args, cfg):
         sk.close()
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port))):
             os.environ.setdefault(k, v)
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    dist.init_process_group(backend="nccl", device_id=device)
+    if on_gpu:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        dist.init_process_group(backend="nccl", device_id=device)
+        dev_sync = torch.cuda.synchronize
+    else:
+        device = torch.device("cpu")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dev_sync = lambda: None
     L, E = cfg["n_layers"], cfg["embedding_length"]
     ls, le = layer_range(rank, world, L)
-    w = ST.make_weights(cfg, seed=0, layers=(ls, le), device=device, need_embed=(rank == 0 or cfg.get("tied", False)),
-                        need_head=(rank == world - 1))
     prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
     steps_per_session = max(1, args.steps // world)
     single_steps = max(8, min(64, args.steps))
     max_ctx = prompt.size + max(steps_per_session, args.warmup, single_steps) + 8
-    engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=world, max_ctx=max_ctx)
+    if engine_factory is not None:
+        engine = engine_factory(rank, world, world, max_ctx)
+    else:
+        from . import synthetic_torch as ST
+        w = ST.make_weights(cfg, seed=0, layers=(ls, le), device=device, need_embed=(rank == 0 or cfg.get("tied", False)),
+                            need_head=(rank == world - 1))
+        engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=world, max_ctx=max_ctx)
     firsts = [pipeline_prefill(dist, engine, rank, world, j, prompt, E, device, torch.float32) for j in range(world)]
     # The decode loop: stream-ordered hops (pipeline_decode_streamed: RCCL send/recv on the sessions' streams, token id as a
     # device word) unless JH_PIPELINE_HOST_SYNC=1 asks for the host-synchronised reference loop.  The first ids of both are
@@ -458,10 +471,10 @@ def bench_pipeline(args, cfg):
 
     def timed(fn):
         dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
         t0 = time.perf_counter()
         r = fn()
-        torch.cuda.synchronize()
+        dev_sync()
         dist.barrier()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
@@ -481,7 +494,10 @@ def bench_pipeline(args, cfg):
         from datetime import timedelta
         from torch.distributed.distributed_c10d import _get_default_store
         store = _get_default_store()
-        if rank == 0:
+        if rank == 0 and not on_gpu:
+            one_proc = {"skipped": "no GPU (control-flow run)"}
+            store.set("jh_one_process_leg_done", "1")
+        elif rank == 0:
             try:
                 env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
                 r = subprocess.run([sys.executable, "-m", "jlama_amd.distributed", "--one-process", "--config", args.config, "--gpus", str(world),

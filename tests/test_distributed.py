@@ -114,3 +114,79 @@ def test_layer_range_matches_distributed_context():
     assert [D.layer_range(r, 4, 32) for r in range(4)] == [(0, 8), (8, 16), (16, 24), (24, 32)]
     with pytest.raises(ValueError):
         D.layer_range(0, 3, 32)
+
+
+def _bench_worker(rank, world, port, cfg, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      OMP_NUM_THREADS="2")
+    import argparse
+    import numpy as np
+    import torch
+    from jlama_amd import distributed as D, synthetic as S
+    from oracle import oracle as O
+
+    class OracleShardEngine(D.ShardEngine):
+        def __init__(self, rank, world, n_sessions, max_ctx):
+            ls, le = D.layer_range(rank, world, cfg["n_layers"])
+            self.m = O.OracleModel(cfg, S.make_weights(cfg, seed=0), layer_range=(ls, le))
+            self.s = [self.m.session() for _ in range(n_sessions)]
+            self.last = [None] * n_sessions
+
+        def forward_tokens(self, session, tokens, start_pos, x_out):
+            x = self.s[session].forward(np.asarray(tokens, dtype=np.int32), start_pos)
+            x_out.copy_(torch.from_numpy(x))
+            self.last[session] = x[-1]
+
+        def forward_x(self, session, x_in, n, start_pos, x_out):
+            x = self.s[session].forward(None, start_pos, x=x_in.numpy()[:n])
+            x_out.copy_(torch.from_numpy(x))
+            self.last[session] = x[-1]
+
+        def sample(self, session):
+            return self.m.sample(self.last[session])[0]
+
+        def stream(self, session):
+            return None
+
+        def stage_step(self, session, token, x_in, pos, x_out, token_out):
+            if token is not None:
+                x = self.s[session].forward(np.array([int(token[0])], dtype=np.int32), pos)
+            else:
+                x = self.s[session].forward(None, pos, x=x_in.numpy()[:1])
+            if x_out is not None:
+                x_out.copy_(torch.from_numpy(x))
+            if token_out is not None:
+                token_out[0] = int(self.m.sample(x[-1])[0])
+
+    args = argparse.Namespace(gpus=world, steps=8, warmup=2, prompt=5, config="TINY")
+    out = D.bench_pipeline(args, cfg, backend="gloo", engine_factory=OracleShardEngine)
+    if rank == 0:
+        q.put(out)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_pipeline_control_flow_on_cpu(world):
+    """Every branch of bench.py's N>1 line that the 1-GPU test boxes cannot reach -- the rank-per-GPU pipeline bench with
+    world > 1: prefill of N sessions, streamed-vs-host-synchronised id check, warm-up, the three timed legs, the host-side
+    wait for the one-process leg on the rendezvous store, the JSON line -- run over gloo with the oracle as the shard engine."""
+    import torch.multiprocessing as mp
+    from jlama_amd import synthetic as S
+    cfg = dict(S.TINY)
+    cfg["n_layers"] = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, cfg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out["n_gpus"] == world and out["steps"] == (8 // world) * world and out["value"] > 0
+    c = out["config"]
+    assert c["sessions_in_flight"] == world and c["streamed_ids_equal_host_synchronised"] is True
+    assert c["single_stream_tokens_per_s"] > 0 and c["host_synchronised_aggregate_tokens_per_s"] > 0
+    assert out["one_process_pipeline"] == {"skipped": "no GPU (control-flow run)"}
+    for key in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "roofline"):
+        assert key in out
