@@ -117,7 +117,7 @@ def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_pe
     x_in = torch.empty((1, E), dtype=dtype, device=device)
     x_out = [torch.empty((1, E), dtype=dtype, device=device) for _ in range(2)]
     tok_in = torch.zeros(1, dtype=torch.int32, device=device)
-    tok_out = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(2)]
+    tok_sends = []
     pending = None
     for tick in range(n_items + N - 1):
         q = tick - rank
@@ -137,19 +137,22 @@ def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_pe
         else:
             dist.recv(x_in, src=rank - 1)
             engine.forward_x(j, x_in, 1, start_pos + k, x_out[buf])
-        if pending is not None:
-            pending.wait()
-            pending = None
         if rank < N - 1:
+            if pending is not None:
+                pending.wait()
             pending = dist.isend(x_out[buf], dst=rank + 1)
         else:
             t = engine.sample(j)
             out[j, k] = t
             if N > 1 and k + 1 < steps_per_session:
-                tok_out[buf][0] = t
-                pending = dist.isend(tok_out[buf], dst=0)
+                # never wait for a token send inside the loop: rank 0 posts its receive S items later, and with more sessions
+                # in flight than stages a blocking send here stalls the whole ring behind it
+                tk = torch.full((1,), int(t), dtype=torch.int32, device=device)
+                tok_sends.append((dist.isend(tk, dst=0), tk))
     if pending is not None:
         pending.wait()
+    for w_, _ in tok_sends:
+        w_.wait()
     return out
 
 
@@ -441,33 +444,41 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
     L, E = cfg["n_layers"], cfg["embedding_length"]
     ls, le = layer_range(rank, world, L)
     prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
-    steps_per_session = max(1, args.steps // world)
+    # Sessions in flight for `value`: one per GPU (the fewest that keep every stage busy).  A second timed leg runs two per GPU:
+    # with one, a stage idles through every launch edge of its graph; two sessions' graphs on two streams fill each other's
+    # edges (one GPU, no sharding: 673 -> 871 tok/s, profiles/r02j_*).  Reported beside `value`, never as it.
+    spg = max(1, int(os.environ.get("JH_BENCH_SESSIONS_PER_GPU", "1")))
+    n_sess = world * spg
+    n_sess2 = 0 if os.environ.get("JH_BENCH_NO_EXTRA_LEG") else 2 * n_sess
+    n_all = max(n_sess, n_sess2)
+    steps_per_session = max(1, args.steps // n_sess)
     single_steps = max(8, min(64, args.steps))
     max_ctx = prompt.size + max(steps_per_session, args.warmup, single_steps) + 8
     if engine_factory is not None:
-        engine = engine_factory(rank, world, world, max_ctx)
+        engine = engine_factory(rank, world, n_all, max_ctx)
     else:
         from . import synthetic_torch as ST
         w = ST.make_weights(cfg, seed=0, layers=(ls, le), device=device, need_embed=(rank == 0 or cfg.get("tied", False)),
                             need_head=(rank == world - 1))
-        engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=world, max_ctx=max_ctx)
-    firsts = [pipeline_prefill(dist, engine, rank, world, j, prompt, E, device, torch.float32) for j in range(world)]
+        engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=n_all, max_ctx=max_ctx)
+    firsts_all = [pipeline_prefill(dist, engine, rank, world, j, prompt, E, device, torch.float32) for j in range(n_all)]
+    firsts = firsts_all[:n_sess]
     # The decode loop: stream-ordered hops (pipeline_decode_streamed: RCCL send/recv on the sessions' streams, token id as a
     # device word) unless JH_PIPELINE_HOST_SYNC=1 asks for the host-synchronised reference loop.  The first ids of both are
     # compared before anything is timed; a mismatch falls back to the reference loop and is reported.
     streamed = not os.environ.get("JH_PIPELINE_HOST_SYNC")
     check_steps = max(1, min(4, steps_per_session))
-    ref_ids = pipeline_decode(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32)
+    ref_ids = pipeline_decode(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32, n_sessions=n_sess)
     streamed_ok = None
     if streamed:
-        got = pipeline_decode_streamed(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32)
+        got = pipeline_decode_streamed(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32, n_sessions=n_sess)
         flag = torch.tensor([1 if (rank != world - 1 or np.array_equal(got, ref_ids)) else 0], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         streamed_ok = bool(int(flag.item()))
         streamed = streamed_ok
     decode = pipeline_decode_streamed if streamed else pipeline_decode
     if args.warmup > 0:  # untimed decode ticks on the same sessions' KV tail (positions beyond the timed range are rewritten)
-        decode(dist, engine, rank, world, firsts, prompt.size, max(1, args.warmup // world), E, device, torch.float32)
+        decode(dist, engine, rank, world, firsts, prompt.size, max(1, args.warmup // n_sess), E, device, torch.float32, n_sessions=n_sess)
 
     def timed(fn):
         dist.barrier()
@@ -480,13 +491,19 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return r, float(dt.item())
 
-    toks, dt = timed(lambda: decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32))
+    toks, dt = timed(lambda: decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32, n_sessions=n_sess))
     _, dt1 = timed(lambda: decode(dist, engine, rank, world, firsts[:1], prompt.size, single_steps, E, device, torch.float32, n_sessions=1))
     host_sync = None
     if streamed:   # the reference loop beside it (what the hops cost when the host sits in them)
-        _, dth = timed(lambda: pipeline_decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32))
-        host_sync = round(steps_per_session * world / dth, 2)
-    total = steps_per_session * world
+        _, dth = timed(lambda: pipeline_decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32, n_sessions=n_sess))
+        host_sync = round(steps_per_session * n_sess / dth, 2)
+    total = steps_per_session * n_sess
+    double_up = None
+    if n_sess2:   # the same K tokens with twice the sessions in flight
+        sps2 = max(1, args.steps // n_sess2)
+        decode(dist, engine, rank, world, firsts_all, prompt.size, 1, E, device, torch.float32, n_sessions=n_sess2)
+        _, dt2 = timed(lambda: decode(dist, engine, rank, world, firsts_all, prompt.size, sps2, E, device, torch.float32, n_sessions=n_sess2))
+        double_up = {"sessions_in_flight": n_sess2, "steps_per_session": sps2, "aggregate_tokens_per_s": round(sps2 * n_sess2 / dt2, 2)}
     one_proc = None
     if world > 1 and not os.environ.get("JH_BENCH_NO_ONE_PROCESS"):
         # The one-process host drives the same GPUs from a child of rank 0 (its own HIP contexts).  The other ranks wait on the
@@ -522,10 +539,10 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
                "value": round(tps, 2), "unit": "tokens/s", "n_gpus": world, "steps": total, "warmup": args.warmup,
                "ms_per_step": round(dt / total * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "i8xq4->f32", "data": "synthetic",
-               "config": {"workload": f"{args.config} JQ4, {prompt.size}-row prefill + {steps_per_session} greedy decode steps x {world} "
+               "config": {"workload": f"{args.config} JQ4, {prompt.size}-row prefill + {steps_per_session} greedy decode steps x {n_sess} "
                                       f"sessions in flight", "parallelism": f"layer-sharded pp{world} ({L // world} layers/GPU), RCCL send/recv of [1,E] F32",
-                          "sessions_in_flight": world, "aggregate_tokens_per_s": round(tps, 2),
-                          "per_session_tokens_per_s": round(tps / world, 2),
+                          "sessions_in_flight": n_sess, "sessions_per_gpu": spg, "aggregate_tokens_per_s": round(tps, 2),
+                          "per_session_tokens_per_s": round(tps / n_sess, 2), "two_sessions_per_gpu": double_up,
                           "single_stream_tokens_per_s": round(single_steps / dt1, 2), "single_stream_steps": single_steps,
                           "hops": "stream-ordered (RCCL send/recv on the session streams, token id fed back as a device word)" if streamed
                                   else "host-synchronised", "streamed_ids_equal_host_synchronised": streamed_ok,

@@ -185,7 +185,8 @@ def test_bench_pipeline_control_flow_on_cpu(world):
         assert p.exitcode == 0
     assert out["n_gpus"] == world and out["steps"] == (8 // world) * world and out["value"] > 0
     c = out["config"]
-    assert c["sessions_in_flight"] == world and c["streamed_ids_equal_host_synchronised"] is True
+    assert c["sessions_in_flight"] == world and c["sessions_per_gpu"] == 1 and c["streamed_ids_equal_host_synchronised"] is True
+    assert c["two_sessions_per_gpu"]["sessions_in_flight"] == 2 * world and c["two_sessions_per_gpu"]["aggregate_tokens_per_s"] > 0
     assert c["single_stream_tokens_per_s"] > 0 and c["host_synchronised_aggregate_tokens_per_s"] > 0
     assert out["one_process_pipeline"] == {"skipped": "no GPU (control-flow run)"}
     for key in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "roofline"):
