@@ -433,6 +433,8 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port))):
             os.environ.setdefault(k, v)
     if on_gpu:
+        if not os.environ.get("JH_KEEP_NCCL_DEBUG"):   # level VERSION and up print a banner on stdout; the JSON line is the contract
+            os.environ["NCCL_DEBUG"] = "NONE"
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
         dist.init_process_group(backend="nccl", device_id=device)
@@ -463,6 +465,12 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
         engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=n_all, max_ctx=max_ctx)
     firsts_all = [pipeline_prefill(dist, engine, rank, world, j, prompt, E, device, torch.float32) for j in range(n_all)]
     firsts = firsts_all[:n_sess]
+    if on_gpu:   # the RCCL banner (printed at communicator creation through buffered C stdio) leaves every rank's buffer NOW,
+        try:     # long before rank 0 prints the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
     # The decode loop: stream-ordered hops (pipeline_decode_streamed: RCCL send/recv on the sessions' streams, token id as a
     # device word) unless JH_PIPELINE_HOST_SYNC=1 asks for the host-synchronised reference loop.  The first ids of both are
     # compared before anything is timed; a mismatch falls back to the reference loop and is reported.
@@ -555,6 +563,13 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
                             "note": "per-GPU average: algorithmic bytes of all sessions / time / GPUs"},
                "cpu_baseline": None, "one_process_pipeline": one_proc}
     dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise land AFTER
+    # the JSON line at exit: flush it now so that the contract line is the last thing on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
     return out
 
 
