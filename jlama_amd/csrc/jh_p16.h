@@ -1,0 +1,826 @@
+// jh_p16.h -- the decode path with every float accumulation in EXACTLY the order of the reference's Panama AVX-512 provider
+// ("reference order"), built to stream at the same rate as the order-free kernels of jh_kernels.h.  Results are bit-identical
+// to a plain-C restatement of that provider (oracle/jlama_oracle.c), not merely inside the Q8 noise floor.
+//
+// Panama-512 order (FloatVector.SPECIES_512 = 16 float lanes), what has to be reproduced:
+//   I8 x Q4  (GemmerI8Q4_512, PTO:807-850):  lane t:  acc_t = fma(da*sb, (float)(short)(lo_t*a[t] + hi_t*a[t+16]), acc_t)
+//            over Q blocks in ascending K, then reduceLanes(ADD) = the halving tree (v[i]+v[i+8], +4, +2, +1).
+//   F32 x Q4 (GemmerF32Q4_512, PTO:336-374): acc_t = fma(a[t], (float)(lo_t-8)*s, acc_t); acc_t = fma(a[t+16], (float)(hi_t-8)*s, acc_t)
+//   F32 x F32 (GemmerF32, PTO:1086-1102):    acc_t = fma(a[l+t], b[l+t], acc_t) for l = 0,16,...; same tree.
+//   softMax (VectorMath.java:69-90): float sum of exp in index order;  saxpy over V (PTO:2593-2611, 2648-2698): one fma chain
+//            per output element over positions in ascending order.
+//
+// MI355X mapping ("p16": a 16-lane DPP row plays the 16 Panama lanes, a wave64 serves 4 weight rows):
+//   * the chain of lane t over the Q blocks is sequential by definition, so ONE GPU lane owns (row, t) and walks K -- but the bytes
+//     arrive the other way round: a coalesced 16-byte load is one whole Q4 block = byte t of 16 DIFFERENT chains.  The 16 lanes of a
+//     row therefore load 16 consecutive blocks of their row (256 contiguous bytes, 1 KiB per wave instruction, exactly the access
+//     pattern of the order-free kernel) and transpose the 16x16 byte matrix in registers: two v_perm rounds with quad_perm DPP
+//     partners (byte / halfword granularity) + two masked-DPP rounds (dword granularity, row_shl/shr:4 and row_ror:8 with bank
+//     masks) = 28 VALU ops per 16 blocks, no LDS;
+//   * nibbles become int8 16*(nib-8) = ((nib << 4) ^ 0x80) with two bit ops per dword (4 blocks), so the pair sum
+//     lo*a[t] + hi*a[t+16] is ONE v_dot4_i32_i8 against a (a[t], a[t+16], 0, 0) activation word (byte-selected by v_perm), exact;
+//     the 1/16 goes into the activation block scale (a power of two: every rounding is unchanged);
+//   * the per-block scale product da*sb lives in the lane that loaded the block and reaches the 16 chains through the DPP
+//     operand of v_fmac_f32 (row_newbcast): acc = fma(bcast(da*sb), (float)isum, acc) is ONE instruction per step;
+//   * per step: perm + dot4 + cvt + fmac  (+ amortised 1.75 transpose + 0.75 unpack) = 6.5 VALU ops for 2 weights -- 5x the
+//     order-free kernel's VALU work, still under the HBM time of every GEMV of the path (decode is HBM-bound);
+//   * a prefetch ring of D groups (16 blocks each) per lane keeps D KiB per wave in flight; the activation row is quantized once
+//     per workgroup into LDS (same fused RMSNorm + Q8 prologue, Panama rule) as pair words, 4 blocks per 8-byte read.
+// Compiled with -ffp-contract=off like the rest: every FMA is explicit.
+#pragma once
+#include "jh_kernels.h"
+
+namespace jh {
+
+// reduceLanes(ADD) of a 16-lane row as the halving tree: after the rotate-by-8 step the row's values have period 8, so
+// rotating by 4 / 2 / 1 pairs lane i with the partner the tree prescribes (float addition commutes): every lane of the
+// row ends with ((v0+v8)+(v4+v12)) + ((v2+v10)+(v6+v14)) + ... in exactly jo_reduce16's association.
+__device__ __forceinline__ float row16_tree_sum(float v) {
+    v = v + dpp_f<0x128>(v);   // row_ror:8
+    v = v + dpp_f<0x124>(v);   // row_ror:4
+    v = v + dpp_f<0x122>(v);   // row_ror:2
+    v = v + dpp_f<0x121>(v);   // row_ror:1
+    return v;
+}
+
+template <int CTRL, int BANK>
+__device__ __forceinline__ int dpp_bank(int old, int src) {   // lanes whose bank (lane>>2 & 3) is not in BANK keep `old`
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, BANK, false);
+}
+__device__ __forceinline__ int perm_b(int hi_src, int lo_src, int sel) {   // selector byte 0-3: lo_src, 4-7: hi_src, 0x0C: zero
+    return (int)__builtin_amdgcn_perm((unsigned)hi_src, (unsigned)lo_src, (unsigned)sel);
+}
+
+// Lane i (0..15 of its row) holds bytes B_i[0..15] (one Q4 block) in x; afterwards lane t holds B_c[t] at byte c: the 16x16 byte
+// matrix of the row is transposed by swapping lane bit d with column bit d for d = 0..3 (element (i, c) <-> (i^d, c^d) wherever
+// bit d of i and c differ).  Lane bits 0,1 pair with the byte / halfword column bits (partner through quad_perm, merge with v_perm,
+// selector by lane parity); lane bits 2,3 pair with the dword index bits, where a bank-masked DPP move writes exactly the half of
+// the lanes that receive (no select).  tools/p16_transpose_sim.py replays these rounds on the host.
+struct RowSel { int a, b; };
+__device__ __forceinline__ RowSel row16_selectors(int lane) {
+    RowSel s;
+    s.a = (lane & 1) ? 0x03070105 : 0x06020400;   // bit0 = 0: [self0, partner0, self2, partner2]; 1: [partner1, self1, partner3, self3]
+    s.b = (lane & 2) ? 0x03020706 : 0x05040100;   // bit1 = 0: [self0, self1, partner0, partner1]; 1: [partner2, partner3, self2, self3]
+    return s;
+}
+__device__ __forceinline__ void row16_transpose(i32x4& v, const RowSel sel) {
+    int x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+    {   // partner = lane ^ 1.  The four partner fetches first, then the four merges: a DPP read needs 2 wait states behind the VALU
+        // write of its source, which the three other dwords' instructions provide (no s_nop)
+        const int p0 = __builtin_amdgcn_mov_dpp(x0, 0xB1, 0xf, 0xf, true), p1 = __builtin_amdgcn_mov_dpp(x1, 0xB1, 0xf, 0xf, true);
+        const int p2 = __builtin_amdgcn_mov_dpp(x2, 0xB1, 0xf, 0xf, true), p3 = __builtin_amdgcn_mov_dpp(x3, 0xB1, 0xf, 0xf, true);
+        x0 = perm_b(p0, x0, sel.a); x1 = perm_b(p1, x1, sel.a); x2 = perm_b(p2, x2, sel.a); x3 = perm_b(p3, x3, sel.a);
+    }
+    {   // partner = lane ^ 2
+        const int p0 = __builtin_amdgcn_mov_dpp(x0, 0x4E, 0xf, 0xf, true), p1 = __builtin_amdgcn_mov_dpp(x1, 0x4E, 0xf, 0xf, true);
+        const int p2 = __builtin_amdgcn_mov_dpp(x2, 0x4E, 0xf, 0xf, true), p3 = __builtin_amdgcn_mov_dpp(x3, 0x4E, 0xf, 0xf, true);
+        x0 = perm_b(p0, x0, sel.b); x1 = perm_b(p1, x1, sel.b); x2 = perm_b(p2, x2, sel.b); x3 = perm_b(p3, x3, sel.b);
+    }
+    {   // partner = lane ^ 4: lanes with bit2 = 1 (banks 1,3) take the partner's odd dword into their even one (row_shr:4), lanes
+        // with bit2 = 0 (banks 0,2) the partner's even dword into their odd one (row_shl:4)
+        const int t0 = x0, t2 = x2;
+        x0 = dpp_bank<0x114, 0xA>(x0, x1); x2 = dpp_bank<0x114, 0xA>(x2, x3);
+        x1 = dpp_bank<0x104, 0x5>(x1, t0); x3 = dpp_bank<0x104, 0x5>(x3, t2);
+    }
+    {   // partner = lane ^ 8 (row_ror:8): dword pairs (0,2) and (1,3); bit3 = 1 lanes are banks 2,3
+        const int t0 = x0, t1 = x1;
+        x0 = dpp_bank<0x128, 0xC>(x0, x2); x1 = dpp_bank<0x128, 0xC>(x1, x3);
+        x2 = dpp_bank<0x128, 0x3>(x2, t0); x3 = dpp_bank<0x128, 0x3>(x3, t1);
+    }
+    v.x = x0; v.y = x1; v.z = x2; v.w = x3;
+}
+
+// acc = fma(p[lane N of the row], f, acc) / m = p[lane N of the row] * f: the DPP operand of a VOP2 instruction does the broadcast
+template <int N> __device__ __forceinline__ void fmac_bcast(float& acc, float p, float f);
+template <int N> __device__ __forceinline__ float mul_bcast(float p, float f);
+#define JH_P16_BCAST(N)                                                                                                          \
+    template <> __device__ __forceinline__ void fmac_bcast<N>(float& acc, float p, float f) {                                    \
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(p), "v"(f));   \
+    }                                                                                                                            \
+    template <> __device__ __forceinline__ float mul_bcast<N>(float p, float f) { /* hipcc folds the move into v_mul_f32_dpp */ \
+        return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(p), 0x150 + N, 0xf, 0xf, true)) * f;               \
+    }
+JH_P16_BCAST(0) JH_P16_BCAST(1) JH_P16_BCAST(2) JH_P16_BCAST(3) JH_P16_BCAST(4) JH_P16_BCAST(5) JH_P16_BCAST(6) JH_P16_BCAST(7)
+JH_P16_BCAST(8) JH_P16_BCAST(9) JH_P16_BCAST(10) JH_P16_BCAST(11) JH_P16_BCAST(12) JH_P16_BCAST(13) JH_P16_BCAST(14) JH_P16_BCAST(15)
+#undef JH_P16_BCAST
+
+// (float)(int8) of byte N of x in one instruction (SDWA source select + sign extension)
+template <int N> __device__ __forceinline__ float cvt_sbyte(int x) {
+    float f;
+    if constexpr (N == 0) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(f) : "v"(x));
+    else if constexpr (N == 1) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(f) : "v"(x));
+    else if constexpr (N == 2) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(f) : "v"(x));
+    else asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(f) : "v"(x));
+    return f;
+}
+// 4 blocks' nibbles (byte t of each) -> int8 16*(nib-8): low nibbles (element t) / high nibbles (element t+16)
+__device__ __forceinline__ int nib_lo16(int x) { return ((x << 4) & (int)0xF0F0F0F0) ^ (int)0x80808080; }
+__device__ __forceinline__ int nib_hi16(int x) { return (x & (int)0xF0F0F0F0) ^ (int)0x80808080; }
+
+// ------------------------------------------------------------------------------------------------ activation row in LDS
+struct ActP16 {
+    i32x2* pt;     // [ceil(nblk/4)][16 lanes]: the 4 pair words (a[b*32+t] & 0xff) | (a[b*32+16+t] & 0xff) << 8 of blocks 4j..4j+3
+    float* d16;    // [nblk] activation block scale / 16
+    double* red;   // [32] reduction scratch
+};
+__device__ __forceinline__ ActP16 carve_p16(char* smem, int nblk) {
+    ActP16 a;
+    a.pt = (i32x2*)smem;
+    a.d16 = (float*)(a.pt + ((nblk + 15) >> 4) * 64);   // whole groups: the reads of a short last group stay inside the table
+    a.red = (double*)(a.d16 + ((nblk + 1) & ~1));
+    return a;
+}
+static inline size_t lds_bytes_p16(int K) {
+    const size_t nblk = (size_t)K / QB;
+    return ((nblk + 15) / 16) * 512 + ((nblk + 1) & ~(size_t)1) * 4 + 32 * 8;
+}
+
+// Quantize 8 consecutive values held by one lane (Panama quantizeQ8_512, PTO:1684-1723, exactly as quad_quantize_store) and file
+// them as pair words: the lanes of a quad hold elements 0-7, 8-15 (codes of a[t]) and 16-23, 24-31 (codes of a[t+16]) of one
+// block; sub and sub^2 exchange their packed codes, the lower lane pairs t = 8*(sub&1)+0..3, the upper one t = ...+4..7.
+__device__ __forceinline__ void quad_quantize_store_p16(const float (&y)[8], int unit, const ActP16& a) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(y[i]));
+    amax = fmaxf(amax, dpp_f<0xB1>(amax));
+    amax = fmaxf(amax, dpp_f<0x4E>(amax));
+    const float d = amax / 127.0f;
+    const float id = (amax != 0.0f) ? 127.0f / amax : 0.0f;
+    int q[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float v = y[i] * id;
+        v = v + 0.5f;
+        q[i] = f2b(v);
+    }
+    const int px = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+    const int py = q[4] | (q[5] << 8) | (q[6] << 16) | (q[7] << 24);
+    const int ox = __builtin_amdgcn_mov_dpp(px, 0x4E, 0xf, 0xf, true);   // the lane two over (sub ^ 2)
+    const int oy = __builtin_amdgcn_mov_dpp(py, 0x4E, 0xf, 0xf, true);
+    const int blk = unit >> 2, sub = unit & 3;
+    const bool lower = sub < 2;
+    const int lo_dw = lower ? px : oy, hi_dw = lower ? ox : py;
+    const int w0 = perm_b(hi_dw, lo_dw, 0x05010400);   // [lo0, hi0, lo1, hi1]
+    const int w1 = perm_b(hi_dw, lo_dw, 0x07030602);   // [lo2, hi2, lo3, hi3]
+    const int t0 = (sub & 1) * 8 + (lower ? 0 : 4);
+    uint16_t* dst = (uint16_t*)a.pt + ((size_t)((blk >> 2) * 16 + t0)) * 4 + (blk & 3);
+    dst[0] = (uint16_t)(w0 & 0xffff);
+    dst[4] = (uint16_t)((unsigned)w0 >> 16);
+    dst[8] = (uint16_t)(w1 & 0xffff);
+    dst[12] = (uint16_t)((unsigned)w1 >> 16);
+    if (sub == 0) a.d16[blk] = d * 0.0625f;
+}
+
+// Activation prologue of the p16 GEMVs in two halves (the weight ring is requested between them: vmcnt retires oldest-first, the
+// row must be asked for before the weights).  The whole row lives in registers: UM 8-element units per thread of the 512-thread
+// workgroup (the host picks UM >= K / 4096) -- no second, serialised round trip and no load loop whose waits would drain the ring.
+constexpr int P16_THREADS = 512;
+template <int UM>
+struct ActRegsP16 {
+    float xv[UM][8];
+    float wv[UM][8];
+};
+template <int PRO, int UM>
+__device__ __forceinline__ void stage_issue_p16(const GemvParams& p, ActRegsP16<UM>& r) {
+    const int units = p.K / 8;
+#pragma unroll
+    for (int u = 0; u < UM; u++) {
+        int unit = threadIdx.x + u * P16_THREADS;
+        unit = unit < units ? unit : units - 1;             // branch-free (clamped): a guarded load is waited for at the end of its block
+        const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
+        r.xv[u][0] = xa.x; r.xv[u][1] = xa.y; r.xv[u][2] = xa.z; r.xv[u][3] = xa.w;
+        r.xv[u][4] = xb.x; r.xv[u][5] = xb.y; r.xv[u][6] = xb.z; r.xv[u][7] = xb.w;
+        if (PRO == PRO_RMS_Q8 || PRO == PRO_RMS_F32) load8_norm(p.nw, unit * 8, r.wv[u]);
+    }
+}
+// RMSNorm scale factor of the row held in r (RMSNorm.java:41-49: float squares, double sum, /E, +eps, 1/sqrt in double)
+template <int UM>
+__device__ __forceinline__ float rms_factor_p16(const GemvParams& p, const ActRegsP16<UM>& r, double* red) {
+    const int units = p.K / 8;
+    double ss = 0.0;
+#pragma unroll
+    for (int u = 0; u < UM; u++)
+        if ((int)threadIdx.x + u * P16_THREADS < units)
+#pragma unroll
+            for (int i = 0; i < 8; i++) ss += (double)(r.xv[u][i] * r.xv[u][i]);
+    ss = block_sum_d(ss, red);
+    ss /= (double)p.K;
+    ss += (double)p.eps;
+    ss = 1.0 / sqrt(ss);
+    return (float)ss;
+}
+template <int PRO, int UM>
+__device__ __forceinline__ void stage_finish_p16(const GemvParams& p, const ActP16& a, ActRegsP16<UM>& r) {
+    static_assert(PRO == PRO_RMS_Q8 || PRO == PRO_QUANT_Q8, "p16 prologues: RMSNorm+Q8 or plain Q8");
+    const int units = p.K / 8;
+    float fs = 1.0f;
+    if (PRO == PRO_RMS_Q8) fs = rms_factor_p16<UM>(p, r, a.red);
+#pragma unroll
+    for (int u = 0; u < UM; u++) {
+        const int unit = threadIdx.x + u * P16_THREADS;
+        if (unit < units) {
+            float y[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = (PRO == PRO_RMS_Q8) ? r.wv[u][i] * (fs * r.xv[u][i]) : r.xv[u][i];   // (0 + w) * ((float)ss * x)
+            quad_quantize_store_p16(y, unit, a);
+        }
+    }
+    lds_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------ I8 x Q4 GEMV, reference order
+// one group of 16 blocks: 4 dwords x (byte t of 4 consecutive blocks)
+// Four steps' pair sums at once: 4 x v_dot4_i32_i8 (the non-accumulating VOP3P form: hipcc only emits v_dot4c + a zeroing move) followed
+// by their 4 converts.  Inside one asm block on purpose: a DOT result needs 3 wait states before a VALU read, which hipcc cannot
+// know about asm -- here every convert sits 4 instructions behind its dot.
+__device__ __forceinline__ void dot4x4_cvt(int a01, int a23, int w0, int w1, int w2, int w3, float& f0, float& f1, float& f2, float& f3) {
+    int i0, i1, i2, i3;
+    asm("v_dot4_i32_i8 %4, %8, %10, 0\n\t"
+        "v_dot4_i32_i8 %5, %8, %11, 0\n\t"
+        "v_dot4_i32_i8 %6, %9, %12, 0\n\t"
+        "v_dot4_i32_i8 %7, %9, %13, 0\n\t"
+        "v_cvt_f32_i32_e32 %0, %4\n\t"
+        "v_cvt_f32_i32_e32 %1, %5\n\t"
+        "v_cvt_f32_i32_e32 %2, %6\n\t"
+        "v_cvt_f32_i32_e32 %3, %7"
+        : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
+        : "v"(a01), "v"(a23), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+}
+struct Quad4 { float f0, f1, f2, f3; };
+__device__ __forceinline__ Quad4 p16_quad_sums(int x, const i32x2 pp) {   // (float) pair sums of 4 consecutive blocks (x16)
+    const int lo = nib_lo16(x), hi = nib_hi16(x);
+    Quad4 q;
+    dot4x4_cvt(pp.x, pp.y, perm_b(hi, lo, 0x0C0C0400), perm_b(hi, lo, 0x05010C0C), perm_b(hi, lo, 0x0C0C0602), perm_b(hi, lo, 0x07030C0C),
+               q.f0, q.f1, q.f2, q.f3);
+    return q;
+}
+template <int K4, bool FULL>
+__device__ __forceinline__ void p16_quad_chain(const Quad4& q, float pscale, int nb, float& acc) {
+    if (FULL || 4 * K4 + 0 < nb) fmac_bcast<4 * K4 + 0>(acc, pscale, q.f0);
+    if (FULL || 4 * K4 + 1 < nb) fmac_bcast<4 * K4 + 1>(acc, pscale, q.f1);
+    if (FULL || 4 * K4 + 2 < nb) fmac_bcast<4 * K4 + 2>(acc, pscale, q.f2);
+    if (FULL || 4 * K4 + 3 < nb) fmac_bcast<4 * K4 + 3>(acc, pscale, q.f3);
+}
+// One group: the pair sums of quad k+1 are computed beside the 4 chained fmacs of quad k (independent work for the chain's
+// latency); a scheduling fence per quad, because the chain is serial and hipcc otherwise hoists every independent unpack /
+// convert of the group in front of it (hundreds of live registers, spills).  Blocks past a short last group hold clamped
+// copies: their sums are computed and dropped.
+template <bool FULL>
+__device__ __forceinline__ void p16_group_i8(const i32x4& x, const i32x2* pt, float pscale, int nb, float& acc) {
+    const Quad4 q0 = p16_quad_sums(x.x, pt[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    const Quad4 q1 = p16_quad_sums(x.y, pt[16]);
+    p16_quad_chain<0, FULL>(q0, pscale, nb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    const Quad4 q2 = p16_quad_sums(x.z, pt[32]);
+    p16_quad_chain<1, FULL>(q1, pscale, nb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    const Quad4 q3 = p16_quad_sums(x.w, pt[48]);
+    p16_quad_chain<2, FULL>(q2, pscale, nb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    p16_quad_chain<3, FULL>(q3, pscale, nb, acc);
+}
+
+// (da/16) * sb of the block this lane loaded, later read through the DPP operand of v_fmac_f32.  Written by asm with two idle
+// states behind it: a DPP read of a VGPR needs 2 wait states after the VALU write, and hipcc's hazard recognizer does not see
+// inside the asm blocks that do the reading.
+__device__ __forceinline__ float p16_scale_product(float da16, float sb) {
+    float r;
+    asm volatile("v_mul_f32_e32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(da16), "v"(sb));
+    return r;
+}
+
+// Work of a wave: row quads [q0, q1) (4 consecutive weight rows, one per 16-lane row of the wave), NP passes each (gate then up
+// for EPI_SILU_MUL), G groups of 16 blocks per pass -- a flat list of items streamed through a ring of D prefetched groups,
+// consumed in blocks of D (the host picks D | G, so a pass ends exactly at a block end and the ring needs no bounds checks).
+// `per` = row quads per task wave, `tw` = task waves per workgroup (the host sizes grid x tw x per so that every CU gets the same
+// number of row quads).
+template <int PRO, int EPI, int D, int UM>
+__global__ __launch_bounds__(P16_THREADS) void gemv_i8q4_p16_kernel(GemvParams p, int per, int tw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nblk = p.K / QB, G = (nblk + 15) >> 4;        // host: G % D == 0
+    const ActP16 a = carve_p16(smem, nblk);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane >> 4, t = lane & 15;
+    const RowSel sel = row16_selectors(lane);
+    constexpr int NP = (EPI == EPI_SILU_MUL) ? 2 : 1;
+    const int nq = (p.nrows + 3) >> 2;
+    // waves [0, tw) of a workgroup own row quads, the others only help with the activation prologue (a 16-lane row per chain
+    // caps the useful waves at rows/4: the o- and down-projections have 4 per CU)
+    int q0 = wave < tw ? (blockIdx.x * tw + wave) * per : nq;
+    if (q0 > nq) q0 = nq;
+    int q1 = q0 + per;
+    if (q1 > nq) q1 = nq;
+    const int items = (q1 - q0) * NP * G;                   // a multiple of D
+
+    i32x4 wq[D];
+    float sq[D];
+    int lq = q0, lpass = 0, lg = 0;                         // load cursor (wave-uniform)
+    const uint8_t* wrow;                                    // this lane's weight / scale row of the pass being requested
+    const float* srow;
+    auto set_row = [&]() __attribute__((always_inline)) {
+        int row = 4 * lq + r;
+        row = row < p.nrows ? row : p.nrows - 1;
+        wrow = ((NP == 2 && lpass) ? p.w2 : p.w) + (size_t)row * p.ldb;
+        srow = ((NP == 2 && lpass) ? p.ws2 : p.ws) + (size_t)row * p.ldbf;
+    };
+    set_row();
+    auto issue = [&](i32x4& w, float& s) __attribute__((always_inline)) {
+        int b = 16 * lg + t;
+        b = b < nblk ? b : nblk - 1;                        // short last group: the surplus lanes reload its last block (unused)
+        w = __builtin_nontemporal_load((const i32x4*)wrow + b);
+        s = __builtin_nontemporal_load(srow + b);
+        if (++lg == G) {
+            lg = 0;
+            if (++lpass == NP) { lpass = 0; ++lq; }
+            set_row();
+        }
+    };
+    // Results are parked: the 16 lanes of a row all hold a finished row sum, lane t keeps the one of the wave's task n == t, and the
+    // wave stores once per 16 tasks (normally once, after the loop): no store or residual load inside the streaming loop, whose
+    // vmcnt waits then count ring loads only.
+    auto resid_of_batch = [&](int qb) __attribute__((always_inline)) {   // residual of (task qb + t, row r), requested a batch ahead
+        int row = 4 * (qb + t) + r;
+        row = row < p.nrows ? row : p.nrows - 1;
+        return p.resid[row];
+    };
+    ActRegsP16<UM> ar;
+    if (items == 0) {
+        // helper wave: its own copy of the prologue (same barriers).  The two paths must not join: hipcc computes ONE vmcnt per wait
+        // and would size the working waves' waits for the path without ring loads, i.e. drain the ring inside the prologue.
+        stage_issue_p16<PRO, UM>(p, ar);
+        stage_finish_p16<PRO, UM>(p, a, ar);
+        return;
+    }
+    stage_issue_p16<PRO, UM>(p, ar);                        // activation loads first: vmcnt retires oldest-first
+    float rv = 0.0f;
+    if (EPI == EPI_RESID) rv = resid_of_batch(q0);
+#pragma unroll
+    for (int d = 0; d < D; d++) {                           // the ring is in flight across the prologue
+        issue(wq[d], sq[d]);
+        __builtin_amdgcn_sched_barrier(0);                  // request order = consumption order (the loop's vmcnt waits count on it)
+    }
+    stage_finish_p16<PRO, UM>(p, a, ar);
+
+    float acc = 0.0f, gres = 0.0f, gsel = 0.0f, usel = 0.0f;
+    int cq = q0, cpass = 0, cg = 0;                         // compute cursor
+    // one group in two halves with the slot's refill between them: prep() uses up the loaded registers (transpose, scale product),
+    // so the next load can land in the same registers and hipcc has no old value to copy out of the way
+    auto prep = [&](i32x4& x, float s, int g) __attribute__((always_inline)) {
+        row16_transpose(x, sel);
+        int bd = 16 * g + t;
+        bd = bd < nblk ? bd : nblk - 1;
+        return p16_scale_product(a.d16[bd], s);             // lane t carries the scale product of block 16*g + t
+    };
+    auto compute = [&](const i32x4& x, float pscale, int g, bool can_be_short) __attribute__((always_inline)) {
+        const i32x2* pt = a.pt + (size_t)(4 * g) * 16 + t;
+        const int nb = nblk - 16 * g;
+        if (can_be_short && nb < 16) p16_group_i8<false>(x, pt, pscale, nb, acc);
+        else p16_group_i8<true>(x, pt, pscale, 16, acc);
+    };
+    auto pass_end = [&]() __attribute__((always_inline)) {
+        const float res = row16_tree_sum(acc);
+        acc = 0.0f;
+        if (EPI == EPI_SILU_MUL && cpass == 0) {
+            gres = res;                                     // gate pass done, the up pass of the same rows follows
+            cpass = 1;
+            return;
+        }
+        cpass = 0;
+        const int n = (cq - q0) & 15;
+        if (t == n) { gsel = gres; usel = res; }
+        if (n == 15 || cq + 1 == q1) {
+            const int row = 4 * (cq - n + t) + r;
+            if (t <= n && row < p.nrows) {
+                float v = usel;
+                if (EPI == EPI_SILU_MUL) v = silu_ref(gsel) * usel;   // MLPBlock.java:132-142; SiLU in double (~500 SIMD cycles) once per 16 tasks
+                if (EPI == EPI_RESID) v = v + rv;                      // accumulate(...) TransformerBlock.java:185,203
+                p.out[row] = v;
+            }
+            if (EPI == EPI_RESID && cq + 1 < q1) rv = resid_of_batch(cq + 1);
+        }
+        ++cq;
+    };
+    for (int it = 0; it + D < items; it += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            i32x4 x = wq[d];
+            const float pscale = prep(x, sq[d], cg + d);
+            __builtin_amdgcn_sched_barrier(0);              // keep the slots in program order (hipcc otherwise hoists all D transposes
+            issue(wq[d], sq[d]);                            // to the top of the block, which then waits for every load in flight)
+            __builtin_amdgcn_sched_barrier(0);
+            compute(x, pscale, cg + d, d == D - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cg += D;
+        if (cg == G) { cg = 0; pass_end(); }
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) {                           // last block: nothing left to request
+        i32x4 x = wq[d];
+        const float pscale = prep(x, sq[d], cg + d);
+        compute(x, pscale, cg + d, d == D - 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    pass_end();
+}
+
+// ------------------------------------------------------------------------------------------------ F32 x Q4 GEMV (LM head), reference order
+// acc_t = fma(a[t], (float)(lo_t-8)*s, acc_t); acc_t = fma(a[t+16], (float)(hi_t-8)*s, acc_t) per block (PTO:336-374) with the final
+// RMSNorm prologue and the per-workgroup argmax partials of gemv_f32q4_kernel (strict >, lowest index first: AbstractModel.java:455-469).
+// (float)(nib-8)*s == (float)(16*(nib-8)) * (s/16) exactly, and the left factor is one SDWA convert of the unpacked int8.
+struct ActF32P16 {
+    float2* af;    // [nblk][16]: (y[b*32+t], y[b*32+16+t])
+    double* red;   // [32]
+    float* bestv;  // [16]
+    int* besti;    // [16]
+};
+__device__ __forceinline__ ActF32P16 carve_f32_p16(char* smem, int nblk) {
+    ActF32P16 a;
+    a.af = (float2*)smem;
+    a.red = (double*)(a.af + (size_t)((nblk + 15) & ~15) * 16);
+    a.bestv = (float*)(a.red + 32);
+    a.besti = (int*)(a.bestv + 16);
+    return a;
+}
+static inline size_t lds_bytes_f32_p16(int K) { return (size_t)(((K / QB) + 15) & ~15) * 128 + 32 * 8 + 16 * 4 + 16 * 4; }
+
+// acc = fma(a, b, acc), pinned where it is written: the chain's only reader is the end of the row, and hipcc otherwise sinks every
+// fma of a ring block down there, keeping all their operands alive (256 VGPRs + spills)
+__device__ __forceinline__ void fmac_pinned(float& acc, float a, float b) {
+    asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+struct QuadW { float wl0, wl1, wl2, wl3, wh0, wh1, wh2, wh3; float2 a0, a1, a2, a3; };
+// dequantized weights (float)(nib-8)*s of 4 consecutive blocks for this lane's element pair, and the matching activation pairs
+template <int K4>
+__device__ __forceinline__ QuadW p16_quad_deq(int x, const float2* af, float s16) {
+    const int lo = nib_lo16(x), hi = nib_hi16(x);
+    QuadW q;
+    q.a0 = af[(4 * K4 + 0) * 16]; q.a1 = af[(4 * K4 + 1) * 16]; q.a2 = af[(4 * K4 + 2) * 16]; q.a3 = af[(4 * K4 + 3) * 16];
+    const float l0 = cvt_sbyte<0>(lo), l1 = cvt_sbyte<1>(lo), l2 = cvt_sbyte<2>(lo), l3 = cvt_sbyte<3>(lo);
+    const float h0 = cvt_sbyte<0>(hi), h1 = cvt_sbyte<1>(hi), h2 = cvt_sbyte<2>(hi), h3 = cvt_sbyte<3>(hi);
+    q.wl0 = mul_bcast<4 * K4 + 0>(s16, l0); q.wh0 = mul_bcast<4 * K4 + 0>(s16, h0);
+    q.wl1 = mul_bcast<4 * K4 + 1>(s16, l1); q.wh1 = mul_bcast<4 * K4 + 1>(s16, h1);
+    q.wl2 = mul_bcast<4 * K4 + 2>(s16, l2); q.wh2 = mul_bcast<4 * K4 + 2>(s16, h2);
+    q.wl3 = mul_bcast<4 * K4 + 3>(s16, l3); q.wh3 = mul_bcast<4 * K4 + 3>(s16, h3);
+    return q;
+}
+template <int K4, bool FULL>
+__device__ __forceinline__ void p16_quad_chain_f32(const QuadW& q, int nb, float& acc) {
+    if (FULL || 4 * K4 + 0 < nb) { fmac_pinned(acc, q.a0.x, q.wl0); fmac_pinned(acc, q.a0.y, q.wh0); }
+    if (FULL || 4 * K4 + 1 < nb) { fmac_pinned(acc, q.a1.x, q.wl1); fmac_pinned(acc, q.a1.y, q.wh1); }
+    if (FULL || 4 * K4 + 2 < nb) { fmac_pinned(acc, q.a2.x, q.wl2); fmac_pinned(acc, q.a2.y, q.wh2); }
+    if (FULL || 4 * K4 + 3 < nb) { fmac_pinned(acc, q.a3.x, q.wl3); fmac_pinned(acc, q.a3.y, q.wh3); }
+}
+// the dequantization of quad k+1 runs beside the 8 chained fmas of quad k (see p16_group_i8)
+template <bool FULL>
+__device__ __forceinline__ void p16_group_f32(const i32x4& x, const float2* af, float s16, int nb, float& acc) {
+    const QuadW q0 = p16_quad_deq<0>(x.x, af, s16);
+    __builtin_amdgcn_sched_barrier(0);
+    const QuadW q1 = p16_quad_deq<1>(x.y, af, s16);
+    p16_quad_chain_f32<0, FULL>(q0, nb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    const QuadW q2 = p16_quad_deq<2>(x.z, af, s16);
+    p16_quad_chain_f32<1, FULL>(q1, nb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    const QuadW q3 = p16_quad_deq<3>(x.w, af, s16);
+    p16_quad_chain_f32<2, FULL>(q2, nb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    p16_quad_chain_f32<3, FULL>(q3, nb, acc);
+}
+
+template <int PRO, int D, int UM>
+__global__ __launch_bounds__(P16_THREADS) void gemv_f32q4_p16_kernel(GemvParams p, int per, int tw) {
+    static_assert(PRO == PRO_RMS_F32 || PRO == PRO_F32, "LM head prologues");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = p.K, nblk = K / QB, G = (nblk + 15) >> 4;   // host: G % D == 0, K <= UM * 4096
+    const ActF32P16 a = carve_f32_p16(smem, nblk);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int r = lane >> 4, t = lane & 15;
+    const RowSel sel = row16_selectors(lane);
+    const int nq = (p.nrows + 3) >> 2;
+    int q0 = wave < tw ? (blockIdx.x * tw + wave) * per : nq;
+    if (q0 > nq) q0 = nq;
+    int q1 = q0 + per;
+    if (q1 > nq) q1 = nq;
+    const int items = (q1 - q0) * G;
+
+    ActRegsP16<UM> ar;
+    auto fill_row = [&]() __attribute__((always_inline)) {  // second half of the prologue: final RMSNorm, the row as (y[t], y[t+16]) pairs
+        float fs = 1.0f;
+        if (PRO == PRO_RMS_F32) fs = rms_factor_p16<UM>(p, ar, a.red);
+        const int units = K / 8;
+#pragma unroll
+        for (int u = 0; u < UM; u++) {
+            const int unit = threadIdx.x + u * P16_THREADS;
+            if (unit < units) {
+                // elements e0..e0+7 of block b: half = (e0 & 16) != 0, lanes t = (e0 & 15) .. +7
+                const int e0 = unit * 8, b = e0 >> 5, half = (e0 >> 4) & 1, t0 = e0 & 15;
+                float* dst = (float*)(a.af + (size_t)b * 16 + t0) + half;
+#pragma unroll
+                for (int i = 0; i < 8; i++) dst[2 * i] = (PRO == PRO_RMS_F32) ? ar.wv[u][i] * (fs * ar.xv[u][i]) : ar.xv[u][i];
+            }
+        }
+        lds_barrier();
+    };
+    i32x4 wq[D];
+    float sq[D];
+    int lq = q0, lg = 0;
+    const uint8_t* wrow;
+    const float* srow;
+    auto set_row = [&]() __attribute__((always_inline)) {
+        int row = 4 * lq + r;
+        row = row < p.nrows ? row : p.nrows - 1;
+        wrow = p.w + (size_t)row * p.ldb;
+        srow = p.ws + (size_t)row * p.ldbf;
+    };
+    set_row();
+    auto issue = [&](i32x4& w, float& s) __attribute__((always_inline)) {
+        int b = 16 * lg + t;
+        b = b < nblk ? b : nblk - 1;
+        w = __builtin_nontemporal_load((const i32x4*)wrow + b);
+        s = __builtin_nontemporal_load(srow + b);
+        if (++lg == G) { lg = 0; ++lq; set_row(); }
+    };
+    float bestv = -INFINITY;
+    int besti = 0x7fffffff;
+    if (items == 0) {
+        // helper wave: own copy of the prologue, never joins the streaming path before the argmax merge (see gemv_i8q4_p16_kernel)
+        stage_issue_p16<PRO, UM>(p, ar);
+        fill_row();
+    } else {
+    stage_issue_p16<PRO, UM>(p, ar);                        // activation row (+ norm weights) requested before the weight ring
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        issue(wq[d], sq[d]);
+        __builtin_amdgcn_sched_barrier(0);                  // request order = consumption order
+    }
+    fill_row();
+
+    float acc = 0.0f;
+    int cq = q0, cg = 0;
+    auto prep = [&](i32x4& x, float s) __attribute__((always_inline)) {
+        row16_transpose(x, sel);
+        return p16_scale_product(0.0625f, s);               // s/16 (exact), pinned here so that the slot's registers are free for the refill
+    };
+    auto compute = [&](const i32x4& x, float s16, int g, bool can_be_short) __attribute__((always_inline)) {
+        const float2* af = a.af + (size_t)(16 * g) * 16 + t;
+        const int nb = nblk - 16 * g;
+        if (can_be_short && nb < 16) p16_group_f32<false>(x, af, s16, nb, acc);
+        else p16_group_f32<true>(x, af, s16, 16, acc);
+    };
+    float park = 0.0f;
+    auto row_end = [&]() __attribute__((always_inline)) {
+        const float res = row16_tree_sum(acc);
+        acc = 0.0f;
+        const int row = 4 * cq + r;
+        if (row < p.nrows && res > bestv) { bestv = res; besti = row; }   // rows ascend within a lane: strict > keeps the first
+        const int n = (cq - q0) & 15;                       // logits parked in lane t == n, stored once per 16 tasks (no store in the loop)
+        if (t == n) park = res;
+        if (n == 15 || cq + 1 == q1) {
+            const int orow = 4 * (cq - n + t) + r;
+            if (t <= n && orow < p.nrows) p.out[orow] = park;
+        }
+        ++cq;
+    };
+    {
+        for (int it = 0; it + D < items; it += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                i32x4 x = wq[d];
+                const float s16 = prep(x, sq[d]);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(wq[d], sq[d]);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(x, s16, cg + d, d == D - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cg += D;
+            if (cg == G) { cg = 0; row_end(); }
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            i32x4 x = wq[d];
+            const float s16 = prep(x, sq[d]);
+            compute(x, s16, cg + d, d == D - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        row_end();
+    }
+    }   // streaming path
+    if (p.amax_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {   // per-lane bests -> wave best (value desc, index asc)
+            const float ov = __shfl_xor(bestv, o);
+            const int oi = __shfl_xor(besti, o);
+            if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+        }
+        if (lane == 0) { a.bestv[wave] = bestv; a.besti[wave] = besti; }
+        lds_barrier();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < nwaves; w++)
+                if (a.bestv[w] > bestv || (a.bestv[w] == bestv && a.besti[w] < besti)) { bestv = a.bestv[w]; besti = a.besti[w]; }
+            p.amax_part[blockIdx.x] = bestv;
+            p.amax_idx[blockIdx.x] = besti;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ decode attention, reference order
+// CausalSelfAttention.java:199-357 in two launches, because the reference's order makes two parts of it sequential over the whole
+// context -- the float sum of the exponentials and the fma chain of every output element over the positions -- while its traffic
+// (K and V of the context) must be spread over many CUs to arrive in time (one CU ingests ~25 GB/s):
+//   attn_p16_scores_kernel  grid (position slices, kv heads): KV row write + RoPE (q of the group's heads, k of the new row), then
+//        scores[t] = GemmerF32 16-lane dot (fma over 16-element steps, halving tree) * attentionScale for its slice, for the GROUP
+//        query heads sharing the kv head (K is read once per group) -> scaled scores in global memory;
+//   attn_p16_av_kernel      grid (32-column slices of the head, query heads): softMax over the whole score row (max, (float)exp in
+//        double, FLOAT sum in index order by one lane, division), then value[d] = one fma chain per element over positions 0..pos
+//        (saxpy per position, PTO:2648-2698) for its 32 columns; V tiles go through LDS with 16-byte loads.
+constexpr int P16_ATT_THREADS = 256;
+template <int HS, int GROUP>
+__global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnParams p, float* scores, int sc_stride) {
+    __shared__ float qs[GROUP * HS];
+    __shared__ float knew[HS];
+    constexpr int NT = P16_ATT_THREADS, half = HS / 2, NC = HS / 16, RP = NT / 16;   // RP positions per pass
+    const int pos = p.st->pos, n = pos + 1;
+    const int kvh = blockIdx.y, split = blockIdx.x, S = gridDim.x;
+    const int chunk = (((n + S - 1) / S) + RP - 1) / RP * RP;   // whole passes per slice
+    const int t0 = split * chunk;
+    if (t0 >= n) return;
+    const int t1 = t0 + chunk < n ? t0 + chunk : n;
+    const int KV = p.n_kv_heads * HS, A = p.n_heads * HS;
+    const int tid = threadIdx.x, l = tid & 15, prow = tid >> 4;
+    // ---- RoPE of the group's q heads and of the new k row (table row pos + 2*kvHead: CausalSelfAttention.java:247-286); every
+    // slice rotates them locally, bit-identically; the slice that owns `pos` writes the KV page rows
+    const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
+    const bool owner = (pos >= t0 && pos < t1);
+    for (int i = tid; i < (GROUP + 1) * half; i += NT) {
+        const int gi = i / half, d = i - gi * half;
+        const float c = rf[2 * d], s = rf[2 * d + 1];
+        if (gi < GROUP) {
+            const float* qh = p.qkv + (size_t)(kvh * GROUP + gi) * HS;
+            const float q0 = qh[d], q1 = qh[d + half];
+            const float r0 = q0 * c - q1 * s, r1 = q0 * s + q1 * c;   // contraction off: mul, mul, sub / add as in Java
+            qs[gi * HS + d] = r0; qs[gi * HS + d + half] = r1;
+            if (p.tap_q && split == 0) {
+                p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d] = r0;
+                p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d + half] = r1;
+            }
+        } else {
+            const float* kh = p.qkv + A + (size_t)kvh * HS;
+            const float k0 = kh[d], k1 = kh[d + half];
+            const float r0 = k0 * c - k1 * s, r1 = k0 * s + k1 * c;
+            knew[d] = r0; knew[d + half] = r1;
+            if (owner) {   // K is stored post-RoPE (:273-286 rotates the page row in place)
+                float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
+                kdst[d] = r0; kdst[d + half] = r1;
+            }
+        }
+    }
+    if (owner)
+        for (int d = tid; d < HS; d += NT) ((float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS)[d] = p.qkv[A + KV + (size_t)kvh * HS + d];
+    __syncthreads();
+    float q[GROUP][NC];
+#pragma unroll
+    for (int gi = 0; gi < GROUP; gi++)
+#pragma unroll
+        for (int c = 0; c < NC; c++) q[gi][c] = qs[gi * HS + 16 * c + l];
+    // ---- scores: a 16-lane row per position, two passes of loads in flight
+    constexpr int PB = 2;
+    for (int tb = t0 + prow; tb < t1; tb += RP * PB) {
+        float kv[PB][NC];
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            int tt = tb + u * RP;
+            tt = tt < n ? tt : n - 1;
+            const float* krow = kv_row(p, 0, tt, KV) + (size_t)kvh * HS + l;
+#pragma unroll
+            for (int c = 0; c < NC; c++) kv[u][c] = krow[16 * c];
+        }
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            const int tt = tb + u * RP;
+            if (tt >= t1) break;   // uniform per 16-lane row; the DPP tree below stays inside the row
+            if (tt == pos) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) kv[u][c] = knew[16 * c + l];   // the page row was written by another workgroup just now
+            }
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NC; c++) acc = fmaf(q[gi][c], kv[u][c], acc);   // GemmerF32 (PTO:1086-1102): lane l, steps of 16
+                acc = row16_tree_sum(acc);
+                if (l == 0) scores[(size_t)(kvh * GROUP + gi) * sc_stride + tt] = acc * p.scale;   // ops.scale after the dot (:332)
+            }
+        }
+    }
+}
+
+template <int HS>
+__global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams p, const float* scores, int sc_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 64;   // columns per workgroup, positions per V tile
+    const int h = blockIdx.y, group = p.n_heads / p.n_kv_heads, kvh = h / group, d0 = blockIdx.x * DW;
+    const int pos = p.st->pos, n = pos + 1;
+    const int KV = p.n_kv_heads * HS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* vt = (float*)smem;              // [TP][DW] V tile
+    float* redf = vt + TP * DW;            // [16]
+    float* w = redf + 16;                  // [n] scores -> softmax weights
+    // V tile loads: thread (row = tid / 8, c4 = tid % 8) covers 32 rows per pass, two passes per tile
+    const int vr = tid >> 3, vc = tid & 7;
+    float4 vreg0, vreg1;
+    auto load_row = [&](int tt) __attribute__((always_inline)) {
+        tt = tt < n ? tt : n - 1;
+        return ((const float4*)(kv_row(p, 1, tt, KV) + (size_t)kvh * HS + d0))[vc];
+    };
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        vreg0 = load_row(tile * TP + vr);
+        vreg1 = load_row(tile * TP + vr + 32);
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+        ((float4*)(vt + (size_t)vr * DW))[vc] = vreg0;
+        ((float4*)(vt + (size_t)(vr + 32) * DW))[vc] = vreg1;
+    };
+    load_tile(0);                           // in flight across the softmax
+    const float* srow = scores + (size_t)h * sc_stride;
+    float m = -INFINITY;
+    for (int tt = tid; tt < n; tt += NT) {
+        const float s = srow[tt];
+        w[tt] = s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    if (lane == 0) redf[wave] = m;
+    __syncthreads();
+    m = redf[0];
+    for (int i = 1; i < NT / 64; i++) m = fmaxf(m, redf[i]);
+    for (int tt = tid; tt < n; tt += NT) w[tt] = (float)exp((double)(w[tt] - m));   // (float)FastMath.exp(x - max)
+    __syncthreads();
+    if (tid == 0) {
+        float sum = 0.0f;                   // VectorMath.java:80-85: one float accumulator, index order
+        int tt = 0;
+        for (; tt + 8 <= n; tt += 8) {
+            const float4 e0 = *(const float4*)(w + tt), e1 = *(const float4*)(w + tt + 4);
+            sum += e0.x; sum += e0.y; sum += e0.z; sum += e0.w;
+            sum += e1.x; sum += e1.y; sum += e1.z; sum += e1.w;
+        }
+        for (; tt < n; tt++) sum += w[tt];
+        redf[8] = sum;
+    }
+    __syncthreads();
+    const float sum = redf[8];
+    for (int tt = tid; tt < n; tt += NT) w[tt] = w[tt] / sum;
+    // ---- value[d] = fma chain over positions: lanes 0..31 of wave 0 own one column each, the V tiles stream through LDS
+    float acc = 0.0f;
+    const int ntiles = (n + TP - 1) / TP;
+    for (int tile = 0; tile < ntiles; tile++) {
+        __syncthreads();                    // the previous tile has been consumed (first pass: w[] is complete)
+        store_tile();
+        if (tile + 1 < ntiles) load_tile(tile + 1);
+        __syncthreads();
+        if (tid < DW) {
+            // 16 steps per chunk; the next chunk's LDS reads are issued before the current chunk's dependent fmas
+            const int tbase = tile * TP, cnt = n - tbase < TP ? n - tbase : TP;
+            float va[16], vb[16];
+            float4 wa[4], wb[4];
+            auto ldchunk = [&](int i0, float (&v)[16], float4 (&ww)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) v[j] = vt[(i0 + j) * DW + tid];          // i0 + j < TP: rows past cnt hold clamped copies
+#pragma unroll
+                for (int j = 0; j < 4; j++) ww[j] = *(const float4*)(w + tbase + i0 + 4 * j);   // 16-byte aligned; w[] is padded to TP
+            };
+            auto dochunk = [&](int i0, const float (&v)[16], const float4 (&ww)[4]) __attribute__((always_inline)) {
+                if (i0 + 16 <= cnt) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        acc = fmaf(v[4 * j + 0], ww[j].x, acc);
+                        acc = fmaf(v[4 * j + 1], ww[j].y, acc);
+                        acc = fmaf(v[4 * j + 2], ww[j].z, acc);
+                        acc = fmaf(v[4 * j + 3], ww[j].w, acc);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (i0 + 4 * j + 0 < cnt) acc = fmaf(v[4 * j + 0], ww[j].x, acc);
+                        if (i0 + 4 * j + 1 < cnt) acc = fmaf(v[4 * j + 1], ww[j].y, acc);
+                        if (i0 + 4 * j + 2 < cnt) acc = fmaf(v[4 * j + 2], ww[j].z, acc);
+                        if (i0 + 4 * j + 3 < cnt) acc = fmaf(v[4 * j + 3], ww[j].w, acc);
+                    }
+                }
+            };
+            ldchunk(0, va, wa);
+            for (int i0 = 0; i0 < cnt; i0 += 32) {
+                if (i0 + 16 < cnt) ldchunk(i0 + 16, vb, wb);
+                dochunk(i0, va, wa);
+                if (i0 + 32 < cnt) ldchunk(i0 + 32, va, wa);
+                if (i0 + 16 < cnt) dochunk(i0 + 16, vb, wb);
+            }
+        }
+    }
+    if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
+}
+static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)64 * 32 + 16 + (size_t)((max_ctx + 63) & ~63)) * 4; }
+
+}  // namespace jh

@@ -1,4 +1,6 @@
-// jh_strict.h -- "strict order" kernels: the decode path with every float accumulation performed in EXACTLY the
+// jh_strict.h -- the FIRST implementation of the reference-order kernels, kept as the cross-check of jh_p16.h (JH_STRICT_LEGACY=1):
+// byte-granular weight loads, one workgroup per query head -- simple enough to audit line by line against the oracle, 5x slower.
+// "strict order" kernels: the decode path with every float accumulation performed in EXACTLY the
 // order of the reference's Panama AVX-512 provider, so that results are bit-identical to a plain-C restatement of that
 // provider (what the parity tests compare against) instead of merely within the Q8 noise floor.  Selected per session
 // (jh_session_set_strict / JH_STRICT_ORDER=1).  Purpose: prove that the only difference between the fast kernels
@@ -13,20 +15,9 @@
 //            one fma chain per output element over positions in ascending order.
 // GPU mapping: a 16-lane DPP row plays the 16 SIMD lanes; a wave64 therefore serves 4 output rows at a time.
 #pragma once
-#include "jh_kernels.h"
+#include "jh_p16.h"   // row16_tree_sum
 
 namespace jh {
-
-// reduceLanes(ADD) of a 16-lane row as the halving tree: after the rotate-by-8 step the row's values have period 8, so
-// rotating by 4 / 2 / 1 pairs lane i with the partner the tree prescribes (float addition commutes): every lane of the
-// row ends with ((v0+v8)+(v4+v12)) + ((v2+v10)+(v6+v14)) + ... in exactly jo_reduce16's association.
-__device__ __forceinline__ float row16_tree_sum(float v) {
-    v = v + dpp_f<0x128>(v);   // row_ror:8
-    v = v + dpp_f<0x124>(v);   // row_ror:4
-    v = v + dpp_f<0x122>(v);   // row_ror:2
-    v = v + dpp_f<0x121>(v);   // row_ror:1
-    return v;
-}
 
 // ---- I8 x Q4 GEMV, Panama order.  Same prologues / epilogues as gemv_i8q4_kernel.  Lane (r, t) of a wave: output row
 // group r (0..3), SIMD lane t (0..15); it reads byte t of every 16-byte Q4 block of its row (low nibble = element t, high

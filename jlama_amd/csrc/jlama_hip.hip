@@ -1114,7 +1114,10 @@ struct jh_session {
     std::map<uint64_t, hipGraphExec_t> pb_graphs;   // captured layer loops, key = rows | key-count bucket << 32
     std::vector<hipGraph_t> pb_graph_src;
     int prefill_batch_min = 4;
-    int strict = 0;           // jh_session_set_strict: Panama-order kernels (jh_strict.h)
+    int strict = 0;           // jh_session_set_strict: reference-order kernels (jh_p16.h)
+    int strict_legacy = 0;    // JH_STRICT_LEGACY=1: the first, byte-granular implementation of them (jh_strict.h), kept as a cross-check
+    float* p16_scores = nullptr;   // [n_heads][p16_sc_stride] scaled attention scores between the two reference-order attention launches
+    int p16_sc_stride = 0, p16_att_splits = 16, p16_depth = 8;
     // stop tokens (jh_session_set_eos): device copy for finish_token_kernel + host-side feeding control
     int* eos_dev = nullptr;
     int n_eos = 0;
@@ -1140,7 +1143,7 @@ namespace {
 
 bool is_global_slot(int which) { return which == JH_W_EMBED || which == JH_W_LMHEAD || which == JH_W_FINALNORM; }
 
-// ---- strict-order launchers (jh_strict.h): 4 waves x 4 output rows per workgroup
+// ---- reference-order launchers, first implementation (jh_strict.h): 4 waves x 4 output rows per workgroup
 template <int PRO, int EPI>
 int launch_gemv_i8q4_strict(const GemvParams& p, hipStream_t st) {
     const size_t lds = lds_bytes_i8(p.K);
@@ -1161,6 +1164,87 @@ int launch_gemv_f32q4_strict(const GemvParams& p, int* grid_out, hipStream_t st)
     hipLaunchKernelGGL((gemv_f32q4_strict_kernel<PRO_RMS_F32>), dim3(grid), dim3(256), lds, st, p);
     HIPCHK(hipGetLastError());
     return JH_OK;
+}
+
+// ---- reference-order launchers (jh_p16.h).  A wave serves 4 weight rows ("row quad"); the plan gives every CU the same
+// number of row quads: one 512-thread workgroup per CU, `tw` of its 8 waves own `per` row quads each (the others help
+// with the activation prologue only -- a 16-lane row per chain caps the useful waves at rows / 4).
+struct P16Plan { int grid, per, tw; };
+P16Plan p16_plan(int nrows, int wgs_per_cu) {
+    const int nq = (nrows + 3) / 4;
+    int grid = g_cu_count * wgs_per_cu;
+    if (grid > nq) grid = nq;
+    if (grid < 1) grid = 1;
+    const int q_wg = (nq + grid - 1) / grid;
+    const int per = (q_wg + 7) / 8;
+    const int tw = (q_wg + per - 1) / per;
+    return P16Plan{grid, per, tw};
+}
+// prefetch depth D = groups (16 Q blocks) in flight per lane: the largest of {8, 7, 4, 2, 1} that divides the groups of a row, so
+// that a pass ends exactly at the end of a ring block (K = 4096: 8 = the whole row; 14336: 7; 2048: 4)
+int p16_depth_for(int K, int want) {
+    const int G = (K / QB + 15) / 16;
+    static const int ds[] = {8, 7, 4, 2, 1};
+    for (int d : ds)
+        if (d <= want && G % d == 0) return d;
+    return 1;
+}
+// UM = 8-element units of the activation row per thread, all held in registers (no load loop in the kernel): 2 (K <= 8192) / 4 for
+// the RMSNorm prologues, 4 (K <= 16384) / 8 for the plain-quantize ones
+template <int PRO, int EPI, int D>
+int launch_gemv_i8q4_p16_d(const GemvParams& p, const P16Plan& pl, hipStream_t st) {
+    const size_t lds = lds_bytes_p16(p.K);
+    constexpr int UM_LO = (PRO == PRO_RMS_Q8) ? 2 : 4;
+    if (p.K <= UM_LO * 4096) {
+        JHCHK(allow_lds((gemv_i8q4_p16_kernel<PRO, EPI, D, UM_LO>), lds));
+        hipLaunchKernelGGL((gemv_i8q4_p16_kernel<PRO, EPI, D, UM_LO>), dim3(pl.grid), dim3(P16_THREADS), lds, st, p, pl.per, pl.tw);
+    } else if (p.K <= 2 * UM_LO * 4096) {
+        JHCHK(allow_lds((gemv_i8q4_p16_kernel<PRO, EPI, D, 2 * UM_LO>), lds));
+        hipLaunchKernelGGL((gemv_i8q4_p16_kernel<PRO, EPI, D, 2 * UM_LO>), dim3(pl.grid), dim3(P16_THREADS), lds, st, p, pl.per, pl.tw);
+    } else {
+        return set_err(JH_ERR_UNSUPPORTED, "reference-order GEMV: K = " + std::to_string(p.K) + " exceeds the register-resident activation row");
+    }
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+template <int PRO, int EPI>
+int launch_gemv_i8q4_p16(const GemvParams& p, int depth, hipStream_t st) {
+    const P16Plan pl = p16_plan(p.nrows, 1);
+    switch (p16_depth_for(p.K, depth)) {
+        case 8: return launch_gemv_i8q4_p16_d<PRO, EPI, 8>(p, pl, st);
+        case 7: return launch_gemv_i8q4_p16_d<PRO, EPI, 7>(p, pl, st);
+        case 4: return launch_gemv_i8q4_p16_d<PRO, EPI, 4>(p, pl, st);
+        case 2: return launch_gemv_i8q4_p16_d<PRO, EPI, 2>(p, pl, st);
+        default: return launch_gemv_i8q4_p16_d<PRO, EPI, 1>(p, pl, st);
+    }
+}
+template <int PRO, int D>
+int launch_gemv_f32q4_p16_d(const GemvParams& p, const P16Plan& pl, hipStream_t st) {
+    const size_t lds = lds_bytes_f32_p16(p.K);
+    if (p.K <= 8192) {
+        JHCHK(allow_lds((gemv_f32q4_p16_kernel<PRO, D, 2>), lds));
+        hipLaunchKernelGGL((gemv_f32q4_p16_kernel<PRO, D, 2>), dim3(pl.grid), dim3(P16_THREADS), lds, st, p, pl.per, pl.tw);
+    } else if (p.K <= 16384) {
+        JHCHK(allow_lds((gemv_f32q4_p16_kernel<PRO, D, 4>), lds));
+        hipLaunchKernelGGL((gemv_f32q4_p16_kernel<PRO, D, 4>), dim3(pl.grid), dim3(P16_THREADS), lds, st, p, pl.per, pl.tw);
+    } else {
+        return set_err(JH_ERR_UNSUPPORTED, "reference-order LM head: K exceeds the register-resident activation row");
+    }
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+template <int PRO>
+int launch_gemv_f32q4_p16(const GemvParams& p, int* grid_out, hipStream_t st) {
+    static const int gx = env_int("JH_P16_LM_GRIDX", 2);
+    const P16Plan pl = p16_plan(p.nrows, gx > 0 && gx <= 16 ? gx : 2);   // argmax partial buffers hold 4096 entries
+    if (grid_out) *grid_out = pl.grid;
+    switch (p16_depth_for(p.K, 8)) {
+        case 8: return launch_gemv_f32q4_p16_d<PRO, 8>(p, pl, st);
+        case 7: return launch_gemv_f32q4_p16_d<PRO, 7>(p, pl, st);
+        case 4: return launch_gemv_f32q4_p16_d<PRO, 4>(p, pl, st);
+        case 2: return launch_gemv_f32q4_p16_d<PRO, 2>(p, pl, st);
+        default: return launch_gemv_f32q4_p16_d<PRO, 1>(p, pl, st);
+    }
 }
 
 int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg = nullptr) {
@@ -1198,6 +1282,25 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     p.tap_q = tap ? s->tapq : nullptr;
     p.dbg = dbg;
     p.combine_kernel = (s->attn_combine && s->direct_max == 0 && p.max_splits <= 64) ? 1 : 0;
+    if (s->strict && !s->strict_legacy) {
+        // reference order in two launches (jh_p16.h): scores of every position slice, then softmax + the value chains
+        const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
+        const size_t lds_av = lds_bytes_attn_p16(s->max_ctx);
+        if (lds_av > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "reference-order attention: the score row of max_ctx positions must fit in LDS");
+        const dim3 grid_s(s->p16_att_splits, c.n_kv_heads), grid_v(hs / 32, c.n_heads);
+#define JH_P16_ATTN(HSV, GV)                                                                                                   \
+    if (hs == HSV && group == GV) {                                                                                            \
+        hipLaunchKernelGGL((attn_p16_scores_kernel<HSV, GV>), grid_s, dim3(P16_ATT_THREADS), 0, st, p, s->p16_scores, s->p16_sc_stride); \
+        HIPCHK(hipGetLastError());                                                                                             \
+        JHCHK(allow_lds((attn_p16_av_kernel<HSV>), lds_av));                                                                   \
+        hipLaunchKernelGGL((attn_p16_av_kernel<HSV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
+        HIPCHK(hipGetLastError());                                                                                             \
+        return JH_OK;                                                                                                          \
+    }
+        JH_P16_ATTN(128, 4) JH_P16_ATTN(128, 8) JH_P16_ATTN(64, 4) JH_P16_ATTN(128, 1) JH_P16_ATTN(128, 2) JH_P16_ATTN(64, 1) JH_P16_ATTN(64, 2) JH_P16_ATTN(64, 8)
+#undef JH_P16_ATTN
+        return set_err(JH_ERR_UNSUPPORTED, "attention: head_size must be 64 or 128 and heads/kv_heads in {1,2,4,8}");
+    }
     if (s->strict) {
         const size_t lds_s = lds_bytes_attn_strict(c.head_size, s->max_ctx);
         if (lds_s > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "strict attention: the score row of max_ctx positions must fit in LDS");
@@ -1267,7 +1370,8 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
         p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st))); }
-        else if (s->strict) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_STORE>(p, st)));
+        else if (s->strict && s->strict_legacy) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_STORE>(p, st)));
+        else if (s->strict) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_STORE>(p, s->p16_depth, st)));
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
         JHCHK(trace_sync("qkv", st));
     }
@@ -1295,9 +1399,12 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
             p.ldb = A * 2;
             if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
             else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
-        } else if (s->strict) {
+        } else if (s->strict && s->strict_legacy) {
             if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
             else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
+        } else if (s->strict) {
+            if (resid) JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
+            else JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_STORE>(p, s->p16_depth, st)));
         } else if (!resid) {
             JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_STORE>(p, s->cfg_o, st)));
         } else if (s->direct_max > 0) {
@@ -1334,7 +1441,8 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
         p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
         p.out = s->hf;   // silu(gate)*up, F32; the down projection's prologue quantizes it (MLPBlock.java:144)
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, g_cu_count * 4, nullptr, st))); }
-        else if (s->strict) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
+        else if (s->strict && s->strict_legacy) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
+        else if (s->strict) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->p16_depth, st)));
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
         JHCHK(trace_sync("gateup", st));
     }
@@ -1349,9 +1457,12 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
             p.ldb = H * 2;
             if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
             else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
-        } else if (s->strict) {
+        } else if (s->strict && s->strict_legacy) {
             if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
             else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
+        } else if (s->strict) {
+            if (resid) JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
+            else JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_STORE>(p, s->p16_depth, st)));
         } else if (resid) {
             JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
         } else {
@@ -1708,8 +1819,10 @@ int lmhead_launch(jh_session* s, hipStream_t st) {
     if (w->dtype == JH_DT_BF16) {
         p.ldb = p.K * 2;
         JHCHK((launch_gemv_bf16<PROB_RMS_F32, EPI_STORE, true>(p, 4096, &grid, st)));   // F32 x BF16 (GemmerF32BF16)
-    } else if (s->strict) {
+    } else if (s->strict && s->strict_legacy) {
         JHCHK(launch_gemv_f32q4_strict(p, &grid, st));
+    } else if (s->strict) {
+        JHCHK((launch_gemv_f32q4_p16<PRO_RMS_F32>(p, &grid, st)));
     } else {
         JHCHK((launch_gemv_f32q4<PRO_RMS_F32>(p, s->cfg_lm, &grid, st)));
     }
@@ -1996,6 +2109,16 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     HIPCHK(hipEventCreateWithFlags(&s->ev_chunk[0], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&s->ev_chunk[1], hipEventDisableTiming));
     s->strict = env_int("JH_STRICT_ORDER", 0) ? 1 : 0;
+    s->strict_legacy = env_int("JH_STRICT_LEGACY", 0) ? 1 : 0;
+    s->p16_depth = env_int("JH_P16_D", 8);   // upper bound of the prefetch depth (p16_depth_for)
+    // reference-order attention: one slice of the context per 16 positions of max_ctx, at least 16, at most 256 (the slices that
+    // lie beyond the current position return at once)
+    s->p16_att_splits = env_int("JH_P16_ATT_SPLITS", 0);
+    if (s->p16_att_splits <= 0) s->p16_att_splits = (max_ctx + 15) / 16;
+    if (s->p16_att_splits < 16) s->p16_att_splits = 16;
+    if (s->p16_att_splits > 256) s->p16_att_splits = 256;
+    s->p16_sc_stride = (max_ctx + 63) & ~63;
+    HIPCHK(hipMalloc(&s->p16_scores, (size_t)c.n_heads * s->p16_sc_stride * 4));
     if (s->strict && c.weight_dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "JH_STRICT_ORDER: strict-order kernels exist for JQ4 models only");
     if (prefill_batch_ok(s)) {
         // the MFMA-ordered weight copies of the prefill GEMM are made here, once per model, not inside the first prompt
@@ -2059,6 +2182,7 @@ int jh_session_destroy(jh_session* s) {
     for (hipEvent_t e : s->ev_chunk) if (e) hipEventDestroy(e);
     if (s->st_host) hipHostFree(s->st_host);
     if (s->eos_dev) hipFree(s->eos_dev);
+    if (s->p16_scores) hipFree(s->p16_scores);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
     return JH_OK;
@@ -2151,6 +2275,8 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
     const int nl = c.layer_end - c.layer_start;
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, s->max_ctx / 2, 0, 0);
     s->attn_variant = attn_variant_for(s, s->max_ctx / 2);
+    const bool p16 = s->strict && !s->strict_legacy;   // reference-order kernels (jh_p16.h) when the session is in that mode
+    if (s->strict && s->strict_legacy) return set_err(JH_ERR_UNSUPPORTED, "kernel_bench: not for the legacy strict kernels");
     int launches = 0;
     for (int it = -1; it < iters; it++) {
         if (it == 0) HIPCHK(hipEventRecord(s->ev0, st));
@@ -2158,18 +2284,23 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
             const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
             GemvParams p;
             memset(&p, 0, sizeof(p));
-            if (which == 0) {
+            if (which == 9) {          // LM head (+ final norm, argmax partials): one weight, re-streamed per launch
+                JHCHK(lmhead_launch(s, st));
+            } else if (which == 0) {
                 const JWeight& F = m->qkv[(size_t)li];
                 p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
                 p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
                 p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
-                JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
+                if (p16) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_STORE>(p, s->p16_depth, st)));
+                else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
             } else if (which == 1) {
                 JHCHK(attn_launch(s, li - c.layer_start, st, false));
             } else if (which == 2) {
                 p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = s->x1;
                 p.K = A; p.ldb = A / 2; p.ldbf = A / QB; p.x = s->attf; p.resid = s->x;
-                if (s->direct_max > 0) {
+                if (p16) {
+                    JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
+                } else if (s->direct_max > 0) {
                     p.part_o = s->part_o; p.part_ml = s->part_ml; p.st = s->st; p.direct_max = s->direct_max;
                     p.direct_chunk = s->direct_chunk; p.part_stride = s->part_stride; p.head_size = hs; p.n_heads = c.n_heads;
                     JHCHK((launch_gemv_i8q4<PRO_ATTN_Q8, EPI_RESID>(p, s->cfg_o, st)));
@@ -2182,11 +2313,13 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                 p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
                 p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
                 p.out = s->hf;
-                JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
+                if (p16) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->p16_depth, st)));
+                else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
             } else if (which == 4) {
                 p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x1;
                 p.K = H; p.ldb = H / 2; p.ldbf = H / QB; p.x = s->hf; p.resid = s->x;
-                JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
+                if (p16) JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
+                else JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
             } else if (which >= 5 && which <= 8) {
                 // the same GEMVs fed a pre-quantized activation row (PRO_Q8): what the fused prologue costs
                 JHCHK(prefill_alloc(s));
@@ -2211,7 +2344,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                     JHCHK((launch_gemv_i8q4<PRO_Q8, EPI_RESID>(p, s->cfg_down, st)));
                 }
             } else {
-                return set_err(JH_ERR_INVALID, "kernel_bench: which in 0..8 (qkv, attn, oproj, gateup, down; 5..8 = the GEMVs with pre-quantized input)");
+                return set_err(JH_ERR_INVALID, "kernel_bench: which in 0..9 (qkv, attn, oproj, gateup, down; 5..8 = the GEMVs with pre-quantized input; 9 = LM head)");
             }
             if (it >= 0) launches++;
         }
@@ -2228,6 +2361,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
         else if (which == 1) b = (int64_t)2 * (s->max_ctx / 2 + 1) * KV * 4 + (int64_t)2 * KV * 4;
         else if (which == 2) b = (int64_t)((double)E * A * bpw);
         else if (which == 3 || which == 7) b = (int64_t)((double)2 * H * E * bpw);
+        else if (which == 9) b = (int64_t)((double)c.vocab_size * E * bpw);
         else if (which == 5) b = (int64_t)((double)(A + 2 * KV) * E * bpw);
         else if (which == 6) b = (int64_t)((double)E * A * bpw);
         else b = (int64_t)((double)E * H * bpw);
@@ -2483,7 +2617,7 @@ static int build_graph(jh_session* s, int v) {
     if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     s->graph[v] = g;
     HIPCHK(hipGraphInstantiate(&s->exec[v], g, nullptr, nullptr, 0));
-    const int per_layer = 5 + ((s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0);
+    const int per_layer = 5 + ((s->strict && !s->strict_legacy) || (!s->strict && s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0);
     s->kernels_per_token = (c.layer_end - c.layer_start) * per_layer + (has_out ? 2 : 0);
     return JH_OK;
 }

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Reference-order (jh_p16.h) vs order-free kernels on one GPU: decode tok/s and per-kernel probes (HIP events on the
+session stream), full-size synthetic model.  usage: strict_bench.py [CONFIG] [steps]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
+    from jlama_amd.model import HipLlamaModel
+    config = sys.argv[1] if len(sys.argv) > 1 else "LLAMA3_8B"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    cfg = dict(getattr(S, config))
+    torch.cuda.set_device(0)
+    N.init(0)
+    w = ST.make_weights(cfg, seed=0, device="cuda")
+    model = HipLlamaModel(cfg, w)
+    prompt = S.prompt_tokens(cfg, n=128, seed=1234)
+    out = {"config": config, "steps": steps}
+    names = ["qkv", "attention", "o_proj", "gate_up", "down"]
+    for mode in ("fast", "strict"):
+        s = model.session(prompt.size + steps + 8)
+        s.batch_forward(prompt, 0)           # fast prefill in both modes: this tool measures kernels, not parity
+        first = s.sample()
+        if mode == "strict":
+            s.set_strict(True)
+        s.decode_n(first, prompt.size, 4)
+        s.synchronize()
+        t0 = time.perf_counter()
+        toks = s.decode_n(first, prompt.size, steps)
+        dt = time.perf_counter() - t0
+        ev_ms, kernels = s.decode_stats()
+        probe = {}
+        for i, nm in enumerate(names + [None] * 4 + ["lm_head"]):
+            if nm is None:
+                continue
+            ms, b = s.kernel_bench(i, 3)
+            probe[nm] = {"us": round(ms * 1e3, 2), "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
+        out[mode] = {"tok_s": round(steps / dt, 1), "event_ms_per_token": round(ev_ms, 4), "kernels_per_token": kernels,
+                     "kernels": probe, "first_ids": [int(t) for t in toks[:8]]}
+        s.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
