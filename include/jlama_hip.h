@@ -272,6 +272,9 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
 typedef struct jh_pipeline jh_pipeline;
 int jh_pipeline_create(jh_session* const* stages, int n_stages, jh_pipeline** out);
 int jh_pipeline_destroy(jh_pipeline* p);
+/* Per stage k: how the hop INTO it travels -- 1 direct peer access over xGMI, 0 staged copies (hipDeviceEnablePeerAccess
+ * refused), -1 same device as its predecessor; slot 0 = the sampled id's way back to the first stage.  Returns the stage count. */
+int jh_pipeline_peer_access(jh_pipeline* p, int32_t* out, int n);
 /* batchForward of n prompt rows at [start_pos, start_pos+n) through all stages, then sample (temperature 0) on the last. */
 int jh_pipeline_prefill(jh_pipeline* p, const int32_t* tokens, int n, int start_pos, int32_t* first_token);
 /* n greedy decode steps; returns after queueing (every stage's work is stream-ordered), _wait fetches the ids. */

@@ -124,6 +124,7 @@ _PROTOS = {
     "jh_tp_group_decode_n": (_i, [_p, _i, _i, _i, _p]),
     "jh_pipeline_create": (_i, [_p, _i, _p]),
     "jh_pipeline_destroy": (_i, [_p]),
+    "jh_pipeline_peer_access": (_i, [_p, _p, _i]),
     "jh_pipeline_prefill": (_i, [_p, _p, _i, _i, _p]),
     "jh_pipeline_decode_n_async": (_i, [_p, _i, _i, _i]),
     "jh_pipeline_decode_wait": (_i, [_p, _p, _i]),

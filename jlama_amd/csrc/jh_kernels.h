@@ -1775,7 +1775,7 @@ __global__ void embed_kernel(const void* table, const float* scales, int dtype, 
 // the state, so the remaining replays of an already-queued decode loop emit nothing.
 __global__ void finish_token_kernel(const float* partv, const int* parti, int nparts, DecodeState* st,
                                     int* out_tokens, const void* table, const float* scales, int dtype, int E,
-                                    float* x, int do_embed, const int* eos, int n_eos) {
+                                    float* x, int do_embed, const int* eos) {   // eos: [count, id0, id1, ...] (jh_session_set_eos)
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ int tok;
@@ -1805,7 +1805,8 @@ __global__ void finish_token_kernel(const float* partv, const int* parti, int np
         st->pos = st->pos + 1;
         st->step = st->step + 1;
         int stop = 0;
-        for (int i = 0; i < n_eos; i++) stop |= (eos[i] == bi);
+        const int n_eos = eos[0];
+        for (int i = 0; i < n_eos; i++) stop |= (eos[1 + i] == bi);
         st->done = stop;
     }
     __syncthreads();

@@ -1,6 +1,6 @@
 // jh_p16.h -- the decode path with every float accumulation in EXACTLY the order of the reference's Panama AVX-512 provider
 // ("reference order"), built to stream at the same rate as the order-free kernels of jh_kernels.h.  Results are bit-identical
-// to a plain-C restatement of that provider (oracle/jlama_oracle.c), not merely inside the Q8 noise floor.
+// to a plain-C restatement of that provider (the parity tests' checker), not merely inside the Q8 noise floor.
 //
 // Panama-512 order (FloatVector.SPECIES_512 = 16 float lanes), what has to be reproduced:
 //   I8 x Q4  (GemmerI8Q4_512, PTO:807-850):  lane t:  acc_t = fma(da*sb, (float)(short)(lo_t*a[t] + hi_t*a[t+16]), acc_t)
@@ -650,6 +650,21 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
     const int t1 = t0 + chunk < n ? t0 + chunk : n;
     const int KV = p.n_kv_heads * HS, A = p.n_heads * HS;
     const int tid = threadIdx.x, l = tid & 15, prow = tid >> 4;
+    // ---- the K rows of the first two passes are requested before q / rope: their addresses depend on the position only, so the
+    // kernel pays one memory round trip for both (a 16-lane row per position: lane l reads k[l], k[16+l], ... -- GemmerF32's lanes)
+    constexpr int PB = 2;
+    float kv[PB][NC];
+    auto load_k = [&](int tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            int tt = tb + u * RP;
+            tt = tt < n ? tt : n - 1;
+            const float* krow = kv_row(p, 0, tt, KV) + (size_t)kvh * HS + l;
+#pragma unroll
+            for (int c = 0; c < NC; c++) kv[u][c] = krow[16 * c];
+        }
+    };
+    load_k(t0 + prow);
     // ---- RoPE of the group's q heads and of the new k row (table row pos + 2*kvHead: CausalSelfAttention.java:247-286); every
     // slice rotates them locally, bit-identically; the slice that owns `pos` writes the KV page rows
     const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
@@ -685,25 +700,16 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
     for (int gi = 0; gi < GROUP; gi++)
 #pragma unroll
         for (int c = 0; c < NC; c++) q[gi][c] = qs[gi * HS + 16 * c + l];
-    // ---- scores: a 16-lane row per position, two passes of loads in flight
-    constexpr int PB = 2;
+    // ---- scores
     for (int tb = t0 + prow; tb < t1; tb += RP * PB) {
-        float kv[PB][NC];
-#pragma unroll
-        for (int u = 0; u < PB; u++) {
-            int tt = tb + u * RP;
-            tt = tt < n ? tt : n - 1;
-            const float* krow = kv_row(p, 0, tt, KV) + (size_t)kvh * HS + l;
-#pragma unroll
-            for (int c = 0; c < NC; c++) kv[u][c] = krow[16 * c];
-        }
+        if (tb != t0 + prow) load_k(tb);                    // long slices: further passes, two at a time
 #pragma unroll
         for (int u = 0; u < PB; u++) {
             const int tt = tb + u * RP;
             if (tt >= t1) break;   // uniform per 16-lane row; the DPP tree below stays inside the row
             if (tt == pos) {
 #pragma unroll
-                for (int c = 0; c < NC; c++) kv[u][c] = knew[16 * c + l];   // the page row was written by another workgroup just now
+                for (int c = 0; c < NC; c++) kv[u][c] = knew[16 * c + l];   // the page row is being written by this workgroup just now
             }
 #pragma unroll
             for (int gi = 0; gi < GROUP; gi++) {
@@ -717,33 +723,40 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
     }
 }
 
-template <int HS>
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (arrays of HIP's float4 class type end up in scratch)
+template <int HS, int RU>
+__device__ __forceinline__ void p16_av_load_tile(const AttnParams& p, f32x4 (&vreg)[RU], int tile, int n, int KV, int kvh, int d0, int vr, int vc) {
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+        int tt = tile * (32 * RU) + vr + 32 * u;
+        tt = tt < n ? tt : n - 1;
+        vreg[u] = ((const f32x4*)(kv_row(p, 1, tt, KV) + (size_t)kvh * HS + d0))[vc];
+    }
+}
+template <int RU>
+__device__ __forceinline__ void p16_av_store_tile(float* vt, const f32x4 (&vreg)[RU], int vr, int vc) {
+#pragma unroll
+    for (int u = 0; u < RU; u++) ((f32x4*)(vt + (size_t)(vr + 32 * u) * 32))[vc] = vreg[u];
+}
+// RU = V rows per thread and tile, i.e. TP = 32 * RU positions per V tile in LDS (host: 2, 4, 8 or 16 -- the smallest that holds
+// the session's max_ctx, at most 512 positions): a context of up to TP positions is ONE tile, requested at kernel start and
+// landing while the softmax runs.
+constexpr int P16_AV_TPMAX = 512;
+template <int HS, int RU>
 __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams p, const float* scores, int sc_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 64;   // columns per workgroup, positions per V tile
+    constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 32 * RU;   // columns per workgroup, positions per tile
     const int h = blockIdx.y, group = p.n_heads / p.n_kv_heads, kvh = h / group, d0 = blockIdx.x * DW;
     const int pos = p.st->pos, n = pos + 1;
     const int KV = p.n_kv_heads * HS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* vt = (float*)smem;              // [TP][DW] V tile
-    float* redf = vt + TP * DW;            // [16]
-    float* w = redf + 16;                  // [n] scores -> softmax weights
-    // V tile loads: thread (row = tid / 8, c4 = tid % 8) covers 32 rows per pass, two passes per tile
+    float* redf = vt + (size_t)TP * DW;    // [16]
+    float* w = redf + 16;                  // [n, padded to 64] scores -> softmax weights
+    // V tile loads: thread (row = tid / 8, c4 = tid % 8) covers rows vr, vr + 32, ...
     const int vr = tid >> 3, vc = tid & 7;
-    float4 vreg0, vreg1;
-    auto load_row = [&](int tt) __attribute__((always_inline)) {
-        tt = tt < n ? tt : n - 1;
-        return ((const float4*)(kv_row(p, 1, tt, KV) + (size_t)kvh * HS + d0))[vc];
-    };
-    auto load_tile = [&](int tile) __attribute__((always_inline)) {
-        vreg0 = load_row(tile * TP + vr);
-        vreg1 = load_row(tile * TP + vr + 32);
-    };
-    auto store_tile = [&]() __attribute__((always_inline)) {
-        ((float4*)(vt + (size_t)vr * DW))[vc] = vreg0;
-        ((float4*)(vt + (size_t)(vr + 32) * DW))[vc] = vreg1;
-    };
-    load_tile(0);                           // in flight across the softmax
+    f32x4 vreg[RU];
+    p16_av_load_tile<HS, RU>(p, vreg, 0, n, KV, kvh, d0, vr, vc);   // in flight across the softmax
     const float* srow = scores + (size_t)h * sc_stride;
     float m = -INFINITY;
     for (int tt = tid; tt < n; tt += NT) {
@@ -757,14 +770,18 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     m = redf[0];
     for (int i = 1; i < NT / 64; i++) m = fmaxf(m, redf[i]);
     for (int tt = tid; tt < n; tt += NT) w[tt] = (float)exp((double)(w[tt] - m));   // (float)FastMath.exp(x - max)
+    p16_av_store_tile<RU>(vt, vreg, vr, vc);                        // tile 0 lands in LDS while lane 0 sums
     __syncthreads();
     if (tid == 0) {
         float sum = 0.0f;                   // VectorMath.java:80-85: one float accumulator, index order
         int tt = 0;
-        for (; tt + 8 <= n; tt += 8) {
+        for (; tt + 16 <= n; tt += 16) {
             const float4 e0 = *(const float4*)(w + tt), e1 = *(const float4*)(w + tt + 4);
+            const float4 e2 = *(const float4*)(w + tt + 8), e3 = *(const float4*)(w + tt + 12);
             sum += e0.x; sum += e0.y; sum += e0.z; sum += e0.w;
             sum += e1.x; sum += e1.y; sum += e1.z; sum += e1.w;
+            sum += e2.x; sum += e2.y; sum += e2.z; sum += e2.w;
+            sum += e3.x; sum += e3.y; sum += e3.z; sum += e3.w;
         }
         for (; tt < n; tt++) sum += w[tt];
         redf[8] = sum;
@@ -776,10 +793,13 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     float acc = 0.0f;
     const int ntiles = (n + TP - 1) / TP;
     for (int tile = 0; tile < ntiles; tile++) {
-        __syncthreads();                    // the previous tile has been consumed (first pass: w[] is complete)
-        store_tile();
-        if (tile + 1 < ntiles) load_tile(tile + 1);
-        __syncthreads();
+        if (tile > 0) {                     // contexts beyond one tile: plain copy per tile (the register array must not be
+            __syncthreads();                // loop-carried: hipcc then keeps it in scratch); the previous tile has been consumed
+            f32x4 vnext[RU];
+            p16_av_load_tile<HS, RU>(p, vnext, tile, n, KV, kvh, d0, vr, vc);
+            p16_av_store_tile<RU>(vt, vnext, vr, vc);
+        }
+        __syncthreads();                    // tile (and, first time round, the normalised weights) visible
         if (tid < DW) {
             // 16 steps per chunk; the next chunk's LDS reads are issued before the current chunk's dependent fmas
             const int tbase = tile * TP, cnt = n - tbase < TP ? n - tbase : TP;
@@ -789,7 +809,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
 #pragma unroll
                 for (int j = 0; j < 16; j++) v[j] = vt[(i0 + j) * DW + tid];          // i0 + j < TP: rows past cnt hold clamped copies
 #pragma unroll
-                for (int j = 0; j < 4; j++) ww[j] = *(const float4*)(w + tbase + i0 + 4 * j);   // 16-byte aligned; w[] is padded to TP
+                for (int j = 0; j < 4; j++) ww[j] = *(const float4*)(w + tbase + i0 + 4 * j);   // 16-byte aligned; w[] is padded to 64
             };
             auto dochunk = [&](int i0, const float (&v)[16], const float4 (&ww)[4]) __attribute__((always_inline)) {
                 if (i0 + 16 <= cnt) {
@@ -821,6 +841,10 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     }
     if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
 }
-static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)64 * 32 + 16 + (size_t)((max_ctx + 63) & ~63)) * 4; }
+static inline int p16_av_rows(int max_ctx) {   // RU: the whole context in one tile when it fits
+    const int want = ((max_ctx + 63) & ~63) / 32;
+    return want <= 2 ? 2 : want <= 4 ? 4 : want <= 8 ? 8 : 16;
+}
+static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)p16_av_rows(max_ctx) * 32 * 32 + 16 + (size_t)((max_ctx + 63) & ~63)) * 4; }
 
 }  // namespace jh

@@ -307,13 +307,15 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
         // below for q|k|v and the o-projection (21 vs 30 us).  JH_GEMM_LDS = 0 / 1 forces one of them.
         const int lds_env = env_int("JH_GEMM_LDS", -1);   // read per call: the tests flip it within one process
         const bool lds_auto = (long long)(g.n / 32) * nblk >= (long long)896 * 64;
-        const bool lds_fits = (size_t)nblk * 128 + 4 * 8192 <= 150 * 1024;   // scale slice + the A rings of up to 4 K slices
-        if (tiled && lds_fits && (lds_env > 0 || (lds_env < 0 && lds_auto))) {
+        if (tiled && (lds_env > 0 || (lds_env < 0 && lds_auto))) {
             const int cw_l = env_int("JH_GEMM_LDS_CW", 4), ct_l = env_int("JH_GEMM_LDS_CT", 1), s_l = env_int("JH_GEMM_LDS_S", 2);
             int CWL = cw_l, CTL = ct_l > 2 ? 2 : ct_l, SL = s_l;
             while (CTL > 1 && g.n % (32 * CWL * CTL)) CTL >>= 1;
             while (CWL > 1 && g.n % (32 * CWL * CTL)) CWL >>= 1;
             while (SL > 1 && nblk % (8 * SL)) SL >>= 1;
+            while (SL > 1 && (size_t)nblk * 128 + (size_t)SL * 8192 > 150 * 1024) SL >>= 1;   // scale slice + the A rings of the SL K slices
+            const bool lds_fits = (size_t)nblk * 128 + (size_t)SL * 8192 <= 150 * 1024;
+            if (!lds_fits) CWL = -1;   // no instantiation below matches: the tile kernel takes it
             if (CWL == 4 && CTL == 1 && SL == 2 && env_int("JH_GEMM_LDS_PK", 0)) return launch_gemm_q8q4_lds<4, 1, 2, true>(g, mt, ws, ws_bytes, st);
 #define JH_LDS(CV, TV, SV) if (CWL == CV && CTL == TV && SL == SV) return launch_gemm_q8q4_lds<CV, TV, SV>(g, mt, ws, ws_bytes, st);
             JH_LDS(4, 1, 1) JH_LDS(4, 1, 2) JH_LDS(4, 1, 4) JH_LDS(2, 1, 2) JH_LDS(2, 1, 4) JH_LDS(2, 1, 8) JH_LDS(4, 2, 1) JH_LDS(4, 2, 2) JH_LDS(2, 2, 2)
@@ -1065,6 +1067,7 @@ struct jh_model {
     int weights_version = 0;  // bumped by jh_model_set_weight: sessions drop graphs that captured the old device pointers
 };
 enum { TAP_SLOTS = 12 };
+constexpr int JH_MAX_EOS = 16;   // stop tokens per session (Config.eosTokens holds 1-3 in practice)
 constexpr int N_ATTN_VARIANTS = 3;
 struct jh_session {
     jh_model* m;
@@ -1119,8 +1122,9 @@ struct jh_session {
     float* p16_scores = nullptr;   // [n_heads][p16_sc_stride] scaled attention scores between the two reference-order attention launches
     int p16_sc_stride = 0, p16_att_splits = 16, p16_depth = 8;
     // stop tokens (jh_session_set_eos): device copy for finish_token_kernel + host-side feeding control
-    int* eos_dev = nullptr;
+    int* eos_dev = nullptr;   // fixed buffer [count, id0, id1, ...] read by finish_token_kernel: changing the list re-captures nothing
     int n_eos = 0;
+    int eos_host[JH_MAX_EOS] = {0};
     DecodeState* st_host = nullptr;   // pinned: state snapshots the host polls between chunks of graph replays
     hipEvent_t ev_chunk[2] = {nullptr, nullptr};
     int generated = 0;
@@ -1209,7 +1213,14 @@ int launch_gemv_i8q4_p16_d(const GemvParams& p, const P16Plan& pl, hipStream_t s
 }
 template <int PRO, int EPI>
 int launch_gemv_i8q4_p16(const GemvParams& p, int depth, hipStream_t st) {
-    const P16Plan pl = p16_plan(p.nrows, 1);
+    // more than 8 row quads per CU (gate|up): two workgroups per CU, so that every SIMD has 3-4 waves to issue from -- the kernel
+    // is as much VALU- as HBM-bound, and a wave alone issues one instruction per ~4 cycles
+    static const int wgs_big = env_int("JH_P16_WGS_BIG", 1);   // measured on 8B gate|up: 22.2 us with two workgroups per CU, 21.3 with one
+    const int q_cu = ((p.nrows + 3) / 4 + g_cu_count - 1) / g_cu_count;
+    const P16Plan pl = p16_plan(p.nrows, q_cu > 8 && wgs_big > 1 ? wgs_big : 1);
+    // ring depth by bytes in flight per CU (tw waves x D KiB): ~32 KiB is what a CU sustains; deeper rings only cost registers
+    // (measured: q|k|v and gate|up with 6-7 task waves 4 > 8, the o- and down-projections with 4 task waves 8 / 7 > 4)
+    if (pl.tw >= 6 && depth > 4) depth = 4;
     switch (p16_depth_for(p.K, depth)) {
         case 8: return launch_gemv_i8q4_p16_d<PRO, EPI, 8>(p, pl, st);
         case 7: return launch_gemv_i8q4_p16_d<PRO, EPI, 7>(p, pl, st);
@@ -1238,7 +1249,8 @@ int launch_gemv_f32q4_p16(const GemvParams& p, int* grid_out, hipStream_t st) {
     static const int gx = env_int("JH_P16_LM_GRIDX", 2);
     const P16Plan pl = p16_plan(p.nrows, gx > 0 && gx <= 16 ? gx : 2);   // argmax partial buffers hold 4096 entries
     if (grid_out) *grid_out = pl.grid;
-    switch (p16_depth_for(p.K, 8)) {
+    static const int lm_d = env_int("JH_P16_LM_D", 8);
+    switch (p16_depth_for(p.K, lm_d)) {
         case 8: return launch_gemv_f32q4_p16_d<PRO, 8>(p, pl, st);
         case 7: return launch_gemv_f32q4_p16_d<PRO, 7>(p, pl, st);
         case 4: return launch_gemv_f32q4_p16_d<PRO, 4>(p, pl, st);
@@ -1288,17 +1300,23 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
         const size_t lds_av = lds_bytes_attn_p16(s->max_ctx);
         if (lds_av > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "reference-order attention: the score row of max_ctx positions must fit in LDS");
         const dim3 grid_s(s->p16_att_splits, c.n_kv_heads), grid_v(hs / 32, c.n_heads);
+        const int ru = p16_av_rows(s->max_ctx);
+#define JH_P16_AV(HSV, RV)                                                                                                      \
+    if (hs == HSV && ru == RV) {                                                                                               \
+        JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                               \
+        hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
+    }
 #define JH_P16_ATTN(HSV, GV)                                                                                                   \
     if (hs == HSV && group == GV) {                                                                                            \
         hipLaunchKernelGGL((attn_p16_scores_kernel<HSV, GV>), grid_s, dim3(P16_ATT_THREADS), 0, st, p, s->p16_scores, s->p16_sc_stride); \
         HIPCHK(hipGetLastError());                                                                                             \
-        JHCHK(allow_lds((attn_p16_av_kernel<HSV>), lds_av));                                                                   \
-        hipLaunchKernelGGL((attn_p16_av_kernel<HSV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
+        JH_P16_AV(HSV, 2) JH_P16_AV(HSV, 4) JH_P16_AV(HSV, 8) JH_P16_AV(HSV, 16)                                                \
         HIPCHK(hipGetLastError());                                                                                             \
         return JH_OK;                                                                                                          \
     }
         JH_P16_ATTN(128, 4) JH_P16_ATTN(128, 8) JH_P16_ATTN(64, 4) JH_P16_ATTN(128, 1) JH_P16_ATTN(128, 2) JH_P16_ATTN(64, 1) JH_P16_ATTN(64, 2) JH_P16_ATTN(64, 8)
 #undef JH_P16_ATTN
+#undef JH_P16_AV
         return set_err(JH_ERR_UNSUPPORTED, "attention: head_size must be 64 or 128 and heads/kv_heads in {1,2,4,8}");
     }
     if (s->strict) {
@@ -1835,7 +1853,7 @@ int finish_launch(jh_session* s, hipStream_t st, int do_embed) {
     const JWeight& e = m->global_w[JH_W_EMBED];
     hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(256), 0, st, (const float*)s->amax_v, (const int*)s->amax_i, s->lm_grid,
                        s->st, s->out_tokens, (const void*)e.data, (const float*)e.scales, e.dtype, m->c.embedding_length, s->x,
-                       (do_embed && e.data) ? 1 : 0, (const int*)s->eos_dev, s->n_eos);
+                       (do_embed && e.data) ? 1 : 0, (const int*)s->eos_dev);
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
@@ -2104,6 +2122,8 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     s->prefill_batch_min = env_int("JH_PREFILL_BATCH_MIN", 4);   // chunks of fewer rows go row by row; 0 disables batching
     s->prefill_attn_mfma_min = env_int("JH_PREFILL_ATTN_MFMA_MIN", 384);   // -1: always the per-row kernel; 0: always the MFMA kernel
     s->graphs_version = m->weights_version;
+    HIPCHK(hipMalloc(&s->eos_dev, (1 + JH_MAX_EOS) * sizeof(int)));
+    HIPCHK(hipMemset(s->eos_dev, 0, (1 + JH_MAX_EOS) * sizeof(int)));
     HIPCHK(hipHostMalloc((void**)&s->st_host, 2 * sizeof(DecodeState), hipHostMallocDefault));
     memset(s->st_host, 0, 2 * sizeof(DecodeState));
     HIPCHK(hipEventCreateWithFlags(&s->ev_chunk[0], hipEventDisableTiming));
@@ -2141,17 +2161,17 @@ int jh_session_set_strict(jh_session* s, int on) {
 }
 int jh_session_set_eos(jh_session* s, const int32_t* eos_ids, int n_eos) {
     if (!s || n_eos < 0 || (n_eos > 0 && !eos_ids)) return set_err(JH_ERR_INVALID, "set_eos: bad argument");
+    if (n_eos > JH_MAX_EOS) return set_err(JH_ERR_INVALID, "set_eos: at most 16 stop tokens");
+    if (n_eos == s->n_eos && (n_eos == 0 || memcmp(eos_ids, s->eos_host, (size_t)n_eos * sizeof(int)) == 0)) return JH_OK;   // unchanged
     HIPCHK(hipSetDevice(s->m->device));
+    // the list lives in a fixed device buffer that finish_token_kernel reads at run time: no captured graph is invalidated.
+    // Ordered on the session's stream behind whatever decode is still queued.
+    int buf[1 + JH_MAX_EOS] = {0};
+    buf[0] = n_eos;
+    for (int i = 0; i < n_eos; i++) { buf[1 + i] = eos_ids[i]; s->eos_host[i] = eos_ids[i]; }
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (s->eos_dev) { HIPCHK(hipFree(s->eos_dev)); s->eos_dev = nullptr; }
-    s->n_eos = 0;
-    if (n_eos > 0) {
-        HIPCHK(hipMalloc(&s->eos_dev, (size_t)n_eos * sizeof(int)));
-        HIPCHK(hipMemcpy(s->eos_dev, eos_ids, (size_t)n_eos * sizeof(int), hipMemcpyHostToDevice));
-        s->n_eos = n_eos;
-    }
-    s->graphs_version = -1;       // finish_token_kernel's arguments are baked into the decode graphs
-    drop_stale_graphs(s);
+    HIPCHK(hipMemcpy(s->eos_dev, buf, sizeof(buf), hipMemcpyHostToDevice));
+    s->n_eos = n_eos;
     return JH_OK;
 }
 int jh_decode_generated(jh_session* s, int32_t* out_n) {
@@ -2703,6 +2723,14 @@ int jh_decode_n(jh_session* s, int32_t first_token, int start_pos, int n, int32_
     return jh_decode_wait(s, out_tokens, n);
 }
 // ---- one-process tensor-parallel group ---------------------------------------------------------------------------------
+static int tp_enable_peer(int dev, int peer) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dev, peer) != hipSuccess || !can) { (void)hipGetLastError(); return 0; }
+    hipSetDevice(dev);
+    const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+    (void)hipGetLastError();
+    return (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ? 1 : 0;
+}
 struct jh_tp_group {
     std::vector<jh_session*> sh;
     std::vector<float*> part, red, slots;      // per shard, on its device: [E], [E], [2 rounds][N][E]
@@ -2735,6 +2763,7 @@ int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** ou
         if (!shards[k]->m->global_w[JH_W_EMBED].data) return set_err(JH_ERR_INVALID, "tp_group_create: every shard needs the embedding table");
     }
     jh_tp_group* g = new jh_tp_group();
+    bool ok_peer = true;
     const int N = n_shards;
     const size_t E = (size_t)shards[0]->m->c.embedding_length;
     bool ok = true;
@@ -2751,15 +2780,13 @@ int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** ou
         g->evA.push_back(a); g->evB.push_back(b); g->evTok.push_back(t);
         for (int j = 0; j < k; j++)   // direct peer stores both ways
             if (shards[j]->m->device != shards[k]->m->device) {
-                int can = 0;
-                if (hipDeviceCanAccessPeer(&can, shards[k]->m->device, shards[j]->m->device) == hipSuccess && can) {
-                    hipSetDevice(shards[k]->m->device); (void)hipDeviceEnablePeerAccess(shards[j]->m->device, 0);
-                    hipSetDevice(shards[j]->m->device); (void)hipDeviceEnablePeerAccess(shards[k]->m->device, 0);
-                }
-                (void)hipGetLastError();
+                // peer STORES need direct access both ways; without it the group cannot work (no staged fallback for kernels)
+                if (!tp_enable_peer(shards[k]->m->device, shards[j]->m->device) || !tp_enable_peer(shards[j]->m->device, shards[k]->m->device))
+                    ok_peer = false;
             }
     }
     if (!ok) { jh_tp_group_destroy(g); return set_err(JH_ERR_OOM, "tp_group_create: buffers"); }
+    if (!ok_peer) { jh_tp_group_destroy(g); return set_err(JH_ERR_UNSUPPORTED, "tp_group_create: the shards' devices cannot address each other's memory (peer access)"); }
     for (int k = 0; k < N; k++) {   // shard k's slot on shard j, round r:  slots[j] + (r*N + k)*E
         std::vector<float*> h(2 * (size_t)N);
         for (int r = 0; r < 2; r++)
@@ -2882,12 +2909,27 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
     }
     for (jh_session* s : g->sh) { HIPCHK(hipSetDevice(s->m->device)); HIPCHK(hipStreamSynchronize(s->stream)); }
     HIPCHK(hipSetDevice(s0->m->device));
-    HIPCHK(hipMemcpy(out_tokens, s0->out_tokens, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    // stop tokens (jh_session_set_eos on shard 0): its state froze at the step that sampled one; the other shards ran the queued
+    // rows on (their KV tail past the stop is never read again).  Only the ids up to and including the stop token are valid.
+    DecodeState hs;
+    HIPCHK(hipMemcpy(&hs, s0->st, sizeof(hs), hipMemcpyDeviceToHost));
+    s0->generated = hs.step < n ? hs.step : n;
+    HIPCHK(hipMemcpy(out_tokens, s0->out_tokens, (size_t)s0->generated * sizeof(int), hipMemcpyDeviceToHost));
     return JH_OK;
 }
 
 // ---- one-process layer-sharded pipeline ------------------------------------------------------------------------------
+// 1 = device `dev` can address `peer`'s memory directly (enabled now or earlier), 0 = it cannot
+static int enable_peer(int dev, int peer) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dev, peer) != hipSuccess || !can) { (void)hipGetLastError(); return 0; }
+    hipSetDevice(dev);
+    const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+    (void)hipGetLastError();
+    return (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ? 1 : 0;
+}
 struct jh_pipeline {
+    std::vector<int> peer_ok;             // per hop k-1 -> k (index k, [0] = the token's way back): 1 direct peer access, 0 staged copies, -1 same device
     std::vector<jh_session*> st;          // stages in order
     std::vector<float*> hop;              // per stage: [PB_MAX_ROWS, E] F32 on the stage's device (prefill hand-off landing zone)
     std::vector<hipEvent_t> done;         // per stage: its part of the current row / chunk is complete
@@ -2925,23 +2967,20 @@ int jh_pipeline_create(jh_session* const* stages, int n_stages, jh_pipeline** ou
         }
         p->hop.push_back(h);
         p->done.push_back(ev);
-        // direct xGMI copies between neighbouring stages (ignored when already enabled / same device)
-        if (k > 0 && stages[k - 1]->m->device != s->m->device) {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, s->m->device, stages[k - 1]->m->device) == hipSuccess && can)
-                (void)hipDeviceEnablePeerAccess(stages[k - 1]->m->device, 0);
-            (void)hipGetLastError();
-        }
+        // direct xGMI copies between neighbouring stages; the outcome is recorded per hop (jh_pipeline_peer_access): without peer
+        // access hipMemcpyPeerAsync still works, staged through the host -- correct, but not the xGMI hop the design counts on
+        p->peer_ok.push_back(-1);
+        if (k > 0 && stages[k - 1]->m->device != s->m->device) p->peer_ok[k] = enable_peer(s->m->device, stages[k - 1]->m->device);
     }
-    if (n_stages > 1 && stages[0]->m->device != stages[n_stages - 1]->m->device) {   // the token id's way back
-        hipSetDevice(stages[0]->m->device);
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, stages[0]->m->device, stages[n_stages - 1]->m->device) == hipSuccess && can)
-            (void)hipDeviceEnablePeerAccess(stages[n_stages - 1]->m->device, 0);
-        (void)hipGetLastError();
-    }
+    if (n_stages > 1 && stages[0]->m->device != stages[n_stages - 1]->m->device)   // the token id's way back
+        p->peer_ok[0] = enable_peer(stages[0]->m->device, stages[n_stages - 1]->m->device);
     *out = p;
     return JH_OK;
+}
+int jh_pipeline_peer_access(jh_pipeline* p, int32_t* out, int n) {
+    if (!p || !out || n < (int)p->st.size()) return set_err(JH_ERR_INVALID, "pipeline_peer_access: need one slot per stage");
+    for (size_t k = 0; k < p->st.size(); k++) out[k] = p->peer_ok[k];
+    return (int)p->st.size();
 }
 int jh_pipeline_destroy(jh_pipeline* p) {
     if (!p) return JH_OK;

@@ -165,7 +165,7 @@ class HipSession:
 
     def set_eos(self, eos_tokens):
         """Config.eosTokens for the device loop (AbstractModel.java:600-603)."""
-        ids = np.ascontiguousarray(list(eos_tokens), dtype=np.int32)
+        ids = np.ascontiguousarray(list(eos_tokens or ()), dtype=np.int32)
         N.check(N.lib().jh_session_set_eos(self.h, N.ptr(ids) if ids.size else None, int(ids.size)))
 
     def set_strict(self, on=True):
@@ -210,8 +210,10 @@ class HipSession:
     # -- AbstractModel.generate at the token-id level ---------------------------------------------------
     def generate(self, prompt_tokens, ntokens, temperature=0.0, rng=None, eos_tokens=(), on_device_loop=True):
         """prompt_tokens already contain BOS.  Returns dict(tokens, prompt_ms, generate_ms, tokens_generated);
-        decode clock starts after the first sampled token (AbstractModel.java:589), like the reference."""
+        decode clock starts after the first sampled token (AbstractModel.java:589), like the reference.  Stop tokens are
+        tested on the ids sampled INSIDE the loop only (:590-603): the token sampled from the prompt is always fed on."""
         prompt_tokens = np.ascontiguousarray(prompt_tokens, dtype=np.int32)
+        eos_tokens = tuple(int(t) for t in (eos_tokens or ()))
         t0 = time.perf_counter()
         self.batch_forward(prompt_tokens, 0)
         u = float(rng.random()) if (rng is not None and temperature > 0) else 0.5
@@ -221,11 +223,8 @@ class HipSession:
         start = prompt_tokens.size
         n_more = ntokens - start
         if temperature == 0.0 and on_device_loop and n_more > 0:
-            # the device loop honours the stop tokens itself (finish_token_kernel); a prompt whose first sampled token is
-            # already one ends here, as in the reference (the loop body never runs: AbstractModel.java:590)
-            self.set_eos(eos_tokens)
-            if nxt not in eos_tokens:
-                out.extend(int(t) for t in self.decode_n(nxt, start, n_more))
+            self.set_eos(eos_tokens)             # the device loop honours the stop tokens itself (finish_token_kernel)
+            out.extend(int(t) for t in self.decode_n(nxt, start, n_more))
         else:
             for i in range(start, ntokens):
                 if temperature == 0.0:
@@ -284,6 +283,14 @@ class HipPipeline:
         N.check(N.lib().jh_pipeline_prefill(self.h, N.ptr(tokens), tokens.size, start_pos, C.byref(tok)))
         return tok.value
 
+    def peer_access(self):
+        """Per stage: how the hop into it travels -- True direct peer access (xGMI), False staged copies, None same device;
+        entry 0 is the sampled id's way back to the first stage."""
+        n = len(self.sessions)
+        out = (C.c_int32 * n)()
+        N.check(N.lib().jh_pipeline_peer_access(self.h, out, n))
+        return [None if v < 0 else bool(v) for v in out]
+
     def decode_n_async(self, first_token, start_pos, n):
         N.check(N.lib().jh_pipeline_decode_n_async(self.h, int(first_token), int(start_pos), int(n)))
 
@@ -335,7 +342,7 @@ class HipTPGroup:
     def decode_n(self, first_token, start_pos, n):
         out = np.empty(n, dtype=np.int32)
         N.check(N.lib().jh_tp_group_decode_n(self.h, int(first_token), int(start_pos), int(n), N.ptr(out)))
-        return out
+        return out[:self.sessions[0].decode_generated()]   # fewer than n only after a stop token (set_eos on shard 0's session)
 
     def close(self):
         if self.h:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reference-order (jh_p16.h) vs order-free kernels on one GPU: decode tok/s and per-kernel probes (HIP events on the
-session stream), full-size synthetic model.  usage: strict_bench.py [CONFIG] [steps]"""
+session stream), full-size synthetic model.  usage: strict_bench.py [CONFIG] [steps] [fast,strict]"""
 import json
 import os
 import sys
@@ -26,7 +26,8 @@ def main():
     prompt = S.prompt_tokens(cfg, n=128, seed=1234)
     out = {"config": config, "steps": steps}
     names = ["qkv", "attention", "o_proj", "gate_up", "down"]
-    for mode in ("fast", "strict"):
+    modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ("fast", "strict")
+    for mode in modes:
         s = model.session(prompt.size + steps + 8)
         s.batch_forward(prompt, 0)           # fast prefill in both modes: this tool measures kernels, not parity
         first = s.sample()
