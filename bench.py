@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense BF16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
 MFMA_I8_PEAK_TOPS = 5000.0       # dense I8 MFMA ~ 2x the BF16 rate (MI355X_MICROARCH.md: >= 3944 TOPS measured)
+DOMINANT_KERNEL = "gemv_i8q4_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV, fused RMSNorm+Q8 prologue, SiLU*up epilogue)"
 
 
 def _profiled(config):
@@ -60,6 +61,7 @@ def parse():
     ap.add_argument("--prompt", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-strict", action="store_true")     # skip the reference-order leg (strict_tokens_per_s)
     ap.add_argument("--cpu-steps", type=int, default=256)   # ~12 s of CPU work at the reference path's ~21 tok/s
     ap.add_argument("--parity-steps", type=int, default=256)   # free-running strict-order ids compared with the oracle
     ap.add_argument("--probe-iters", type=int, default=3)
@@ -135,6 +137,8 @@ def full_size_parity(cfg, model, host_w, n_prompt=8, n_free=256, n_tf=TF_STEPS):
     last_logits_o = lg
     out["oracle_panama_order_s"] = round(time.perf_counter() - t0, 1)
     ids_o = np.array(ids_o, dtype=np.int32)
+    if cfg["weight_dtype"] != O.DT_Q4:
+        return _full_size_parity_dense(cfg, model, prompt, out, ids_o, logits_o, n_free, n_tf), ids_o
     # ---- B: GPU strict order, free-running
     ss = model.session(prompt.size + n_free + 8)
     ss.set_strict(True)
@@ -193,6 +197,41 @@ def full_size_parity(cfg, model, host_w, n_prompt=8, n_free=256, n_tf=TF_STEPS):
     return out, ids_o
 
 
+def _full_size_parity_dense(cfg, model, prompt, out, ids_o, logits_o, n_free, n_tf):
+    """BF16 model (config 4): one kernel set, no Q8 step function on the path.  Teacher-forced on the oracle's ids the logits
+    must sit within 1e-3 of the logit scale (BASELINE north_star's F32 tolerance; what remains is F32 summation order plus the
+    rare BF16 rounding flip of an activation), and the free-running greedy ids are compared token for token."""
+    fs = model.session(prompt.size + max(n_tf, n_free) + 8)
+    fs.batch_forward(prompt, 0)
+    tok_f, lg_f = fs.sample(0.0, 0.5, want_logits=True)
+    logits_f, ids_tf = [lg_f], [tok_f]
+    for i in range(n_tf):
+        ids_tf.append(fs.decode_step(int(ids_o[i]), prompt.size + i))
+        logits_f.append(fs.logits())
+    fs.close()
+    logits_o_tf = logits_o[:n_tf + 1]
+    scale = float(np.abs(logits_o[0]).max())
+    d = _dist(logits_f, logits_o_tf)
+    out["teacher_forced_logits_vs_oracle"] = dict(d, max_rel_to_logit_scale=round(d["max"] / scale, 7))
+    out["logit_scale"] = scale
+    out["teacher_forced_argmax_equal"] = int(sum(int(a == int(np.argmax(w))) for a, w in zip(ids_tf, logits_o_tf)))
+    out["teacher_forced_steps_compared"] = len(logits_o_tf)
+    # free-running greedy ids: batched (MFMA) prefill + the on-device loop, exactly what the timed run executes
+    gs = model.session(prompt.size + n_free + 8)
+    gs.batch_forward(prompt, 0)
+    g0 = gs.sample()
+    ids_g = np.concatenate([[g0], gs.decode_n(g0, prompt.size, n_free)]).astype(np.int32)
+    gs.close()
+    out["free_running_ids_equal_prefix"] = int((ids_g == ids_o[:ids_g.size]).cumprod().sum())
+    out["free_running_ids_compared"] = int(ids_g.size)
+    margins = []
+    for w in logits_o_tf:
+        top2 = np.partition(w, -2)[-2:]
+        margins.append(float(top2[1] - top2[0]))
+    out["oracle_min_top2_margin_teacher_forced"] = round(min(margins), 6)
+    return out
+
+
 def run_single(args, cfg):
     import torch
     from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
@@ -237,6 +276,33 @@ def run_single(args, cfg):
     assert toks.size == args.steps
     ev_ms, kernels = s.decode_stats()
     tps = args.steps / dt
+    # ---- the same K steps in REFERENCE ORDER (jh_p16.h: every float accumulation in the Panama provider's order; ids and logits
+    # bit-identical to the oracle, see parity_full_size): timed exactly like `value`, in this same process
+    strict = None
+    if cfg["weight_dtype"] == N.DT_Q4 and not args.no_strict:
+        ss = model.session(max_ctx)
+        ss.batch_forward(prompt, 0)            # (the prompt's KV rows: which kernels wrote them does not change the decode rate)
+        sfirst = ss.sample()
+        ss.set_strict(True)
+        for p0 in sorted({prompt.size, last_pos}):
+            ss.decode_n(sfirst, p0, 1)         # graph capture, untimed
+        torch.cuda.synchronize(); ss.synchronize()
+        t0 = time.perf_counter()
+        ss.decode_n_async(sfirst, prompt.size, args.steps)
+        stoks = ss.decode_wait(args.steps)
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - t0
+        assert stoks.size == args.steps
+        sev_ms, skernels = ss.decode_stats()
+        sprobe = {}
+        for i, nm in ((0, "qkv"), (1, "attention"), (2, "o_proj"), (3, "gate_up"), (4, "down"), (9, "lm_head")):
+            ms, b = ss.kernel_bench(i, args.probe_iters)
+            sprobe[nm] = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
+        ss.close()
+        strict = {"tokens_per_s": round(args.steps / sdt, 2), "ms_per_step": round(sdt / args.steps * 1e3, 4),
+                  "event_ms_per_token": round(sev_ms, 4), "kernels_per_token": skernels, "kernels": sprobe,
+                  "note": "reference-order kernels (jh_p16.h): bit-identical ids and logits vs the Panama-order oracle "
+                          "(parity_full_size.strict_order), same K steps, same bracket as `value`"}
     # roofline of the dominant kernel (gate/up GEMV: 54% of the weight bytes), HIP events on the session's stream
     probe = {}
     names = ["qkv", "attention", "o_proj", "gate_up", "down"]
@@ -267,7 +333,7 @@ def run_single(args, cfg):
                                f"{args.steps} greedy decode steps, batch 1", "parallelism": "1 GPU",
                    "kernels_per_token": kernels, "prefill_ms": round(prompt_ms, 2), "prefill_cold_ms": round(prompt_cold_ms, 2),
                    "prefill_tokens_per_s": round(prompt.size / prompt_ms * 1e3, 1)},
-        "roofline": ({"bound": "hbm", "kernel": "gemv_i8q4_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV, fused RMSNorm+Q8 prologue, SiLU*up epilogue)",
+        "roofline": ({"bound": "hbm", "kernel": DOMINANT_KERNEL,
                       "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                       "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"], "us_per_launch_rocprof": us_rocprof,
@@ -287,10 +353,18 @@ def run_single(args, cfg):
         "kernels": probe,
         "weights_gen_s": round(gen_s, 1),
     }
+    if strict:
+        out["strict_tokens_per_s"] = strict["tokens_per_s"]
+        out["strict_order"] = strict
     host_w = None
     if not args.no_cpu_baseline:
         host_w = ST.to_host(w)
         out["cpu_baseline"] = cpu_baseline(cfg, host_w, 8, args.cpu_steps)
+    if not args.no_parity and not is_q4:
+        host_w = host_w or ST.to_host(w)
+        # the BF16 oracle streams 14 GB per row on the host cores: a bounded sample (8-row prompt, 16 teacher-forced + 16 free steps)
+        par, _ = full_size_parity(cfg, model, host_w, 8, min(args.parity_steps, 16), 16)
+        out["parity_full_size"] = par
     if not args.no_parity and is_q4:
         host_w = host_w or ST.to_host(w)
         par, ids_o = full_size_parity(cfg, model, host_w, 8, args.parity_steps, TF_STEPS)
@@ -306,17 +380,69 @@ def run_single(args, cfg):
     return out, toks
 
 
+def run_one_process(args, cfg):
+    """`--gpus N` WITHOUT a launcher (no RANK in the environment): the one-process N-device host BASELINE's north_star names
+    (jh_pipeline_*: stage k on HIP device k, activations hop by stream-ordered peer copies over xGMI).  Always ends with
+    exactly one JSON line: the result, or {"error": ..., "n_gpus_visible": k} when the node has fewer devices."""
+    import torch
+    from jlama_amd import distributed as D, synthetic as S
+    n = args.gpus
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    base = {"metric": "decode tokens/sec Llama-3-8B JQ4, 128-tok prompt" if args.config == "LLAMA3_8B" else f"decode tokens/sec {args.config}",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup}
+    if visible < n:
+        return dict(base, error=f"--gpus {n} but only {visible} HIP device(s) visible", n_gpus_visible=visible, value=None), 1
+    if cfg["n_layers"] % n:
+        return dict(base, error=f"{cfg['n_layers']} layers do not split evenly over {n} stages", n_gpus_visible=visible, value=None), 1
+    try:
+        r = D.one_process_pipeline_bench(args.config, n, args.steps, args.warmup, args.prompt, probe_iters=args.probe_iters)
+        roof, cpu = D.multi_gpu_extras(args, cfg, r["gate_up_probe"], 0)
+    except Exception as e:   # noqa: BLE001 -- the contract is one JSON line, never a traceback
+        return dict(base, error=repr(e)[:600], n_gpus_visible=visible, value=None), 1
+    is_q4 = cfg["weight_dtype"] == 3
+    tokens = r["steps_per_session"] * r["sessions"]
+    value = r["aggregate_tokens_per_s"] if n > 1 else r["single_stream_tokens_per_s"]
+    ms_per_step = (r["aggregate_s"] / tokens * 1e3) if n > 1 else r["single_stream_ms_per_token"]
+    wbytes, kvb = S.weight_bytes(cfg), S.kv_bytes_per_position(cfg)
+    bytes_per_token = wbytes + kvb * (r["prompt_rows"] + (args.steps - 1) / 2.0 + 2)
+    out = dict(base, value=value, unit="tokens/s", steps=tokens if n > 1 else args.steps, ms_per_step=round(ms_per_step, 4),
+               higher_is_better=True, scaling="strong",
+               scaling_detail=(f"fixed total of {tokens} tokens; value = throughput of {n} sessions in flight (one per GPU): a single stream "
+                               "passes through all GPUs in sequence and cannot exceed the 1-GPU rate (SURVEY.md 8d)") if n > 1 else "1 GPU, batch 1",
+               single_stream_tokens_per_s=r["single_stream_tokens_per_s"], vs_baseline=None,
+               dtype="i8xq4->f32" if is_q4 else "bf16xbf16->f32", data="synthetic",
+               config={"workload": f"{args.config}, {r['prompt_rows']}-row prefill + {r['steps_per_session']} greedy decode steps x "
+                                   f"{r['sessions']} sessions in flight" + (" (single stream)" if n == 1 else ""),
+                       "parallelism": f"one process, layer-sharded pp{n} ({cfg['n_layers'] // n} layers/GPU), stream-ordered "
+                                      "hipMemcpyPeerAsync hops of [1,E] F32 (xGMI peer copies, not RCCL send/recv: one host, no communicator)",
+                       "peer_access": r["peer_access"], "sessions_in_flight": r["sessions"], "sessions_agree": r["sessions_agree"],
+                       "single_stream_ms_per_token": r["single_stream_ms_per_token"], "prefill_ms": r["prefill_ms_per_session"],
+                       "first_ids": r["first_ids"]},
+               roofline=roof if roof else {"bound": "hbm", "kernel": "whole decode step", "achieved": round(bytes_per_token * value / 1e9 / n, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_per_token * value / 1e9 / n / HBM_PEAK_GBS, 4),
+                                           "traffic": None},
+               pipeline_roofline={"achieved_GBps_per_gpu": round(bytes_per_token * value / 1e9 / n, 1),
+                                  "frac_of_8TBps": round(bytes_per_token * value / 1e9 / n / HBM_PEAK_GBS, 4)},
+               cpu_baseline=cpu)
+    return out, 0
+
+
 def main():
     args = parse()
     from jlama_amd import synthetic as S
     cfg = dict(getattr(S, args.config))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or os.environ.get("JH_BENCH_FORCE_PIPELINE"):
+    if "RANK" in os.environ and world > 1:
+        # one rank per GPU under torch.distributed.run: the RCCL send/recv pipeline
         from jlama_amd import distributed as D
         out = D.bench_pipeline(args, cfg)
         if out is not None:
             print(json.dumps(out), flush=True)
         return
+    if args.gpus > 1 or os.environ.get("JH_BENCH_FORCE_PIPELINE"):
+        out, rc = run_one_process(args, cfg)   # bare invocation: the one-process host, never a rendezvous
+        print(json.dumps(out), flush=True)
+        sys.exit(rc)
     out, _ = run_single(args, cfg)
     print(json.dumps(out), flush=True)
 

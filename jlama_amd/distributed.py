@@ -363,10 +363,11 @@ def tp_generate(dist, engine, rank, prompt, n_gen, cfg, device, dtype):
     return np.asarray(out, dtype=np.int32)
 
 
-def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=None):
+def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=None, probe_iters=3):
     """The one-process N-device host (jh_pipeline_*, BASELINE north_star): stage k on HIP device k, hops are stream-ordered
     peer copies.  Measures the single-stream (batch-1) decode rate and the aggregate rate of N sessions in flight over the
-    same stage models.  Returns a dict (also printed as JSON by `python -m jlama_amd.distributed --one-process ...`)."""
+    same stage models -- EXACTLY `steps` tokens in each timed leg, bracketed by a synchronize of every stage stream.
+    Returns a dict (also printed as JSON by `python -m jlama_amd.distributed --one-process ...`)."""
     import torch
     from . import _native as N, synthetic as S, synthetic_torch as ST
     from .model import HipPipeline, build_stage_models
@@ -385,24 +386,69 @@ def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=
 
     models = build_stage_models(cfg, weights_for_stage, devices)
     pipes = [HipPipeline(models, max_ctx) for _ in range(n)]
+    tp0 = time.perf_counter()
     firsts = [p.prefill(prompt) for p in pipes]
+    prefill_ms = (time.perf_counter() - tp0) * 1e3 / n
+
+    def sync_all():
+        for p in pipes:
+            for s in p.sessions:
+                s.synchronize()
+
     if warmup > 0:
         pipes[0].decode_n(firsts[0], prompt.size, warmup)
+    for p in pipes[1:]:                       # every pipeline's graphs captured before anything is timed
+        p.decode_n(firsts[pipes.index(p)], prompt.size, 1)
     # single stream: one session, `steps` tokens
+    sync_all()
     t0 = time.perf_counter()
     toks = pipes[0].decode_n(firsts[0], prompt.size, steps)
+    sync_all()
     dt_single = time.perf_counter() - t0
     # N sessions in flight: every pipeline queued before any is awaited
+    sync_all()
     t0 = time.perf_counter()
     for p, f in zip(pipes, firsts):
         p.decode_n_async(f, prompt.size, per_session)
     outs = [p.decode_wait(per_session) for p in pipes]
+    sync_all()
     dt_agg = time.perf_counter() - t0
     same = all(np.array_equal(o, outs[0]) for o in outs) and np.array_equal(outs[0], toks[:per_session])
+    probe = None
+    if cfg["weight_dtype"] == N.DT_Q4:         # dominant kernel (gate|up GEMV) on stage 0's layers, HIP events on its stream
+        ms, b = pipes[0].sessions[0].kernel_bench(3, probe_iters)
+        probe = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
     return {"mode": "one process, %d devices, hipMemcpyPeerAsync hops ordered by events" % n, "devices": devices,
             "single_stream_tokens_per_s": round(steps / dt_single, 2), "single_stream_ms_per_token": round(dt_single / steps * 1e3, 4),
-            "aggregate_tokens_per_s": round(per_session * n / dt_agg, 2), "sessions": n, "steps_per_session": per_session,
-            "sessions_agree": bool(same)}
+            "aggregate_tokens_per_s": round(per_session * n / dt_agg, 2), "aggregate_s": dt_agg, "sessions": n,
+            "steps_per_session": per_session, "sessions_agree": bool(same), "peer_access": pipes[0].peer_access(),
+            "prefill_ms_per_session": round(prefill_ms, 2), "prompt_rows": int(prompt.size), "gate_up_probe": probe,
+            "first_ids": [int(t) for t in toks[:8]]}
+
+
+def multi_gpu_extras(args, cfg, gate_up_probe, device_index=0):
+    """What every N>1 bench line carries besides its throughput: the dominant kernel's roofline (measured on one stage: the
+    kernels of a layer shard are the 1-GPU kernels) with the committed counter traffic, and the CPU baseline (same leg as N=1,
+    full model on the host cores)."""
+    import bench
+    from . import synthetic_torch as ST
+    traffic, us_rocprof, prof = bench._profiled(args.config)
+    roof = None
+    if gate_up_probe:
+        roof = {"bound": "hbm", "kernel": bench.DOMINANT_KERNEL, "achieved": gate_up_probe["GBps"], "peak": bench.HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gate_up_probe["GBps"] / bench.HBM_PEAK_GBS, 4), "traffic": traffic, "bytes_per_launch": gate_up_probe["bytes"],
+                "us_per_launch": gate_up_probe["us"], "us_per_launch_rocprof": us_rocprof, "profile": prof,
+                "note": "dominant kernel of one stage (the layer shards run the 1-GPU kernels), HIP events on the stage's stream"}
+    cpu = None
+    if not args.no_cpu_baseline:
+        import torch
+        torch.cuda.set_device(device_index)
+        w = ST.make_weights(cfg, seed=0, device=f"cuda:{device_index}")
+        host_w = ST.to_host(w)
+        del w
+        torch.cuda.empty_cache()
+        cpu = bench.cpu_baseline(cfg, host_w, 8, args.cpu_steps)
+    return roof, cpu
 
 
 def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
@@ -446,6 +492,11 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
     L, E = cfg["n_layers"], cfg["embedding_length"]
     ls, le = layer_range(rank, world, L)
     prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
+    cpu_base = None
+    if on_gpu and rank == 0 and not getattr(args, "no_cpu_baseline", False):
+        # the CPU leg of the N=1 line (full model on the host cores), before this rank's shard occupies the GPU; the other
+        # ranks meanwhile build their shards and wait in the first collective
+        _, cpu_base = multi_gpu_extras(args, cfg, None, local)
     # Sessions in flight for `value`: one per GPU (the fewest that keep every stage busy).  A second timed leg runs two per GPU:
     # with one, a stage idles through every launch edge of its graph; two sessions' graphs on two streams fill each other's
     # edges (one GPU, no sharding: 673 -> 871 tok/s, profiles/r02j_*).  Reported beside `value`, never as it.
@@ -540,12 +591,25 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
     dist.barrier()
     out = None
     if rank == 0:
+        gate_up = None
+        if on_gpu and cfg["weight_dtype"] == 3:   # DT_Q4: dominant kernel on this rank's layers
+            ms_p, b_p = engine.sessions[0].kernel_bench(3, getattr(args, "probe_iters", 3))
+            gate_up = {"us": round(ms_p * 1e3, 3), "bytes": b_p, "GBps": round(b_p / (ms_p * 1e-3) / 1e9, 1)}
+        roof_k = None
+        if on_gpu:
+            saved = getattr(args, "no_cpu_baseline", False)
+            args.no_cpu_baseline = True
+            roof_k, _ = multi_gpu_extras(args, cfg, gate_up, local)
+            args.no_cpu_baseline = saved
         tps = total / dt
         wbytes, kvb = S.weight_bytes(cfg), S.kv_bytes_per_position(cfg)
         bytes_per_token = wbytes + kvb * (prompt.size + (steps_per_session - 1) / 2.0 + 2)
         out = {"metric": "decode tokens/sec Llama-3-8B JQ4, 128-tok prompt" if args.config == "LLAMA3_8B" else f"decode tokens/sec {args.config} JQ4",
                "value": round(tps, 2), "unit": "tokens/s", "n_gpus": world, "steps": total, "warmup": args.warmup,
-               "ms_per_step": round(dt / total * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "ms_per_step": round(dt / total * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+               "scaling_detail": f"fixed total of {total} tokens; value = throughput of {n_sess} sessions in flight (one per GPU), the "
+                                 "batch-1 single-stream rate is single_stream_tokens_per_s",
+               "single_stream_tokens_per_s": round(single_steps / dt1, 2), "vs_baseline": None,
                "dtype": "i8xq4->f32", "data": "synthetic",
                "config": {"workload": f"{args.config} JQ4, {prompt.size}-row prefill + {steps_per_session} greedy decode steps x {n_sess} "
                                       f"sessions in flight", "parallelism": f"layer-sharded pp{world} ({L // world} layers/GPU), RCCL send/recv of [1,E] F32",
@@ -557,11 +621,12 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
                           "host_synchronised_aggregate_tokens_per_s": host_sync,
                           "note": "value = aggregate of the sessions in flight; a single stream passes through all GPUs in sequence and "
                                   "cannot exceed the 1-GPU rate (SURVEY.md 8d multi-GPU accounting)"},
-               "roofline": {"bound": "hbm", "kernel": "whole pipeline (per-kernel roofline is the 1-GPU run's: same kernels per stage)",
-                            "achieved": round(bytes_per_token * tps / 1e9 / world, 1), "peak": 8000.0, "unit": "GB/s",
-                            "frac": round(bytes_per_token * tps / 1e9 / world / 8000.0, 4), "traffic": None,
-                            "note": "per-GPU average: algorithmic bytes of all sessions / time / GPUs"},
-               "cpu_baseline": None, "one_process_pipeline": one_proc}
+               "roofline": roof_k if roof_k else {"bound": "hbm", "kernel": "whole pipeline (control-flow run: no GPU)", "achieved": None,
+                                                   "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None},
+               "pipeline_roofline": {"achieved_GBps_per_gpu": round(bytes_per_token * tps / 1e9 / world, 1),
+                                     "frac_of_8TBps": round(bytes_per_token * tps / 1e9 / world / 8000.0, 4),
+                                     "note": "per-GPU average: algorithmic bytes of all sessions / time / GPUs"},
+               "cpu_baseline": cpu_base, "one_process_pipeline": one_proc}
     dist.destroy_process_group()
     # RCCL prints its version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise land AFTER
     # the JSON line at exit: flush it now so that the contract line is the last thing on stdout

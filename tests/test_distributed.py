@@ -191,3 +191,26 @@ def test_bench_pipeline_control_flow_on_cpu(world):
     assert out["one_process_pipeline"] == {"skipped": "no GPU (control-flow run)"}
     for key in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "roofline"):
         assert key in out
+
+
+def test_bare_multi_gpu_bench_invocation_always_prints_one_json_line():
+    """`python bench.py --gpus 2 --steps 8` without a launcher (no RANK): the one-process host is the path -- never a
+    rendezvous, never a traceback.  Here (no GPU) it must end with exactly one JSON line carrying the structured error."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "8"], capture_output=True, text=True, cwd=root, env=env,
+                       timeout=240)
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-400:] + r.stderr[-400:]
+    out = json.loads(lines[0])
+    assert "Traceback" not in r.stderr
+    try:
+        import torch
+        visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:   # noqa: BLE001
+        visible = 0
+    if visible < 2:
+        assert out["n_gpus_visible"] == visible and "error" in out and out["value"] is None and r.returncode != 0
+    else:
+        assert out["n_gpus"] == 2 and out["value"] > 0 and "single_stream_tokens_per_s" in out and out["cpu_baseline"]

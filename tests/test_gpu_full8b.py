@@ -49,8 +49,9 @@ def test_full_size_strict_ids_and_provider_envelope(full8b, oracle):
         for k in ("gpu_fast__panama_oracle", "gpu_fast__reference_c_gemm"):
             # three implementations that differ only in float summation order are three draws from the same noise
             # process (Q8 code flips cascading through 32 layers); a defect would add to it
-            assert pw[k]["max"] <= 2.0 * env["max"] + 1e-3, (k, pw)
-            assert pw[k]["mean_of_max"] <= 1.6 * env["mean_of_max"] + 1e-3, (k, pw)
+            # (measured ratios 1.10 / 1.02: the gate leaves room for another seed, not for a regression)
+            assert pw[k]["max"] <= 1.3 * env["max"] + 1e-3, (k, pw)
+            assert pw[k]["mean_of_max"] <= 1.2 * env["mean_of_max"] + 1e-3, (k, pw)
     d = par["fast_argmax_vs_oracle_at_margin_0.25"]
     assert d["agree"] == d["decided_steps"], d
 
@@ -65,8 +66,11 @@ def test_full_size_every_layer_in_isolation(full8b, oracle):
     print("per-layer teacher-forced (fast kernels): max", rel.max(), "share <= 1e-5:", float((rel <= NOFLIP_TOL).mean()))
     assert rel.max() <= FLIP_TOL, (rel.max(), np.unravel_index(rel.argmax(), rel.shape))
     assert (rel <= NOFLIP_TOL).mean() >= 0.5
-    # a layer's median sits at float-ordering level unless most of its 8 rows caught a flip (layer 0, whose inputs are
-    # Q4-lattice embedding rows, did in the first run: 4 of 8); an addressing defect in a layer would lift ALL its rows
+    # every layer past the first: the median row sits at float-ordering level (a flip is the exception; an addressing defect
+    # in a layer would lift ALL its rows).  Layer 0 is pinned by itself: its inputs are Q4-lattice embedding rows, whose block
+    # maxima sit on quantizer boundaries far more often (4 of its 8 rows caught a flip in round 2) -- there at least 3 of the 8
+    # rows must match to float-ordering level and none may exceed the single-flip bound
     med = np.median(rel, axis=1)
-    assert (med <= NOFLIP_TOL).mean() >= 0.9, med
+    assert (med[1:] <= NOFLIP_TOL).all(), med
+    assert (rel[0] <= NOFLIP_TOL).sum() >= 3 and rel[0].max() <= FLIP_TOL, rel[0]
     assert (rel.min(axis=1) <= NOFLIP_TOL).all(), rel.min(axis=1)       # every layer has rows that match to 1e-5

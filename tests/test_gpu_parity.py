@@ -218,6 +218,31 @@ def test_device_loop_stops_at_eos(gpu, oracle):
         np.testing.assert_array_equal(res["tokens"], np.concatenate([[first], free[:kf + 1]]))
 
 
+def test_first_sampled_token_is_never_tested_against_the_stop_set(gpu, oracle):
+    """AbstractModel.java:573-603: the token sampled from the prompt is always forwarded; only ids sampled INSIDE the loop
+    are compared with eosTokens.  Device loop, host loop and the reference order (oracle ids with the same rule) agree, and an
+    unchanged stop list re-captures nothing."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.TINY)
+    hm, om, _ = _pair(cfg, 2, oracle)
+    prompt = S.prompt_tokens(cfg, n=20, seed=2)
+    want, _, _ = om.session().generate(prompt, 60)            # free-running oracle ids: want[0] is sampled from the prompt
+    first = int(want[0])
+    # expected: stop at the first LATER occurrence of `first`, or run to the end
+    later = np.nonzero(want[1:] == first)[0]
+    expect = want[:later[0] + 2] if later.size else want
+    for device_loop in (True, False):
+        s = hm.session(128)
+        s.set_strict(True)
+        res = s.generate(prompt, prompt.size + 59, eos_tokens=(first,), on_device_loop=device_loop)
+        np.testing.assert_array_equal(res["tokens"], expect, err_msg=f"device_loop={device_loop}")
+        assert res["tokens_generated"] == expect.size - 1
+        # eos_tokens=None is an empty set
+        res2 = s.generate(prompt, prompt.size + 9, eos_tokens=None, on_device_loop=device_loop)
+        np.testing.assert_array_equal(res2["tokens"], want[:10])
+        s.close()
+
+
 def test_positions_at_the_context_tail_are_refused(gpu):
     """kv head h reads RoPE table row position + 2*h (CausalSelfAttention.java:260-283); the reference's table has
     context_length rows and Java throws ArrayIndexOutOfBounds for the last 2*(kvHeads-1) positions.  Same positions are
