@@ -307,6 +307,11 @@ int jh_decode_step(jh_session* s, int32_t token, int pos, int32_t* next_token);
 /* n greedy decode iterations chained on the device (argmax feeds the next embedding lookup without a host
  * round trip; one hipGraph replay per token).  out_tokens: HOST [n].  Timing region of the metric. */
 int jh_decode_n(jh_session* s, int32_t first_token, int start_pos, int n, int32_t* out_tokens);
+/* The same device-resident loop with AbstractModel.sample's temperature branch (core/model/AbstractModel.java:471-489):
+ * softmax((logit - max) / temperature) with a FLOAT running sum in index order, inverse CDF against u[i], the uniform of the
+ * i-th sampled token (the reference draws ThreadLocalRandom.nextFloat() per call, :594 -- the caller supplies them).  One graph
+ * replay per token, no host round trip; temperature == 0 is jh_decode_n.  Honours jh_session_set_eos like jh_decode_n. */
+int jh_decode_n_sampled(jh_session* s, int32_t first_token, int start_pos, int n, float temperature, const float* u, int32_t* out_tokens);
 /* Stop tokens of the device loop (Config.eosTokens; AbstractModel.java:600-603: generation ends with the step that
  * samples one).  n_eos == 0 clears the set.  With a non-empty set jh_decode_n stops feeding the GPU once a stop token
  * was sampled (checked every few steps without draining the queue); the ids up to and including the stop token are

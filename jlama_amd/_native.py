@@ -135,6 +135,7 @@ _PROTOS = {
     "jh_decode_step": (_i, [_p, _i, _i, _p]),
     "jh_decode_n": (_i, [_p, _i, _i, _i, _p]),
     "jh_decode_n_async": (_i, [_p, _i, _i, _i]),
+    "jh_decode_n_sampled": (_i, [_p, _i, _i, _i, _f, _p, _p]),
     "jh_decode_wait": (_i, [_p, _p, _i]),
     "jh_session_set_eos": (_i, [_p, _p, _i]),
     "jh_decode_generated": (_i, [_p, _p]),

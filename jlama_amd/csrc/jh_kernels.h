@@ -1731,6 +1731,72 @@ __global__ void tp_sum_kernel(const float* slots, int n, int E, float* out) {
     for (int k = 1; k < n; k++) v = v + slots[(size_t)k * E + i];
     out[i] = v;
 }
+// ---- the same reduction without the host in it: every shard replays ONE captured graph per token, the shards meet in kernels.
+// A shard's scatter workgroup b stores its 256 elements into its slot on every shard (system-scope stores: peer memory over
+// xGMI), fences, then raises its flag word b on every shard to the sequence number of this (token, layer); the consumer's
+// workgroup b waits for the N producers' flag b -- the element ranges coincide, so no grid-wide meeting is needed -- and sums the
+// N slots in shard order 0..N-1 (+ residual).  Sequence numbers only grow, slots are reused two rounds later (by then every
+// shard has consumed them: it could not have produced its next partial otherwise).
+struct TPMail { int token, pos; unsigned seq; int pad; };   // shard 0 -> the others: the row to process next
+// Every wait is bounded (50 ms of the 100 MHz wall clock): a peer that never arrives -- e.g. two shards' streams serialised onto
+// one hardware queue -- must end in an error code on the host (word seqp[1]), never in a hung GPU.  Once raised the flag makes
+// every later wait of the launch fall through at once.
+__device__ __forceinline__ bool tp_wait_ge(const unsigned* f, unsigned want, unsigned* err) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        if (wall_clock64() - t0 > 5000000LL) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return true;
+}
+__device__ __forceinline__ void st_sys(float* p, float v) {
+    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float ld_sys(const float* p) {
+    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__global__ __launch_bounds__(256) void tp_scatter_flag_kernel(const float* part, float* const* dst, unsigned* const* fdst, int n_dst, int E,
+                                                              const unsigned* seqp, int li, int L) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < E) {
+        const float v = part[i];
+        for (int j = 0; j < n_dst; j++) st_sys(dst[j] + i, v);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned seq = *seqp * (unsigned)L + (unsigned)li + 1u;
+        for (int j = 0; j < n_dst; j++) __hip_atomic_store(fdst[j] + blockIdx.x, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ __launch_bounds__(256) void tp_sum_wait_kernel(const float* slots, const unsigned* flags, int n, int E, int nwg, unsigned* seqp,
+                                                          int li, int L, const float* resid, float* out) {
+    const unsigned seq = *seqp * (unsigned)L + (unsigned)li + 1u;
+    if ((int)threadIdx.x < n) tp_wait_ge(flags + (size_t)threadIdx.x * nwg + blockIdx.x, seq, seqp + 1);
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    float v = ld_sys(slots + i);
+    for (int k = 1; k < n; k++) v = v + ld_sys(slots + (size_t)k * E + i);   // shard order: the lock-step order
+    out[i] = resid[i] + v;                                                      // TransformerBlock.java:185 / :203
+}
+// shard 0, after finish_token_kernel: the next row (token, position) to every other shard's mailbox
+__global__ void tp_publish_token_kernel(const DecodeState* st, TPMail* const* mails, int n, const unsigned* seqp) {
+    if (threadIdx.x >= (unsigned)n) return;
+    TPMail* m = mails[threadIdx.x];
+    __hip_atomic_store(&m->token, st->token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&m->pos, st->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(&m->seq, *seqp + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the other shards, first node of their token graph: wait for the row of this replay, take it over
+__global__ void tp_wait_token_kernel(const TPMail* mail, unsigned* seqp, DecodeState* st) {
+    tp_wait_ge(&mail->seq, *seqp, seqp + 1);
+    st->token = __hip_atomic_load(&mail->token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    st->pos = __hip_atomic_load(&mail->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void tp_bump_seq_kernel(unsigned* seqp) { *seqp = *seqp + 1u; }
 __global__ void set_pos_kernel(DecodeState* st, int pos) { st->pos = pos; }   // pipeline stages: the token / step words stay
 // one pipeline stage per process: the token id arrives in device memory (shipped by the last stage), never through the host
 __global__ void set_state_dev_kernel(DecodeState* st, int pos, const int* token_dev) {
@@ -1773,9 +1839,70 @@ __global__ void embed_kernel(const void* table, const float* scales, int dtype, 
 // next embedding row, so a greedy decode step needs no host round trip (AbstractModel.java:590-599).
 // Stop tokens (Config.eosTokens, AbstractModel.java:600-603): the step that samples one is the last; st->done freezes
 // the state, so the remaining replays of an already-queued decode loop emit nothing.
+// ---- temperature sampling inside the device loop (AbstractModel.sample, core/model/AbstractModel.java:471-489):
+//   v_i = (float)exp((logit_i - max) / T) in double;  sum = float running sum over i in INDEX ORDER;  acc += v_i / sum until
+//   acc >= u -> token i (V-1 if never).  The exponentials are independent (sample_exp_kernel, whole chip); the two float
+//   accumulations are sequential by definition -- one lane walks the V values through LDS chunks (sample_pick_kernel), which
+//   costs ~0.3-0.5 ms at V = 128256 and keeps a T > 0 generation at one graph replay per token, no host round trip.
+__global__ __launch_bounds__(256) void sample_exp_kernel(const float* logits, int V, const float* partv, int nparts, float temperature, float* prob) {
+    __shared__ float red[4];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, partv[i]);   // the LM head's per-workgroup maxima
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const double maxv = (double)fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < V) prob[i] = (float)exp(((double)logits[i] - maxv) / (double)temperature);
+}
+constexpr int SAMPLE_CHUNK = 8192;
+__global__ __launch_bounds__(1024) void sample_pick_kernel(const float* prob, int V, const float* u, const DecodeState* st, int* tok_out) {
+    __shared__ __attribute__((aligned(16))) float buf[SAMPLE_CHUNK];
+    __shared__ float sh_sum;
+    __shared__ int sh_pick;
+    if (st->done) return;
+    const int tid = threadIdx.x;
+    float sum = 0.0f;
+    for (int base = 0; base < V; base += SAMPLE_CHUNK) {
+        const int cnt = V - base < SAMPLE_CHUNK ? V - base : SAMPLE_CHUNK;
+        for (int i = tid; i < cnt; i += 1024) buf[i] = prob[base + i];
+        __syncthreads();
+        if (tid == 0) {
+            int i = 0;
+            for (; i + 8 <= cnt; i += 8) {
+                const float4 a = *(const float4*)(buf + i), b = *(const float4*)(buf + i + 4);
+                sum += a.x; sum += a.y; sum += a.z; sum += a.w;
+                sum += b.x; sum += b.y; sum += b.z; sum += b.w;
+            }
+            for (; i < cnt; i++) sum += buf[i];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { sh_sum = sum; sh_pick = -1; }
+    __syncthreads();
+    sum = sh_sum;
+    const float uu = u[st->step];
+    float acc = 0.0f;
+    for (int base = 0; base < V; base += SAMPLE_CHUNK) {
+        const int cnt = V - base < SAMPLE_CHUNK ? V - base : SAMPLE_CHUNK;
+        for (int i = tid; i < cnt; i += 1024) buf[i] = prob[base + i] / sum;
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 0; i < cnt; i++) {
+                acc += buf[i];
+                if (acc >= uu) { sh_pick = base + i; break; }
+            }
+        }
+        __syncthreads();
+        if (sh_pick >= 0) break;   // uniform: read after the barrier
+    }
+    if (tid == 0) *tok_out = sh_pick >= 0 ? sh_pick : V - 1;
+}
+
 __global__ void finish_token_kernel(const float* partv, const int* parti, int nparts, DecodeState* st,
                                     int* out_tokens, const void* table, const float* scales, int dtype, int E,
-                                    float* x, int do_embed, const int* eos) {   // eos: [count, id0, id1, ...] (jh_session_set_eos)
+                                    float* x, int do_embed, const int* eos,   // eos: [count, id0, id1, ...] (jh_session_set_eos)
+                                    const int* forced) {                      // non-null: the sampled id (sample_pick_kernel) replaces the argmax
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ int tok;
@@ -1799,6 +1926,7 @@ __global__ void finish_token_kernel(const float* partv, const int* parti, int np
     if (threadIdx.x == 0) {
         for (int w = 0; w < nw; w++)
             if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        if (forced) bi = *forced;
         tok = bi;
         out_tokens[st->step] = bi;
         st->token = bi;

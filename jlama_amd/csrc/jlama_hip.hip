@@ -1119,6 +1119,15 @@ struct jh_session {
     int prefill_batch_min = 4;
     int strict = 0;           // jh_session_set_strict: reference-order kernels (jh_p16.h)
     int strict_legacy = 0;    // JH_STRICT_LEGACY=1: the first, byte-granular implementation of them (jh_strict.h), kept as a cross-check
+    // temperature sampling inside the device loop: exp((l - max)/T) of every logit, the caller's uniforms, the picked id; the
+    // decode graphs of this mode are captured per temperature (a kernel argument)
+    float* prob = nullptr;
+    float* u_dev = nullptr;
+    int u_cap = 0;
+    int* pick = nullptr;
+    float sampled_temp = 0.0f;
+    hipGraph_t graph_s[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t exec_s[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
     float* p16_scores = nullptr;   // [n_heads][p16_sc_stride] scaled attention scores between the two reference-order attention launches
     int p16_sc_stride = 0, p16_att_splits = 16, p16_depth = 8;
     // stop tokens (jh_session_set_eos): device copy for finish_token_kernel + host-side feeding control
@@ -1848,12 +1857,18 @@ int lmhead_launch(jh_session* s, hipStream_t st) {
     return JH_OK;
 }
 
-int finish_launch(jh_session* s, hipStream_t st, int do_embed) {
+int finish_launch(jh_session* s, hipStream_t st, int do_embed, float temperature = 0.0f) {
     jh_model* m = s->m;
     const JWeight& e = m->global_w[JH_W_EMBED];
+    const int V = m->c.vocab_size;
+    if (temperature != 0.0f) {   // AbstractModel.java:471-489 on the device: exponentials, then the two sequential float accumulations
+        hipLaunchKernelGGL(sample_exp_kernel, dim3((V + 255) / 256), dim3(256), 0, st, (const float*)s->logits, V, (const float*)s->amax_v, s->lm_grid,
+                           temperature, s->prob);
+        hipLaunchKernelGGL(sample_pick_kernel, dim3(1), dim3(1024), 0, st, (const float*)s->prob, V, (const float*)s->u_dev, (const DecodeState*)s->st, s->pick);
+    }
     hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(256), 0, st, (const float*)s->amax_v, (const int*)s->amax_i, s->lm_grid,
                        s->st, s->out_tokens, (const void*)e.data, (const float*)e.scales, e.dtype, m->c.embedding_length, s->x,
-                       (do_embed && e.data) ? 1 : 0, (const int*)s->eos_dev);
+                       (do_embed && e.data) ? 1 : 0, (const int*)s->eos_dev, temperature != 0.0f ? (const int*)s->pick : (const int*)nullptr);
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
@@ -1863,9 +1878,9 @@ int ensure_out_tokens(jh_session* s, int n) {
     if (s->out_tokens) HIPCHK(hipFree(s->out_tokens));
     HIPCHK(hipMalloc(&s->out_tokens, (size_t)n * sizeof(int)));
     s->out_cap = n;
-    for (int v = 0; v < N_ATTN_VARIANTS; v++) if (s->exec[v]) {  // out_tokens pointer is baked into the captured graphs
-        hipGraphExecDestroy(s->exec[v]); s->exec[v] = nullptr;
-        hipGraphDestroy(s->graph[v]); s->graph[v] = nullptr;
+    for (int v = 0; v < N_ATTN_VARIANTS; v++) {   // out_tokens pointer is baked into the captured graphs
+        if (s->exec[v]) { hipGraphExecDestroy(s->exec[v]); s->exec[v] = nullptr; hipGraphDestroy(s->graph[v]); s->graph[v] = nullptr; }
+        if (s->exec_s[v]) { hipGraphExecDestroy(s->exec_s[v]); s->exec_s[v] = nullptr; hipGraphDestroy(s->graph_s[v]); s->graph_s[v] = nullptr; }
     }
     return JH_OK;
 }
@@ -2184,6 +2199,8 @@ int jh_session_destroy(jh_session* s) {
     hipSetDevice(s->m->device);
     if (s->stream) hipStreamSynchronize(s->stream);
     for (int v = 0; v < N_ATTN_VARIANTS; v++) {
+        if (s->exec_s[v]) hipGraphExecDestroy(s->exec_s[v]);
+        if (s->graph_s[v]) hipGraphDestroy(s->graph_s[v]);
         if (s->exec[v]) hipGraphExecDestroy(s->exec[v]);
         if (s->graph[v]) hipGraphDestroy(s->graph[v]);
         if (s->row_exec[v]) hipGraphExecDestroy(s->row_exec[v]);
@@ -2203,6 +2220,9 @@ int jh_session_destroy(jh_session* s) {
     if (s->st_host) hipHostFree(s->st_host);
     if (s->eos_dev) hipFree(s->eos_dev);
     if (s->p16_scores) hipFree(s->p16_scores);
+    if (s->prob) hipFree(s->prob);
+    if (s->u_dev) hipFree(s->u_dev);
+    if (s->pick) hipFree(s->pick);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
     return JH_OK;
@@ -2395,6 +2415,8 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
 static void drop_stale_graphs(jh_session* s) {
     if (s->graphs_version == s->m->weights_version) return;
     for (int v = 0; v < N_ATTN_VARIANTS; v++) {
+        if (s->exec_s[v]) { hipGraphExecDestroy(s->exec_s[v]); s->exec_s[v] = nullptr; }
+        if (s->graph_s[v]) { hipGraphDestroy(s->graph_s[v]); s->graph_s[v] = nullptr; }
         if (s->exec[v]) { hipGraphExecDestroy(s->exec[v]); s->exec[v] = nullptr; }
         if (s->graph[v]) { hipGraphDestroy(s->graph[v]); s->graph[v] = nullptr; }
         if (s->row_exec[v]) { hipGraphExecDestroy(s->row_exec[v]); s->row_exec[v] = nullptr; }
@@ -2616,9 +2638,15 @@ int jh_decode_step(jh_session* s, int32_t token, int pos, int32_t* next_token) {
     return jh_sample(s, 0.0f, 0.5f, next_token, nullptr);
 }
 
-static int build_graph(jh_session* s, int v) {
+static int build_graph(jh_session* s, int v, float temperature = 0.0f) {
     drop_stale_graphs(s);
-    if (s->exec[v]) return JH_OK;
+    const bool sampled = temperature != 0.0f;
+    if (sampled && s->sampled_temp != temperature) {   // the temperature is a kernel argument of the captured graphs
+        for (int vv = 0; vv < N_ATTN_VARIANTS; vv++)
+            if (s->exec_s[vv]) { hipGraphExecDestroy(s->exec_s[vv]); s->exec_s[vv] = nullptr; hipGraphDestroy(s->graph_s[vv]); s->graph_s[vv] = nullptr; }
+        s->sampled_temp = temperature;
+    }
+    if (sampled ? s->exec_s[v] != nullptr : s->exec[v] != nullptr) return JH_OK;
     s->attn_variant = v;
     hipStream_t st = s->stream;
     const jh_config& c = s->m->c;
@@ -2629,12 +2657,17 @@ static int build_graph(jh_session* s, int v) {
     int rc = layers_launch(s, st, 0);
     const bool has_out = lm_head_weight(s->m)->data && s->m->global_w[JH_W_FINALNORM].data;
     if (rc == JH_OK && has_out) rc = lmhead_launch(s, st);
-    if (rc == JH_OK && has_out) rc = finish_launch(s, st, 1);
+    if (rc == JH_OK && has_out) rc = finish_launch(s, st, 1, temperature);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(st, &g);
     s->tap_layer = saved_tap;
     if (rc != JH_OK) { if (g) hipGraphDestroy(g); return rc; }
     if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    if (sampled) {
+        s->graph_s[v] = g;
+        HIPCHK(hipGraphInstantiate(&s->exec_s[v], g, nullptr, nullptr, 0));
+        return JH_OK;
+    }
     s->graph[v] = g;
     HIPCHK(hipGraphInstantiate(&s->exec[v], g, nullptr, nullptr, 0));
     const int per_layer = 5 + ((s->strict && !s->strict_legacy) || (!s->strict && s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0);
@@ -2642,7 +2675,18 @@ static int build_graph(jh_session* s, int v) {
     return JH_OK;
 }
 
+static int decode_n_async_impl(jh_session* s, int32_t first_token, int start_pos, int n, float temperature, const float* u);
 int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) {
+    return decode_n_async_impl(s, first_token, start_pos, n, 0.0f, nullptr);
+}
+// The same loop with AbstractModel.sample's temperature branch on the device: u[i] is the uniform of the i-th sampled token (the
+// reference draws ThreadLocalRandom.nextFloat() per call, AbstractModel.java:594 -- not seedable, hence the caller's array).
+int jh_decode_n_sampled(jh_session* s, int32_t first_token, int start_pos, int n, float temperature, const float* u, int32_t* out_tokens) {
+    if (temperature != 0.0f && !u) return set_err(JH_ERR_INVALID, "decode_n_sampled: temperature > 0 needs n uniforms");
+    JHCHK(decode_n_async_impl(s, first_token, start_pos, n, temperature, u));
+    return jh_decode_wait(s, out_tokens, n);
+}
+static int decode_n_async_impl(jh_session* s, int32_t first_token, int start_pos, int n, float temperature, const float* u) {
     if (!s || n <= 0 || start_pos < 0) return set_err(JH_ERR_INVALID, "decode_n: bad argument");
     if (start_pos + n > s->max_ctx) return set_err(JH_ERR_INVALID, "decode_n: positions beyond the session's max_ctx");
     JHCHK(check_positions(s, start_pos + n - 1));
@@ -2653,10 +2697,24 @@ int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) 
     if (first_token < 0 || first_token >= m->c.vocab_size) return set_err(JH_ERR_INVALID, "decode_n: token id out of range");
     JHCHK(ensure_out_tokens(s, n));
     hipStream_t st = s->stream;
+    const bool sampled = temperature != 0.0f;
+    if (sampled) {
+        if (!s->prob) HIPCHK(hipMalloc(&s->prob, (size_t)m->c.vocab_size * 4));
+        if (!s->pick) HIPCHK(hipMalloc(&s->pick, 64));
+        if (s->u_cap < n) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (s->u_dev) HIPCHK(hipFree(s->u_dev));
+            HIPCHK(hipMalloc(&s->u_dev, (size_t)n * 4));
+            s->u_cap = n;
+            for (int v = 0; v < N_ATTN_VARIANTS; v++)   // the buffer's address is baked into the sampled graphs
+                if (s->exec_s[v]) { hipGraphExecDestroy(s->exec_s[v]); s->exec_s[v] = nullptr; hipGraphDestroy(s->graph_s[v]); s->graph_s[v] = nullptr; }
+        }
+        HIPCHK(hipMemcpyAsync(s->u_dev, u, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    }
     const bool use_graph = !env_int("JH_NO_GRAPH", 0);
     if (use_graph) {   // capture the graph variants this call needs before the timed region (a capture costs milliseconds)
         for (int v = 0; v < N_ATTN_VARIANTS; v++)
-            if (attn_variant_in_range(s, v, start_pos, start_pos + n - 1)) JHCHK(build_graph(s, v));
+            if (attn_variant_in_range(s, v, start_pos, start_pos + n - 1)) JHCHK(build_graph(s, v, temperature));
     }
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, start_pos, first_token, 0);
     hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
@@ -2671,15 +2729,15 @@ int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n) 
     for (int i = 0; i < n; i++) {
         const int v = attn_variant_for(s, start_pos + i);   // the host knows every token's position in advance
         if (use_graph) {
-            JHCHK(build_graph(s, v));
-            HIPCHK(hipGraphLaunch(s->exec[v], st));
+            JHCHK(build_graph(s, v, temperature));
+            HIPCHK(hipGraphLaunch(sampled ? s->exec_s[v] : s->exec[v], st));
         } else {
             const int saved = s->tap_layer;
             s->tap_layer = -1;
             s->attn_variant = v;
             int rc = layers_launch(s, st, 0);
             if (rc == JH_OK) rc = lmhead_launch(s, st);
-            if (rc == JH_OK) rc = finish_launch(s, st, 1);
+            if (rc == JH_OK) rc = finish_launch(s, st, 1, temperature);
             s->tap_layer = saved;
             JHCHK(rc);
         }
@@ -2736,7 +2794,26 @@ struct jh_tp_group {
     std::vector<float*> part, red, slots;      // per shard, on its device: [E], [E], [2 rounds][N][E]
     std::vector<float**> peers;                // per shard, on its device: [2 rounds][N] destination pointers of ITS slot on every shard
     std::vector<hipEvent_t> evA, evB, evTok;
+    // graph-replayed decode (no host inside a token): flag words per (round, producing shard, workgroup), the producers' pointer
+    // tables into every shard's flags, the token mailboxes, a per-shard token counter, and one captured graph per attention variant
+    int nwg = 0;
+    std::vector<unsigned*> flags;              // per shard: [2][N][nwg]
+    std::vector<unsigned**> peers_f;           // per shard: [2][N] -> ITS flag row on every shard
+    std::vector<TPMail*> mail;                 // per shard (shard 0's is unused)
+    TPMail** mails_dev = nullptr;              // on shard 0's device: the other shards' mailboxes
+    std::vector<unsigned*> seq;                // per shard: tokens replayed so far
+    std::vector<hipGraph_t> graph[N_ATTN_VARIANTS];
+    std::vector<hipGraphExec_t> exec[N_ATTN_VARIANTS];
+    int graphs_strict = -1, graphs_version = -1;
+    bool graph_ok = true;                      // false after a wait timed out once: this group stays on the event-ordered loop
 };
+// memory that kernels of several devices meet in: fine-grained (coherent at system scope inside a kernel) where the runtime
+// offers it, plain device memory otherwise (enough when all shards share one device)
+static hipError_t tp_shared_malloc(void** p, size_t bytes) {
+    hipError_t e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(p, bytes); }
+    return e;
+}
 int jh_tp_group_destroy(jh_tp_group* g) {
     if (!g) return JH_OK;
     for (size_t k = 0; k < g->sh.size(); k++) {
@@ -2745,11 +2822,20 @@ int jh_tp_group_destroy(jh_tp_group* g) {
         if (k < g->part.size() && g->part[k]) hipFree(g->part[k]);
         if (k < g->red.size() && g->red[k]) hipFree(g->red[k]);
         if (k < g->slots.size() && g->slots[k]) hipFree(g->slots[k]);
+        if (k < g->flags.size() && g->flags[k]) hipFree(g->flags[k]);
+        if (k < g->peers_f.size() && g->peers_f[k]) hipFree(g->peers_f[k]);
+        if (k < g->mail.size() && g->mail[k]) hipFree(g->mail[k]);
+        if (k < g->seq.size() && g->seq[k]) hipFree(g->seq[k]);
+        for (int v = 0; v < N_ATTN_VARIANTS; v++) {
+            if (k < g->exec[v].size() && g->exec[v][k]) hipGraphExecDestroy(g->exec[v][k]);
+            if (k < g->graph[v].size() && g->graph[v][k]) hipGraphDestroy(g->graph[v][k]);
+        }
         if (k < g->peers.size() && g->peers[k]) hipFree(g->peers[k]);
         if (k < g->evA.size() && g->evA[k]) hipEventDestroy(g->evA[k]);
         if (k < g->evB.size() && g->evB[k]) hipEventDestroy(g->evB[k]);
         if (k < g->evTok.size() && g->evTok[k]) hipEventDestroy(g->evTok[k]);
     }
+    if (g->mails_dev) { hipSetDevice(g->sh[0]->m->device); hipFree(g->mails_dev); }
     delete g;
     return JH_OK;
 }
@@ -2773,10 +2859,19 @@ int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** ou
         float *p = nullptr, *r = nullptr, *sl = nullptr;
         float** pe = nullptr;
         hipEvent_t a = nullptr, b = nullptr, t = nullptr;
-        ok = hipMalloc(&p, E * 4) == hipSuccess && hipMalloc(&r, E * 4) == hipSuccess && hipMalloc(&sl, 2 * (size_t)N * E * 4) == hipSuccess &&
+        g->nwg = (int)((E + 255) / 256);
+        unsigned *fl = nullptr, *sq = nullptr;
+        unsigned** pf = nullptr;
+        TPMail* ml = nullptr;
+        ok = hipMalloc(&p, E * 4) == hipSuccess && hipMalloc(&r, E * 4) == hipSuccess && tp_shared_malloc((void**)&sl, 2 * (size_t)N * E * 4) == hipSuccess &&
+             tp_shared_malloc((void**)&fl, 2 * (size_t)N * g->nwg * 4) == hipSuccess && hipMemset(fl, 0, 2 * (size_t)N * g->nwg * 4) == hipSuccess &&
+             hipMalloc(&pf, 2 * (size_t)N * sizeof(unsigned*)) == hipSuccess && tp_shared_malloc((void**)&ml, sizeof(TPMail)) == hipSuccess &&
+             hipMemset(ml, 0, sizeof(TPMail)) == hipSuccess && hipMalloc(&sq, 64) == hipSuccess && hipMemset(sq, 0, 64) == hipSuccess &&
              hipMalloc(&pe, 2 * (size_t)N * sizeof(float*)) == hipSuccess && hipEventCreateWithFlags(&a, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&t, hipEventDisableTiming) == hipSuccess;
         g->part.push_back(p); g->red.push_back(r); g->slots.push_back(sl); g->peers.push_back(pe);
+        g->flags.push_back(fl); g->peers_f.push_back(pf); g->mail.push_back(ml); g->seq.push_back(sq);
+        for (int v = 0; v < N_ATTN_VARIANTS; v++) { g->graph[v].push_back(nullptr); g->exec[v].push_back(nullptr); }
         g->evA.push_back(a); g->evB.push_back(b); g->evTok.push_back(t);
         for (int j = 0; j < k; j++)   // direct peer stores both ways
             if (shards[j]->m->device != shards[k]->m->device) {
@@ -2791,10 +2886,24 @@ int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** ou
         std::vector<float*> h(2 * (size_t)N);
         for (int r = 0; r < 2; r++)
             for (int j = 0; j < N; j++) h[(size_t)r * N + j] = g->slots[j] + ((size_t)r * N + k) * E;
+        std::vector<unsigned*> hf(2 * (size_t)N);   // shard k's flag row on shard j, round r: flags[j] + (r*N + k)*nwg
+        for (int r = 0; r < 2; r++)
+            for (int j = 0; j < N; j++) hf[(size_t)r * N + j] = g->flags[j] + ((size_t)r * N + k) * g->nwg;
         hipSetDevice(shards[k]->m->device);
-        if (hipMemcpy(g->peers[k], h.data(), h.size() * sizeof(float*), hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMemcpy(g->peers[k], h.data(), h.size() * sizeof(float*), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(g->peers_f[k], hf.data(), hf.size() * sizeof(unsigned*), hipMemcpyHostToDevice) != hipSuccess) {
             jh_tp_group_destroy(g);
             return set_err(JH_ERR_HIP, "tp_group_create: peer table upload");
+        }
+    }
+    if (N > 1) {
+        std::vector<TPMail*> hm;
+        for (int k = 1; k < N; k++) hm.push_back(g->mail[k]);
+        hipSetDevice(shards[0]->m->device);
+        if (hipMalloc(&g->mails_dev, hm.size() * sizeof(TPMail*)) != hipSuccess ||
+            hipMemcpy(g->mails_dev, hm.data(), hm.size() * sizeof(TPMail*), hipMemcpyHostToDevice) != hipSuccess) {
+            jh_tp_group_destroy(g);
+            return set_err(JH_ERR_HIP, "tp_group_create: mailbox table upload");
         }
     }
     *out = g;
@@ -2840,6 +2949,70 @@ int tp_group_layers(jh_tp_group* g, int pos) {
     return JH_OK;
 }
 }  // namespace
+namespace {
+// One token of shard k as a captured graph (attention variant v): [wait for the row | embed]  ->  per layer: attention half,
+// scatter + flags, wait + sum + residual, feed-forward half, scatter + flags, wait + sum + residual  ->  [LM head, argmax, next
+// row, publish] -> count the token.  Nothing in it depends on the host: the position / token / sequence number are device words.
+int tp_build_graph(jh_tp_group* g, int k, int v) {
+    jh_session* s = g->sh[k];
+    const int strict_key = s->strict * 2 + s->strict_legacy;
+    if (g->graphs_strict != strict_key || g->graphs_version != s->m->weights_version) {
+        for (int vv = 0; vv < N_ATTN_VARIANTS; vv++)
+            for (size_t j = 0; j < g->sh.size(); j++) {
+                if (g->exec[vv][j]) { hipGraphExecDestroy(g->exec[vv][j]); g->exec[vv][j] = nullptr; }
+                if (g->graph[vv][j]) { hipGraphDestroy(g->graph[vv][j]); g->graph[vv][j] = nullptr; }
+            }
+        g->graphs_strict = strict_key;
+        g->graphs_version = s->m->weights_version;
+    }
+    if (g->exec[v][k]) return JH_OK;
+    const int N = (int)g->sh.size();
+    const jh_config& c = s->m->c;
+    const int E = c.embedding_length, L = c.n_layers;
+    const dim3 eg(g->nwg), eb(256);
+    HIPCHK(hipSetDevice(s->m->device));
+    hipStream_t st = s->stream;
+    s->attn_variant = v;
+    std::lock_guard<std::mutex> cap(g_capture_mu);
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = JH_OK;
+    if (k > 0) {
+        const JWeight& emb = s->m->global_w[JH_W_EMBED];
+        hipLaunchKernelGGL(tp_wait_token_kernel, dim3(1), dim3(1), 0, st, (const TPMail*)g->mail[k], g->seq[k], s->st);
+        hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                           (const DecodeState*)s->st, E, s->x);
+    }
+    for (int li = 0; li < L && rc == JH_OK; li++) {
+        rc = layer_attn_launch(s, li, st, false, 0, g->part[k], nullptr);
+        if (rc != JH_OK) break;
+        hipLaunchKernelGGL(tp_scatter_flag_kernel, eg, eb, 0, st, (const float*)g->part[k], (float* const*)g->peers[k], (unsigned* const*)g->peers_f[k], N, E,
+                           (const unsigned*)g->seq[k], li, L);
+        hipLaunchKernelGGL(tp_sum_wait_kernel, eg, eb, 0, st, (const float*)g->slots[k], (const unsigned*)g->flags[k], N, E, g->nwg, g->seq[k],
+                           li, L, (const float*)s->x, s->x1);
+        rc = layer_ffn_launch(s, li, st, false, g->part[k], nullptr);
+        if (rc != JH_OK) break;
+        hipLaunchKernelGGL(tp_scatter_flag_kernel, eg, eb, 0, st, (const float*)g->part[k], (float* const*)(g->peers[k] + N),
+                           (unsigned* const*)(g->peers_f[k] + N), N, E, (const unsigned*)g->seq[k], li, L);
+        hipLaunchKernelGGL(tp_sum_wait_kernel, eg, eb, 0, st, (const float*)(g->slots[k] + (size_t)N * E), (const unsigned*)(g->flags[k] + (size_t)N * g->nwg), N, E,
+                           g->nwg, g->seq[k], li, L, (const float*)s->x1, s->x);
+    }
+    if (rc == JH_OK && k == 0) {
+        rc = lmhead_launch(s, st);
+        if (rc == JH_OK) rc = finish_launch(s, st, 1);
+        if (rc == JH_OK && N > 1)
+            hipLaunchKernelGGL(tp_publish_token_kernel, dim3(1), dim3(64), 0, st, (const DecodeState*)s->st, (TPMail* const*)g->mails_dev, N - 1,
+                               (const unsigned*)g->seq[0]);
+    }
+    hipLaunchKernelGGL(tp_bump_seq_kernel, dim3(1), dim3(1), 0, st, g->seq[k]);
+    hipGraph_t gr = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &gr);
+    if (rc != JH_OK) { if (gr) hipGraphDestroy(gr); return rc; }
+    if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture (tp): ") + hipGetErrorString(e));
+    g->graph[v][k] = gr;
+    HIPCHK(hipGraphInstantiate(&g->exec[v][k], gr, nullptr, nullptr, 0));
+    return JH_OK;
+}
+}  // namespace
 int jh_tp_group_forward(jh_tp_group* g, const int32_t* tokens, int n, int start_pos) {
     if (!g || !tokens || n <= 0 || start_pos < 0) return set_err(JH_ERR_INVALID, "tp_group_forward: bad argument");
     for (jh_session* s : g->sh) {
@@ -2871,6 +3044,74 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
     HIPCHK(hipSetDevice(s0->m->device));
     JHCHK(ensure_out_tokens(s0, n));
     const int E = s0->m->c.embedding_length;
+    static const int tp_graph = env_int("JH_TP_GRAPH", 1);
+    if (tp_graph && g->graph_ok) {
+        // ---- one graph replay per shard and token, the shards meet in kernels (tp_build_graph)
+        for (int v = 0; v < N_ATTN_VARIANTS; v++)
+            if (attn_variant_in_range(s0, v, start_pos, start_pos + n - 1))
+                for (int k = 0; k < N; k++) JHCHK(tp_build_graph(g, k, v));
+        for (int k = 0; k < N; k++) {
+            jh_session* s = g->sh[k];
+            HIPCHK(hipSetDevice(s->m->device));
+            HIPCHK(hipStreamSynchronize(s->stream));            // counters below are read on the host
+        }
+        for (int k = 0; k < N; k++) {
+            jh_session* s = g->sh[k];
+            const JWeight& emb = s->m->global_w[JH_W_EMBED];
+            HIPCHK(hipSetDevice(s->m->device));
+            if (k == 0) {
+                hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s->stream, s->st, start_pos, first_token, 0);
+                hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, s->stream, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                                   (const DecodeState*)s->st, E, s->x);
+            } else {
+                // the first row reaches the other shards through their mailbox, like every later one: seq = this shard's counter
+                unsigned cur = 0;
+                HIPCHK(hipMemcpy(&cur, g->seq[k], sizeof(cur), hipMemcpyDeviceToHost));
+                TPMail m0{first_token, start_pos, cur, 0};
+                HIPCHK(hipMemcpy(g->mail[k], &m0, sizeof(m0), hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s->stream, s->st, start_pos, first_token, 0);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        for (int i = 0; i < n; i++) {
+            const int v = attn_variant_for(s0, start_pos + i);
+            for (int k = 0; k < N; k++) {
+                jh_session* s = g->sh[k];
+                HIPCHK(hipSetDevice(s->m->device));
+                HIPCHK(hipGraphLaunch(g->exec[v][k], s->stream));
+            }
+        }
+        for (jh_session* s : g->sh) { HIPCHK(hipSetDevice(s->m->device)); HIPCHK(hipStreamSynchronize(s->stream)); }
+        bool timed_out = false;
+        for (int k = 0; k < N; k++) {      // a wait that timed out (tp_wait_ge): the shards' streams did not run side by side
+            unsigned w2[2] = {0, 0};
+            HIPCHK(hipSetDevice(g->sh[k]->m->device));
+            HIPCHK(hipMemcpy(w2, g->seq[k], sizeof(w2), hipMemcpyDeviceToHost));
+            if (w2[1]) timed_out = true;
+        }
+        if (timed_out) {
+            // A wait ran into its bound: the shards' kernels did not run side by side.  Seen when several shards share ONE device
+            // and their streams were mapped onto the same hardware queue (the runtime multiplexes streams over GPU_MAX_HW_QUEUES
+            // = 4 queues): a spinning kernel then blocks the very kernel it waits for.  With one shard per device every stream has
+            // its own queue.  Recover: reset the meeting points, stay on the event-ordered loop for this group, redo the call.
+            for (int k = 0; k < N; k++) {
+                HIPCHK(hipSetDevice(g->sh[k]->m->device));
+                HIPCHK(hipMemset(g->flags[k], 0, 2 * (size_t)N * g->nwg * 4));
+                HIPCHK(hipMemset(g->seq[k], 0, 64));
+                HIPCHK(hipMemset(g->mail[k], 0, sizeof(TPMail)));
+            }
+            g->graph_ok = false;
+            if (env_int("JH_TP_GRAPH_STRICT", 0))
+                return set_err(JH_ERR_HIP, "tp_group_decode_n: a shard waited for a peer that never arrived (streams serialised on one hardware queue?)");
+            return jh_tp_group_decode_n(g, first_token, start_pos, n, out_tokens);
+        }
+        HIPCHK(hipSetDevice(s0->m->device));
+        DecodeState hs;
+        HIPCHK(hipMemcpy(&hs, s0->st, sizeof(hs), hipMemcpyDeviceToHost));
+        s0->generated = hs.step < n ? hs.step : n;
+        HIPCHK(hipMemcpy(out_tokens, s0->out_tokens, (size_t)s0->generated * sizeof(int), hipMemcpyDeviceToHost));
+        return JH_OK;
+    }
     for (int k = 0; k < N; k++) {   // row of the first token on every shard; shard 0's step counter starts at 0
         jh_session* s = g->sh[k];
         const JWeight& emb = s->m->global_w[JH_W_EMBED];

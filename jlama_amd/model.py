@@ -158,6 +158,14 @@ class HipSession:
         N.check(N.lib().jh_decode_n(self.h, int(first_token), int(start_pos), int(n), N.ptr(out)))
         return out[:self.decode_generated()]
 
+    def decode_n_sampled(self, first_token, start_pos, n, temperature, uniforms):
+        """n steps of the device loop with temperature sampling: uniforms[i] decides the i-th sampled token (AbstractModel.java:475-489)."""
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        assert u.size >= n
+        out = np.empty(n, dtype=np.int32)
+        N.check(N.lib().jh_decode_n_sampled(self.h, int(first_token), int(start_pos), int(n), float(temperature), N.ptr(u), N.ptr(out)))
+        return out[:self.decode_generated()]
+
     def decode_generated(self):
         k = C.c_int32()
         N.check(N.lib().jh_decode_generated(self.h, C.byref(k)))
@@ -222,9 +230,13 @@ class HipSession:
         out = [nxt]
         start = prompt_tokens.size
         n_more = ntokens - start
-        if temperature == 0.0 and on_device_loop and n_more > 0:
+        if on_device_loop and n_more > 0:
             self.set_eos(eos_tokens)             # the device loop honours the stop tokens itself (finish_token_kernel)
-            out.extend(int(t) for t in self.decode_n(nxt, start, n_more))
+            if temperature == 0.0:
+                out.extend(int(t) for t in self.decode_n(nxt, start, n_more))
+            else:                                # one uniform per sampled token, drawn in the order the host loop would draw them
+                us = [float(rng.random()) if rng is not None else 0.5 for _ in range(n_more)]
+                out.extend(int(t) for t in self.decode_n_sampled(nxt, start, n_more, temperature, us))
         else:
             for i in range(start, ntokens):
                 if temperature == 0.0:

@@ -243,6 +243,47 @@ def test_first_sampled_token_is_never_tested_against_the_stop_set(gpu, oracle):
         s.close()
 
 
+@pytest.mark.parametrize("vocab", [512, 20000])
+def test_device_loop_temperature_sampling_follows_the_reference_rule(gpu, oracle, vocab):
+    """AbstractModel.sample with temperature > 0 (AbstractModel.java:471-489) inside the device loop (jh_decode_n_sampled): the
+    float running sum in index order, the inverse CDF against the caller's uniform.  In reference order the sampled ids equal the
+    oracle's jo_sample sequence bit for bit; 20000 ids cross the sampler's LDS chunk boundary (8192)."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.TINY)
+    cfg["vocab_size"] = vocab
+    hm, om, _ = _pair(cfg, 11, oracle)
+    prompt = S.prompt_tokens(cfg, n=9, seed=4)
+    n, T = 24, 0.8
+    u = np.random.default_rng(5).random(n + 1).astype(np.float32)
+    osess = om.session()
+    x = osess.forward(prompt, 0)
+    tok, _ = om.sample(x[-1], T, float(u[0]))
+    want = [tok]
+    for i in range(n):
+        x = osess.forward([tok], prompt.size + i)
+        tok, _ = om.sample(x[-1], T, float(u[i + 1]))
+        want.append(tok)
+    s = hm.session(64)
+    s.set_strict(True)
+    s.batch_forward(prompt, 0)
+    first = s.sample(T, float(u[0]))
+    assert first == want[0]
+    got = s.decode_n_sampled(first, prompt.size, n, T, u[1:])
+    np.testing.assert_array_equal(got, np.array(want[1:], dtype=np.int32))
+    assert len(set(want)) > 4                                   # the uniforms really pick different ids (not an argmax in disguise)
+    # the same through generate(): uniforms drawn from the rng in the host loop's order
+    class Rng:
+        def __init__(self, vals): self.v = list(vals)
+        def random(self): return self.v.pop(0)
+    res_d = s.generate(prompt, prompt.size + n, temperature=T, rng=Rng(u.tolist()), on_device_loop=True)
+    res_h = hm.session(64)
+    res_h.set_strict(True)
+    res_h = res_h.generate(prompt, prompt.size + n, temperature=T, rng=Rng(u.tolist()), on_device_loop=False)
+    np.testing.assert_array_equal(res_d["tokens"], np.array(want, dtype=np.int32))
+    np.testing.assert_array_equal(res_h["tokens"], res_d["tokens"])
+    s.close()
+
+
 def test_positions_at_the_context_tail_are_refused(gpu):
     """kv head h reads RoPE table row position + 2*h (CausalSelfAttention.java:260-283); the reference's table has
     context_length rows and Java throws ArrayIndexOutOfBounds for the last 2*(kvHeads-1) positions.  Same positions are

@@ -1,6 +1,9 @@
-"""Single-stream decode rate of the one-process tensor-parallel group (jh_tp_group_*) with all head-split shards on ONE device:
-what the host-launched (not graph-captured) halves + the peer-write reductions cost against the un-sharded model."""
+"""Single-stream decode rate of the one-process tensor-parallel group (jh_tp_group_*) with all head-split shards on ONE device
+against the un-sharded model: graph-replayed shards that meet in kernels (default) and the event-ordered host loop (JH_TP_GRAPH=0).
+All shards on one device need one HARDWARE queue per shard stream (a spinning kernel blocks a queue it shares with the kernel it
+waits for): GPU_MAX_HW_QUEUES is raised before HIP initialises; with one shard per device this does not arise."""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from jlama_amd import _native as N, distributed as D, synthetic as S
@@ -16,6 +19,7 @@ f = full.sample()
 full.decode_n(f, prompt.size, 4)
 t0 = time.perf_counter(); ref = full.decode_n(f, prompt.size, steps); dt = time.perf_counter() - t0
 print(f"un-sharded, graph-captured loop: {steps / dt:8.1f} tok/s", flush=True)
+full.close()
 for size in (2, 4):
     models = []
     for r in range(size):
@@ -27,5 +31,6 @@ for size in (2, 4):
     g.decode_n(f2, prompt.size, 4)
     t0 = time.perf_counter(); got = g.decode_n(f2, prompt.size, steps); dt = time.perf_counter() - t0
     agree = int(np.argmin(got == ref)) if not (got == ref).all() else steps
-    print(f"TP group, {size} shards on one device (host-launched halves): {steps / dt:8.1f} tok/s; first token {f2 == f}, ids equal for {agree} steps", flush=True)
+    mode = "event-ordered host loop" if os.environ.get("JH_TP_GRAPH") == "0" else "graph replay per shard, kernels meet on flags"
+    print(f"TP group, {size} shards on one device ({mode}): {steps / dt:8.1f} tok/s; first token {f2 == f}, ids equal for {agree} steps", flush=True)
     g.close()
