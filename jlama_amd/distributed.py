@@ -104,7 +104,16 @@ def pipeline_prefill(dist, engine, rank, world, session, prompt, E, device, dtyp
     return int(tok.item())
 
 
-def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_per_session, E, device, dtype, n_sessions=None):
+def _grp(tok_group):
+    """kwargs of a token-path send/recv: the id travels on its OWN communicator when one is given (bench_pipeline makes one).
+    Rows (rank r -> r+1) and ids (last rank -> rank 0) cross between the same pair of ranks when N = 2; on one communicator
+    their sends and receives interleave in one issue order, and a row send would sit in front of the receive the peer's id send
+    is waiting for -- legal only while the transport buffers small sends eagerly.  Two communicators never order one direction
+    behind the other."""
+    return {"group": tok_group} if tok_group is not None else {}
+
+
+def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_per_session, E, device, dtype, n_sessions=None, tok_group=None):
     """Greedy-decode ``steps_per_session`` tokens for each of ``n_sessions`` (default: ``world``) sessions with the sessions
     staggered across the pipeline.  Work item q = (session q % S, step q // S); every rank handles the items in that
     order, so with S = world every GPU is busy on every tick and with S = 1 the run is the single-stream (batch-1) case.
@@ -131,7 +140,7 @@ def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_pe
             elif N == 1:
                 token = int(out[j, k - 1])
             else:
-                dist.recv(tok_in, src=N - 1)      # sampled by the last shard one tick ago
+                dist.recv(tok_in, src=N - 1, **_grp(tok_group))      # sampled by the last shard one tick ago
                 token = int(tok_in.item())
             engine.forward_tokens(j, [token], start_pos + k, x_out[buf])
         else:
@@ -148,7 +157,7 @@ def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_pe
                 # never wait for a token send inside the loop: rank 0 posts its receive S items later, and with more sessions
                 # in flight than stages a blocking send here stalls the whole ring behind it
                 tk = torch.full((1,), int(t), dtype=torch.int32, device=device)
-                tok_sends.append((dist.isend(tk, dst=0), tk))
+                tok_sends.append((dist.isend(tk, dst=0, **_grp(tok_group)), tk))
     if pending is not None:
         pending.wait()
     for w_, _ in tok_sends:
@@ -156,7 +165,7 @@ def pipeline_decode(dist, engine, rank, world, first_tokens, start_pos, steps_pe
     return out
 
 
-def pipeline_decode_streamed(dist, engine, rank, world, first_tokens, start_pos, steps_per_session, E, device, dtype, n_sessions=None):
+def pipeline_decode_streamed(dist, engine, rank, world, first_tokens, start_pos, steps_per_session, E, device, dtype, n_sessions=None, tok_group=None):
     """pipeline_decode without a single host round trip inside the loop.  Same schedule (work item q = (session q % S, step
     q // S) in that order on every rank), but every hop is issued under the session's own HIP stream (``engine.stream``):
     ``dist.recv`` makes that stream wait for the RCCL transfer, ``engine.stage_step`` queues the shard's graph behind it,
@@ -185,7 +194,7 @@ def pipeline_decode_streamed(dist, engine, rank, world, first_tokens, start_pos,
         with torch.cuda.stream(engine.stream(j) if on_gpu else None):
             if first:
                 if k > 0 and N > 1:
-                    dist.recv(tok_in[j], src=N - 1)            # id sampled for step k-1 of this session
+                    dist.recv(tok_in[j], src=N - 1, **_grp(tok_group))            # id sampled for step k-1 of this session
                 elif k > 0:
                     tok_in[j].copy_(out_dev[j, k - 1:k])       # one rank: first and last stage are the same session
             else:
@@ -198,7 +207,7 @@ def pipeline_decode_streamed(dist, engine, rank, world, first_tokens, start_pos,
             if not last:
                 sent[j] = dist.isend(x_out[j], dst=rank + 1)
             elif N > 1 and k + 1 < steps:
-                keep.append(dist.isend(out_dev[j, k:k + 1], dst=0))
+                keep.append(dist.isend(out_dev[j, k:k + 1], dst=0, **_grp(tok_group)))
     for w in keep + [w for w in sent if w is not None]:
         w.wait()
     sync()
@@ -489,6 +498,7 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
         device = torch.device("cpu")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         dev_sync = lambda: None
+    tok_group = dist.new_group() if world > 1 else None   # the sampled id's way back: its own communicator (see _grp)
     L, E = cfg["n_layers"], cfg["embedding_length"]
     ls, le = layer_range(rank, world, L)
     prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
@@ -527,17 +537,17 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
     # compared before anything is timed; a mismatch falls back to the reference loop and is reported.
     streamed = not os.environ.get("JH_PIPELINE_HOST_SYNC")
     check_steps = max(1, min(4, steps_per_session))
-    ref_ids = pipeline_decode(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32, n_sessions=n_sess)
+    ref_ids = pipeline_decode(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32, n_sessions=n_sess, tok_group=tok_group)
     streamed_ok = None
     if streamed:
-        got = pipeline_decode_streamed(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32, n_sessions=n_sess)
+        got = pipeline_decode_streamed(dist, engine, rank, world, firsts, prompt.size, check_steps, E, device, torch.float32, n_sessions=n_sess, tok_group=tok_group)
         flag = torch.tensor([1 if (rank != world - 1 or np.array_equal(got, ref_ids)) else 0], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         streamed_ok = bool(int(flag.item()))
         streamed = streamed_ok
     decode = pipeline_decode_streamed if streamed else pipeline_decode
     if args.warmup > 0:  # untimed decode ticks on the same sessions' KV tail (positions beyond the timed range are rewritten)
-        decode(dist, engine, rank, world, firsts, prompt.size, max(1, args.warmup // n_sess), E, device, torch.float32, n_sessions=n_sess)
+        decode(dist, engine, rank, world, firsts, prompt.size, max(1, args.warmup // n_sess), E, device, torch.float32, n_sessions=n_sess, tok_group=tok_group)
 
     def timed(fn):
         dist.barrier()
@@ -550,18 +560,18 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return r, float(dt.item())
 
-    toks, dt = timed(lambda: decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32, n_sessions=n_sess))
-    _, dt1 = timed(lambda: decode(dist, engine, rank, world, firsts[:1], prompt.size, single_steps, E, device, torch.float32, n_sessions=1))
+    toks, dt = timed(lambda: decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32, n_sessions=n_sess, tok_group=tok_group))
+    _, dt1 = timed(lambda: decode(dist, engine, rank, world, firsts[:1], prompt.size, single_steps, E, device, torch.float32, n_sessions=1, tok_group=tok_group))
     host_sync = None
     if streamed:   # the reference loop beside it (what the hops cost when the host sits in them)
-        _, dth = timed(lambda: pipeline_decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32, n_sessions=n_sess))
+        _, dth = timed(lambda: pipeline_decode(dist, engine, rank, world, firsts, prompt.size, steps_per_session, E, device, torch.float32, n_sessions=n_sess, tok_group=tok_group))
         host_sync = round(steps_per_session * n_sess / dth, 2)
     total = steps_per_session * n_sess
     double_up = None
     if n_sess2:   # the same K tokens with twice the sessions in flight
         sps2 = max(1, args.steps // n_sess2)
-        decode(dist, engine, rank, world, firsts_all, prompt.size, 1, E, device, torch.float32, n_sessions=n_sess2)
-        _, dt2 = timed(lambda: decode(dist, engine, rank, world, firsts_all, prompt.size, sps2, E, device, torch.float32, n_sessions=n_sess2))
+        decode(dist, engine, rank, world, firsts_all, prompt.size, 1, E, device, torch.float32, n_sessions=n_sess2, tok_group=tok_group)
+        _, dt2 = timed(lambda: decode(dist, engine, rank, world, firsts_all, prompt.size, sps2, E, device, torch.float32, n_sessions=n_sess2, tok_group=tok_group))
         double_up = {"sessions_in_flight": n_sess2, "steps_per_session": sps2, "aggregate_tokens_per_s": round(sps2 * n_sess2 / dt2, 2)}
     one_proc = None
     if world > 1 and not os.environ.get("JH_BENCH_NO_ONE_PROCESS"):
