@@ -41,12 +41,19 @@ def _profiled(config):
     sources this run uses (source hash recorded by tools/profile_round.sh); otherwise `traffic` is null and the stale
     figure is named as such."""
     from jlama_amd import _native as N
-    path = os.path.join(ROOT, "profiles", f"r02_{config}_dominant_kernel.json")
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
+    import glob
+    cands = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{config}_dominant_kernel.json"))):
+        try:
+            cands.append((path, json.load(open(path))))
+        except (OSError, ValueError):
+            pass
+    if not cands:
         return None, None, None
-    fresh = d.get("source_hash") == N.source_hash()
+    want = N.source_hash()
+    match = [c for c in cands if c[1].get("source_hash") == want]
+    path, d = (match or cands)[-1]          # the newest round's record of THIS build, else the newest record (reported as stale)
+    fresh = d.get("source_hash") == want
     return (d.get("traffic_bytes_per_launch") if fresh else None), (d.get("us_per_launch_rocprof") if fresh else None), \
         {"file": os.path.relpath(path, ROOT), "source_hash": d.get("source_hash"), "matches_this_build": fresh,
          "traffic_bytes_per_launch": d.get("traffic_bytes_per_launch"), "us_per_launch_rocprof": d.get("us_per_launch_rocprof")}

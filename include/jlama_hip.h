@@ -227,6 +227,9 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
                         int rows, int cols, int from_device);
 /* Bytes of weights resident in HBM (for the roofline's algorithmic-bytes accounting). */
 int64_t jh_model_weight_bytes(jh_model* m);
+/* Bytes of the SECOND, MFMA-ordered copy of the projection weights the batched prefill keeps resident (0 until the first
+ * prefill made it; always 0 with JH_TILED_COPY=transient, where each GEMM's operand is rebuilt in a per-session scratch). */
+int64_t jh_model_tiled_bytes(jh_model* m);
 
 /* One KV buffer (KvBufferCache.getKvBuffer, KvBufferCache.java:58-60): pages of max_page_bytes (0 => 8 MiB)
  * shaped [layersPerPage, 2, ctxPerPage, kvLength] F32, enough pages for positions [0, max_ctx). */

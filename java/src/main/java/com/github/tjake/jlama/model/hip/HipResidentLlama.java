@@ -138,6 +138,19 @@ public final class HipResidentLlama implements AutoCloseable {
             }
         }
 
+        /** The same loop at temperature > 0 (AbstractModel.java:471-489): softmax((l - max) / T), inverse CDF against
+         *  uniforms[i] -- the caller draws them (the reference: ThreadLocalRandom.nextFloat() per token, :594). */
+        public int[] decodeSampled(int firstToken, int position, int maxTokens, float temperature, float[] uniforms) {
+            try (Arena a = Arena.ofConfined()) {
+                MemorySegment out = a.allocate(JAVA_INT, maxTokens);
+                MemorySegment u = a.allocateFrom(JAVA_FLOAT, uniforms);
+                check(NativeHipModel.jh_decode_n_sampled(s, firstToken, position, maxTokens, temperature, u, out));
+                MemorySegment n = a.allocate(JAVA_INT);
+                check(NativeHipModel.jh_decode_generated(s, n));
+                return out.asSlice(0, 4L * n.get(JAVA_INT, 0)).toArray(JAVA_INT);
+            }
+        }
+
         /** Verification: the reference's Panama summation order, bit-identical ids and logits (DESIGN.md section 4). */
         public void setStrictOrder(boolean on) {
             check(NativeHipModel.jh_session_set_strict(s, on ? 1 : 0));

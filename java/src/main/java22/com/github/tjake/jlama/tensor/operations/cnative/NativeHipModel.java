@@ -84,6 +84,8 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
     private static final MethodHandle jh_decode_step = h("jh_decode_step", JAVA_INT, sig("piip"));
     // int jh_decode_n(jh_session* s, int32_t first_token, int start_pos, int n, int32_t* out_tokens)
     private static final MethodHandle jh_decode_n = h("jh_decode_n", JAVA_INT, sig("piiip"));
+    // int jh_decode_n_sampled(jh_session* s, int32_t first_token, int start_pos, int n, float temperature, const float* u, int32_t* out_tokens)
+    private static final MethodHandle jh_decode_n_sampled = h("jh_decode_n_sampled", JAVA_INT, sig("piiifpp"));
     // int jh_decode_n_async(jh_session* s, int32_t first_token, int start_pos, int n)
     private static final MethodHandle jh_decode_n_async = h("jh_decode_n_async", JAVA_INT, sig("piii"));
     // int jh_decode_wait(jh_session* s, int32_t* out_tokens, int n)
@@ -98,6 +100,10 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
     private static final MethodHandle jh_get_tap = h("jh_get_tap", JAVA_INT, sig("pipi"));
     // int jh_stage_decode_async(jh_session* s, const int32_t* token_dev, const float* x_in_dev, int pos, float* x_out_dev, int32_t* token_out_dev)
     private static final MethodHandle jh_stage_decode_async = h("jh_stage_decode_async", JAVA_INT, sig("pppipp"));
+    // int64_t jh_model_tiled_bytes(jh_model* m)
+    private static final MethodHandle jh_model_tiled_bytes = h("jh_model_tiled_bytes", JAVA_LONG, sig("p"));
+    // int jh_pipeline_peer_access(jh_pipeline* p, int32_t* out, int n)
+    private static final MethodHandle jh_pipeline_peer_access = h("jh_pipeline_peer_access", JAVA_INT, sig("ppi"));
     // int jh_pipeline_create(jh_session* const* stages, int n_stages, jh_pipeline** out)
     private static final MethodHandle jh_pipeline_create = h("jh_pipeline_create", JAVA_INT, sig("pip"));
     // int jh_pipeline_destroy(jh_pipeline* p)
@@ -191,6 +197,10 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
         try { return (int) jh_decode_n.invokeExact(s, first_token, start_pos, n, out_tokens); } catch (Throwable t) { throw rethrow(t); }
     }
 
+    public static int jh_decode_n_sampled(MemorySegment s, int first_token, int start_pos, int n, float temperature, MemorySegment u, MemorySegment out_tokens) {
+        try { return (int) jh_decode_n_sampled.invokeExact(s, first_token, start_pos, n, temperature, u, out_tokens); } catch (Throwable t) { throw rethrow(t); }
+    }
+
     public static int jh_decode_n_async(MemorySegment s, int first_token, int start_pos, int n) {
         try { return (int) jh_decode_n_async.invokeExact(s, first_token, start_pos, n); } catch (Throwable t) { throw rethrow(t); }
     }
@@ -217,6 +227,14 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
 
     public static int jh_stage_decode_async(MemorySegment s, MemorySegment token_dev, MemorySegment x_in_dev, int pos, MemorySegment x_out_dev, MemorySegment token_out_dev) {
         try { return (int) jh_stage_decode_async.invokeExact(s, token_dev, x_in_dev, pos, x_out_dev, token_out_dev); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static long jh_model_tiled_bytes(MemorySegment m) {
+        try { return (long) jh_model_tiled_bytes.invokeExact(m); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_pipeline_peer_access(MemorySegment p, MemorySegment out, int n) {
+        try { return (int) jh_pipeline_peer_access.invokeExact(p, out, n); } catch (Throwable t) { throw rethrow(t); }
     }
 
     public static int jh_pipeline_create(MemorySegment stages, int n_stages, MemorySegment out) {

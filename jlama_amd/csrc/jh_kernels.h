@@ -146,6 +146,14 @@ __device__ __forceinline__ i32x4 ldg_nt(const i32x4* p) {
     return __builtin_nontemporal_load(p);
 }
 
+// system-scope accesses: memory that kernels of several devices meet in (tensor-parallel slots, flags)
+__device__ __forceinline__ void st_sys(float* p, float v) {
+    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float ld_sys(const float* p) {
+    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
 // ------------------------------------------------------------------------------------------------ decode state
 struct DecodeState {
     int pos;     // position of the row being forwarded
@@ -164,7 +172,8 @@ enum { PRO_Q8 = 0,       // already I8 + scales in global memory (Tier-1 jh_gemm
        PRO_ATTN_Q8 = 5 };// combine the attention slices (softmax-weighted sum) then Q8 quantize: o-projection input
 enum { EPI_STORE = 0,    // out[j] = dot
        EPI_RESID = 1,    // out[j] = dot + resid[j]            (TransformerBlock.java:185,203)
-       EPI_SILU_MUL = 2 };// out[j] = silu(dot_gate[j]) * dot_up[j] (MLPBlock.java:132-142)
+       EPI_SILU_MUL = 2, // out[j] = silu(dot_gate[j]) * dot_up[j] (MLPBlock.java:132-142)
+       EPI_TP = 3 };     // tensor-parallel shard: dot -> this shard's slot on every shard + workgroup flags (GemvParams::tp_*)
 
 struct GemvParams {
     // No arrays in here on purpose: a kernarg array indexed by a runtime value makes hipcc spill the whole struct to
@@ -192,7 +201,27 @@ struct GemvParams {
     const DecodeState* st;
     int direct_max, direct_chunk, part_stride, head_size, n_heads;
     float* tap_att;        // optional: combined attention output [A] ("after_attention" tap), written by workgroup 0
+    // EPI_TP (tensor-parallel shard inside a replayed token graph): the partial row goes straight into this shard's slot on
+    // EVERY shard (system-scope stores: peer memory over xGMI) instead of `out`, and each workgroup then raises its flag word
+    // on every shard to the sequence number of this (token, layer) -- no separate scatter launch.
+    float* const* tp_dst;        // [tp_n] slot of this shard on shard j
+    unsigned* const* tp_flags;   // [tp_n] flag row of this shard on shard j, one word per workgroup of THIS launch
+    const unsigned* tp_seq;      // tokens replayed so far (device word)
+    int tp_n, tp_li, tp_L;
 };
+// EPI_TP's store: the shard's slot on every shard
+__device__ __forceinline__ void tp_store(const GemvParams& p, int row, float v) {
+    for (int j = 0; j < p.tp_n; j++) st_sys(p.tp_dst[j] + row, v);
+}
+// last statement of an EPI_TP kernel, passed once by EVERY wave of the workgroup (it holds a barrier)
+__device__ __forceinline__ void tp_signal(const GemvParams& p) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned seq = *p.tp_seq * (unsigned)p.tp_L + (unsigned)p.tp_li + 1u;
+        for (int j = 0; j < p.tp_n; j++) __hip_atomic_store(p.tp_flags[j] + blockIdx.x, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 // LDS carve for an I8 activation row of nblk blocks
 struct ActI8 {
@@ -510,7 +539,8 @@ __device__ __forceinline__ void store_group(const GemvParams& p, int g, int lane
             if (lane == r) v = acc[r];
         if (lane < R) {
             if (EPI == EPI_RESID) v = v + p.resid[g * R + lane];   // accumulate(...) TransformerBlock.java:185,203
-            p.out[g * R + lane] = v;
+            if (EPI == EPI_TP) tp_store(p, g * R + lane, v);
+            else p.out[g * R + lane] = v;
         }
     }
 }
@@ -643,6 +673,7 @@ __global__ __launch_bounds__((R * NB > 4) ? 512 : 1024) void gemv_i8q4_kernel(Ge
             store_group<EPI, R>(p, g, lane, acc);
         }
     }
+    if constexpr (EPI == EPI_TP) tp_signal(p);
 }
 
 // ------------------------------------------------------------------------------------------------ K1c: streaming GEMV F32 x Q4
@@ -1090,7 +1121,7 @@ __global__ void splitk_reduce_kernel(const float* ws, int nsplit, int m, int n, 
 // ---- K3t: BF16 GEMM on MFMA-ordered operands (the prefill path of a BF16 model).
 // Both operands are tiled so that one wave-load is one MFMA operand, 1 KB contiguous:
 //   A  [row tile][k slice of 16][h][m][8 bf16]     written by rows_bf16_kernel (ldq < 0)
-//   W  [col tile][k slice of 16][h][n][8 bf16]     resident re-tiled copy (retile_bf16_kernel)
+//   W  [col tile][k slice of 16][h][n][8 bf16]     re-tiled copy (retile16_kernel)
 // A wave owns one column tile and ALL row tiles (MT accumulator tiles): every weight byte is fetched once, straight into
 // registers; per k slice it loads one W fragment and MT A fragments (no LDS, no barrier).  The CWB waves of a
 // workgroup take adjacent column tiles and walk K in step, so an A fragment missed by one wave is an L1 hit for the
@@ -1249,17 +1280,6 @@ __global__ __launch_bounds__(CWB * 64) void gemm_bf16_lds_kernel(MfmaBf16TilePar
             }
         }
 }
-// row-major BF16 weight [N][K] -> MFMA order [N/32][K/16][h][n][8]; one thread per 16-byte chunk
-__global__ void retile_bf16_kernel(const uint16_t* w, int N, int K, uint16_t* wt) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t chunks = (size_t)N * (K / 8);
-    if (i >= chunks) return;
-    const int row = (int)(i / (K / 8)), c8 = (int)(i % (K / 8));
-    const int ksl = c8 >> 1, hh = c8 & 1;
-    const size_t dst = (((size_t)(row >> 5) * (K / 16) + ksl) * 2 + hh) * 32 + (row & 31);
-    ((i32x4*)wt)[dst] = ((const i32x4*)w)[i];
-}
-
 // ------------------------------------------------------------------------------------------------ K2: batched I8 x Q4 GEMM on MFMA
 // batchDotProduct I8 x Q4 -> F32 for M > 1 (prefill of a JQ4 model; GemmerI8Q4_512 2x2 tile PTO:958-1043, C twin
 // nc/simd/vector_simd.c:261-437):  C[i,j] = sum_blk (da[i,blk]*sb[j,blk]) * sum_t a[i,blk,t]*(nib[j,blk,t]-8).
@@ -1750,12 +1770,6 @@ __device__ __forceinline__ bool tp_wait_ge(const unsigned* f, unsigned want, uns
     }
     return true;
 }
-__device__ __forceinline__ void st_sys(float* p, float v) {
-    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ float ld_sys(const float* p) {
-    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-}
 __global__ __launch_bounds__(256) void tp_scatter_flag_kernel(const float* part, float* const* dst, unsigned* const* fdst, int n_dst, int E,
                                                               const unsigned* seqp, int li, int L) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1774,6 +1788,21 @@ __global__ __launch_bounds__(256) void tp_sum_wait_kernel(const float* slots, co
                                                           int li, int L, const float* resid, float* out) {
     const unsigned seq = *seqp * (unsigned)L + (unsigned)li + 1u;
     if ((int)threadIdx.x < n) tp_wait_ge(flags + (size_t)threadIdx.x * nwg + blockIdx.x, seq, seqp + 1);
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    float v = ld_sys(slots + i);
+    for (int k = 1; k < n; k++) v = v + ld_sys(slots + (size_t)k * E + i);   // shard order: the lock-step order
+    out[i] = resid[i] + v;                                                      // TransformerBlock.java:185 / :203
+}
+// the same meeting when the producers were the o-proj / down GEMVs themselves (GemvParams::tp_*): their workgroups own row ranges
+// that depend on the launch plan, so every consumer workgroup waits for ALL nflags workgroup flags of the N producers (a few
+// hundred words polled by 16 workgroups -- not the 256 x 256 of a grid barrier)
+__global__ __launch_bounds__(256) void tp_sum_wait_all_kernel(const float* slots, const unsigned* flags, int n, int E, int nflags, int stride,
+                                                              unsigned* seqp, int li, int L, const float* resid, float* out) {
+    const unsigned seq = *seqp * (unsigned)L + (unsigned)li + 1u;
+    for (int i = threadIdx.x; i < n * nflags; i += 256)
+        if (!tp_wait_ge(flags + (size_t)(i / nflags) * stride + (i % nflags), seq, seqp + 1)) break;
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= E) return;
@@ -2503,15 +2532,42 @@ __global__ __launch_bounds__(256) void rows_bf16_kernel(RowsParams p) {
     }
 }
 
-// Re-tile a row-major Q4 weight [N][K/2] (+ scales [N][K/32]) into MFMA order for the prefill GEMM:
-//   wt [N/32][K/32][32][16 B],  st [N/32][K/32][32].   One thread per (row, block).
-__global__ void retile_q4_kernel(const uint8_t* w, const float* ws, int N, int nblk, uint8_t* wt, float* st) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)N * nblk) return;
-    const int row = (int)(i / nblk), blk = (int)(i % nblk);
-    const size_t dst = ((size_t)(row >> 5) * nblk + blk) * 32 + (row & 31);
-    ((i32x4*)wt)[dst] = ((const i32x4*)(w + (size_t)row * nblk * 16))[blk];
-    st[dst] = ws[(size_t)row * nblk + blk];
+// Re-tile a row-major weight into MFMA order for the prefill GEMMs:
+//   Q4   [N][K/2] (+ scales [N][K/32])  ->  wt [N/32][K/32][32 rows][16 B],  st [N/32][K/32][32]
+//   BF16 [N][K]                         ->  wt [N/32][K/16][h][32 rows][8 values]
+// At streaming rate, for both weight types (it also runs in front of every prefill GEMM when the MFMA-ordered copy is NOT kept
+// resident, JH_TILED_COPY=transient):  a weight row is `nch` 16-byte chunks (Q4: one block of 32 nibbles; BF16: 8 values --
+// the [k slice][h] pair is chunk index c8 = 2*ksl + h, so both layouts are dst = ((panel*nch + chunk)*32 + row)*16 B), the
+// destination is [N/32][nch][32 rows][16 B] (+ Q4 scales [N/32][nch][32]).  One workgroup moves a 32-row x 64-chunk tile
+// through LDS: reads are 1 KiB contiguous per wave (a row's 64 chunks), writes 1 KiB contiguous per wave (2 chunks x 32 rows).
+// LDS rows are padded by one chunk so that the transposed ds_read_b128 (32 lanes = 32 rows of one chunk) is conflict-free.
+__global__ __launch_bounds__(256) void retile16_kernel(const i32x4* __restrict__ w, const float* __restrict__ ws, int N, int nch,
+                                                       i32x4* __restrict__ wt, float* __restrict__ st) {
+    __shared__ i32x4 tile[32 * 65];
+    __shared__ float stile[32 * 65];
+    const int panel = blockIdx.y, c0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cin = c0 + lane;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int r = wave + 4 * i;
+        if (cin < nch) {
+            const size_t src = (size_t)(panel * 32 + r) * nch + cin;
+            tile[r * 65 + lane] = __builtin_nontemporal_load(w + src);
+            if (ws) stile[r * 65 + lane] = __builtin_nontemporal_load(ws + src);
+        }
+    }
+    __syncthreads();
+    const int row = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int cl = 2 * (wave + 4 * i) + hh;        // chunk within the tile
+        if (c0 + cl < nch) {
+            const size_t dst = ((size_t)panel * nch + c0 + cl) * 32 + row;
+            wt[dst] = tile[row * 65 + cl];
+            if (ws) st[dst] = stile[row * 65 + cl];
+        }
+    }
 }
 
 __global__ void embed_rows_kernel(const void* table, const float* scales, int dtype, const int* tokens, int E, float* x) {

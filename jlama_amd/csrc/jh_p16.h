@@ -350,6 +350,7 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_i8q4_p16_kernel(GemvParams p
         // and would size the working waves' waits for the path without ring loads, i.e. drain the ring inside the prologue.
         stage_issue_p16<PRO, UM>(p, ar);
         stage_finish_p16<PRO, UM>(p, a, ar);
+        if constexpr (EPI == EPI_TP) tp_signal(p);       // every wave of the workgroup passes one tp_signal (its barrier)
         return;
     }
     stage_issue_p16<PRO, UM>(p, ar);                        // activation loads first: vmcnt retires oldest-first
@@ -395,7 +396,8 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_i8q4_p16_kernel(GemvParams p
                 float v = usel;
                 if (EPI == EPI_SILU_MUL) v = silu_ref(gsel) * usel;   // MLPBlock.java:132-142; SiLU in double (~500 SIMD cycles) once per 16 tasks
                 if (EPI == EPI_RESID) v = v + rv;                      // accumulate(...) TransformerBlock.java:185,203
-                p.out[row] = v;
+                if (EPI == EPI_TP) tp_store(p, row, v);                // (a tensor-parallel shard stores into every shard's slot)
+                else p.out[row] = v;
             }
             if (EPI == EPI_RESID && cq + 1 < q1) rv = resid_of_batch(cq + 1);
         }
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_i8q4_p16_kernel(GemvParams p
         __builtin_amdgcn_sched_barrier(0);
     }
     pass_end();
+    if constexpr (EPI == EPI_TP) tp_signal(p);
 }
 
 // ------------------------------------------------------------------------------------------------ F32 x Q4 GEMV (LM head), reference order

@@ -132,6 +132,7 @@ int nb_for(int K) {
 
 // ---- launchers -------------------------------------------------------------------------------------------
 struct LaunchCfg { int R, waves, grid_cap, pipe; };   // 0 / -1 = let the planner decide
+thread_local int g_last_gemv_grid = 0;                // workgroups of the GEMV launched last on this thread (EPI_TP: its flag count)
 
 // (R, NB, PIPE) instantiations of gemv_i8q4_kernel
 #define JH_GEMV_COMBOS(X)                                                                                         \
@@ -147,6 +148,7 @@ int launch_gemv_i8q4_combo(const GemvParams& p, int R, int NB, int PIPE, int gri
         if constexpr (!(EPI == EPI_SILU_MUL && ((RV) & 1))) {                                                   \
             JHCHK(allow_lds(gemv_i8q4_kernel<PRO, EPI, RV, NBV, PV>, lds));                                     \
             hipLaunchKernelGGL((gemv_i8q4_kernel<PRO, EPI, RV, NBV, PV>), dim3(grid), dim3(threads), lds, st, p); \
+            g_last_gemv_grid = grid;                                                                            \
             HIPCHK(hipGetLastError());                                                                          \
             return JH_OK;                                                                                       \
         }                                                                                                       \
@@ -1065,7 +1067,19 @@ struct jh_model {
     int64_t weight_bytes = 0;
     int kv_head_offset = 0;   // tensor-parallel shard (jh_model_set_kv_head_offset)
     int weights_version = 0;  // bumped by jh_model_set_weight: sessions drop graphs that captured the old device pointers
+    int tiled_mode = 0;       // TILED_*: where the prefill GEMM's MFMA-ordered weight operand lives (decided at the first prefill)
 };
+// The prefill GEMM reads its weight operand in MFMA order.  RESIDENT keeps a second, re-tiled copy of every projection weight in
+// HBM (2x the checkpoint; the default while the device has room: this part has 288 GB).  TRANSIENT keeps only the row-major
+// weights and rebuilds the operand of each GEMM in a per-session scratch (the largest single weight) right in front of it:
+// 1.0x the checkpoint, at the price of one extra read + write of the weights per prompt chunk (retile16_kernel).
+// JH_TILED_COPY = auto | resident | transient;  auto = resident when the copy leaves >= 1/4 of the device memory free.
+enum { TILED_UNSET = 0, TILED_RESIDENT = 1, TILED_TRANSIENT = 2 };
+// Where the o-proj / down GEMV of a tensor-parallel shard delivers its partial row when it runs inside the group's token graph
+// (EPI_TP): this shard's slot on every shard + one flag word per workgroup; `grid` returns the flag count of the launch (0 = the
+// GEMV could not push -- BF16 model, first-generation strict kernels -- and the caller adds the scatter launch).
+constexpr int TP_MAX_FLAGS = 4096;
+struct TPPush { float* const* dst; unsigned* const* flags; const unsigned* seq; int n, li, L; int grid; };
 enum { TAP_SLOTS = 12 };
 constexpr int JH_MAX_EOS = 16;   // stop tokens per session (Config.eosTokens holds 1-3 in practice)
 constexpr int N_ATTN_VARIANTS = 3;
@@ -1111,6 +1125,10 @@ struct jh_session {
     int8_t* pb_aq = nullptr;
     float* pb_ws = nullptr;   // split-K workspace of the BF16 prefill GEMM
     float *pb_att_o = nullptr, *pb_att_ml = nullptr;   // key-range split partials of the MFMA prefill attention
+    struct TPPush* tp_push = nullptr;                  // set while a tensor-parallel token graph is captured: o-proj / down push their partials
+    uint8_t* tile_w = nullptr;                         // TILED_TRANSIENT: scratch for ONE weight in MFMA order (+ its scales)
+    float* tile_s = nullptr;
+    size_t tile_w_bytes = 0, tile_s_bytes = 0;
     int prefill_attn_mfma_min = 384;   // chunks whose newest position reaches this many keys take attn_prefill_mfma_kernel
     int* pb_tok = nullptr;
     int* pb_start = nullptr;  // device word: start position of the chunk being prefilled
@@ -1218,6 +1236,7 @@ int launch_gemv_i8q4_p16_d(const GemvParams& p, const P16Plan& pl, hipStream_t s
         return set_err(JH_ERR_UNSUPPORTED, "reference-order GEMV: K = " + std::to_string(p.K) + " exceeds the register-resident activation row");
     }
     HIPCHK(hipGetLastError());
+    g_last_gemv_grid = pl.grid;
     return JH_OK;
 }
 template <int PRO, int EPI>
@@ -1377,6 +1396,17 @@ int tap_copy(jh_session* s, int which, const float* src, int n, hipStream_t st) 
 // 5 launches -- qkv(+rmsnorm+q8) | attention(+rope+kv write+q8) | o-proj(+residual) | gate/up(+rmsnorm+q8,+silu*up+q8) | down(+residual)
 // in two halves, split where tensor-parallel shards synchronise (tensorReducer: CausalSelfAttention.java:378,
 // MLPBlock.java:160).  resid == nullptr => the projection's partial result is stored WITHOUT the residual.
+// o-proj / down of a tensor-parallel shard inside its token graph: the GEMV stores its partial row into every shard's slot and
+// raises its workgroup flags itself (EPI_TP)
+int tp_push_gemv(jh_session* s, GemvParams& p, const LaunchCfg& cfg, hipStream_t st) {
+    TPPush* t = s->tp_push;
+    p.tp_dst = t->dst; p.tp_flags = t->flags; p.tp_seq = t->seq; p.tp_n = t->n; p.tp_li = t->li; p.tp_L = t->L;
+    if (s->strict) JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_TP>(p, s->p16_depth, st)));
+    else JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_TP>(p, cfg, st)));
+    if (g_last_gemv_grid > TP_MAX_FLAGS) return set_err(JH_ERR_UNSUPPORTED, "tensor-parallel push: the GEMV has more workgroups than flag words");
+    t->grid = g_last_gemv_grid;
+    return JH_OK;
+}
 int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_for_tap, float* out, const float* resid) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
@@ -1429,6 +1459,8 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         } else if (s->strict && s->strict_legacy) {
             if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
             else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
+        } else if (!resid && s->tp_push) {
+            JHCHK(tp_push_gemv(s, p, s->cfg_o, st));
         } else if (s->strict) {
             if (resid) JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
             else JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_STORE>(p, s->p16_depth, st)));
@@ -1487,6 +1519,8 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
         } else if (s->strict && s->strict_legacy) {
             if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
             else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
+        } else if (!resid && s->tp_push) {
+            JHCHK(tp_push_gemv(s, p, s->cfg_down, st));
         } else if (s->strict) {
             if (resid) JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
             else JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_STORE>(p, s->p16_depth, st)));
@@ -1567,75 +1601,129 @@ bool prefill_tiled(jh_session* s, int K) {
     if (s->m->c.weight_dtype == JH_DT_BF16) return enabled && (K % 32) == 0;
     return enabled && s->m->c.weight_dtype == JH_DT_Q4 && nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024;
 }
-// resident re-tiled copy of a Q4 weight, made on first use (costs a second copy of the weights in HBM)
-int ensure_tiled(JWeight& W, hipStream_t st) {
-    if (W.tiled) return JH_OK;
-    if (W.dtype == JH_DT_BF16) {
-        if ((W.rows % 32) || (W.cols % 16)) return set_err(JH_ERR_INVALID, "tiled copy: shape");
-        hipError_t e2 = hipMalloc((void**)&W.tiled, (size_t)W.rows * W.cols * 2);
-        if (e2 != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled weight copy");
-        const size_t chunks = (size_t)W.rows * (W.cols / 8);
-        hipLaunchKernelGGL(retile_bf16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const uint16_t*)W.data, W.rows, W.cols, (uint16_t*)W.tiled);
-        HIPCHK(hipGetLastError());
-        return JH_OK;
-    }
-    if (W.dtype != JH_DT_Q4 || (W.rows % 32) || (W.cols % QB)) return set_err(JH_ERR_INVALID, "tiled copy: shape");
-    const int nblk = W.cols / QB;
-    hipError_t e = hipMalloc((void**)&W.tiled, (size_t)W.rows * nblk * 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&W.tiled_scales, (size_t)W.rows * nblk * 4);
-    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled weight copy");
-    const size_t n = (size_t)W.rows * nblk;
-    hipLaunchKernelGGL(retile_q4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)W.data, (const float*)W.scales,
-                       W.rows, nblk, W.tiled, W.tiled_scales);
+// one weight, row-major -> MFMA order, into wt (+ st for Q4)
+int retile_launch(const JWeight& W, uint8_t* wt, float* st_out, hipStream_t st) {
+    const bool bf = W.dtype == JH_DT_BF16;
+    if ((!bf && W.dtype != JH_DT_Q4) || (W.rows % 32) || (W.cols % (bf ? 16 : QB))) return set_err(JH_ERR_INVALID, "tiled copy: shape");
+    const int nch = bf ? W.cols / 8 : W.cols / QB;    // 16-byte chunks per row
+    hipLaunchKernelGGL(retile16_kernel, dim3((unsigned)((nch + 63) / 64), (unsigned)(W.rows / 32)), dim3(256), 0, st, (const i32x4*)W.data,
+                       bf ? (const float*)nullptr : (const float*)W.scales, W.rows, nch, (i32x4*)wt, bf ? (float*)nullptr : st_out);
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
-// gate and up stacked along N in ONE MFMA-ordered copy: the prefill runs a single [rows, 2H] GEMM for both
+static size_t tiled_w_bytes(const JWeight& W) { return W.dtype == JH_DT_BF16 ? (size_t)W.rows * W.cols * 2 : (size_t)W.rows * (W.cols / QB) * 16; }
+static size_t tiled_s_bytes(const JWeight& W) { return W.dtype == JH_DT_BF16 ? 0 : (size_t)W.rows * (W.cols / QB) * 4; }
+int tiled_mode_for(jh_model* m) {
+    if (m->tiled_mode != TILED_UNSET) return m->tiled_mode;
+    const char* e = getenv("JH_TILED_COPY");
+    const std::string v = e ? e : "auto";
+    int mode = TILED_RESIDENT;
+    if (v == "transient") mode = TILED_TRANSIENT;
+    else if (v != "resident") {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < (size_t)m->weight_bytes + tot / 4) mode = TILED_TRANSIENT;
+        (void)hipGetLastError();
+    }
+    m->tiled_mode = mode;
+    return mode;
+}
+// resident re-tiled copy of a weight, made on first use (costs a second copy of the weights in HBM)
+int ensure_tiled(JWeight& W, hipStream_t st) {
+    if (W.tiled) return JH_OK;
+    if ((W.dtype != JH_DT_Q4 && W.dtype != JH_DT_BF16) || (W.rows % 32) || (W.cols % QB)) return set_err(JH_ERR_INVALID, "tiled copy: shape");
+    hipError_t e = hipMalloc((void**)&W.tiled, tiled_w_bytes(W));
+    if (e == hipSuccess && W.dtype == JH_DT_Q4) e = hipMalloc((void**)&W.tiled_scales, tiled_s_bytes(W));
+    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled weight copy");
+    return retile_launch(W, W.tiled, W.tiled_scales, st);
+}
+// the MFMA-ordered operand of W for the GEMM that is launched next on `st`: the resident copy, or the session's scratch filled now
+int tiled_operand(jh_session* s, JWeight& W, hipStream_t st, const uint8_t** tw, const float** ts) {
+    if (tiled_mode_for(s->m) == TILED_RESIDENT) {
+        JHCHK(ensure_tiled(W, st));
+        *tw = W.tiled; *ts = W.tiled_scales;
+        return JH_OK;
+    }
+    if (tiled_w_bytes(W) > s->tile_w_bytes || tiled_s_bytes(W) > s->tile_s_bytes) return set_err(JH_ERR_INVALID, "tiled operand: scratch too small");
+    JHCHK(retile_launch(W, s->tile_w, s->tile_s, st));
+    *tw = s->tile_w; *ts = s->tile_s;
+    return JH_OK;
+}
+// gate and up stacked along N in ONE MFMA-ordered operand: the prefill runs a single [rows, 2H] GEMM for both
 // (MLPBlock.java:117-130 issues them over the same quantized activation), out[:, :H] = gate, out[:, H:] = up
+bool gateup_fusable(jh_session* s, int li) {
+    const JWeight* W = &s->m->layer_w[(size_t)li * JH_W_COUNT];
+    const JWeight &G = W[JH_W_GATE], &U = W[JH_W_UP];
+    return G.data && U.data && G.rows == U.rows && G.cols == U.cols && G.dtype == U.dtype && (G.rows % 32) == 0 &&
+           (G.dtype == JH_DT_Q4 || G.dtype == JH_DT_BF16) && prefill_tiled(s, G.cols);
+}
+// fills (wt, st_out) with [gate ; up] in MFMA order
+int retile_gateup(const JWeight& G, const JWeight& U, uint8_t* wt, float* st_out, hipStream_t st) {
+    JHCHK(retile_launch(G, wt, st_out, st));
+    return retile_launch(U, wt + tiled_w_bytes(G), st_out ? st_out + tiled_s_bytes(G) / 4 : nullptr, st);
+}
 int ensure_gateup_tiled(jh_session* s, int li, hipStream_t st) {
     jh_model* m = s->m;
     JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     JWeight& G = W[JH_W_GATE];
     JWeight& U = W[JH_W_UP];
     JWeight& F = m->gateup[(size_t)li];
-    if (F.tiled || !G.data || !U.data) return JH_OK;
-    if (G.rows != U.rows || G.cols != U.cols || G.dtype != U.dtype || (G.rows % 32) || !prefill_tiled(s, G.cols)) return JH_OK;
-    const size_t H = (size_t)G.rows, K = (size_t)G.cols;
-    F.dtype = G.dtype; F.rows = (int)(2 * H); F.cols = (int)K;
-    if (G.dtype == JH_DT_BF16) {
-        hipError_t e = hipMalloc((void**)&F.tiled, 2 * H * K * 2);
-        if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled gate|up copy");
-        const size_t chunks = H * (K / 8);
-        hipLaunchKernelGGL(retile_bf16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const uint16_t*)G.data, (int)H, (int)K, (uint16_t*)F.tiled);
-        hipLaunchKernelGGL(retile_bf16_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const uint16_t*)U.data, (int)H, (int)K,
-                           (uint16_t*)F.tiled + H * K);
-        HIPCHK(hipGetLastError());
+    if (F.tiled || !gateup_fusable(s, li)) return JH_OK;
+    F.dtype = G.dtype; F.rows = 2 * G.rows; F.cols = G.cols;
+    hipError_t e = hipMalloc((void**)&F.tiled, tiled_w_bytes(F));
+    if (e == hipSuccess && F.dtype == JH_DT_Q4) e = hipMalloc((void**)&F.tiled_scales, tiled_s_bytes(F));
+    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled gate|up copy");
+    return retile_gateup(G, U, F.tiled, F.tiled_scales, st);
+}
+int gateup_operand(jh_session* s, int li, hipStream_t st, const uint8_t** tw, const float** ts) {
+    jh_model* m = s->m;
+    JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    if (tiled_mode_for(m) == TILED_RESIDENT) {
+        JHCHK(ensure_gateup_tiled(s, li, st));
+        *tw = m->gateup[(size_t)li].tiled; *ts = m->gateup[(size_t)li].tiled_scales;
         return JH_OK;
     }
-    if (G.dtype != JH_DT_Q4) return JH_OK;
-    const size_t nblk = K / QB;
-    hipError_t e = hipMalloc((void**)&F.tiled, 2 * H * nblk * 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&F.tiled_scales, 2 * H * nblk * 4);
-    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc tiled gate|up copy");
-    const size_t n = H * nblk;
-    hipLaunchKernelGGL(retile_q4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)G.data, (const float*)G.scales, (int)H,
-                       (int)nblk, F.tiled, F.tiled_scales);
-    hipLaunchKernelGGL(retile_q4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t*)U.data, (const float*)U.scales, (int)H,
-                       (int)nblk, F.tiled + H * nblk * 16, F.tiled_scales + H * nblk);
-    HIPCHK(hipGetLastError());
+    if (2 * tiled_w_bytes(W[JH_W_GATE]) > s->tile_w_bytes || 2 * tiled_s_bytes(W[JH_W_GATE]) > s->tile_s_bytes)
+        return set_err(JH_ERR_INVALID, "tiled operand: scratch too small");
+    JHCHK(retile_gateup(W[JH_W_GATE], W[JH_W_UP], s->tile_w, s->tile_s, st));
+    *tw = s->tile_w; *ts = s->tile_s;
     return JH_OK;
 }
-// every weight the prefill GEMMs of this shard will touch (allocation must not happen inside a graph capture)
+// every weight the prefill GEMMs of this shard will touch (allocation must not happen inside a graph capture): the resident
+// MFMA-ordered copies, or -- TILED_TRANSIENT -- the session's scratch, sized for the largest operand
 int ensure_all_tiled(jh_session* s, hipStream_t st) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
+    const bool resident = tiled_mode_for(m) == TILED_RESIDENT;
+    size_t need_w = 0, need_s = 0;
     for (int li = c.layer_start; li < c.layer_end; li++) {
         JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
-        JWeight* list[] = {&m->qkv[(size_t)li], &W[JH_W_O], &W[JH_W_DOWN]};
-        for (JWeight* w : list)
-            if (w->data && !w->tiled && (w->dtype == JH_DT_Q4 || w->dtype == JH_DT_BF16) && prefill_tiled(s, w->cols) && (w->rows % 32) == 0)
-                JHCHK(ensure_tiled(*w, st));
-        JHCHK(ensure_gateup_tiled(s, li, st));
+        JWeight* list[] = {&m->qkv[(size_t)li], &W[JH_W_O], &W[JH_W_DOWN], &W[JH_W_GATE], &W[JH_W_UP]};
+        for (JWeight* w : list) {
+            if (!(w->data && (w->dtype == JH_DT_Q4 || w->dtype == JH_DT_BF16) && prefill_tiled(s, w->cols) && (w->rows % 32) == 0)) continue;
+            const bool gu = (w == &W[JH_W_GATE] || w == &W[JH_W_UP]);
+            const bool fused = gu && gateup_fusable(s, li);
+            if (resident) {
+                if (!fused && !w->tiled) JHCHK(ensure_tiled(*w, st));
+            } else {
+                const size_t f = fused ? 2 : 1;
+                if (f * tiled_w_bytes(*w) > need_w) need_w = f * tiled_w_bytes(*w);
+                if (f * tiled_s_bytes(*w) > need_s) need_s = f * tiled_s_bytes(*w);
+            }
+        }
+        if (resident) JHCHK(ensure_gateup_tiled(s, li, st));
+    }
+    if (!resident && (need_w > s->tile_w_bytes || need_s > s->tile_s_bytes)) {
+        HIPCHK(hipStreamSynchronize(st));
+        if (s->tile_w) hipFree(s->tile_w);
+        if (s->tile_s) hipFree(s->tile_s);
+        s->tile_w = nullptr; s->tile_s = nullptr; s->tile_w_bytes = s->tile_s_bytes = 0;
+        if (hipMalloc((void**)&s->tile_w, need_w) != hipSuccess || (need_s && hipMalloc((void**)&s->tile_s, need_s) != hipSuccess))
+            return set_err(JH_ERR_OOM, "hipMalloc tiled operand scratch");
+        s->tile_w_bytes = need_w; s->tile_s_bytes = need_s;
+        for (auto& kv : s->pb_graphs) hipGraphExecDestroy(kv.second);   // prefill graphs captured the old scratch address
+        s->pb_graphs.clear();
+        for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
+        s->pb_graph_src.clear();
     }
     return JH_OK;
 }
@@ -1649,30 +1737,28 @@ int rows_quant_launch(jh_session* s, const float* x, int ldx, const float* x2, i
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
-// the same on a weight that exists only as an MFMA-ordered copy (fused gate|up)
-int prefill_gemm_tiled(jh_session* s, const JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
-    if (W.dtype == JH_DT_BF16) {
-        MfmaBf16TileParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.tiled, out, resid, rows, N, K, ldc, s->pb_ws, 1};
+// out[rows, N] = act[rows, K] x W^T (+ resid) with W given as an MFMA-ordered operand (tw, ts)
+int prefill_gemm_operand(jh_session* s, int dtype, const uint8_t* tw, const float* ts, int N, int K, int rows, float* out, int ldc, const float* resid,
+                         hipStream_t st) {
+    if (dtype == JH_DT_BF16) {
+        MfmaBf16TileParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)tw, out, resid, rows, N, K, ldc, s->pb_ws, 1};
         return launch_gemm_bf16_tile(g, st);
     }
-    MfmaQ4Params g{s->pb_aq, s->pb_ad, W.tiled, W.tiled_scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
+    MfmaQ4Params g{s->pb_aq, s->pb_ad, tw, ts, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
     return launch_gemm_q8q4_mfma(g, st, true, s->pb_ws, BF16_SPLITK_WS_BYTES);
 }
 // out[rows, N] = act[rows, K] x W[N, K]^T (+ resid): I8 x Q4 (exact integer MFMA) or BF16 x BF16 (MFMA), by model dtype
 int prefill_gemm(jh_session* s, JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, hipStream_t st) {
-    if (s->m->c.weight_dtype == JH_DT_BF16) {
-        if (prefill_tiled(s, K) && (N % 32) == 0) {
-            JHCHK(ensure_tiled(W, st));
-            MfmaBf16TileParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.tiled, out, resid, rows, N, K, ldc, s->pb_ws, 1};
-            return launch_gemm_bf16_tile(g, st);
-        }
+    const bool bf = s->m->c.weight_dtype == JH_DT_BF16;
+    if (prefill_tiled(s, K) && (!bf || (N % 32) == 0)) {   // (a Q4 weight whose row count is no multiple of 32 is refused by the re-tiler)
+        const uint8_t* tw = nullptr;
+        const float* ts = nullptr;
+        JHCHK(tiled_operand(s, W, st, &tw, &ts));
+        return prefill_gemm_operand(s, bf ? JH_DT_BF16 : JH_DT_Q4, tw, ts, N, K, rows, out, ldc, resid, st);
+    }
+    if (bf) {
         MfmaGemmParams g{(const uint16_t*)s->pb_aq, (const uint16_t*)W.data, out, rows, 0, N, K, K, K, ldc, 0, resid, s->pb_ws, 1};
         return launch_gemm_bf16_mfma(g, st);
-    }
-    if (prefill_tiled(s, K)) {
-        JHCHK(ensure_tiled(W, st));
-        MfmaQ4Params g{s->pb_aq, s->pb_ad, W.tiled, W.tiled_scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
-        return launch_gemm_q8q4_mfma(g, st, true, s->pb_ws, BF16_SPLITK_WS_BYTES);
     }
     MfmaQ4Params g{s->pb_aq, s->pb_ad, (const uint8_t*)W.data, W.scales, out, resid, rows, 0, N, K, K, K / QB, K / 2, K / QB, ldc, 0};
     return launch_gemm_q8q4_mfma(g, st);
@@ -1756,8 +1842,11 @@ int prefill_layers(jh_session* s, int rows, int nkeys_bound, bool attn_mfma, hip
         JHCHK(prefill_gemm(s, W[JH_W_O], E, A, rows, s->pb_x1, E, s->pb_x, st));
         // preFFNorm + maybeQuantize, gate / up, SiLU*up + maybeQuantize, down + residual (MLPBlock.java:117-158)
         JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
-        if (m->gateup[(size_t)li].tiled) {   // one GEMM for gate|up: out[:, :H] = gate, out[:, H:] = up
-            JHCHK(prefill_gemm_tiled(s, m->gateup[(size_t)li], 2 * H, E, rows, s->pb_g, 2 * H, nullptr, st));
+        if (gateup_fusable(s, li)) {   // one GEMM for gate|up: out[:, :H] = gate, out[:, H:] = up
+            const uint8_t* tw = nullptr;
+            const float* ts = nullptr;
+            JHCHK(gateup_operand(s, li, st, &tw, &ts));
+            JHCHK(prefill_gemm_operand(s, W[JH_W_GATE].dtype, tw, ts, 2 * H, E, rows, s->pb_g, 2 * H, nullptr, st));
             JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, 2 * H, s->pb_g + H, 2 * H, nullptr, 0.f, H, rows, st)));
         } else {
             JHCHK(prefill_gemm(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, st));
@@ -2036,6 +2125,15 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     return JH_OK;
 }
 int64_t jh_model_weight_bytes(jh_model* m) { return m ? m->weight_bytes : 0; }
+int64_t jh_model_tiled_bytes(jh_model* m) {
+    if (!m) return 0;
+    int64_t b = 0;
+    auto add = [&](const JWeight& w) { if (w.tiled) b += (int64_t)(tiled_w_bytes(w) + (w.tiled_scales ? tiled_s_bytes(w) : 0)); };
+    for (const JWeight& w : m->layer_w) add(w);
+    for (const JWeight& w : m->qkv) add(w);
+    for (const JWeight& w : m->gateup) add(w);
+    return b;
+}
 
 static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_page_bytes);
 int jh_session_create(jh_model* m, int max_ctx, int64_t max_page_bytes, jh_session** out) {
@@ -2211,7 +2309,7 @@ int jh_session_destroy(jh_session* s) {
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
-    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start, (void*)s->pb_att_o, (void*)s->pb_att_ml}) if (b) hipFree(b);
+    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start, (void*)s->pb_att_o, (void*)s->pb_att_ml, (void*)s->tile_w, (void*)s->tile_s}) if (b) hipFree(b);
     for (auto& kv : s->pb_graphs) hipGraphExecDestroy(kv.second);
     for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -2797,7 +2895,7 @@ struct jh_tp_group {
     // graph-replayed decode (no host inside a token): flag words per (round, producing shard, workgroup), the producers' pointer
     // tables into every shard's flags, the token mailboxes, a per-shard token counter, and one captured graph per attention variant
     int nwg = 0;
-    std::vector<unsigned*> flags;              // per shard: [2][N][nwg]
+    std::vector<unsigned*> flags;              // per shard: [2][N][TP_MAX_FLAGS] (a producer launch uses as many words as it has workgroups)
     std::vector<unsigned**> peers_f;           // per shard: [2][N] -> ITS flag row on every shard
     std::vector<TPMail*> mail;                 // per shard (shard 0's is unused)
     TPMail** mails_dev = nullptr;              // on shard 0's device: the other shards' mailboxes
@@ -2864,7 +2962,7 @@ int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** ou
         unsigned** pf = nullptr;
         TPMail* ml = nullptr;
         ok = hipMalloc(&p, E * 4) == hipSuccess && hipMalloc(&r, E * 4) == hipSuccess && tp_shared_malloc((void**)&sl, 2 * (size_t)N * E * 4) == hipSuccess &&
-             tp_shared_malloc((void**)&fl, 2 * (size_t)N * g->nwg * 4) == hipSuccess && hipMemset(fl, 0, 2 * (size_t)N * g->nwg * 4) == hipSuccess &&
+             tp_shared_malloc((void**)&fl, 2 * (size_t)N * TP_MAX_FLAGS * 4) == hipSuccess && hipMemset(fl, 0, 2 * (size_t)N * TP_MAX_FLAGS * 4) == hipSuccess &&
              hipMalloc(&pf, 2 * (size_t)N * sizeof(unsigned*)) == hipSuccess && tp_shared_malloc((void**)&ml, sizeof(TPMail)) == hipSuccess &&
              hipMemset(ml, 0, sizeof(TPMail)) == hipSuccess && hipMalloc(&sq, 64) == hipSuccess && hipMemset(sq, 0, 64) == hipSuccess &&
              hipMalloc(&pe, 2 * (size_t)N * sizeof(float*)) == hipSuccess && hipEventCreateWithFlags(&a, hipEventDisableTiming) == hipSuccess &&
@@ -2886,9 +2984,9 @@ int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** ou
         std::vector<float*> h(2 * (size_t)N);
         for (int r = 0; r < 2; r++)
             for (int j = 0; j < N; j++) h[(size_t)r * N + j] = g->slots[j] + ((size_t)r * N + k) * E;
-        std::vector<unsigned*> hf(2 * (size_t)N);   // shard k's flag row on shard j, round r: flags[j] + (r*N + k)*nwg
+        std::vector<unsigned*> hf(2 * (size_t)N);   // shard k's flag row on shard j, round r: flags[j] + (r*N + k)*TP_MAX_FLAGS
         for (int r = 0; r < 2; r++)
-            for (int j = 0; j < N; j++) hf[(size_t)r * N + j] = g->flags[j] + ((size_t)r * N + k) * g->nwg;
+            for (int j = 0; j < N; j++) hf[(size_t)r * N + j] = g->flags[j] + ((size_t)r * N + k) * TP_MAX_FLAGS;
         hipSetDevice(shards[k]->m->device);
         if (hipMemcpy(g->peers[k], h.data(), h.size() * sizeof(float*), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(g->peers_f[k], hf.data(), hf.size() * sizeof(unsigned*), hipMemcpyHostToDevice) != hipSuccess) {
@@ -2982,19 +3080,34 @@ int tp_build_graph(jh_tp_group* g, int k, int v) {
         hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
                            (const DecodeState*)s->st, E, s->x);
     }
+    // the o-proj / down GEMVs push their partial rows and raise the flags themselves (EPI_TP) where a kernel for it exists;
+    // otherwise (grid == 0: BF16 model, first-generation strict kernels) a scatter launch follows the GEMV
+    const int tp_fuse = env_int("JH_TP_FUSE", 1);
+    TPPush push[2];
+    for (int r = 0; r < 2; r++) push[r] = TPPush{(float* const*)(g->peers[k] + (size_t)r * N), (unsigned* const*)(g->peers_f[k] + (size_t)r * N), g->seq[k], N, 0, L, 0};
+    auto meet = [&](int r, int li, const float* resid, float* out) {
+        const float* slots = g->slots[k] + (size_t)r * N * E;
+        const unsigned* flags = g->flags[k] + (size_t)r * N * TP_MAX_FLAGS;
+        if (push[r].grid > 0) {
+            hipLaunchKernelGGL(tp_sum_wait_all_kernel, eg, eb, 0, st, slots, flags, N, E, push[r].grid, TP_MAX_FLAGS, g->seq[k], li, L, resid, out);
+        } else {
+            hipLaunchKernelGGL(tp_scatter_flag_kernel, eg, eb, 0, st, (const float*)g->part[k], push[r].dst, push[r].flags, N, E, (const unsigned*)g->seq[k], li, L);
+            hipLaunchKernelGGL(tp_sum_wait_kernel, eg, eb, 0, st, slots, flags, N, E, TP_MAX_FLAGS, g->seq[k], li, L, resid, out);
+        }
+    };
     for (int li = 0; li < L && rc == JH_OK; li++) {
+        push[0].li = push[1].li = li;
+        push[0].grid = push[1].grid = 0;
+        s->tp_push = tp_fuse ? &push[0] : nullptr;
         rc = layer_attn_launch(s, li, st, false, 0, g->part[k], nullptr);
+        s->tp_push = nullptr;
         if (rc != JH_OK) break;
-        hipLaunchKernelGGL(tp_scatter_flag_kernel, eg, eb, 0, st, (const float*)g->part[k], (float* const*)g->peers[k], (unsigned* const*)g->peers_f[k], N, E,
-                           (const unsigned*)g->seq[k], li, L);
-        hipLaunchKernelGGL(tp_sum_wait_kernel, eg, eb, 0, st, (const float*)g->slots[k], (const unsigned*)g->flags[k], N, E, g->nwg, g->seq[k],
-                           li, L, (const float*)s->x, s->x1);
+        meet(0, li, s->x, s->x1);
+        s->tp_push = tp_fuse ? &push[1] : nullptr;
         rc = layer_ffn_launch(s, li, st, false, g->part[k], nullptr);
+        s->tp_push = nullptr;
         if (rc != JH_OK) break;
-        hipLaunchKernelGGL(tp_scatter_flag_kernel, eg, eb, 0, st, (const float*)g->part[k], (float* const*)(g->peers[k] + N),
-                           (unsigned* const*)(g->peers_f[k] + N), N, E, (const unsigned*)g->seq[k], li, L);
-        hipLaunchKernelGGL(tp_sum_wait_kernel, eg, eb, 0, st, (const float*)(g->slots[k] + (size_t)N * E), (const unsigned*)(g->flags[k] + (size_t)N * g->nwg), N, E,
-                           g->nwg, g->seq[k], li, L, (const float*)s->x1, s->x);
+        meet(1, li, s->x1, s->x);
     }
     if (rc == JH_OK && k == 0) {
         rc = lmhead_launch(s, st);
@@ -3096,7 +3209,7 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
             // its own queue.  Recover: reset the meeting points, stay on the event-ordered loop for this group, redo the call.
             for (int k = 0; k < N; k++) {
                 HIPCHK(hipSetDevice(g->sh[k]->m->device));
-                HIPCHK(hipMemset(g->flags[k], 0, 2 * (size_t)N * g->nwg * 4));
+                HIPCHK(hipMemset(g->flags[k], 0, 2 * (size_t)N * TP_MAX_FLAGS * 4));
                 HIPCHK(hipMemset(g->seq[k], 0, 64));
                 HIPCHK(hipMemset(g->mail[k], 0, sizeof(TPMail)));
             }

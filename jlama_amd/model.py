@@ -54,6 +54,10 @@ class HipLlamaModel:
     def weight_bytes(self):
         return N.lib().jh_model_weight_bytes(self.h)
 
+    def tiled_bytes(self):
+        """bytes of the resident MFMA-ordered second copy the batched prefill made (0 with JH_TILED_COPY=transient)"""
+        return N.lib().jh_model_tiled_bytes(self.h)
+
     def session(self, max_ctx, max_page_bytes=0):
         return HipSession(self, max_ctx, max_page_bytes)
 

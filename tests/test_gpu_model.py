@@ -335,6 +335,36 @@ def test_batched_prefill_matches_row_path_and_oracle(gpu, oracle, monkeypatch, d
         tok = int(g)
 
 
+@pytest.mark.parametrize("dtype", ["Q4", "BF16"])
+def test_prefill_without_a_resident_second_copy_of_the_weights(gpu, oracle, monkeypatch, dtype):
+    """JH_TILED_COPY=transient: the MFMA-ordered operand of every prefill GEMM is rebuilt in a per-session scratch in front
+    of the GEMM instead of living in HBM as a second copy of the model.  Same kernels, same operand bytes: the rows must be
+    bit-identical to the resident mode's, across two chunks (the scratch is reused by every GEMM of every layer and by the
+    replayed prefill graph), and the model must report no tiled bytes."""
+    from jlama_amd import _native as N, synthetic as S
+    cfg = dict(S.SMALL)
+    if dtype == "BF16":
+        cfg["weight_dtype"] = N.DT_BF16
+    prompt = S.prompt_tokens(cfg, n=300, seed=22)
+    monkeypatch.setenv("JH_TILED_COPY", "resident")
+    hm, om, _ = _pair(cfg, 21, oracle)
+    s1 = hm.session(512)
+    res = s1.forward(prompt, 0)
+    assert hm.tiled_bytes() > 0.8 * sum(r * c for r, c in S.layer_shapes(cfg).values()) * cfg["n_layers"] * (0.625 if dtype == "Q4" else 2.0)
+    monkeypatch.setenv("JH_TILED_COPY", "transient")
+    hm2, _, _ = _pair(cfg, 21, oracle)
+    s2 = hm2.session(512)
+    tra = s2.forward(prompt, 0)
+    again = hm2.session(512).forward(prompt, 0)
+    assert hm2.tiled_bytes() == 0
+    assert np.array_equal(tra, res) and np.array_equal(again, res)
+    assert _rel(tra, om.session().forward(prompt, 0)) <= TRUNK_TOL
+    t1, l1 = s1.sample(0.0, 0.5, want_logits=True)
+    t2, l2 = s2.sample(0.0, 0.5, want_logits=True)
+    assert t1 == t2 and np.array_equal(l1, l2)
+    assert list(s1.decode_n(t1, prompt.size, 8)) == list(s2.decode_n(t2, prompt.size, 8))
+
+
 @pytest.mark.parametrize("shards", [1, 2])
 def test_checkpoint_loads_straight_into_hbm(gpu, oracle, tmp_path, shards):
     """f1: a JQ4 safetensors checkpoint directory (config.json + model.safetensors[.index.json]) -> resident model via
@@ -1037,13 +1067,19 @@ def test_rccl_world1_stream_ordered_hosts(gpu, oracle):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("size", [2, 4])
-def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, size):
+@pytest.mark.parametrize("size,mode", [(2, "fast"), (4, "fast"), (2, "fast-unfused"), (2, "strict"), (4, "strict"), (2, "strict-unfused")])
+def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, monkeypatch, size, mode):
     """f2: jh_tp_group_* -- all head-split shards in one process (here on one device), the two reductions of a layer as
     one-shot slot writes + local sums in shard order, nothing synchronised on the host inside a layer.  Bit-identical to
     the same shards driven by hand with the partials summed in shard order (the path test_tensor_parallel_shards_loopback
-    checks against the oracle's lock-step restatement), and greedy decode through the group equals decode by hand."""
+    checks against the oracle's lock-step restatement), and greedy decode through the group equals decode by hand.
+    Decode replays one graph per shard and token in which the o-proj / down GEMVs push their partial rows into every shard's
+    slot themselves (EPI_TP); "-unfused" keeps the separate scatter launch (JH_TP_FUSE=0), "strict" runs the reference-order
+    kernels -- every combination must give the hand loop's bits."""
     import torch
+    monkeypatch.setenv("JH_TP_FUSE", "0" if mode.endswith("unfused") else "1")
+    monkeypatch.setenv("JH_TP_GRAPH_STRICT", "1")      # a wait that times out is an error here, not a silent fall-back to the event loop
+    strict = mode.startswith("strict")
     from jlama_amd import distributed as D, synthetic as S
     from jlama_amd.model import HipLlamaModel, HipTPGroup
     cfg = dict(S.SMALL)
@@ -1059,6 +1095,8 @@ def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, size):
         osess.append(oracle.OracleModel(lc, sw, kv_head_offset=off).session())
     # by hand: partials summed in shard order on the host side of the ABI
     hand = [m.session(64) for m in models]
+    for hs in hand:
+        hs.set_strict(strict)
     dev = torch.device("cuda", 0)
     part = [torch.empty(E, dtype=torch.float32, device=dev) for _ in range(size)]
 
@@ -1084,6 +1122,8 @@ def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, size):
 
     rows = [hand_row(t, i) for i, t in enumerate(prompt)]
     grp = HipTPGroup(models, 64)
+    for gs in grp.sessions:
+        gs.set_strict(strict)
     grp.forward(prompt, 0)
     for s in grp.sessions:
         np.testing.assert_array_equal(s.current_row(), rows[-1])          # every shard: the same residual stream, same bits
