@@ -1093,6 +1093,11 @@ def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, monkeypatch, s
         sw = D.tp_shard_weights(cfg, w, r, size)
         models.append(HipLlamaModel(lc, sw, kv_head_offset=off))
         osess.append(oracle.OracleModel(lc, sw, kv_head_offset=off).session())
+    # the group first: its shard streams then get hardware queues of their own (conftest.py raises GPU_MAX_HW_QUEUES to 8;
+    # shards that meet in kernels must not share a queue)
+    grp = HipTPGroup(models, 64)
+    for gs in grp.sessions:
+        gs.set_strict(strict)
     # by hand: partials summed in shard order on the host side of the ABI
     hand = [m.session(64) for m in models]
     for hs in hand:
@@ -1121,9 +1126,6 @@ def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, monkeypatch, s
         return hand[0].current_row()
 
     rows = [hand_row(t, i) for i, t in enumerate(prompt)]
-    grp = HipTPGroup(models, 64)
-    for gs in grp.sessions:
-        gs.set_strict(strict)
     grp.forward(prompt, 0)
     for s in grp.sessions:
         np.testing.assert_array_equal(s.current_row(), rows[-1])          # every shard: the same residual stream, same bits

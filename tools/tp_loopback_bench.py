@@ -31,6 +31,7 @@ for size in (2, 4):
     g.decode_n(f2, prompt.size, 4)
     t0 = time.perf_counter(); got = g.decode_n(f2, prompt.size, steps); dt = time.perf_counter() - t0
     agree = int(np.argmin(got == ref)) if not (got == ref).all() else steps
-    mode = "event-ordered host loop" if os.environ.get("JH_TP_GRAPH") == "0" else "graph replay per shard, kernels meet on flags"
+    mode = "event-ordered host loop" if os.environ.get("JH_TP_GRAPH") == "0" else (
+        "graph replay per shard, kernels meet on flags, " + ("separate scatter launches" if os.environ.get("JH_TP_FUSE") == "0" else "o-proj / down push their partial rows"))
     print(f"TP group, {size} shards on one device ({mode}): {steps / dt:8.1f} tok/s; first token {f2 == f}, ids equal for {agree} steps", flush=True)
     g.close()
