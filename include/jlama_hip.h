@@ -63,6 +63,10 @@ int jh_preferred_working_qtype(void);
 const char* jh_last_error(void);
 /* Hash of the sources this binary was compiled from (lets the host side detect a stale library). */
 const char* jh_source_hash(void);
+/* Layout of jh_config as THIS binary was compiled: out[0] = sizeof(jh_config), out[1..] = offsetof of its fields in declaration
+ * order (at most n ints are written; returns the number of ints available = 1 + field count).  A binding checks its own struct
+ * layout against it at load time (ctypes: jlama_amd/_native.py; FFM: HipResidentLlama's static initialiser). */
+int jh_abi_config_layout(int32_t* out, int n);
 /* Block until all work queued by this thread's stream has finished. */
 int jh_synchronize(void);
 

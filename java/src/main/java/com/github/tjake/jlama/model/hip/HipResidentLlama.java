@@ -37,6 +37,18 @@ public final class HipResidentLlama implements AutoCloseable {
         JAVA_INT.withName("context_length"), JAVA_INT.withName("weight_dtype"), JAVA_INT.withName("layer_start"),
         JAVA_INT.withName("layer_end"), JAVA_FLOAT.withName("rms_eps"), JAVA_FLOAT.withName("rope_theta"), JAVA_FLOAT.withName("rope_scaling"));
 
+    static {   // the struct passed by pointer must be the struct the library was compiled with (size + every field offset)
+        try (Arena a = Arena.ofConfined()) {
+            MemorySegment lay = a.allocate(JAVA_INT, 32);
+            int cnt = NativeHipModel.jh_abi_config_layout(lay, 32);
+            List<MemoryLayout> fields = JH_CONFIG.memberLayouts();
+            boolean ok = cnt == fields.size() + 1 && lay.getAtIndex(JAVA_INT, 0) == JH_CONFIG.byteSize();
+            for (int i = 0; ok && i < fields.size(); i++)
+                ok = lay.getAtIndex(JAVA_INT, i + 1) == JH_CONFIG.byteOffset(MemoryLayout.PathElement.groupElement(i));
+            if (!ok) throw new IllegalStateException("jlama-hip: jh_config layout of libjlamahip.so differs from this binding");
+        }
+    }
+
     // weight slots and dtypes of include/jlama_hip.h
     static final int W_Q = 0, W_K = 1, W_V = 2, W_O = 3, W_GATE = 4, W_UP = 5, W_DOWN = 6, W_NORM1 = 7, W_NORM2 = 8, W_EMBED = 9,
         W_LMHEAD = 10, W_FINALNORM = 11;

@@ -100,6 +100,8 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
     private static final MethodHandle jh_get_tap = h("jh_get_tap", JAVA_INT, sig("pipi"));
     // int jh_stage_decode_async(jh_session* s, const int32_t* token_dev, const float* x_in_dev, int pos, float* x_out_dev, int32_t* token_out_dev)
     private static final MethodHandle jh_stage_decode_async = h("jh_stage_decode_async", JAVA_INT, sig("pppipp"));
+    // int jh_abi_config_layout(int32_t* out, int n)
+    private static final MethodHandle jh_abi_config_layout = h("jh_abi_config_layout", JAVA_INT, sig("pi"));
     // int64_t jh_model_tiled_bytes(jh_model* m)
     private static final MethodHandle jh_model_tiled_bytes = h("jh_model_tiled_bytes", JAVA_LONG, sig("p"));
     // int jh_pipeline_peer_access(jh_pipeline* p, int32_t* out, int n)
@@ -227,6 +229,10 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
 
     public static int jh_stage_decode_async(MemorySegment s, MemorySegment token_dev, MemorySegment x_in_dev, int pos, MemorySegment x_out_dev, MemorySegment token_out_dev) {
         try { return (int) jh_stage_decode_async.invokeExact(s, token_dev, x_in_dev, pos, x_out_dev, token_out_dev); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_abi_config_layout(MemorySegment out, int n) {
+        try { return (int) jh_abi_config_layout.invokeExact(out, n); } catch (Throwable t) { throw rethrow(t); }
     }
 
     public static long jh_model_tiled_bytes(MemorySegment m) {

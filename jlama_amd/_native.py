@@ -142,6 +142,7 @@ _PROTOS = {
     "jh_decode_generated": (_i, [_p, _p]),
     "jh_session_set_strict": (_i, [_p, _i]),
     "jh_source_hash": (C.c_char_p, []),
+    "jh_abi_config_layout": (_i, [_p, _i]),
     "jh_get_logits": (_i, [_p, _p]),
     "jh_model_set_kv_head_offset": (_i, [_p, _i]),
     "jh_tp_set_row": (_i, [_p, _i, _p, _i]),
@@ -173,6 +174,12 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        # the struct this binding passes by pointer must be the struct the binary was compiled with
+        lay = (C.c_int32 * 32)()
+        cnt = L.jh_abi_config_layout(lay, 32)
+        mine = [C.sizeof(Config)] + [getattr(Config, f).offset for f, _ in Config._fields_]
+        if list(lay[:cnt]) != mine:
+            raise RuntimeError(f"jh_config layout mismatch: library {list(lay[:cnt])}, binding {mine}")
         _lib = L
     return _lib
 

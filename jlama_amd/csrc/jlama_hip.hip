@@ -534,6 +534,17 @@ const char* jh_last_error(void) { return g_err.c_str(); }
 #endif
 static const char g_src_hash_marker[] = "JHSRCHASH:" JH_SRC_HASH;   // the host side finds it by scanning the file (no dlopen)
 const char* jh_source_hash(void) { return g_src_hash_marker + 10; }
+int jh_abi_config_layout(int32_t* out, int n) {
+    const int32_t v[] = {(int32_t)sizeof(jh_config),
+                         (int32_t)offsetof(jh_config, embedding_length), (int32_t)offsetof(jh_config, hidden_length),
+                         (int32_t)offsetof(jh_config, n_heads), (int32_t)offsetof(jh_config, n_kv_heads), (int32_t)offsetof(jh_config, head_size),
+                         (int32_t)offsetof(jh_config, n_layers), (int32_t)offsetof(jh_config, vocab_size), (int32_t)offsetof(jh_config, context_length),
+                         (int32_t)offsetof(jh_config, weight_dtype), (int32_t)offsetof(jh_config, layer_start), (int32_t)offsetof(jh_config, layer_end),
+                         (int32_t)offsetof(jh_config, rms_eps), (int32_t)offsetof(jh_config, rope_theta), (int32_t)offsetof(jh_config, rope_scaling)};
+    const int cnt = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; out && i < n && i < cnt; i++) out[i] = v[i];
+    return cnt;
+}
 int jh_synchronize(void) {
     JHCHK(ensure_ctx());
     HIPCHK(hipStreamSynchronize(tctx.stream));
