@@ -2018,6 +2018,11 @@ struct AttnParams {
     float* tap_q;          // roped q [A] (tap), may be null
     long long* dbg;        // optional phase timestamps (wall_clock64, 100 MHz) of workgroups with kvh == 0: [split][16]
     int combine_kernel;    // 1: slices only publish (plain stores); attn_combine_kernel merges them after the kernel edge
+    // reference-order prefill (jh_p16.h, batch != 0): blockIdx.z = prompt row, at position batch_pos0 + z, q|k|v row z at
+    // qkv + z*ldqkv, its output row at outf + z*ldo, its score rows at scores + z*sc_batch; the KV rows of the whole chunk were
+    // written before (rows_rope_kv_p16_kernel), nothing is written to the pages here
+    int batch, batch_pos0, ldqkv, ldo;
+    long long sc_batch;
 };
 #define JH_ATT_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && blockIdx.y == 0) p.dbg[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 

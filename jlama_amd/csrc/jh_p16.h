@@ -645,7 +645,10 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
     __shared__ float qs[GROUP * HS];
     __shared__ float knew[HS];
     constexpr int NT = P16_ATT_THREADS, half = HS / 2, NC = HS / 16, RP = NT / 16;   // RP positions per pass
-    const int pos = p.st->pos, n = pos + 1;
+    const int z = blockIdx.z;                                   // prompt row of a batched (prefill) launch, 0 in decode
+    const int pos = p.batch ? p.batch_pos0 + z : p.st->pos, n = pos + 1;
+    const float* qkv_row = p.qkv + (size_t)z * p.ldqkv;
+    scores += (size_t)z * p.sc_batch;
     const int kvh = blockIdx.y, split = blockIdx.x, S = gridDim.x;
     const int chunk = (((n + S - 1) / S) + RP - 1) / RP * RP;   // whole passes per slice
     const int t0 = split * chunk;
@@ -671,12 +674,12 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
     // ---- RoPE of the group's q heads and of the new k row (table row pos + 2*kvHead: CausalSelfAttention.java:247-286); every
     // slice rotates them locally, bit-identically; the slice that owns `pos` writes the KV page rows
     const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
-    const bool owner = (pos >= t0 && pos < t1);
+    const bool owner = !p.batch && (pos >= t0 && pos < t1);
     for (int i = tid; i < (GROUP + 1) * half; i += NT) {
         const int gi = i / half, d = i - gi * half;
         const float c = rf[2 * d], s = rf[2 * d + 1];
         if (gi < GROUP) {
-            const float* qh = p.qkv + (size_t)(kvh * GROUP + gi) * HS;
+            const float* qh = qkv_row + (size_t)(kvh * GROUP + gi) * HS;
             const float q0 = qh[d], q1 = qh[d + half];
             const float r0 = q0 * c - q1 * s, r1 = q0 * s + q1 * c;   // contraction off: mul, mul, sub / add as in Java
             qs[gi * HS + d] = r0; qs[gi * HS + d + half] = r1;
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
                 p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d + half] = r1;
             }
         } else {
-            const float* kh = p.qkv + A + (size_t)kvh * HS;
+            const float* kh = qkv_row + A + (size_t)kvh * HS;
             const float k0 = kh[d], k1 = kh[d + half];
             const float r0 = k0 * c - k1 * s, r1 = k0 * s + k1 * c;
             knew[d] = r0; knew[d + half] = r1;
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
         }
     }
     if (owner)
-        for (int d = tid; d < HS; d += NT) ((float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS)[d] = p.qkv[A + KV + (size_t)kvh * HS + d];
+        for (int d = tid; d < HS; d += NT) ((float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS)[d] = qkv_row[A + KV + (size_t)kvh * HS + d];
     __syncthreads();
     float q[GROUP][NC];
 #pragma unroll
@@ -750,7 +753,9 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 32 * RU;   // columns per workgroup, positions per tile
     const int h = blockIdx.y, group = p.n_heads / p.n_kv_heads, kvh = h / group, d0 = blockIdx.x * DW;
-    const int pos = p.st->pos, n = pos + 1;
+    const int z = blockIdx.z;                                   // prompt row of a batched (prefill) launch, 0 in decode
+    const int pos = p.batch ? p.batch_pos0 + z : p.st->pos, n = pos + 1;
+    scores += (size_t)z * p.sc_batch;
     const int KV = p.n_kv_heads * HS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* vt = (float*)smem;              // [TP][DW] V tile
@@ -842,12 +847,176 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
             }
         }
     }
-    if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
+    if (tid < DW) p.outf[(size_t)z * p.ldo + (size_t)h * HS + d0 + tid] = acc;
 }
 static inline int p16_av_rows(int max_ctx) {   // RU: the whole context in one tile when it fits
     const int want = ((max_ctx + 63) & ~63) / 32;
     return want <= 2 ? 2 : want <= 4 ? 4 : want <= 8 ? 8 : 16;
 }
 static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)p16_av_rows(max_ctx) * 32 * 32 + 16 + (size_t)((max_ctx + 63) & ~63)) * 4; }
+
+// ------------------------------------------------------------------------------------------------ prompt rows in reference order
+// AbstractModel.batchForward (AbstractModel.java:295-312) with every GEMM output summed exactly like the M = 1 kernels above: the
+// reference's Gemmer tiles (PTO:852-1043) keep one 16-lane accumulator per output and walk K in ascending blocks whatever the
+// tile, so a prompt row's result does not depend on how many rows are processed together -- and neither does it here: each
+// (prompt row, weight row) pair owns a 16-lane chain fed in the same block order by the same instructions.  What batching buys
+// is the weight side: a group of 16 blocks is loaded, transposed and unpacked ONCE and then serves MT prompt rows (the GEMV
+// spends a third of its VALU work there), and the activation prologue runs once per row instead of once per workgroup.
+//   rows_act_p16_kernel   one workgroup per prompt row: the GEMVs' own prologue code (RMSNorm + Q8 / plain Q8, pair-word layout),
+//                         LDS image copied to global memory [rows][G*512 B] + block scales [rows][nblk]
+//   gemm_i8q4_p16_kernel  workgroup = 8 row quads (32 weight rows) x MT prompt rows, the MT activation images resident in LDS
+//   rows_rope_kv_p16_kernel  K (post-RoPE) and V rows of the whole chunk into the KV pages, before any row's scores are taken
+struct RowsP16Params {
+    const float* x; int ldx;          // [rows][ldx] F32
+    const float* nw; float eps;       // PRO_RMS_Q8
+    int K;
+    uint8_t* apt; float* ad16;        // out: pair-word images [rows][pt_stride bytes], block scales / 16 [rows][d_stride]
+    int pt_stride, d_stride;
+};
+template <int PRO, int UM>
+__global__ __launch_bounds__(P16_THREADS) void rows_act_p16_kernel(RowsP16Params rp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nblk = rp.K / QB, G = (nblk + 15) >> 4;
+    const ActP16 a = carve_p16(smem, nblk);
+    GemvParams p{};
+    p.x = rp.x + (size_t)blockIdx.x * rp.ldx; p.nw = rp.nw; p.eps = rp.eps; p.K = rp.K;
+    ActRegsP16<UM> ar;
+    stage_issue_p16<PRO, UM>(p, ar);
+    stage_finish_p16<PRO, UM>(p, a, ar);
+    i32x4* dst = (i32x4*)(rp.apt + (size_t)blockIdx.x * rp.pt_stride);
+    const i32x4* src = (const i32x4*)a.pt;
+    for (int i = threadIdx.x; i < G * 32; i += P16_THREADS) dst[i] = src[i];
+    for (int i = threadIdx.x; i < nblk; i += P16_THREADS) rp.ad16[(size_t)blockIdx.x * rp.d_stride + i] = a.d16[i];
+}
+
+struct GemmP16Params {
+    const uint8_t* w; const float* ws;       // Q4 weight [nrows][K/2] + scales [nrows][K/32]
+    const uint8_t* w2; const float* ws2;     // EPI_SILU_MUL: the up projection (w = gate)
+    int ldb, ldbf, nrows, K, M;
+    const uint8_t* apt; const float* ad16;   // activation images of the M prompt rows (rows_act_p16_kernel)
+    int pt_stride, d_stride;
+    float* out; int ldc;                     // [M][ldc]
+    const float* resid; int ldr;             // EPI_RESID
+};
+// the 4 chained steps of blocks 4*K4 .. 4*K4+3 of a group for MT prompt rows: the weight bytes are unpacked once (2 bit ops + 4
+// perms), every row then pays pair-word read + 4 dots + 4 converts + 4 chained fmacs
+template <int K4, int MT>
+__device__ __forceinline__ void p16_quad_rows(int xk, const i32x2* pt_q, int row_stride, const float (&sp)[MT], float (&acc)[MT]) {
+    const int lo = nib_lo16(xk), hi = nib_hi16(xk);
+    const int w0 = perm_b(hi, lo, 0x0C0C0400), w1 = perm_b(hi, lo, 0x05010C0C), w2 = perm_b(hi, lo, 0x0C0C0602), w3 = perm_b(hi, lo, 0x07030C0C);
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        const i32x2 pp = pt_q[(size_t)m * row_stride];
+        float f0, f1, f2, f3;
+        dot4x4_cvt(pp.x, pp.y, w0, w1, w2, w3, f0, f1, f2, f3);
+        fmac_bcast<4 * K4 + 0>(acc[m], sp[m], f0);
+        fmac_bcast<4 * K4 + 1>(acc[m], sp[m], f1);
+        fmac_bcast<4 * K4 + 2>(acc[m], sp[m], f2);
+        fmac_bcast<4 * K4 + 3>(acc[m], sp[m], f3);
+    }
+}
+template <int EPI, int MT>
+__global__ __launch_bounds__(P16_THREADS) void gemm_i8q4_p16_kernel(GemmP16Params p) {
+    static_assert(MT <= 16, "one prompt row per lane of a 16-lane row in the epilogue");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nblk = p.K / QB, G = nblk >> 4;                  // host: nblk % 16 == 0
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane >> 4, t = lane & 15;
+    const RowSel sel = row16_selectors(lane);
+    const int m0 = blockIdx.y * MT;
+    constexpr int NP = (EPI == EPI_SILU_MUL) ? 2 : 1;
+    i32x2* pts = (i32x2*)smem;                                 // [MT][G*64] pair-word images
+    float* ds = (float*)(pts + (size_t)MT * G * 64);           // [MT][nblk] block scales / 16
+    const int row_stride = G * 64;
+    {
+        const int n16 = G * 32;                                // 16-byte chunks per image
+        for (int i = threadIdx.x; i < MT * n16; i += P16_THREADS) {
+            const int m = i / n16, j = i - m * n16;
+            int mm = m0 + m;
+            mm = mm < p.M ? mm : p.M - 1;                      // rows past M replicate the last row (never stored)
+            ((i32x4*)pts)[i] = ((const i32x4*)(p.apt + (size_t)mm * p.pt_stride))[j];
+        }
+        for (int i = threadIdx.x; i < MT * nblk; i += P16_THREADS) {
+            const int m = i / nblk, j = i - m * nblk;
+            int mm = m0 + m;
+            mm = mm < p.M ? mm : p.M - 1;
+            ds[i] = p.ad16[(size_t)mm * p.d_stride + j];
+        }
+    }
+    const int quad = blockIdx.x * (P16_THREADS / 64) + wave;
+    int row = 4 * quad + r;
+    const bool row_ok = row < p.nrows;
+    row = row_ok ? row : p.nrows - 1;
+    __syncthreads();
+    float gres[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) gres[m] = 0.0f;
+#pragma unroll
+    for (int pass = 0; pass < NP; pass++) {
+        const uint8_t* wrow = ((NP == 2 && pass) ? p.w2 : p.w) + (size_t)row * p.ldb;
+        const float* srow = ((NP == 2 && pass) ? p.ws2 : p.ws) + (size_t)row * p.ldbf;
+        float acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; m++) acc[m] = 0.0f;
+        i32x4 wn = __builtin_nontemporal_load((const i32x4*)wrow + t);
+        float sn = __builtin_nontemporal_load(srow + t);
+        for (int g = 0; g < G; g++) {
+            i32x4 x = wn;
+            const float sc = sn;
+            const int gn = g + 1 < G ? g + 1 : g;              // branch-free: the last group is requested twice
+            wn = __builtin_nontemporal_load((const i32x4*)wrow + 16 * gn + t);
+            sn = __builtin_nontemporal_load(srow + 16 * gn + t);
+            row16_transpose(x, sel);
+            float sp[MT];
+#pragma unroll
+            for (int m = 0; m < MT; m++) sp[m] = p16_scale_product(ds[m * nblk + 16 * g + t], sc);
+            const i32x2* pq = pts + (size_t)(4 * g) * 16 + t;
+            p16_quad_rows<0, MT>(x.x, pq, row_stride, sp, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            p16_quad_rows<1, MT>(x.y, pq + 16, row_stride, sp, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            p16_quad_rows<2, MT>(x.z, pq + 32, row_stride, sp, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            p16_quad_rows<3, MT>(x.w, pq + 48, row_stride, sp, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every lane of a 16-lane row ends with the finished sums; lane t keeps prompt row m0 + t
+        float mine = 0.0f, gate = 0.0f;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            const float res = row16_tree_sum(acc[m]);
+            if (NP == 2 && pass == 0) gres[m] = res;
+            else if (t == m) { mine = res; gate = gres[m]; }
+        }
+        if (NP == 2 && pass == 0) continue;
+        const int mrow = m0 + t;
+        if (t < MT && mrow < p.M && row_ok) {
+            float v = mine;
+            if (EPI == EPI_SILU_MUL) v = silu_ref(gate) * mine;                          // MLPBlock.java:132-142
+            if (EPI == EPI_RESID) v = v + p.resid[(size_t)mrow * p.ldr + row];           // TransformerBlock.java:185,203
+            p.out[(size_t)mrow * p.ldc + row] = v;
+        }
+    }
+}
+static inline size_t lds_bytes_gemm_p16(int K, int MT) { return (size_t)MT * ((size_t)(K / QB / 16) * 512 + (size_t)(K / QB) * 4); }
+
+template <int HS>
+__global__ __launch_bounds__(128) void rows_rope_kv_p16_kernel(AttnParams p) {
+    constexpr int half = HS / 2;
+    const int z = blockIdx.x, kvh = blockIdx.y, pos = p.batch_pos0 + z;
+    const int KV = p.n_kv_heads * HS, A = p.n_heads * HS;
+    const float* qkv_row = p.qkv + (size_t)z * p.ldqkv;
+    const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
+    const float* kh = qkv_row + A + (size_t)kvh * HS;
+    float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
+    for (int d = threadIdx.x; d < half; d += 128) {
+        const float c = rf[2 * d], s = rf[2 * d + 1];
+        const float k0 = kh[d], k1 = kh[d + half];
+        const float r0 = k0 * c - k1 * s, r1 = k0 * s + k1 * c;   // as attn_p16_scores_kernel (CausalSelfAttention.java:273-286)
+        kdst[d] = r0; kdst[d + half] = r1;
+    }
+    float* vdst = (float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS;
+    for (int d = threadIdx.x; d < HS; d += 128) vdst[d] = qkv_row[A + KV + (size_t)kvh * HS + d];
+}
 
 }  // namespace jh

@@ -1137,6 +1137,7 @@ struct jh_session {
     float* pb_ws = nullptr;   // split-K workspace of the BF16 prefill GEMM
     float *pb_att_o = nullptr, *pb_att_ml = nullptr;   // key-range split partials of the MFMA prefill attention
     struct TPPush* tp_push = nullptr;                  // set while a tensor-parallel token graph is captured: o-proj / down push their partials
+    float* p16_scores_b = nullptr;                     // reference-order prefill: score rows of a whole chunk [rows][n_heads][p16_sc_stride]
     uint8_t* tile_w = nullptr;                         // TILED_TRANSIENT: scratch for ONE weight in MFMA order (+ its scales)
     float* tile_s = nullptr;
     size_t tile_w_bytes = 0, tile_s_bytes = 0;
@@ -1562,9 +1563,20 @@ int layers_launch(jh_session* s, hipStream_t st, int pos_for_tap) {
 constexpr int PB_MAX_ROWS = 256;   // rows per chunk = the MFMA GEMM's M limit (8 tiles of 32)
 constexpr int PF_MAX_SPLIT = 8;    // key-range splits of the MFMA prefill attention
 
+// reference-order sessions: prompt rows through the M-row p16 GEMM (jh_p16.h) -- whole groups of 16 Q blocks in every K
+bool prefill_p16_ok(jh_session* s) {
+    static const int enabled = env_int("JH_P16_PREFILL", 1);
+    const jh_config& c = s->m->c;
+    if (!enabled || !s->strict || s->strict_legacy || c.weight_dtype != JH_DT_Q4) return false;
+    const int hs = c.head_size, A = c.n_heads * hs, group = c.n_heads / c.n_kv_heads;
+    if (c.embedding_length % 512 || c.hidden_length % 512 || A % 512 || c.hidden_length > 32768 || c.embedding_length > 32768 || A > 32768) return false;
+    return (hs == 128 || hs == 64) && (group == 1 || group == 2 || group == 4 || group == 8);
+}
 bool prefill_batch_ok(jh_session* s) {
     const jh_config& c = s->m->c;
-    if (s->prefill_batch_min <= 0 || s->tap_layer >= 0 || s->strict || (c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16)) return false;
+    if (s->prefill_batch_min <= 0 || s->tap_layer >= 0) return false;
+    if (s->strict) return prefill_p16_ok(s);
+    if (c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16) return false;
     const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
     if (c.embedding_length % 64 || c.hidden_length % 64 || A % 64 || (A + 2 * KV) % 32) return false;
     if (c.weight_dtype == JH_DT_Q4 && (c.embedding_length % 256 || c.hidden_length % 256 || A % 256)) return false;   // tiled MFMA GEMMs only
@@ -1869,13 +1881,120 @@ int prefill_layers(jh_session* s, int rows, int nkeys_bound, bool attn_mfma, hip
     }
     return JH_OK;
 }
+// ---- the same chunk in reference order (jh_p16.h): activation images per row, M-row p16 GEMMs, KV rows of the whole chunk, then
+// scores / softmax + value chains of every row in one launch each
+template <int PRO>
+int rows_act_p16_launch(jh_session* s, const float* x, int ldx, const float* nw, float eps, int K, int rows, hipStream_t st) {
+    RowsP16Params rp{x, ldx, nw, eps, K, (uint8_t*)s->pb_aq, s->pb_ad, K, K / QB};
+    const size_t lds = lds_bytes_p16(K);
+#define JH_ACT(UMV)                                                                                   \
+    {                                                                                                 \
+        JHCHK(allow_lds((rows_act_p16_kernel<PRO, UMV>), lds));                                       \
+        hipLaunchKernelGGL((rows_act_p16_kernel<PRO, UMV>), dim3(rows), dim3(P16_THREADS), lds, st, rp); \
+    }
+    if (K <= 8192) JH_ACT(2) else if (K <= 16384) JH_ACT(4) else JH_ACT(8)
+#undef JH_ACT
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+template <int EPI>
+int gemm_p16_launch(jh_session* s, const JWeight& W, const JWeight* W2, int N, int K, int rows, float* out, int ldc, const float* resid, int ldr,
+                    hipStream_t st) {
+    GemmP16Params g{(const uint8_t*)W.data, W.scales, W2 ? (const uint8_t*)W2->data : nullptr, W2 ? W2->scales : nullptr, K / 2, K / QB, N, K, rows,
+                    (const uint8_t*)s->pb_aq, s->pb_ad, K, K / QB, out, ldc, resid, ldr};
+    const int nq = (N + 3) / 4, gx = (nq + 7) / 8;
+#define JH_GEMM(MTV)                                                                                              \
+    {                                                                                                             \
+        const size_t lds = lds_bytes_gemm_p16(K, MTV);                                                            \
+        JHCHK(allow_lds((gemm_i8q4_p16_kernel<EPI, MTV>), lds));                                                  \
+        hipLaunchKernelGGL((gemm_i8q4_p16_kernel<EPI, MTV>), dim3(gx, (rows + MTV - 1) / MTV), dim3(P16_THREADS), lds, st, g); \
+    }
+    if (K <= 8192) JH_GEMM(16) else if (K <= 16384) JH_GEMM(8) else JH_GEMM(4)   // MT activation images of K + K/8 bytes each in LDS
+#undef JH_GEMM
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+int prefill_attn_p16_launch(jh_session* s, int rel, int rows, int start_pos, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.qkv = s->pb_qkv;
+    p.rope = m->rope;
+    p.kv_base = s->kv_slab + (size_t)(rel / s->layers_per_page) * s->n_ctx_alloc * s->page_elems;
+    p.page_elems = (long long)s->page_elems;
+    p.rel_layer_in_page = rel % s->layers_per_page;
+    p.ctx_per_page = s->ctx_per_page;
+    p.cpp_shift = -1;
+    for (int sh = 0; sh < 30; sh++)
+        if ((1 << sh) == s->ctx_per_page) p.cpp_shift = sh;
+    p.n_heads = c.n_heads; p.n_kv_heads = c.n_kv_heads; p.head_size = hs; p.kv_head_offset = m->kv_head_offset;
+    p.st = s->st; p.scale = m->attention_scale;
+    p.outf = s->pb_att;
+    p.batch = 1; p.batch_pos0 = start_pos; p.ldqkv = A + 2 * KV; p.ldo = A;
+    p.sc_batch = (long long)c.n_heads * s->p16_sc_stride;
+    const size_t lds_av = lds_bytes_attn_p16(s->max_ctx);
+    if (lds_av > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "reference-order attention: the score row of max_ctx positions must fit in LDS");
+    const dim3 grid_s(s->p16_att_splits, c.n_kv_heads, rows), grid_v(hs / 32, c.n_heads, rows);
+    const int ru = p16_av_rows(s->max_ctx);
+    if (hs == 128) hipLaunchKernelGGL((rows_rope_kv_p16_kernel<128>), dim3(rows, c.n_kv_heads), dim3(128), 0, st, p);
+    else hipLaunchKernelGGL((rows_rope_kv_p16_kernel<64>), dim3(rows, c.n_kv_heads), dim3(128), 0, st, p);
+    HIPCHK(hipGetLastError());
+#define JH_P16_AVB(HSV, RV)                                                                                                     \
+    if (hs == HSV && ru == RV) {                                                                                               \
+        JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                               \
+        hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores_b, s->p16_sc_stride); \
+    }
+#define JH_P16_ATTNB(HSV, GV)                                                                                                  \
+    if (hs == HSV && group == GV) {                                                                                            \
+        hipLaunchKernelGGL((attn_p16_scores_kernel<HSV, GV>), grid_s, dim3(P16_ATT_THREADS), 0, st, p, s->p16_scores_b, s->p16_sc_stride); \
+        HIPCHK(hipGetLastError());                                                                                             \
+        JH_P16_AVB(HSV, 2) JH_P16_AVB(HSV, 4) JH_P16_AVB(HSV, 8) JH_P16_AVB(HSV, 16)                                            \
+        HIPCHK(hipGetLastError());                                                                                             \
+        return JH_OK;                                                                                                          \
+    }
+    JH_P16_ATTNB(128, 4) JH_P16_ATTNB(128, 8) JH_P16_ATTNB(64, 4) JH_P16_ATTNB(128, 1) JH_P16_ATTNB(128, 2) JH_P16_ATTNB(64, 1) JH_P16_ATTNB(64, 2) JH_P16_ATTNB(64, 8)
+#undef JH_P16_ATTNB
+#undef JH_P16_AVB
+    return set_err(JH_ERR_UNSUPPORTED, "attention: head_size must be 64 or 128 and heads/kv_heads in {1,2,4,8}");
+}
+int prefill_layers_p16(jh_session* s, int rows, int start_pos, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
+    const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    for (int li = c.layer_start; li < c.layer_end; li++) {
+        const int rel = li - c.layer_start;
+        JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+        JWeight& F = m->qkv[(size_t)li];
+        if (!F.data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data || !W[JH_W_NORM1].data || !W[JH_W_NORM2].data)
+            return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": weights not set");
+        JHCHK((rows_act_p16_launch<PRO_RMS_Q8>(s, s->pb_x, E, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
+        JHCHK((gemm_p16_launch<EPI_STORE>(s, F, nullptr, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, 0, st)));
+        JHCHK(prefill_attn_p16_launch(s, rel, rows, start_pos, st));
+        JHCHK((rows_act_p16_launch<PRO_QUANT_Q8>(s, s->pb_att, A, nullptr, 0.f, A, rows, st)));
+        JHCHK((gemm_p16_launch<EPI_RESID>(s, W[JH_W_O], nullptr, E, A, rows, s->pb_x1, E, s->pb_x, E, st)));
+        JHCHK((rows_act_p16_launch<PRO_RMS_Q8>(s, s->pb_x1, E, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
+        JHCHK((gemm_p16_launch<EPI_SILU_MUL>(s, W[JH_W_GATE], &W[JH_W_UP], H, E, rows, s->pb_g, H, nullptr, 0, st)));
+        JHCHK((rows_act_p16_launch<PRO_QUANT_Q8>(s, s->pb_g, H, nullptr, 0.f, H, rows, st)));
+        JHCHK((gemm_p16_launch<EPI_RESID>(s, W[JH_W_DOWN], nullptr, E, H, rows, s->pb_x, E, s->pb_x1, E, st)));
+        JHCHK(trace_sync("prefill layer (reference order)", st));
+    }
+    return JH_OK;
+}
 // One chunk of `rows` prompt rows at positions [start_pos, start_pos+rows) through this shard's layers.
 int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool x_in_dev, int rows, int start_pos,
                   float* x_out, bool x_out_dev, hipStream_t st) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
     JHCHK(prefill_alloc(s));
-    JHCHK(ensure_all_tiled(s, st));
+    const bool p16 = s->strict != 0;                      // reference order: prefill_batch_ok() admitted the session via prefill_p16_ok()
+    if (!p16) JHCHK(ensure_all_tiled(s, st));
+    if (p16 && !s->p16_scores_b) {
+        const hipError_t e = hipMalloc(&s->p16_scores_b, (size_t)PB_MAX_ROWS * c.n_heads * s->p16_sc_stride * 4);
+        if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc score rows of a prompt chunk");
+    }
     const int E = c.embedding_length;
     if (tokens) {
         const JWeight& emb = m->global_w[JH_W_EMBED];
@@ -1896,7 +2015,9 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     const bool attn_mfma = prefill_attn_mfma(s, start_pos, rows);
     if (!attn_mfma && !prefill_chunk_fits(s, 0, bound)) bound = start_pos + rows;
     static const int use_graph = env_int("JH_PREFILL_GRAPH", 1);
-    if (use_graph && !env_int("JH_TRACE", 0)) {
+    if (p16) {
+        JHCHK(prefill_layers_p16(s, rows, start_pos, st));   // positions are launch arguments here: launched directly, no graph
+    } else if (use_graph && !env_int("JH_TRACE", 0)) {
         drop_stale_graphs(s);
         const uint64_t key = (uint64_t)rows | ((uint64_t)(attn_mfma ? 1 : 0) << 16) | ((uint64_t)bound << 32);
         auto it = s->pb_graphs.find(key);
@@ -2264,7 +2385,7 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     s->p16_sc_stride = (max_ctx + 63) & ~63;
     HIPCHK(hipMalloc(&s->p16_scores, (size_t)c.n_heads * s->p16_sc_stride * 4));
     if (s->strict && c.weight_dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "JH_STRICT_ORDER: strict-order kernels exist for JQ4 models only");
-    if (prefill_batch_ok(s)) {
+    if (!s->strict && prefill_batch_ok(s)) {
         // the MFMA-ordered weight copies of the prefill GEMM are made here, once per model, not inside the first prompt
         JHCHK(ensure_all_tiled(s, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -2320,7 +2441,7 @@ int jh_session_destroy(jh_session* s) {
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
-    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start, (void*)s->pb_att_o, (void*)s->pb_att_ml, (void*)s->tile_w, (void*)s->tile_s}) if (b) hipFree(b);
+    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start, (void*)s->pb_att_o, (void*)s->pb_att_ml, (void*)s->tile_w, (void*)s->tile_s, (void*)s->p16_scores_b}) if (b) hipFree(b);
     for (auto& kv : s->pb_graphs) hipGraphExecDestroy(kv.second);
     for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -2590,7 +2711,7 @@ static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in,
     if (prefill_batch_ok(s)) {
         while (n - done >= s->prefill_batch_min) {
             const int rows = n - done < PB_MAX_ROWS ? n - done : PB_MAX_ROWS;
-            if (!prefill_chunk_fits(s, start_pos + done, rows)) break;
+            if (!s->strict && !prefill_chunk_fits(s, start_pos + done, rows)) break;
             JHCHK(prefill_chunk(s, tokens ? tokens + done : nullptr, x_in ? x_in + (size_t)done * E : nullptr, x_in_dev, rows,
                                 start_pos + done, x_out ? x_out + (size_t)done * E : nullptr, x_out_dev, st));
             done += rows;

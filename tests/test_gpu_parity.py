@@ -175,6 +175,44 @@ def test_strict_order_real_shapes(gpu, oracle, name):
         layer_teacher_forced(hm, oracle, cfg, w, prompt[:12], 64, strict=True)
 
 
+def test_reference_order_prefill_in_batches_is_the_row_path_bit_for_bit(gpu, oracle, monkeypatch):
+    """Reference-order sessions run prompts through the M-row p16 GEMM (jh_p16.h: gemm_i8q4_p16_kernel + batched scores / value
+    launches).  Every (prompt row, weight row) pair keeps its own 16-lane chain fed in the same order, so the rows, the KV
+    pages they leave behind and everything decoded afterwards must equal the one-position-at-a-time path bit for bit --
+    across a chunk boundary (300 rows = 256 + 44), a ragged last row tile, KV context pages, and a continuation at
+    start_pos > 0."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.SMALL)
+    hm, om, w = _pair(cfg, 3, oracle)
+    prompt = S.prompt_tokens(cfg, n=300, seed=19)
+    monkeypatch.setenv("JH_PREFILL_BATCH_MIN", "0")            # rows one at a time
+    s_row = hm.session(512)
+    s_row.set_strict(True)
+    rows = s_row.forward(prompt, 0)
+    monkeypatch.delenv("JH_PREFILL_BATCH_MIN")
+    s_bat = hm.session(512)
+    s_bat.set_strict(True)
+    bat = s_bat.forward(prompt, 0)
+    np.testing.assert_array_equal(bat.view(np.uint32), rows.view(np.uint32))
+    s_two = hm.session(512)
+    s_two.set_strict(True)
+    a = s_two.forward(prompt[:100], 0)
+    b = s_two.forward(prompt[100:], 100)
+    np.testing.assert_array_equal(np.concatenate([a, b]).view(np.uint32), rows.view(np.uint32))
+    want = om.session().forward(prompt[:48], 0)                 # the oracle on the first rows (it is the slow one)
+    np.testing.assert_array_equal(bat[:48].view(np.uint32), want.view(np.uint32))
+    firsts, logits = [], []
+    for s in (s_row, s_bat, s_two):
+        t, l = s.sample(0.0, 0.5, want_logits=True)
+        firsts.append(t); logits.append(l)
+    assert firsts[0] == firsts[1] == firsts[2]
+    np.testing.assert_array_equal(logits[0].view(np.uint32), logits[1].view(np.uint32))
+    np.testing.assert_array_equal(logits[0].view(np.uint32), logits[2].view(np.uint32))
+    ids = [list(s.decode_n(firsts[0], prompt.size, 24)) for s in (s_row, s_bat, s_two)]   # reads the KV pages of all 300 positions
+    assert ids[0] == ids[1] == ids[2]
+    np.testing.assert_array_equal(s_row.logits().view(np.uint32), s_bat.logits().view(np.uint32))
+
+
 def test_strict_mode_rejects_bf16_models(gpu):
     from jlama_amd import _native as N, synthetic as S
     from jlama_amd.model import HipLlamaModel
