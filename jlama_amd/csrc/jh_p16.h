@@ -915,9 +915,12 @@ __device__ __forceinline__ void p16_quad_rows(int xk, const i32x2* pt_q, int row
         fmac_bcast<4 * K4 + 3>(acc[m], sp[m], f3);
     }
 }
-template <int EPI, int MT>
-__global__ __launch_bounds__(P16_THREADS) void gemm_i8q4_p16_kernel(GemmP16Params p) {
+// NW = waves (= row quads) per workgroup: they share the MT activation images in LDS; 16 waves put four on every SIMD, which this
+// VALU-bound body (pair-word reads, DPP operands, 3-wait-state dots) needs to keep the SIMDs issuing
+template <int EPI, int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_i8q4_p16_kernel(GemmP16Params p) {
     static_assert(MT <= 16, "one prompt row per lane of a 16-lane row in the epilogue");
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblk = p.K / QB, G = nblk >> 4;                  // host: nblk % 16 == 0
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -930,20 +933,20 @@ __global__ __launch_bounds__(P16_THREADS) void gemm_i8q4_p16_kernel(GemmP16Param
     const int row_stride = G * 64;
     {
         const int n16 = G * 32;                                // 16-byte chunks per image
-        for (int i = threadIdx.x; i < MT * n16; i += P16_THREADS) {
+        for (int i = threadIdx.x; i < MT * n16; i += NT) {
             const int m = i / n16, j = i - m * n16;
             int mm = m0 + m;
             mm = mm < p.M ? mm : p.M - 1;                      // rows past M replicate the last row (never stored)
             ((i32x4*)pts)[i] = ((const i32x4*)(p.apt + (size_t)mm * p.pt_stride))[j];
         }
-        for (int i = threadIdx.x; i < MT * nblk; i += P16_THREADS) {
+        for (int i = threadIdx.x; i < MT * nblk; i += NT) {
             const int m = i / nblk, j = i - m * nblk;
             int mm = m0 + m;
             mm = mm < p.M ? mm : p.M - 1;
             ds[i] = p.ad16[(size_t)mm * p.d_stride + j];
         }
     }
-    const int quad = blockIdx.x * (P16_THREADS / 64) + wave;
+    const int quad = blockIdx.x * NW + wave;
     int row = 4 * quad + r;
     const bool row_ok = row < p.nrows;
     row = row_ok ? row : p.nrows - 1;

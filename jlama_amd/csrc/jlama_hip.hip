@@ -1902,14 +1902,23 @@ int gemm_p16_launch(jh_session* s, const JWeight& W, const JWeight* W2, int N, i
                     hipStream_t st) {
     GemmP16Params g{(const uint8_t*)W.data, W.scales, W2 ? (const uint8_t*)W2->data : nullptr, W2 ? W2->scales : nullptr, K / 2, K / QB, N, K, rows,
                     (const uint8_t*)s->pb_aq, s->pb_ad, K, K / QB, out, ldc, resid, ldr};
-    const int nq = (N + 3) / 4, gx = (nq + 7) / 8;
-#define JH_GEMM(MTV)                                                                                              \
-    {                                                                                                             \
+    static const int nw_env = env_int("JH_P16_GEMM_WAVES", 16), mt_env = env_int("JH_P16_GEMM_MT", 0);
+    const int nq = (N + 3) / 4;
+    // MT activation images of K + K/8 bytes each in LDS.  16 would fit for K <= 8192 and halves the weight-unpack share, but it
+    // costs occupancy (116 VGPRs in the gate|up kernel, 74-147 KB of LDS: one workgroup per CU) and rounds 129 rows up to 144:
+    // measured on the 8B prompt 68.8 ms with MT = 16 where it fits, 59.9 ms with 8 everywhere (profiles/r03l_*)
+    int mt = K <= 16384 ? 8 : 4;
+    if (mt_env == 16 && K <= 8192) mt = 16;
+    else if (mt_env > 0 && mt_env < mt) mt = mt_env;
+    const int nw = nw_env >= 16 ? 16 : 8;
+    const int gx = (nq + nw - 1) / nw;
+#define JH_GEMM(MTV, NWV)                                                                                         \
+    if (mt == MTV && nw == NWV) {                                                                                 \
         const size_t lds = lds_bytes_gemm_p16(K, MTV);                                                            \
-        JHCHK(allow_lds((gemm_i8q4_p16_kernel<EPI, MTV>), lds));                                                  \
-        hipLaunchKernelGGL((gemm_i8q4_p16_kernel<EPI, MTV>), dim3(gx, (rows + MTV - 1) / MTV), dim3(P16_THREADS), lds, st, g); \
+        JHCHK(allow_lds((gemm_i8q4_p16_kernel<EPI, MTV, NWV>), lds));                                             \
+        hipLaunchKernelGGL((gemm_i8q4_p16_kernel<EPI, MTV, NWV>), dim3(gx, (rows + MTV - 1) / MTV), dim3(NWV * 64), lds, st, g); \
     }
-    if (K <= 8192) JH_GEMM(16) else if (K <= 16384) JH_GEMM(8) else JH_GEMM(4)   // MT activation images of K + K/8 bytes each in LDS
+    JH_GEMM(16, 16) JH_GEMM(8, 16) JH_GEMM(4, 16) JH_GEMM(16, 8) JH_GEMM(8, 8) JH_GEMM(4, 8)
 #undef JH_GEMM
     HIPCHK(hipGetLastError());
     return JH_OK;

@@ -13,7 +13,8 @@ w = ST.make_weights(cfg, seed=0, device=torch.device("cuda", 0))
 model = HipLlamaModel(cfg, w)
 prompt = S.prompt_tokens(cfg, n=128, seed=1234)
 res = {}
-for mode, env in (("batched", None), ("row by row", "0")):
+modes = (("batched", None),) if os.environ.get("SPB_SKIP_ROWS") else (("batched", None), ("row by row", "0"))
+for mode, env in modes:
     if env is None:
         os.environ.pop("JH_PREFILL_BATCH_MIN", None)
     else:
@@ -29,6 +30,8 @@ for mode, env in (("batched", None), ("row by row", "0")):
     res[mode] = (out, tok, logits)
     print(f"{name} reference order, {prompt.size}-row prompt, {mode}: {dt * 1e3:8.2f} ms", flush=True)
     s.close()
+if len(res) < 2:
+    sys.exit(0)
 a, b = res["batched"], res["row by row"]
 print("rows bit-identical:", bool(np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))), " first token equal:", a[1] == b[1],
       " logits bit-identical:", bool(np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))))
