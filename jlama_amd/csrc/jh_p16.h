@@ -180,12 +180,12 @@ struct ActRegsP16 {
     float xv[UM][8];
     float wv[UM][8];
 };
-template <int PRO, int UM>
+template <int PRO, int UM, int NT = P16_THREADS>
 __device__ __forceinline__ void stage_issue_p16(const GemvParams& p, ActRegsP16<UM>& r) {
     const int units = p.K / 8;
 #pragma unroll
     for (int u = 0; u < UM; u++) {
-        int unit = threadIdx.x + u * P16_THREADS;
+        int unit = threadIdx.x + u * NT;
         unit = unit < units ? unit : units - 1;             // branch-free (clamped): a guarded load is waited for at the end of its block
         const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
         r.xv[u][0] = xa.x; r.xv[u][1] = xa.y; r.xv[u][2] = xa.z; r.xv[u][3] = xa.w;
@@ -194,13 +194,13 @@ __device__ __forceinline__ void stage_issue_p16(const GemvParams& p, ActRegsP16<
     }
 }
 // RMSNorm scale factor of the row held in r (RMSNorm.java:41-49: float squares, double sum, /E, +eps, 1/sqrt in double)
-template <int UM>
+template <int UM, int NT = P16_THREADS>
 __device__ __forceinline__ float rms_factor_p16(const GemvParams& p, const ActRegsP16<UM>& r, double* red) {
     const int units = p.K / 8;
     double ss = 0.0;
 #pragma unroll
     for (int u = 0; u < UM; u++)
-        if ((int)threadIdx.x + u * P16_THREADS < units)
+        if ((int)threadIdx.x + u * NT < units)
 #pragma unroll
             for (int i = 0; i < 8; i++) ss += (double)(r.xv[u][i] * r.xv[u][i]);
     ss = block_sum_d(ss, red);
@@ -209,15 +209,15 @@ __device__ __forceinline__ float rms_factor_p16(const GemvParams& p, const ActRe
     ss = 1.0 / sqrt(ss);
     return (float)ss;
 }
-template <int PRO, int UM>
+template <int PRO, int UM, int NT = P16_THREADS>
 __device__ __forceinline__ void stage_finish_p16(const GemvParams& p, const ActP16& a, ActRegsP16<UM>& r) {
     static_assert(PRO == PRO_RMS_Q8 || PRO == PRO_QUANT_Q8, "p16 prologues: RMSNorm+Q8 or plain Q8");
     const int units = p.K / 8;
     float fs = 1.0f;
-    if (PRO == PRO_RMS_Q8) fs = rms_factor_p16<UM>(p, r, a.red);
+    if (PRO == PRO_RMS_Q8) fs = rms_factor_p16<UM, NT>(p, r, a.red);
 #pragma unroll
     for (int u = 0; u < UM; u++) {
-        const int unit = threadIdx.x + u * P16_THREADS;
+        const int unit = threadIdx.x + u * NT;
         if (unit < units) {
             float y[8];
 #pragma unroll
@@ -295,8 +295,8 @@ __device__ __forceinline__ float p16_scale_product(float da16, float sb) {
 // consumed in blocks of D (the host picks D | G, so a pass ends exactly at a block end and the ring needs no bounds checks).
 // `per` = row quads per task wave, `tw` = task waves per workgroup (the host sizes grid x tw x per so that every CU gets the same
 // number of row quads).
-template <int PRO, int EPI, int D, int UM>
-__global__ __launch_bounds__(P16_THREADS) void gemv_i8q4_p16_kernel(GemvParams p, int per, int tw) {
+template <int PRO, int EPI, int D, int UM, int NT = P16_THREADS>
+__global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per, int tw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblk = p.K / QB, G = (nblk + 15) >> 4;        // host: G % D == 0
     const ActP16 a = carve_p16(smem, nblk);
@@ -348,12 +348,12 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_i8q4_p16_kernel(GemvParams p
     if (items == 0) {
         // helper wave: its own copy of the prologue (same barriers).  The two paths must not join: hipcc computes ONE vmcnt per wait
         // and would size the working waves' waits for the path without ring loads, i.e. drain the ring inside the prologue.
-        stage_issue_p16<PRO, UM>(p, ar);
-        stage_finish_p16<PRO, UM>(p, a, ar);
+        stage_issue_p16<PRO, UM, NT>(p, ar);
+        stage_finish_p16<PRO, UM, NT>(p, a, ar);
         if constexpr (EPI == EPI_TP) tp_signal(p);       // every wave of the workgroup passes one tp_signal (its barrier)
         return;
     }
-    stage_issue_p16<PRO, UM>(p, ar);                        // activation loads first: vmcnt retires oldest-first
+    stage_issue_p16<PRO, UM, NT>(p, ar);                        // activation loads first: vmcnt retires oldest-first
     float rv = 0.0f;
     if (EPI == EPI_RESID) rv = resid_of_batch(q0);
 #pragma unroll
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_i8q4_p16_kernel(GemvParams p
         issue(wq[d], sq[d]);
         __builtin_amdgcn_sched_barrier(0);                  // request order = consumption order (the loop's vmcnt waits count on it)
     }
-    stage_finish_p16<PRO, UM>(p, a, ar);
+    stage_finish_p16<PRO, UM, NT>(p, a, ar);
 
     float acc = 0.0f, gres = 0.0f, gsel = 0.0f, usel = 0.0f;
     int cq = q0, cpass = 0, cg = 0;                         // compute cursor

@@ -1213,13 +1213,13 @@ int launch_gemv_f32q4_strict(const GemvParams& p, int* grid_out, hipStream_t st)
 // number of row quads: one 512-thread workgroup per CU, `tw` of its 8 waves own `per` row quads each (the others help
 // with the activation prologue only -- a 16-lane row per chain caps the useful waves at rows / 4).
 struct P16Plan { int grid, per, tw; };
-P16Plan p16_plan(int nrows, int wgs_per_cu) {
+P16Plan p16_plan(int nrows, int wgs_per_cu, int nwaves = 8) {
     const int nq = (nrows + 3) / 4;
     int grid = g_cu_count * wgs_per_cu;
     if (grid > nq) grid = nq;
     if (grid < 1) grid = 1;
     const int q_wg = (nq + grid - 1) / grid;
-    const int per = (q_wg + 7) / 8;
+    const int per = (q_wg + nwaves - 1) / nwaves;
     const int tw = (q_wg + per - 1) / per;
     return P16Plan{grid, per, tw};
 }
@@ -1235,9 +1235,18 @@ int p16_depth_for(int K, int want) {
 // UM = 8-element units of the activation row per thread, all held in registers (no load loop in the kernel): 2 (K <= 8192) / 4 for
 // the RMSNorm prologues, 4 (K <= 16384) / 8 for the plain-quantize ones
 template <int PRO, int EPI, int D>
-int launch_gemv_i8q4_p16_d(const GemvParams& p, const P16Plan& pl, hipStream_t st) {
+int launch_gemv_i8q4_p16_d(const GemvParams& p, const P16Plan& pl, bool wide, hipStream_t st) {
     const size_t lds = lds_bytes_p16(p.K);
     constexpr int UM_LO = (PRO == PRO_RMS_Q8) ? 2 : 4;
+    if constexpr (PRO == PRO_RMS_Q8 && EPI == EPI_SILU_MUL && D <= 4) {
+        if (wide && p.K <= 8192) {   // 16 waves: twice the row quads in flight per CU (gate|up has more than 8 per CU)
+            JHCHK(allow_lds((gemv_i8q4_p16_kernel<PRO, EPI, D, 1, 1024>), lds));
+            hipLaunchKernelGGL((gemv_i8q4_p16_kernel<PRO, EPI, D, 1, 1024>), dim3(pl.grid), dim3(1024), lds, st, p, pl.per, pl.tw);
+            HIPCHK(hipGetLastError());
+            g_last_gemv_grid = pl.grid;
+            return JH_OK;
+        }
+    }
     if (p.K <= UM_LO * 4096) {
         JHCHK(allow_lds((gemv_i8q4_p16_kernel<PRO, EPI, D, UM_LO>), lds));
         hipLaunchKernelGGL((gemv_i8q4_p16_kernel<PRO, EPI, D, UM_LO>), dim3(pl.grid), dim3(P16_THREADS), lds, st, p, pl.per, pl.tw);
@@ -1256,17 +1265,21 @@ int launch_gemv_i8q4_p16(const GemvParams& p, int depth, hipStream_t st) {
     // more than 8 row quads per CU (gate|up): two workgroups per CU, so that every SIMD has 3-4 waves to issue from -- the kernel
     // is as much VALU- as HBM-bound, and a wave alone issues one instruction per ~4 cycles
     static const int wgs_big = env_int("JH_P16_WGS_BIG", 1);   // measured on 8B gate|up: 22.2 us with two workgroups per CU, 21.3 with one
+    static const int waves_big = env_int("JH_P16_WAVES_BIG", 8);   // 16: one 1024-thread workgroup per CU for gate|up
     const int q_cu = ((p.nrows + 3) / 4 + g_cu_count - 1) / g_cu_count;
-    const P16Plan pl = p16_plan(p.nrows, q_cu > 8 && wgs_big > 1 ? wgs_big : 1);
+    const bool wide = PRO == PRO_RMS_Q8 && EPI == EPI_SILU_MUL && q_cu > 8 && waves_big >= 16 && p.K <= 8192;
+    const P16Plan pl = p16_plan(p.nrows, q_cu > 8 && wgs_big > 1 && !wide ? wgs_big : 1, wide ? 16 : 8);
     // ring depth by bytes in flight per CU (tw waves x D KiB): ~32 KiB is what a CU sustains; deeper rings only cost registers
     // (measured: q|k|v and gate|up with 6-7 task waves 4 > 8, the o- and down-projections with 4 task waves 8 / 7 > 4)
     if (pl.tw >= 6 && depth > 4) depth = 4;
+    static const int wide_d = env_int("JH_P16_WIDE_D", 4);
+    if (wide && depth > wide_d) depth = wide_d;
     switch (p16_depth_for(p.K, depth)) {
-        case 8: return launch_gemv_i8q4_p16_d<PRO, EPI, 8>(p, pl, st);
-        case 7: return launch_gemv_i8q4_p16_d<PRO, EPI, 7>(p, pl, st);
-        case 4: return launch_gemv_i8q4_p16_d<PRO, EPI, 4>(p, pl, st);
-        case 2: return launch_gemv_i8q4_p16_d<PRO, EPI, 2>(p, pl, st);
-        default: return launch_gemv_i8q4_p16_d<PRO, EPI, 1>(p, pl, st);
+        case 8: return launch_gemv_i8q4_p16_d<PRO, EPI, 8>(p, pl, wide, st);
+        case 7: return launch_gemv_i8q4_p16_d<PRO, EPI, 7>(p, pl, wide, st);
+        case 4: return launch_gemv_i8q4_p16_d<PRO, EPI, 4>(p, pl, wide, st);
+        case 2: return launch_gemv_i8q4_p16_d<PRO, EPI, 2>(p, pl, wide, st);
+        default: return launch_gemv_i8q4_p16_d<PRO, EPI, 1>(p, pl, wide, st);
     }
 }
 template <int PRO, int D>
