@@ -283,6 +283,16 @@ def run_single(args, cfg):
     assert toks.size == args.steps
     ev_ms, kernels = s.decode_stats()
     tps = args.steps / dt
+    # roofline of the dominant kernel (gate/up GEMV: 54% of the weight bytes), HIP events on the session's stream -- probed right
+    # after the timed decode, before the reference-order leg (a VALU-heavy prompt in front of it costs the probe ~0.6 us of clocks)
+    probe = {}
+    names = ["qkv", "attention", "o_proj", "gate_up", "down"]
+    is_q4 = cfg["weight_dtype"] == N.DT_Q4
+    if is_q4:
+        for i, nm in enumerate(names):
+            ms, b = s.kernel_bench(i, args.probe_iters)
+            probe[nm] = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
+        dom = probe["gate_up"]
     # ---- the same K steps in REFERENCE ORDER (jh_p16.h: every float accumulation in the Panama provider's order; ids and logits
     # bit-identical to the oracle, see parity_full_size): timed exactly like `value`, in this same process
     strict = None
@@ -314,15 +324,6 @@ def run_single(args, cfg):
                   "event_ms_per_token": round(sev_ms, 4), "kernels_per_token": skernels, "kernels": sprobe,
                   "note": "reference-order kernels (jh_p16.h): bit-identical ids and logits vs the Panama-order oracle "
                           "(parity_full_size.strict_order), same K steps, same bracket as `value`"}
-    # roofline of the dominant kernel (gate/up GEMV: 54% of the weight bytes), HIP events on the session's stream
-    probe = {}
-    names = ["qkv", "attention", "o_proj", "gate_up", "down"]
-    is_q4 = cfg["weight_dtype"] == N.DT_Q4
-    if is_q4:
-        for i, nm in enumerate(names):
-            ms, b = s.kernel_bench(i, args.probe_iters)
-            probe[nm] = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
-        dom = probe["gate_up"]
     wbytes = S.weight_bytes(cfg)
     kvb = S.kv_bytes_per_position(cfg)
     mean_pos = prompt.size + (args.steps - 1) / 2.0
@@ -434,7 +435,7 @@ def run_one_process(args, cfg):
                                            "traffic": None},
                pipeline_roofline={"achieved_GBps_per_gpu": round(bytes_per_token * value / 1e9 / n, 1),
                                   "frac_of_8TBps": round(bytes_per_token * value / 1e9 / n / HBM_PEAK_GBS, 4)},
-               cpu_baseline=cpu)
+               cpu_baseline=cpu, tensor_parallel=r.get("tensor_parallel"))
     return out, 0
 
 

@@ -234,10 +234,15 @@ def tp_shard_config(cfg, rank, size):
     return c, rank * c["n_kv_heads"]
 
 
+def _contig(a):
+    """contiguous copy of a window: numpy (host weights) or torch (weights generated on a device)"""
+    return a.contiguous() if hasattr(a, "contiguous") else np.ascontiguousarray(a)
+
+
 def _rows(w, r0, n):
     out = dict(w)
-    out["data"] = np.ascontiguousarray(w["data"][r0:r0 + n])
-    out["scales"] = None if w.get("scales") is None else np.ascontiguousarray(w["scales"][r0:r0 + n])
+    out["data"] = _contig(w["data"][r0:r0 + n])
+    out["scales"] = None if w.get("scales") is None else _contig(w["scales"][r0:r0 + n])
     out["shape"] = (n, w["shape"][1])
     return out
 
@@ -248,17 +253,28 @@ def _cols(w, c0, n):
     out = dict(w)
     if w["dtype"] == N.DT_Q4:
         assert c0 % 32 == 0 and n % 32 == 0
-        out["data"] = np.ascontiguousarray(w["data"][:, c0 // 2:(c0 + n) // 2])
-        out["scales"] = np.ascontiguousarray(w["scales"][:, c0 // 32:(c0 + n) // 32])
+        out["data"] = _contig(w["data"][:, c0 // 2:(c0 + n) // 2])
+        out["scales"] = _contig(w["scales"][:, c0 // 32:(c0 + n) // 32])
     else:
-        out["data"] = np.ascontiguousarray(w["data"][:, c0:c0 + n])
+        out["data"] = _contig(w["data"][:, c0:c0 + n])
     out["shape"] = (w["shape"][0], n)
     return out
 
 
-def tp_shard_weights(cfg, weights, rank, size):
-    """The windows of `weights` (full model, host arrays) that model shard `rank` holds.  Norm weights, the embedding
-    table and the LM head are replicated (every shard computes the same residual stream; rank 0 samples)."""
+def tp_shard_weights(cfg, weights, rank, size, device=None):
+    """The windows of `weights` (full model; host arrays, or torch tensors resident on a GPU) that model shard `rank` holds.
+    Norm weights, the embedding table and the LM head are replicated (every shard computes the same residual stream; rank 0
+    samples).  device: torch device the windows are moved to (torch weights only: a shard on another GPU than the generator's)."""
+    if device is not None:
+        out = tp_shard_weights(cfg, weights, rank, size)
+        moved = {}
+        for k, w in out.items():
+            w = dict(w)
+            for f in ("data", "scales"):
+                if w.get(f) is not None and hasattr(w[f], "to"):
+                    w[f] = w[f].to(device)
+            moved[k] = w
+        return moved
     from . import synthetic as S
     hs = cfg["head_size"]
     A, KV, H = cfg["n_heads"] * hs // size, cfg["n_kv_heads"] * hs // size, cfg["hidden_length"] // size
@@ -427,12 +443,58 @@ def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=
     if cfg["weight_dtype"] == N.DT_Q4:         # dominant kernel (gate|up GEMV) on stage 0's layers, HIP events on its stream
         ms, b = pipes[0].sessions[0].kernel_bench(3, probe_iters)
         probe = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
-    return {"mode": "one process, %d devices, hipMemcpyPeerAsync hops ordered by events" % n, "devices": devices,
+    tp = None
+    if n > 1 and cfg["weight_dtype"] == N.DT_Q4 and not os.environ.get("JH_BENCH_NO_TP_LEG"):
+        for p in pipes:
+            p.close()
+        pipes, models = [], None
+        try:
+            tp = one_process_tp_leg(cfg, devices, prompt, steps)
+        except Exception as e:   # noqa: BLE001 -- an optional leg must never cost the line
+            tp = {"error": repr(e)[:400]}
+    return {"mode": "one process, %d devices, hipMemcpyPeerAsync hops ordered by events" % n, "devices": devices, "tensor_parallel": tp,
             "single_stream_tokens_per_s": round(steps / dt_single, 2), "single_stream_ms_per_token": round(dt_single / steps * 1e3, 4),
             "aggregate_tokens_per_s": round(per_session * n / dt_agg, 2), "aggregate_s": dt_agg, "sessions": n,
             "steps_per_session": per_session, "sessions_agree": bool(same), "peer_access": pipes[0].peer_access(),
             "prefill_ms_per_session": round(prefill_ms, 2), "prompt_rows": int(prompt.size), "gate_up_probe": probe,
             "first_ids": [int(t) for t in toks[:8]]}
+
+
+def one_process_tp_leg(cfg, devices, prompt, steps):
+    """The head-split (tensor-parallel) group over the same devices, one shard per device (jh_tp_group_*: one graph replay per
+    shard and token, partial rows pushed into every shard's slot over xGMI, summed in shard order): the single-stream decode
+    rate -- the one number that CAN grow with the GPU count (a layer-split stream cannot).  The full model is
+    generated on the first device and every shard's windows are copied to its own device."""
+    import torch
+    from . import synthetic_torch as ST
+    from .model import HipLlamaModel, HipTPGroup
+    n = len(devices)
+    if cfg["n_kv_heads"] % n or cfg["n_heads"] % n:
+        return {"skipped": f"{cfg['n_kv_heads']} kv heads do not split over {n} shards (the reference caps shards at the kv head count)"}
+    torch.cuda.set_device(devices[0])
+    w = ST.make_weights(cfg, seed=0, device=f"cuda:{devices[0]}")
+    torch.cuda.synchronize()
+    models = []
+    for r, dev in enumerate(devices):
+        lc, off = tp_shard_config(cfg, r, n)
+        sw = tp_shard_weights(cfg, w, r, n, device=torch.device("cuda", dev))
+        torch.cuda.synchronize()
+        models.append(HipLlamaModel(lc, sw, device=dev, kv_head_offset=off))
+        del sw
+    del w
+    torch.cuda.empty_cache()
+    n_prompt = min(int(prompt.size), 16)                     # the group feeds prompt rows one at a time (event-ordered loop)
+    grp = HipTPGroup(models, n_prompt + steps + 16)
+    grp.forward(prompt[:n_prompt], 0)
+    first = grp.sample()
+    grp.decode_n(first, n_prompt, min(8, steps))             # graph capture, untimed
+    t0 = time.perf_counter()
+    ids = grp.decode_n(first, n_prompt, steps)
+    dt = time.perf_counter() - t0
+    grp.close()
+    return {"shards": n, "devices": list(devices), "single_stream_tokens_per_s": round(len(ids) / dt, 2), "steps": int(len(ids)),
+            "prompt_rows": n_prompt, "first_ids": [int(t) for t in ids[:8]],
+            "note": "one-process tensor-parallel group, one head-split shard per device; 2 meetings per layer over xGMI peer stores"}
 
 
 def multi_gpu_extras(args, cfg, gate_up_probe, device_index=0):
@@ -588,14 +650,14 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
                 env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
                 r = subprocess.run([sys.executable, "-m", "jlama_amd.distributed", "--one-process", "--config", args.config, "--gpus", str(world),
                                     "--steps", str(args.steps), "--warmup", str(args.warmup), "--prompt", str(args.prompt)],
-                                   capture_output=True, text=True, timeout=240, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                                   capture_output=True, text=True, timeout=420, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
                 one_proc = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or "")[-400:]}
             except Exception as e:   # noqa: BLE001 -- the contract line must be printed whatever this optional leg does
                 one_proc = {"error": repr(e)[:400]}
             store.set("jh_one_process_leg_done", "1")
         else:
             try:
-                store.wait(["jh_one_process_leg_done"], timedelta(seconds=300))
+                store.wait(["jh_one_process_leg_done"], timedelta(seconds=480))
             except Exception:   # noqa: BLE001 -- fall through to the collective barrier below
                 pass
     dist.barrier()
@@ -636,7 +698,8 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
                "pipeline_roofline": {"achieved_GBps_per_gpu": round(bytes_per_token * tps / 1e9 / world, 1),
                                      "frac_of_8TBps": round(bytes_per_token * tps / 1e9 / world / 8000.0, 4),
                                      "note": "per-GPU average: algorithmic bytes of all sessions / time / GPUs"},
-               "cpu_baseline": cpu_base, "one_process_pipeline": one_proc}
+               "cpu_baseline": cpu_base, "one_process_pipeline": one_proc,
+               "tensor_parallel": (one_proc or {}).get("tensor_parallel") if isinstance(one_proc, dict) else None}
     dist.destroy_process_group()
     # RCCL prints its version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise land AFTER
     # the JSON line at exit: flush it now so that the contract line is the last thing on stdout
@@ -651,6 +714,7 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
 if __name__ == "__main__":
     import argparse
     import json
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # only matters when several shards share one device (loopback runs)
     ap = argparse.ArgumentParser()
     ap.add_argument("--one-process", action="store_true")
     ap.add_argument("--config", default="LLAMA3_8B")

@@ -1067,6 +1067,21 @@ def test_rccl_world1_stream_ordered_hosts(gpu, oracle):
         dist.destroy_process_group()
 
 
+def test_one_process_bench_host_with_its_tensor_parallel_leg(gpu):
+    """What a bare `python bench.py --gpus N` measures (distributed.one_process_pipeline_bench), here with two stages / two
+    head-split shards on ONE device: the layer-split pipeline (single stream + N sessions in flight, all sessions agreeing)
+    and the tensor-parallel group over the same devices, whose weights are generated on the first device and windowed onto
+    each shard's device."""
+    from jlama_amd import distributed as D
+    r = D.one_process_pipeline_bench("TINY", 2, 16, 4, 8, devices=[0, 0], probe_iters=1)
+    assert r["sessions"] == 2 and r["sessions_agree"] is True
+    assert r["single_stream_tokens_per_s"] > 0 and r["aggregate_tokens_per_s"] > 0
+    assert list(r["peer_access"]) == [None, None]                  # both hops stay on the device
+    tp = r["tensor_parallel"]
+    assert "error" not in tp, tp
+    assert tp["shards"] == 2 and tp["steps"] == 16 and tp["single_stream_tokens_per_s"] > 0
+
+
 @pytest.mark.parametrize("size,mode", [(2, "fast"), (4, "fast"), (2, "fast-unfused"), (2, "strict"), (4, "strict"), (2, "strict-unfused")])
 def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, monkeypatch, size, mode):
     """f2: jh_tp_group_* -- all head-split shards in one process (here on one device), the two reductions of a layer as
