@@ -443,6 +443,7 @@ def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=
     if cfg["weight_dtype"] == N.DT_Q4:         # dominant kernel (gate|up GEMV) on stage 0's layers, HIP events on its stream
         ms, b = pipes[0].sessions[0].kernel_bench(3, probe_iters)
         probe = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
+    peer_access = pipes[0].peer_access()
     tp = None
     if n > 1 and cfg["weight_dtype"] == N.DT_Q4 and not os.environ.get("JH_BENCH_NO_TP_LEG"):
         for p in pipes:
@@ -455,7 +456,7 @@ def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=
     return {"mode": "one process, %d devices, hipMemcpyPeerAsync hops ordered by events" % n, "devices": devices, "tensor_parallel": tp,
             "single_stream_tokens_per_s": round(steps / dt_single, 2), "single_stream_ms_per_token": round(dt_single / steps * 1e3, 4),
             "aggregate_tokens_per_s": round(per_session * n / dt_agg, 2), "aggregate_s": dt_agg, "sessions": n,
-            "steps_per_session": per_session, "sessions_agree": bool(same), "peer_access": pipes[0].peer_access(),
+            "steps_per_session": per_session, "sessions_agree": bool(same), "peer_access": peer_access,
             "prefill_ms_per_session": round(prefill_ms, 2), "prompt_rows": int(prompt.size), "gate_up_probe": probe,
             "first_ids": [int(t) for t in toks[:8]]}
 
