@@ -269,6 +269,19 @@ int jh_tp_group_forward(jh_tp_group* g, const int32_t* tokens, int n, int start_
 int jh_tp_group_sample(jh_tp_group* g, int32_t* next_token);
 /* n greedy decode steps, everything queued without a host round trip; out_tokens: HOST [n] */
 int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int n, int32_t* out_tokens);
+/* The same group with ONE PROCESS PER SHARD (one rank per GPU; the reference's one-Worker-per-range shape, Worker.java:193-248):
+ * a rank holds its shard only and addresses the other ranks' slot / flag / mailbox buffers through hipIpc mappings.
+ *   create  -> this rank's buffers;   handles -> 192 bytes (three hipIpcMemHandle_t) for the host side to exchange (any
+ *   transport: jlama_amd/distributed.py all_gathers them);   connect <- the n_ranks * 192 bytes of all ranks, in rank order;
+ *   decode_n: every rank calls it with the same (first_token, start_pos, n) after the prompt rows (jh_tp_attn / jh_tp_ffn /
+ *   jh_tp_finish_layer with the host's all-reduce, as before): one captured graph per token and rank, partial rows pushed into
+ *   every rank's slot by the o-proj / down GEMVs, shard-ordered sums, sampled id through mailboxes -- no collective library on
+ *   the data path, nothing on the host inside a token.  out_tokens (HOST [n]) is filled on rank 0 only.  Destroy with
+ *   jh_tp_group_destroy. */
+int jh_tp_rank_create(jh_session* shard, int rank, int n_ranks, jh_tp_group** out);
+int jh_tp_rank_handles(jh_tp_group* g, void* out192);
+int jh_tp_rank_connect(jh_tp_group* g, const void* all_handles);
+int jh_tp_rank_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int n, int32_t* out_tokens);
 
 /* ---- One-process layer-sharded pipeline (BASELINE north_star: "one-process layer sharding across the GPUs of
  * a single node"): stage k is a session of a model created with its own [layer_start, layer_end) on the device that was

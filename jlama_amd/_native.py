@@ -123,6 +123,10 @@ _PROTOS = {
     "jh_tp_group_forward": (_i, [_p, _p, _i, _i]),
     "jh_tp_group_sample": (_i, [_p, _p]),
     "jh_tp_group_decode_n": (_i, [_p, _i, _i, _i, _p]),
+    "jh_tp_rank_create": (_i, [_p, _i, _i, _p]),
+    "jh_tp_rank_handles": (_i, [_p, _p]),
+    "jh_tp_rank_connect": (_i, [_p, _p]),
+    "jh_tp_rank_decode_n": (_i, [_p, _i, _i, _i, _p]),
     "jh_pipeline_create": (_i, [_p, _i, _p]),
     "jh_pipeline_destroy": (_i, [_p]),
     "jh_pipeline_peer_access": (_i, [_p, _p, _i]),

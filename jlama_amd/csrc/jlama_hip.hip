@@ -3058,6 +3058,13 @@ struct jh_tp_group {
     std::vector<hipGraphExec_t> exec[N_ATTN_VARIANTS];
     int graphs_strict = -1, graphs_version = -1;
     bool graph_ok = true;                      // false after a wait timed out once: this group stays on the event-ordered loop
+    // one process per shard (jh_tp_rank_*): only shard `local` lives here, the others' slot / flag / mailbox buffers are mapped
+    // through hipIpc handles (slots_of / flags_of / mail_of[j] = shard j's buffer as addressable from this process)
+    int local = -1;
+    std::vector<float*> slots_of;
+    std::vector<unsigned*> flags_of;
+    std::vector<TPMail*> mail_of;
+    std::vector<void*> ipc_open;               // mappings to close
 };
 // memory that kernels of several devices meet in: fine-grained (coherent at system scope inside a kernel) where the runtime
 // offers it, plain device memory otherwise (enough when all shards share one device)
@@ -3069,6 +3076,7 @@ static hipError_t tp_shared_malloc(void** p, size_t bytes) {
 int jh_tp_group_destroy(jh_tp_group* g) {
     if (!g) return JH_OK;
     for (size_t k = 0; k < g->sh.size(); k++) {
+        if (!g->sh[k]) continue;               // rank mode: the other shards live in other processes
         hipSetDevice(g->sh[k]->m->device);
         hipStreamSynchronize(g->sh[k]->stream);
         if (k < g->part.size() && g->part[k]) hipFree(g->part[k]);
@@ -3087,7 +3095,11 @@ int jh_tp_group_destroy(jh_tp_group* g) {
         if (k < g->evB.size() && g->evB[k]) hipEventDestroy(g->evB[k]);
         if (k < g->evTok.size() && g->evTok[k]) hipEventDestroy(g->evTok[k]);
     }
-    if (g->mails_dev) { hipSetDevice(g->sh[0]->m->device); hipFree(g->mails_dev); }
+    for (void* p : g->ipc_open) hipIpcCloseMemHandle(p);
+    if (g->mails_dev) {
+        if (g->sh[0]) hipSetDevice(g->sh[0]->m->device);
+        hipFree(g->mails_dev);
+    }
     delete g;
     return JH_OK;
 }
@@ -3423,6 +3435,133 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
     HIPCHK(hipMemcpy(&hs, s0->st, sizeof(hs), hipMemcpyDeviceToHost));
     s0->generated = hs.step < n ? hs.step : n;
     HIPCHK(hipMemcpy(out_tokens, s0->out_tokens, (size_t)s0->generated * sizeof(int), hipMemcpyDeviceToHost));
+    return JH_OK;
+}
+
+// ---- The same group with ONE PROCESS PER SHARD (the reference's one-Worker-per-range shape; rank-per-GPU launches): a rank holds
+// its shard only and maps the other ranks' slot / flag / mailbox buffers through hipIpc handles the host side exchanges (192
+// bytes per rank, any transport: torch.distributed all_gather in jlama_amd/distributed.py).  The token graph is the group's
+// (tp_build_graph): partial rows pushed into every rank's slot by the o-proj / down GEMVs, flags, shard-ordered sums, the
+// sampled id through mailboxes -- no collective library on the data path, no host inside a token.
+int jh_tp_rank_create(jh_session* shard, int rank, int n_ranks, jh_tp_group** out) {
+    if (!shard || !out || n_ranks <= 0 || n_ranks > 64 || rank < 0 || rank >= n_ranks) return set_err(JH_ERR_INVALID, "tp_rank_create: bad argument");
+    const jh_config& c = shard->m->c;
+    if (c.layer_start != 0 || c.layer_end != c.n_layers) return set_err(JH_ERR_INVALID, "tp_rank_create: the shard must hold all layers (head split)");
+    if (!shard->m->global_w[JH_W_EMBED].data) return set_err(JH_ERR_INVALID, "tp_rank_create: every shard needs the embedding table");
+    HIPCHK(hipSetDevice(shard->m->device));
+    jh_tp_group* g = new jh_tp_group();
+    const int N = n_ranks, k = rank;
+    const size_t E = (size_t)c.embedding_length;
+    g->local = k;
+    g->nwg = (int)((E + 255) / 256);
+    g->sh.assign(N, nullptr); g->part.assign(N, nullptr); g->red.assign(N, nullptr); g->slots.assign(N, nullptr);
+    g->peers.assign(N, nullptr); g->flags.assign(N, nullptr); g->peers_f.assign(N, nullptr); g->mail.assign(N, nullptr); g->seq.assign(N, nullptr);
+    g->slots_of.assign(N, nullptr); g->flags_of.assign(N, nullptr); g->mail_of.assign(N, nullptr);
+    for (int v = 0; v < N_ATTN_VARIANTS; v++) { g->graph[v].assign(N, nullptr); g->exec[v].assign(N, nullptr); }
+    g->sh[k] = shard;
+    // the buffers other ranks' kernels store into: fine-grained like the one-process group's (what RCCL shares over IPC too)
+    const bool ok = hipMalloc(&g->part[k], E * 4) == hipSuccess && tp_shared_malloc((void**)&g->slots[k], 2 * (size_t)N * E * 4) == hipSuccess &&
+                    tp_shared_malloc((void**)&g->flags[k], 2 * (size_t)N * TP_MAX_FLAGS * 4) == hipSuccess &&
+                    hipMemset(g->flags[k], 0, 2 * (size_t)N * TP_MAX_FLAGS * 4) == hipSuccess &&
+                    tp_shared_malloc((void**)&g->mail[k], 4096) == hipSuccess && hipMemset(g->mail[k], 0, 4096) == hipSuccess &&
+                    hipMalloc(&g->seq[k], 64) == hipSuccess && hipMemset(g->seq[k], 0, 64) == hipSuccess &&
+                    hipMalloc(&g->peers[k], 2 * (size_t)N * sizeof(float*)) == hipSuccess &&
+                    hipMalloc(&g->peers_f[k], 2 * (size_t)N * sizeof(unsigned*)) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); jh_tp_group_destroy(g); return set_err(JH_ERR_OOM, "tp_rank_create: buffers"); }
+    g->slots_of[k] = g->slots[k]; g->flags_of[k] = g->flags[k]; g->mail_of[k] = g->mail[k];
+    HIPCHK(hipDeviceSynchronize());
+    *out = g;
+    return JH_OK;
+}
+int jh_tp_rank_handles(jh_tp_group* g, void* out192) {
+    if (!g || g->local < 0 || !out192) return set_err(JH_ERR_INVALID, "tp_rank_handles: bad argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+    const int k = g->local;
+    HIPCHK(hipSetDevice(g->sh[k]->m->device));
+    hipIpcMemHandle_t h[3];
+    HIPCHK(hipIpcGetMemHandle(&h[0], g->slots[k]));
+    HIPCHK(hipIpcGetMemHandle(&h[1], g->flags[k]));
+    HIPCHK(hipIpcGetMemHandle(&h[2], g->mail[k]));
+    memcpy(out192, h, sizeof(h));
+    return JH_OK;
+}
+int jh_tp_rank_connect(jh_tp_group* g, const void* all_handles) {
+    if (!g || g->local < 0 || !all_handles) return set_err(JH_ERR_INVALID, "tp_rank_connect: bad argument");
+    const int N = (int)g->sh.size(), k = g->local;
+    const size_t E = (size_t)g->sh[k]->m->c.embedding_length;
+    HIPCHK(hipSetDevice(g->sh[k]->m->device));
+    const hipIpcMemHandle_t* h = (const hipIpcMemHandle_t*)all_handles;
+    for (int j = 0; j < N; j++) {
+        if (j == k) continue;
+        void* p[3] = {nullptr, nullptr, nullptr};
+        for (int i = 0; i < 3; i++) {
+            const hipError_t e = hipIpcOpenMemHandle(&p[i], h[3 * j + i], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { (void)hipGetLastError(); return set_err(JH_ERR_HIP, std::string("tp_rank_connect: hipIpcOpenMemHandle: ") + hipGetErrorString(e)); }
+            g->ipc_open.push_back(p[i]);
+        }
+        g->slots_of[j] = (float*)p[0]; g->flags_of[j] = (unsigned*)p[1]; g->mail_of[j] = (TPMail*)p[2];
+    }
+    std::vector<float*> hs(2 * (size_t)N);     // this shard's slot on shard j, round r:  slots_of[j] + (r*N + k)*E
+    std::vector<unsigned*> hf(2 * (size_t)N);
+    for (int r = 0; r < 2; r++)
+        for (int j = 0; j < N; j++) {
+            hs[(size_t)r * N + j] = g->slots_of[j] + ((size_t)r * N + k) * E;
+            hf[(size_t)r * N + j] = g->flags_of[j] + ((size_t)r * N + k) * TP_MAX_FLAGS;
+        }
+    HIPCHK(hipMemcpy(g->peers[k], hs.data(), hs.size() * sizeof(float*), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->peers_f[k], hf.data(), hf.size() * sizeof(unsigned*), hipMemcpyHostToDevice));
+    if (k == 0 && N > 1) {
+        std::vector<TPMail*> hm;
+        for (int j = 1; j < N; j++) hm.push_back(g->mail_of[j]);
+        HIPCHK(hipMalloc(&g->mails_dev, hm.size() * sizeof(TPMail*)));
+        HIPCHK(hipMemcpy(g->mails_dev, hm.data(), hm.size() * sizeof(TPMail*), hipMemcpyHostToDevice));
+    }
+    return JH_OK;
+}
+// n greedy steps from the row every rank holds (s->x is NOT used: rank 0 embeds first_token, the others receive it through their
+// mailbox like every later id).  Every rank calls it with the same arguments; out_tokens (HOST [n]) is filled on rank 0 only.
+int jh_tp_rank_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int n, int32_t* out_tokens) {
+    if (!g || g->local < 0 || n <= 0 || start_pos < 0) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: bad argument");
+    const int N = (int)g->sh.size(), k = g->local;
+    jh_session* s = g->sh[k];
+    if (k == 0 && !out_tokens) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: rank 0 needs out_tokens");
+    if (start_pos + n > s->max_ctx) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: positions beyond max_ctx");
+    JHCHK(check_positions(s, start_pos + n - 1));
+    if (first_token < 0 || first_token >= s->m->c.vocab_size) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: token id out of range");
+    if (k == 0 && (!lm_head_weight(s->m)->data || !s->m->global_w[JH_W_FINALNORM].data)) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: rank 0 needs the output weights");
+    if (N > 1 && !g->peers[k]) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: not connected");
+    HIPCHK(hipSetDevice(s->m->device));
+    if (k == 0) JHCHK(ensure_out_tokens(s, n));
+    for (int v = 0; v < N_ATTN_VARIANTS; v++)
+        if (attn_variant_in_range(s, v, start_pos, start_pos + n - 1)) JHCHK(tp_build_graph(g, k, v));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const JWeight& emb = s->m->global_w[JH_W_EMBED];
+    const int E = s->m->c.embedding_length;
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, s->stream, s->st, start_pos, first_token, 0);
+    if (k == 0) {
+        hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(256), 0, s->stream, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                           (const DecodeState*)s->st, E, s->x);
+    } else {
+        unsigned cur = 0;
+        HIPCHK(hipMemcpy(&cur, g->seq[k], sizeof(cur), hipMemcpyDeviceToHost));
+        TPMail m0{first_token, start_pos, cur, 0};
+        HIPCHK(hipMemcpy(g->mail[k], &m0, sizeof(m0), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < n; i++) HIPCHK(hipGraphLaunch(g->exec[attn_variant_for(s, start_pos + i)][k], s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    unsigned w2[2] = {0, 0};
+    HIPCHK(hipMemcpy(w2, g->seq[k], sizeof(w2), hipMemcpyDeviceToHost));
+    if (w2[1]) {
+        HIPCHK(hipMemset((char*)g->seq[k] + 4, 0, 4));
+        return set_err(JH_ERR_HIP, "tp_rank_decode_n: this rank waited for a peer that never arrived (is every rank decoding the same steps?)");
+    }
+    if (k == 0) {
+        DecodeState hs;
+        HIPCHK(hipMemcpy(&hs, s->st, sizeof(hs), hipMemcpyDeviceToHost));
+        s->generated = hs.step < n ? hs.step : n;
+        HIPCHK(hipMemcpy(out_tokens, s->out_tokens, (size_t)s->generated * sizeof(int), hipMemcpyDeviceToHost));
+    }
     return JH_OK;
 }
 

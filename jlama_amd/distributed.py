@@ -388,6 +388,61 @@ def tp_generate(dist, engine, rank, prompt, n_gen, cfg, device, dtype):
     return np.asarray(out, dtype=np.int32)
 
 
+def tp_generate_ipc(dist, engine, rank, size, prompt, n_gen, cfg, device, dtype):
+    """tp_generate with the decode steps on IPC-mapped peer memory instead of all-reduces: the prompt rows go through the
+    all-reduce host above (one position at a time), rank 0 samples the first id, then every rank replays the tensor-parallel
+    group's token graph (jh_tp_rank_*: partial rows pushed into every rank's slot over xGMI, shard-ordered sums, ids through
+    device mailboxes).  The only collectives are the 192-byte handle exchange and the broadcast of the first id."""
+    import torch
+    from .model import HipTPRank
+    buf = torch.empty(cfg["embedding_length"], dtype=dtype, device=device)
+    layers = (0, cfg["n_layers"])
+    for pos, t in enumerate(prompt):
+        tp_forward_row(dist, engine, int(t), pos, layers, buf)
+    tok = torch.zeros(1, dtype=torch.int32, device=device)
+    with engine.stream_context():
+        if rank == 0:
+            tok[0] = engine.sample()
+        dist.broadcast(tok, src=0)
+        first = int(tok.item())
+    tpr = HipTPRank(engine.s, rank, size)
+    xdev = device if dist.get_backend() == "nccl" else torch.device("cpu")    # (gloo gathers host tensors only)
+    mine = torch.frombuffer(bytearray(tpr.handles()), dtype=torch.uint8).to(xdev)
+    gathered = [torch.empty_like(mine) for _ in range(size)]
+    dist.all_gather(gathered, mine)
+    tpr.connect(b"".join(bytes(g.cpu().numpy().tobytes()) for g in gathered))
+    dist.barrier()                                   # every rank has mapped every buffer before anyone stores into one
+    ids = tpr.decode_n(first, len(prompt), n_gen - 1) if n_gen > 1 else np.zeros(0, np.int32)
+    dist.barrier()                                   # nobody unmaps while a peer's last graph may still be storing
+    tpr.close()
+    return np.concatenate([[first], ids]).astype(np.int32) if rank == 0 else None
+
+
+def _tp_ipc_selftest(rank, world, port, n_gen, strict):
+    """One rank of tests/test_gpu_model.py::test_rank_per_process_tensor_parallel_over_ipc: both ranks on HIP device 0, gloo for
+    the handle exchange and the prompt's all-reduces; rank 0 prints the generated ids as JSON."""
+    import json
+    import torch
+    import torch.distributed as dist
+    from . import synthetic as S
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    cfg = dict(S.SMALL)
+    if world == 4:
+        cfg["n_kv_heads"] = 4
+    w = S.make_weights(cfg, seed=41)
+    prompt = S.prompt_tokens(cfg, n=12, seed=7)
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    engine = HipTPEngine(cfg, w, rank, world, 0, 96)
+    if strict:
+        engine.s.set_strict(True)
+    ids = tp_generate_ipc(dist, engine, rank, world, prompt, n_gen, cfg, device, torch.float32)
+    if rank == 0:
+        print(json.dumps({"ids": [int(t) for t in ids]}), flush=True)
+    dist.destroy_process_group()
+
+
 def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=None, probe_iters=3):
     """The one-process N-device host (jh_pipeline_*, BASELINE north_star): stage k on HIP device k, hops are stream-ordered
     peer copies.  Measures the single-stream (batch-1) decode rate and the aggregate rate of N sessions in flight over the
@@ -718,6 +773,12 @@ if __name__ == "__main__":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # only matters when several shards share one device (loopback runs)
     ap = argparse.ArgumentParser()
     ap.add_argument("--one-process", action="store_true")
+    ap.add_argument("--tp-ipc-selftest", action="store_true")
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--world", type=int, default=2)
+    ap.add_argument("--port", type=int, default=29533)
+    ap.add_argument("--n-gen", type=int, default=12)
+    ap.add_argument("--strict", type=int, default=0)
     ap.add_argument("--config", default="LLAMA3_8B")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--devices", default="")
@@ -725,5 +786,8 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--prompt", type=int, default=128)
     a = ap.parse_args()
+    if a.tp_ipc_selftest:
+        _tp_ipc_selftest(a.rank, a.world, a.port, a.n_gen, a.strict)
+        raise SystemExit(0)
     devs = [int(d) for d in a.devices.split(",")] if a.devices else None
     print(json.dumps(one_process_pipeline_bench(a.config, a.gpus, a.steps, a.warmup, a.prompt, devs)), flush=True)

@@ -372,3 +372,38 @@ class HipTPGroup:
             self.close()
         except Exception:
             pass
+
+
+class HipTPRank:
+    """One rank of the tensor-parallel group when every shard lives in its own process (include/jlama_hip.h: jh_tp_rank_*): the
+    other ranks' slot / flag / mailbox buffers are mapped through hipIpc handles exchanged by the host side
+    (distributed.tp_generate_ipc does it with an all_gather); decode_n replays one captured graph per token -- the one-process
+    group's graph -- with no collective library on the data path."""
+
+    HANDLE_BYTES = 192
+
+    def __init__(self, session, rank, n_ranks):
+        self.session, self.rank, self.n = session, rank, n_ranks
+        self.h = C.c_void_p()
+        N.check(N.lib().jh_tp_rank_create(session.h, rank, n_ranks, C.byref(self.h)))
+
+    def handles(self):
+        buf = (C.c_ubyte * self.HANDLE_BYTES)()
+        N.check(N.lib().jh_tp_rank_handles(self.h, buf))
+        return bytes(buf)
+
+    def connect(self, all_handles):
+        all_handles = bytes(all_handles)
+        assert len(all_handles) == self.n * self.HANDLE_BYTES
+        buf = (C.c_ubyte * len(all_handles)).from_buffer_copy(all_handles)
+        N.check(N.lib().jh_tp_rank_connect(self.h, buf))
+
+    def decode_n(self, first_token, start_pos, n):
+        out = np.empty(n, dtype=np.int32)
+        N.check(N.lib().jh_tp_rank_decode_n(self.h, int(first_token), int(start_pos), int(n), N.ptr(out)))
+        return out[:self.session.decode_generated()] if self.rank == 0 else None
+
+    def close(self):
+        if self.h:
+            N.lib().jh_tp_group_destroy(self.h)
+            self.h = C.c_void_p()

@@ -1067,6 +1067,46 @@ def test_rccl_world1_stream_ordered_hosts(gpu, oracle):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("strict", [0, 1])
+def test_rank_per_process_tensor_parallel_over_ipc(gpu, oracle, strict):
+    """jh_tp_rank_*: one PROCESS per head-split shard (here two, both on device 0), the other rank's slot / flag / mailbox
+    buffers mapped through hipIpc handles, decode = the group's token graph -- no collective on the data path.  With two shards
+    the prompt's all-reduce (a + b) equals the shard-ordered sum bit for bit, so the ids must equal the one-process group's."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from jlama_amd import distributed as D, synthetic as S
+    from jlama_amd.model import HipLlamaModel, HipTPGroup
+    n_gen = 12
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-m", "jlama_amd.distributed", "--tp-ipc-selftest", "--rank", str(r), "--world", "2", "--port", str(port),
+                               "--n-gen", str(n_gen), "--strict", str(strict)], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    got = json.loads(outs[0][0].strip().splitlines()[-1])["ids"]
+    # the same shards as a one-process group
+    cfg = dict(S.SMALL)
+    w = S.make_weights(cfg, seed=41)
+    prompt = S.prompt_tokens(cfg, n=12, seed=7)
+    models = []
+    for r in range(2):
+        lc, off = D.tp_shard_config(cfg, r, 2)
+        models.append(HipLlamaModel(lc, D.tp_shard_weights(cfg, w, r, 2), kv_head_offset=off))
+    grp = HipTPGroup(models, 96)
+    for gs in grp.sessions:
+        gs.set_strict(bool(strict))
+    grp.forward(prompt, 0)
+    first = grp.sample()
+    want = [first] + list(grp.decode_n(first, prompt.size, n_gen - 1))
+    grp.close()
+    assert got == [int(t) for t in want]
+
+
 def test_one_process_bench_host_with_its_tensor_parallel_leg(gpu):
     """What a bare `python bench.py --gpus N` measures (distributed.one_process_pipeline_bench), here with two stages / two
     head-split shards on ONE device: the layer-split pipeline (single stream + N sessions in flight, all sessions agreeing)
