@@ -102,6 +102,14 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
     private static final MethodHandle jh_stage_decode_async = h("jh_stage_decode_async", JAVA_INT, sig("pppipp"));
     // int jh_abi_config_layout(int32_t* out, int n)
     private static final MethodHandle jh_abi_config_layout = h("jh_abi_config_layout", JAVA_INT, sig("pi"));
+    // int jh_tp_rank_create(jh_session* shard, int rank, int n_ranks, jh_tp_group** out)
+    private static final MethodHandle jh_tp_rank_create = h("jh_tp_rank_create", JAVA_INT, sig("piip"));
+    // int jh_tp_rank_handles(jh_tp_group* g, void* out192)
+    private static final MethodHandle jh_tp_rank_handles = h("jh_tp_rank_handles", JAVA_INT, sig("pp"));
+    // int jh_tp_rank_connect(jh_tp_group* g, const void* all_handles)
+    private static final MethodHandle jh_tp_rank_connect = h("jh_tp_rank_connect", JAVA_INT, sig("pp"));
+    // int jh_tp_rank_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int n, int32_t* out_tokens)
+    private static final MethodHandle jh_tp_rank_decode_n = h("jh_tp_rank_decode_n", JAVA_INT, sig("piiip"));
     // int64_t jh_model_tiled_bytes(jh_model* m)
     private static final MethodHandle jh_model_tiled_bytes = h("jh_model_tiled_bytes", JAVA_LONG, sig("p"));
     // int jh_pipeline_peer_access(jh_pipeline* p, int32_t* out, int n)
@@ -233,6 +241,22 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
 
     public static int jh_abi_config_layout(MemorySegment out, int n) {
         try { return (int) jh_abi_config_layout.invokeExact(out, n); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_tp_rank_create(MemorySegment shard, int rank, int n_ranks, MemorySegment out) {
+        try { return (int) jh_tp_rank_create.invokeExact(shard, rank, n_ranks, out); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_tp_rank_handles(MemorySegment g, MemorySegment out192) {
+        try { return (int) jh_tp_rank_handles.invokeExact(g, out192); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_tp_rank_connect(MemorySegment g, MemorySegment all_handles) {
+        try { return (int) jh_tp_rank_connect.invokeExact(g, all_handles); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_tp_rank_decode_n(MemorySegment g, int first_token, int start_pos, int n, MemorySegment out_tokens) {
+        try { return (int) jh_tp_rank_decode_n.invokeExact(g, first_token, start_pos, n, out_tokens); } catch (Throwable t) { throw rethrow(t); }
     }
 
     public static long jh_model_tiled_bytes(MemorySegment m) {
