@@ -1764,13 +1764,20 @@ struct TPMail { int token, pos; unsigned seq; int pad; };   // shard 0 -> the ot
 // Every wait is bounded (50 ms of the 100 MHz wall clock): a peer that never arrives -- e.g. two shards' streams serialised onto
 // one hardware queue -- must end in an error code on the host (word seqp[1]), never in a hung GPU.  Once raised the flag makes
 // every later wait of the launch fall through at once.
+// the bound in ticks of the 100 MHz wall clock: the word behind the error word (seq buffer: {tokens replayed, error, bound});
+// 50 ms when all shards share a process (their graphs are launched back to back), seconds when every shard is its own process
+// (a rank may still be instantiating its graph when the others already wait)
+__device__ __forceinline__ long long tp_wait_bound(const unsigned* err) {
+    const unsigned b = err[1];
+    return b ? (long long)b : 5000000LL;
+}
 __device__ __forceinline__ bool tp_wait_ge(const unsigned* f, unsigned want, unsigned* err) {
     const long long t0 = wall_clock64();
     // relaxed system-scope polls (an acquire here is a cache invalidate per poll): what the flag guards is read with ld_sys,
     // cache-bypassing loads issued after this loop has ended
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-        if (wall_clock64() - t0 > 5000000LL) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+        if (wall_clock64() - t0 > tp_wait_bound(err)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
         __builtin_amdgcn_s_sleep(2);
     }
     return true;
@@ -1815,7 +1822,7 @@ __global__ __launch_bounds__(256) void tp_sum_wait_all_kernel(const float* slots
                 all &= __hip_atomic_load(flags + (size_t)(i / nflags) * stride + (i % nflags), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= seq;
             if (all) break;
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            if (wall_clock64() - t0 > 5000000LL) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (wall_clock64() - t0 > tp_wait_bound(err)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }

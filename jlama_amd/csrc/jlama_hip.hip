@@ -3469,6 +3469,10 @@ int jh_tp_rank_create(jh_session* shard, int rank, int n_ranks, jh_tp_group** ou
                     hipMalloc(&g->peers_f[k], 2 * (size_t)N * sizeof(unsigned*)) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); jh_tp_group_destroy(g); return set_err(JH_ERR_OOM, "tp_rank_create: buffers"); }
     g->slots_of[k] = g->slots[k]; g->flags_of[k] = g->flags[k]; g->mail_of[k] = g->mail[k];
+    {   // waits of a rank are bounded by seconds, not the group's 50 ms: the ranks start their graphs independently
+        const unsigned bound = (unsigned)env_int("JH_TP_RANK_WAIT_TICKS", 300000000);   // 3 s of the 100 MHz wall clock
+        HIPCHK(hipMemcpy((char*)g->seq[k] + 8, &bound, 4, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipDeviceSynchronize());
     *out = g;
     return JH_OK;
