@@ -1,0 +1,41 @@
+"""CPU checks of the measurement tools under tools/ (no GPU, no library)."""
+import os
+
+
+def test_decode_timeline_tool_on_a_synthetic_trace(tmp_path):
+    """tools/rocpd_timeline.py (the begin/end accounting of DESIGN.md section 5) on a hand-made rocpd-shaped database: two warm-up
+    dispatches, then 6 decode tokens of a 2-layer model (5 dispatches per layer + LM head + finish), 0.5 us between dispatches."""
+    import sqlite3
+    import subprocess
+    import sys
+    db = tmp_path / "trace.db"
+    con = sqlite3.connect(db)
+    con.execute("create table kernels(name text, start int, end int)")
+    t = [1000]
+
+    def k(name, dur):
+        t[0] += 500
+        con.execute("insert into kernels values(?,?,?)", (name, t[0], t[0] + dur))
+        t[0] += dur
+
+    k("void jh::embed_rows_kernel(void const*)", 4000)
+    k("void jh::finish_token_kernel(float const*)", 3000)
+    for _ in range(6):
+        for _ in range(2):
+            k("void jh::gemv_i8q4_kernel<1, 0, 2, 2, 0>(jh::GemvParams)", 5800)
+            k("void jh::attn_decode_kernel<128, 4, 2>(jh::AttnParams)", 7900)
+            k("void jh::gemv_i8q4_kernel<2, 1, 1, 2, 0>(jh::GemvParams)", 4500)
+            k("void jh::gemv_i8q4_kernel<1, 2, 2, 2, 1>(jh::GemvParams)", 15000)
+            k("void jh::gemv_i8q4_kernel<2, 1, 1, 7, 0>(jh::GemvParams)", 9800)
+        k("void jh::gemv_f32q4_kernel<4, 2, 2>(jh::GemvParams)", 65000)
+        k("void jh::finish_token_kernel(float const*)", 3000)
+    con.commit()
+    con.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rocpd_timeline.py"), str(db), "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "6 replayed decode tokens in the trace, longest consecutive run 6" in out
+    per_token = 2 * (5.8 + 7.9 + 4.5 + 15.0 + 9.8) + 65.0 + 3.0
+    assert f"per token: {per_token:.1f} us inside kernels + {12 * 0.5:.1f} us between them" in out
+    assert "| gemv_i8q4_kernel<1, 2, 2, 2, 1> | 2 | 15.00 | 0.50 |" in out
