@@ -2030,6 +2030,7 @@ struct AttnParams {
     // written before (rows_rope_kv_p16_kernel), nothing is written to the pages here
     int batch, batch_pos0, ldqkv, ldo;
     long long sc_batch;
+    int w_cap;             // attn_p16_av_kernel<.., FUSED>: capacity (floats, multiple of 64) of its score row in LDS; q / new-k rows sit behind it
 };
 #define JH_ATT_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && blockIdx.y == 0) p.dbg[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 

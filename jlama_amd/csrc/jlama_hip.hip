@@ -1354,14 +1354,25 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
         if (lds_av > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "reference-order attention: the score row of max_ctx positions must fit in LDS");
         const dim3 grid_s(s->p16_att_splits, c.n_kv_heads), grid_v(hs / 32, c.n_heads);
         const int ru = p16_av_rows(s->max_ctx);
+        // contexts of <= 512 positions (the "short" graph variant) can run scores + softmax + values in ONE launch per layer
+        // (JH_P16_ATTN_FUSED=1).  Measured and left off: every workgroup of a head then ingests the head's whole K, which costs
+        // what the launch saves -- 8B 484.5 vs 488.0 tok/s, 1B 1,444 vs 1,503 (profiles/r03s_*)
+        static const int fused_env = env_int("JH_P16_ATTN_FUSED", 0);
+        const bool fused = fused_env && s->attn_variant == 1;
+        p.w_cap = (s->max_ctx + 63) & ~63;
 #define JH_P16_AV(HSV, RV)                                                                                                      \
     if (hs == HSV && ru == RV) {                                                                                               \
-        JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                               \
-        hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
+        if (fused) {                                                                                                           \
+            JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV, true>), lds_av));                                                     \
+            hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV, true>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
+        } else {                                                                                                               \
+            JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                           \
+            hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
+        }                                                                                                                      \
     }
 #define JH_P16_ATTN(HSV, GV)                                                                                                   \
     if (hs == HSV && group == GV) {                                                                                            \
-        hipLaunchKernelGGL((attn_p16_scores_kernel<HSV, GV>), grid_s, dim3(P16_ATT_THREADS), 0, st, p, s->p16_scores, s->p16_sc_stride); \
+        if (!fused) hipLaunchKernelGGL((attn_p16_scores_kernel<HSV, GV>), grid_s, dim3(P16_ATT_THREADS), 0, st, p, s->p16_scores, s->p16_sc_stride); \
         HIPCHK(hipGetLastError());                                                                                             \
         JH_P16_AV(HSV, 2) JH_P16_AV(HSV, 4) JH_P16_AV(HSV, 8) JH_P16_AV(HSV, 16)                                                \
         HIPCHK(hipGetLastError());                                                                                             \
@@ -2922,7 +2933,9 @@ static int build_graph(jh_session* s, int v, float temperature = 0.0f) {
     }
     s->graph[v] = g;
     HIPCHK(hipGraphInstantiate(&s->exec[v], g, nullptr, nullptr, 0));
-    const int per_layer = 5 + ((s->strict && !s->strict_legacy) || (!s->strict && s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0);
+    static const int p16_fused = env_int("JH_P16_ATTN_FUSED", 0);
+    const bool p16_two_launch_attn = s->strict && !s->strict_legacy && !(p16_fused && v == 1);
+    const int per_layer = 5 + (p16_two_launch_attn || (!s->strict && s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0);
     s->kernels_per_token = (c.layer_end - c.layer_start) * per_layer + (has_out ? 2 : 0);
     return JH_OK;
 }
