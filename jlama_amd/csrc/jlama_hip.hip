@@ -3074,6 +3074,7 @@ struct jh_tp_group {
     // one process per shard (jh_tp_rank_*): only shard `local` lives here, the others' slot / flag / mailbox buffers are mapped
     // through hipIpc handles (slots_of / flags_of / mail_of[j] = shard j's buffer as addressable from this process)
     int local = -1;
+    bool connected = false;                    // jh_tp_rank_connect filled the pointer tables
     std::vector<float*> slots_of;
     std::vector<unsigned*> flags_of;
     std::vector<TPMail*> mail_of;
@@ -3504,6 +3505,7 @@ int jh_tp_rank_handles(jh_tp_group* g, void* out192) {
 }
 int jh_tp_rank_connect(jh_tp_group* g, const void* all_handles) {
     if (!g || g->local < 0 || !all_handles) return set_err(JH_ERR_INVALID, "tp_rank_connect: bad argument");
+    if (g->connected) return set_err(JH_ERR_INVALID, "tp_rank_connect: already connected");
     const int N = (int)g->sh.size(), k = g->local;
     const size_t E = (size_t)g->sh[k]->m->c.embedding_length;
     HIPCHK(hipSetDevice(g->sh[k]->m->device));
@@ -3533,6 +3535,7 @@ int jh_tp_rank_connect(jh_tp_group* g, const void* all_handles) {
         HIPCHK(hipMalloc(&g->mails_dev, hm.size() * sizeof(TPMail*)));
         HIPCHK(hipMemcpy(g->mails_dev, hm.data(), hm.size() * sizeof(TPMail*), hipMemcpyHostToDevice));
     }
+    g->connected = true;
     return JH_OK;
 }
 // n greedy steps from the row every rank holds (s->x is NOT used: rank 0 embeds first_token, the others receive it through their
@@ -3546,7 +3549,7 @@ int jh_tp_rank_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int 
     JHCHK(check_positions(s, start_pos + n - 1));
     if (first_token < 0 || first_token >= s->m->c.vocab_size) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: token id out of range");
     if (k == 0 && (!lm_head_weight(s->m)->data || !s->m->global_w[JH_W_FINALNORM].data)) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: rank 0 needs the output weights");
-    if (N > 1 && !g->peers[k]) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: not connected");
+    if (!g->connected) return set_err(JH_ERR_INVALID, "tp_rank_decode_n: jh_tp_rank_connect has not been called");
     HIPCHK(hipSetDevice(s->m->device));
     if (k == 0) JHCHK(ensure_out_tokens(s, n));
     for (int v = 0; v < N_ATTN_VARIANTS; v++)
