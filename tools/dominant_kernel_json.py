@@ -43,4 +43,21 @@ rec = {"config": cfgname, "source_hash": N.built_hash(), "kernel": trace[0][0] i
 if fetch:
     rec["traffic_bytes_per_launch"] = (2 * rec["FETCH_SIZE_KB_per_dispatch"] + (rec["WRITE_SIZE_KB_per_dispatch"] or 0.0)) * 1024
     rec["ratio_to_algorithmic"] = rec["traffic_bytes_per_launch"] / algo
+
+
+# the same kernel of the reference-order path (jh_p16.h): gemv_i8q4_p16_kernel<PRO_RMS_Q8=1, EPI_SILU_MUL=2, ...>
+def is_gateup_p16(name):
+    return re.match(r"gemv_i8q4_p16_kernel<1, 2,", name) is not None
+
+
+t16 = [r for r in rows(prefix + "_kernel_trace_stats.md") if is_gateup_p16(r[0])]
+f16 = [r for r in rows(prefix + "_pmc_fetch_size.md") if is_gateup_p16(r[0])]
+w16 = [r for r in rows(prefix + "_pmc_write_size.md") if is_gateup_p16(r[0])]
+if t16:
+    ro = {"kernel": t16[0][0], "us_per_launch_rocprof": float(t16[0][2]),
+          "FETCH_SIZE_KB_per_dispatch": float(f16[0][3]) if f16 else None, "WRITE_SIZE_KB_per_dispatch": float(w16[0][3]) if w16 else None}
+    if f16:
+        ro["traffic_bytes_per_launch"] = (2 * ro["FETCH_SIZE_KB_per_dispatch"] + (ro["WRITE_SIZE_KB_per_dispatch"] or 0.0)) * 1024
+        ro["ratio_to_algorithmic"] = ro["traffic_bytes_per_launch"] / algo
+    rec["reference_order"] = ro
 print(json.dumps(rec, indent=1))
