@@ -62,6 +62,24 @@ def _profiled(config):
                              "us_per_launch_rocprof": ro.get("us_per_launch_rocprof")} if ro else None}
 
 
+def _quiesce(torch, kick=None):
+    """Opening bracket of a timed region: torch.cuda.synchronize(), repeated until it returns at once.  After the warm-up session's
+    graph replays the HIP runtime sometimes keeps a default-stream synchronize blocked for ~40-70 ms of WALL time although the
+    device is idle (seen with K = 20: torch.cuda.synchronize() behind a 28 ms decode took 39 ms more; never with K = 256, where
+    that time has long passed) -- a closing synchronize must measure the K steps, not that.  `kick` (a few untimed steps of the
+    same loop) runs after the pauses, so that the timed region does not start on clocks that dropped while this waited."""
+    for _ in range(50):
+        time.sleep(0.02)
+        t = time.perf_counter()
+        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
+        if time.perf_counter() - t < 1e-3:
+            break
+    if kick:
+        kick()
+    torch.cuda.synchronize()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,12 +296,17 @@ def run_single(args, cfg):
     last_pos = prompt.size + args.steps - 1
     for p0 in sorted({prompt.size, last_pos} | {b for b in (512, 513, 2048, 2049) if prompt.size <= b <= last_pos}):
         s.decode_n(first, p0, 1)
-    torch.cuda.synchronize(); s.synchronize()
+    _quiesce(torch, lambda: s.decode_n(first, prompt.size, min(4, args.steps)))
+    s.synchronize()
     t0 = time.perf_counter()
     s.decode_n_async(first, prompt.size, args.steps)
+    t_a = time.perf_counter()
     toks = s.decode_wait(args.steps)
+    t_w = time.perf_counter()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if os.environ.get("JH_BENCH_DEBUG"):
+        print(f"[bench] queue {1e3 * (t_a - t0):.2f} ms, wait {1e3 * (t_w - t_a):.2f} ms, torch sync {1e3 * (t0 + dt - t_w):.2f} ms", file=sys.stderr)
     assert toks.size == args.steps
     ev_ms, kernels = s.decode_stats()
     tps = args.steps / dt
@@ -311,7 +334,8 @@ def run_single(args, cfg):
         sprompt_ms = (time.perf_counter() - tp0) * 1e3
         for p0 in sorted({prompt.size, last_pos}):
             ss.decode_n(sfirst, p0, 1)         # graph capture, untimed
-        torch.cuda.synchronize(); ss.synchronize()
+        _quiesce(torch, lambda: ss.decode_n(sfirst, prompt.size, min(4, args.steps)))
+        ss.synchronize()
         t0 = time.perf_counter()
         ss.decode_n_async(sfirst, prompt.size, args.steps)
         stoks = ss.decode_wait(args.steps)

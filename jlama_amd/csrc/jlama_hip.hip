@@ -2415,6 +2415,9 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     if (s->p16_att_splits <= 0) s->p16_att_splits = (max_ctx + 15) / 16;
     if (s->p16_att_splits < 16) s->p16_att_splits = 16;
     if (s->p16_att_splits > 256) s->p16_att_splits = 256;
+    // the id buffer of the device loop at its final size NOW: its address is baked into the captured decode graphs, and growing it
+    // later (a decode_n(…, 1) that captures, then decode_n(…, K)) would drop and re-capture them inside the caller's timed region
+    JHCHK(ensure_out_tokens(s, max_ctx));
     s->p16_sc_stride = (max_ctx + 63) & ~63;
     HIPCHK(hipMalloc(&s->p16_scores, (size_t)c.n_heads * s->p16_sc_stride * 4));
     if (s->strict && c.weight_dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "JH_STRICT_ORDER: strict-order kernels exist for JQ4 models only");

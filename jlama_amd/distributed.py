@@ -668,6 +668,14 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
         decode(dist, engine, rank, world, firsts, prompt.size, max(1, args.warmup // n_sess), E, device, torch.float32, n_sessions=n_sess, tok_group=tok_group)
 
     def timed(fn):
+        if on_gpu:   # see bench._quiesce: a default-stream synchronize can stay blocked for tens of ms of wall time behind earlier
+            for _ in range(50):   # graph replays although the device is idle; the closing synchronize must not measure that
+                time.sleep(0.02)
+                tq = time.perf_counter()
+                dev_sync()
+                torch.cuda.current_stream().synchronize()
+                if time.perf_counter() - tq < 1e-3:
+                    break
         dist.barrier()
         dev_sync()
         t0 = time.perf_counter()
