@@ -17,6 +17,7 @@
 
 #include "jh_kernels.h"
 #include "jh_strict.h"
+#include "jh_t16.h"
 
 using namespace jh;
 
@@ -1065,6 +1066,8 @@ struct JWeight {
     int rows = 0, cols = 0;
     uint8_t* tiled = nullptr;        // Q4 only: resident copy in MFMA order for the prefill GEMM (made at first use)
     float* tiled_scales = nullptr;
+    uint8_t* t16 = nullptr;          // Q4 only: resident copy in T16 order (jh_t16.h) for the reference-order MFMA GEMV
+    float* t16_scales = nullptr;
 };
 struct jh_model {
     jh_config c;
@@ -1312,6 +1315,68 @@ int launch_gemv_f32q4_p16(const GemvParams& p, int* grid_out, hipStream_t st) {
     }
 }
 
+// ---- reference-order GEMV on the integer MFMA (jh_t16.h): one wave per 16-row tile, one 512-thread workgroup per CU
+// K % 256 == 0 (whole q steps of 4 blocks, an even number of them), K <= 8192 (register-resident activation row at 512 threads)
+bool t16_shape_ok(int K) { return K % 256 == 0 && K <= 8192 && lds_bytes_t16(K) <= 150 * 1024; }
+template <int PRO, int EPI>
+int launch_gemv_t16(const GemvParams& p, hipStream_t st) {
+    constexpr int NT = 512;
+    const int ntiles = (EPI == EPI_SILU_MUL) ? p.nrows / 8 : p.nrows / 16;
+    const int nq = p.K / QB / 4;
+    int cus = g_cu_count < ntiles ? g_cu_count : ntiles;
+    if (cus < 1) cus = 1;
+    const int t_cu = (ntiles + cus - 1) / cus;
+    const int tpw = (t_cu + 7) / 8;
+    const int aw = (t_cu + tpw - 1) / tpw;
+    const int grid = (ntiles + aw * tpw - 1) / (aw * tpw);
+    const size_t lds = lds_bytes_t16(p.K);
+#define JH_T16_LAUNCH(DV, UMV)                                                                                     \
+    do {                                                                                                           \
+        JHCHK(allow_lds((gemv_t16_kernel<PRO, EPI, DV, UMV, NT>), lds));                                           \
+        hipLaunchKernelGGL((gemv_t16_kernel<PRO, EPI, DV, UMV, NT>), dim3(grid), dim3(NT), lds, st, p, tpw, aw);   \
+    } while (0)
+    if (nq % 4 == 0) {
+        if (p.K <= 4096) JH_T16_LAUNCH(4, 1); else JH_T16_LAUNCH(4, 2);
+    } else {
+        if (p.K <= 4096) JH_T16_LAUNCH(2, 1); else JH_T16_LAUNCH(2, 2);
+    }
+#undef JH_T16_LAUNCH
+    HIPCHK(hipGetLastError());
+    g_last_gemv_grid = grid;
+    return JH_OK;
+}
+// gate|up of layer li in T16 order (tile u = gate rows 8u..8u+7, up rows 8u..8u+7): made once, before any graph capture
+bool t16_gateup_ok(const jh_model* m, int li) {
+    static const int enabled = env_int("JH_T16", 1);
+    const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    const JWeight &G = W[JH_W_GATE], &U = W[JH_W_UP];
+    return enabled && G.data && U.data && G.dtype == JH_DT_Q4 && U.dtype == JH_DT_Q4 && G.rows == U.rows && G.cols == U.cols &&
+           G.rows % 8 == 0 && t16_shape_ok(G.cols);
+}
+int ensure_gateup_t16(jh_model* m, int li, hipStream_t st) {
+    JWeight& F = m->gateup[(size_t)li];
+    if (F.t16 || !t16_gateup_ok(m, li)) return JH_OK;
+    const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    const JWeight &G = W[JH_W_GATE], &U = W[JH_W_UP];
+    const int rows = 2 * G.rows, K = G.cols, nblk = K / QB, ntiles = rows / 16;
+    F.dtype = G.dtype; F.rows = rows; F.cols = K;
+    hipError_t e = hipMalloc((void**)&F.t16, t16_w_bytes(rows, K));
+    if (e == hipSuccess) e = hipMalloc((void**)&F.t16_scales, t16_s_bytes(rows, K));
+    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc T16 gate|up copy");
+    const long long threads = (long long)ntiles * (nblk / 4) * 16;
+    hipLaunchKernelGGL(t16_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const i32x4*)G.data, (const float*)G.scales,
+                       (const i32x4*)U.data, (const float*)U.scales, nblk, ntiles, 1, (i32x4*)F.t16, (f32x4t*)F.t16_scales);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+// every T16 operand a reference-order session of this shard will touch (allocation must not happen inside a graph capture)
+int ensure_strict_operands(jh_session* s, hipStream_t st) {
+    if (!s->strict || s->strict_legacy) return JH_OK;
+    jh_model* m = s->m;
+    for (int li = m->c.layer_start; li < m->c.layer_end; li++) JHCHK(ensure_gateup_t16(m, li, st));
+    return JH_OK;
+}
+
 int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg = nullptr) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
@@ -1537,6 +1602,11 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
         p.out = s->hf;   // silu(gate)*up, F32; the down projection's prologue quantizes it (MLPBlock.java:144)
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, g_cu_count * 4, nullptr, st))); }
         else if (s->strict && s->strict_legacy) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
+        else if (s->strict && t16_gateup_ok(m, li)) {
+            JHCHK(ensure_gateup_t16(m, li, st));   // (already there unless a weight was just replaced; never inside a capture: ensure_strict_operands)
+            p.w = m->gateup[(size_t)li].t16; p.ws = m->gateup[(size_t)li].t16_scales; p.w2 = nullptr; p.ws2 = nullptr;
+            JHCHK((launch_gemv_t16<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
+        }
         else if (s->strict) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->p16_depth, st)));
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
         JHCHK(trace_sync("gateup", st));
@@ -2184,7 +2254,7 @@ int jh_model_destroy(jh_model* m) {
         if (w.tiled_scales) hipFree(w.tiled_scales);
     }
     for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); }
-    for (auto& w : m->gateup) { if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); }
+    for (auto& w : m->gateup) { if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); if (w.t16) hipFree(w.t16); if (w.t16_scales) hipFree(w.t16_scales); }
     for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
     if (m->rope) hipFree(m->rope);
     delete m;
@@ -2273,6 +2343,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     if (layer >= 0 && (which == JH_W_GATE || which == JH_W_UP)) {
         JWeight& gu = m->gateup[(size_t)layer];
         if (gu.tiled) { hipFree(gu.tiled); hipFree(gu.tiled_scales); gu.tiled = nullptr; gu.tiled_scales = nullptr; }
+        if (gu.t16) { hipFree(gu.t16); hipFree(gu.t16_scales); gu.t16 = nullptr; gu.t16_scales = nullptr; }
     }
     w->data = nullptr; w->scales = nullptr;
     hipError_t e = hipMalloc(&w->data, bytes + 64);
@@ -2293,7 +2364,10 @@ int64_t jh_model_weight_bytes(jh_model* m) { return m ? m->weight_bytes : 0; }
 int64_t jh_model_tiled_bytes(jh_model* m) {
     if (!m) return 0;
     int64_t b = 0;
-    auto add = [&](const JWeight& w) { if (w.tiled) b += (int64_t)(tiled_w_bytes(w) + (w.tiled_scales ? tiled_s_bytes(w) : 0)); };
+    auto add = [&](const JWeight& w) {
+        if (w.tiled) b += (int64_t)(tiled_w_bytes(w) + (w.tiled_scales ? tiled_s_bytes(w) : 0));
+        if (w.t16) b += (int64_t)(t16_w_bytes(w.rows, w.cols) + t16_s_bytes(w.rows, w.cols));
+    };
     for (const JWeight& w : m->layer_w) add(w);
     for (const JWeight& w : m->qkv) add(w);
     for (const JWeight& w : m->gateup) add(w);
@@ -2437,6 +2511,7 @@ int jh_session_set_strict(jh_session* s, int on) {
         s->strict = on ? 1 : 0;
         s->graphs_version = -1;   // the captured graphs hold the other mode's kernels
         drop_stale_graphs(s);
+        JHCHK(ensure_strict_operands(s, s->stream));   // T16 copies of the weights the MFMA GEMVs read (jh_t16.h)
     }
     return JH_OK;
 }
@@ -2619,7 +2694,12 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                 p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
                 p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
                 p.out = s->hf;
-                if (p16) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->p16_depth, st)));
+                if (p16 && t16_gateup_ok(m, li)) {
+                    JHCHK(ensure_gateup_t16(m, li, st));
+                    p.w = m->gateup[(size_t)li].t16; p.ws = m->gateup[(size_t)li].t16_scales; p.w2 = nullptr; p.ws2 = nullptr;
+                    JHCHK((launch_gemv_t16<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
+                }
+                else if (p16) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->p16_depth, st)));
                 else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
             } else if (which == 4) {
                 p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x1;
@@ -2712,6 +2792,7 @@ static bool attn_variant_in_range(const jh_session* s, int v, int first, int las
 }
 static int build_row_graph(jh_session* s, int v) {
     drop_stale_graphs(s);
+    JHCHK(ensure_strict_operands(s, s->stream));
     if (s->row_exec[v]) return JH_OK;
     s->attn_variant = v;
     hipStream_t st = s->stream;
@@ -2906,6 +2987,7 @@ int jh_decode_step(jh_session* s, int32_t token, int pos, int32_t* next_token) {
 
 static int build_graph(jh_session* s, int v, float temperature = 0.0f) {
     drop_stale_graphs(s);
+    JHCHK(ensure_strict_operands(s, s->stream));
     const bool sampled = temperature != 0.0f;
     if (sampled && s->sampled_temp != temperature) {   // the temperature is a kernel argument of the captured graphs
         for (int vv = 0; vv < N_ATTN_VARIANTS; vv++)
@@ -3247,6 +3329,7 @@ int tp_build_graph(jh_tp_group* g, int k, int v) {
         g->graphs_version = s->m->weights_version;
     }
     if (g->exec[v][k]) return JH_OK;
+    JHCHK(ensure_strict_operands(s, s->stream));
     const int N = (int)g->sh.size();
     const jh_config& c = s->m->c;
     const int E = c.embedding_length, L = c.n_layers;
