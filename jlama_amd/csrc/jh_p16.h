@@ -11,19 +11,20 @@
 //            per output element over positions in ascending order.
 //
 // MI355X mapping ("p16": a 16-lane DPP row plays the 16 Panama lanes, a wave64 serves 4 weight rows):
-//   * the chain of lane t over the Q blocks is sequential by definition, so ONE GPU lane owns (row, t) and walks K -- but the bytes
-//     arrive the other way round: a coalesced 16-byte load is one whole Q4 block = byte t of 16 DIFFERENT chains.  The 16 lanes of a
-//     row therefore load 16 consecutive blocks of their row (256 contiguous bytes, 1 KiB per wave instruction, exactly the access
-//     pattern of the order-free kernel) and transpose the 16x16 byte matrix in registers: two v_perm rounds with quad_perm DPP
-//     partners (byte / halfword granularity) + two masked-DPP rounds (dword granularity, row_shl/shr:4 and row_ror:8 with bank
-//     masks) = 28 VALU ops per 16 blocks, no LDS;
+//   * the chain of lane t over the Q blocks is sequential by definition, so ONE GPU lane owns (row, t) and walks K -- but in the
+//     checkpoint's layout the bytes arrive the other way round: a 16-byte load is one whole Q4 block = byte t of 16 DIFFERENT
+//     chains.  Round 3 transposed the 16x16 byte matrix of a group of 16 blocks in registers (28 DPP / v_perm ops per group, a
+//     fifth of the kernel's VALU work).  Now the weights these kernels read are a resident copy in "P16T" order, made once per
+//     weight by p16t_pack_kernel: inside every group of 16 blocks (256 bytes of a row) byte 16t + c = byte t of block c, so the
+//     16-byte load of lane t IS byte t of the group's 16 blocks -- same 256 contiguous bytes per row and 1 KiB per wave
+//     instruction, no shuffles; rows are padded to whole groups (zeros);
 //   * nibbles become int8 16*(nib-8) = ((nib << 4) ^ 0x80) with two bit ops per dword (4 blocks), so the pair sum
 //     lo*a[t] + hi*a[t+16] is ONE v_dot4_i32_i8 against a (a[t], a[t+16], 0, 0) activation word (byte-selected by v_perm), exact;
 //     the 1/16 goes into the activation block scale (a power of two: every rounding is unchanged);
 //   * the per-block scale product da*sb lives in the lane that loaded the block and reaches the 16 chains through the DPP
 //     operand of v_fmac_f32 (row_newbcast): acc = fma(bcast(da*sb), (float)isum, acc) is ONE instruction per step;
-//   * per step: perm + dot4 + cvt + fmac  (+ amortised 1.75 transpose + 0.75 unpack) = 6.5 VALU ops for 2 weights -- 5x the
-//     order-free kernel's VALU work, still under the HBM time of every GEMV of the path (decode is HBM-bound);
+//   * per step: perm + dot4 + cvt + fmac  (+ amortised 0.75 unpack) = 4.75 VALU ops for 2 weights (matrices with many rows per
+//     CU take the MFMA form of jh_t16.h instead: there the pair sums cost no VALU work at all);
 //   * a prefetch ring of D groups (16 blocks each) per lane keeps D KiB per wave in flight; the activation row is quantized once
 //     per workgroup into LDS (same fused RMSNorm + Q8 prologue, Panama rule) as pair words, 4 blocks per 8-byte read.
 // Compiled with -ffp-contract=off like the rest: every FMA is explicit.
@@ -43,52 +44,30 @@ __device__ __forceinline__ float row16_tree_sum(float v) {
     return v;
 }
 
-template <int CTRL, int BANK>
-__device__ __forceinline__ int dpp_bank(int old, int src) {   // lanes whose bank (lane>>2 & 3) is not in BANK keep `old`
-    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, BANK, false);
-}
 __device__ __forceinline__ int perm_b(int hi_src, int lo_src, int sel) {   // selector byte 0-3: lo_src, 4-7: hi_src, 0x0C: zero
     return (int)__builtin_amdgcn_perm((unsigned)hi_src, (unsigned)lo_src, (unsigned)sel);
 }
 
-// Lane i (0..15 of its row) holds bytes B_i[0..15] (one Q4 block) in x; afterwards lane t holds B_c[t] at byte c: the 16x16 byte
-// matrix of the row is transposed by swapping lane bit d with column bit d for d = 0..3 (element (i, c) <-> (i^d, c^d) wherever
-// bit d of i and c differ).  Lane bits 0,1 pair with the byte / halfword column bits (partner through quad_perm, merge with v_perm,
-// selector by lane parity); lane bits 2,3 pair with the dword index bits, where a bank-masked DPP move writes exactly the half of
-// the lanes that receive (no select).  tools/p16_transpose_sim.py replays these rounds on the host.
-struct RowSel { int a, b; };
-__device__ __forceinline__ RowSel row16_selectors(int lane) {
-    RowSel s;
-    s.a = (lane & 1) ? 0x03070105 : 0x06020400;   // bit0 = 0: [self0, partner0, self2, partner2]; 1: [partner1, self1, partner3, self3]
-    s.b = (lane & 2) ? 0x03020706 : 0x05040100;   // bit1 = 0: [self0, self1, partner0, partner1]; 1: [partner2, partner3, self2, self3]
-    return s;
+// P16T copy of a Q4 weight: row stride G * 256 bytes (G = groups of 16 blocks, the last one zero-padded); inside a group byte
+// 16t + c = byte t of block c (= nibble pair t: elements t and t+16 of block 16g + c).  One thread per output 16-byte chunk.
+__global__ __launch_bounds__(256) void p16t_pack_kernel(const uint8_t* __restrict__ w, int nrows, int nblk, int ldb, uint8_t* __restrict__ out) {
+    const int G = (nblk + 15) >> 4;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)nrows * G * 16) return;
+    const int t = (int)(idx & 15);
+    const long long rg = idx >> 4;
+    const int g = (int)(rg % G);
+    const long long row = rg / G;
+    const uint8_t* src = w + (size_t)row * ldb + (size_t)g * 256 + t;
+    i32x4 v = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const int byte = (16 * g + c < nblk) ? (int)src[c * 16] : 0;
+        v[c >> 2] |= byte << (8 * (c & 3));
+    }
+    ((i32x4*)out)[idx] = v;
 }
-__device__ __forceinline__ void row16_transpose(i32x4& v, const RowSel sel) {
-    int x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-    {   // partner = lane ^ 1.  The four partner fetches first, then the four merges: a DPP read needs 2 wait states behind the VALU
-        // write of its source, which the three other dwords' instructions provide (no s_nop)
-        const int p0 = __builtin_amdgcn_mov_dpp(x0, 0xB1, 0xf, 0xf, true), p1 = __builtin_amdgcn_mov_dpp(x1, 0xB1, 0xf, 0xf, true);
-        const int p2 = __builtin_amdgcn_mov_dpp(x2, 0xB1, 0xf, 0xf, true), p3 = __builtin_amdgcn_mov_dpp(x3, 0xB1, 0xf, 0xf, true);
-        x0 = perm_b(p0, x0, sel.a); x1 = perm_b(p1, x1, sel.a); x2 = perm_b(p2, x2, sel.a); x3 = perm_b(p3, x3, sel.a);
-    }
-    {   // partner = lane ^ 2
-        const int p0 = __builtin_amdgcn_mov_dpp(x0, 0x4E, 0xf, 0xf, true), p1 = __builtin_amdgcn_mov_dpp(x1, 0x4E, 0xf, 0xf, true);
-        const int p2 = __builtin_amdgcn_mov_dpp(x2, 0x4E, 0xf, 0xf, true), p3 = __builtin_amdgcn_mov_dpp(x3, 0x4E, 0xf, 0xf, true);
-        x0 = perm_b(p0, x0, sel.b); x1 = perm_b(p1, x1, sel.b); x2 = perm_b(p2, x2, sel.b); x3 = perm_b(p3, x3, sel.b);
-    }
-    {   // partner = lane ^ 4: lanes with bit2 = 1 (banks 1,3) take the partner's odd dword into their even one (row_shr:4), lanes
-        // with bit2 = 0 (banks 0,2) the partner's even dword into their odd one (row_shl:4)
-        const int t0 = x0, t2 = x2;
-        x0 = dpp_bank<0x114, 0xA>(x0, x1); x2 = dpp_bank<0x114, 0xA>(x2, x3);
-        x1 = dpp_bank<0x104, 0x5>(x1, t0); x3 = dpp_bank<0x104, 0x5>(x3, t2);
-    }
-    {   // partner = lane ^ 8 (row_ror:8): dword pairs (0,2) and (1,3); bit3 = 1 lanes are banks 2,3
-        const int t0 = x0, t1 = x1;
-        x0 = dpp_bank<0x128, 0xC>(x0, x2); x1 = dpp_bank<0x128, 0xC>(x1, x3);
-        x2 = dpp_bank<0x128, 0x3>(x2, t0); x3 = dpp_bank<0x128, 0x3>(x3, t1);
-    }
-    v.x = x0; v.y = x1; v.z = x2; v.w = x3;
-}
+static inline size_t p16t_row_bytes(int K) { return (size_t)((K / QB + 15) / 16) * 256; }
 
 // acc = fma(p[lane N of the row], f, acc) / m = p[lane N of the row] * f: the DPP operand of a VOP2 instruction does the broadcast
 template <int N> __device__ __forceinline__ void fmac_bcast(float& acc, float p, float f);
@@ -302,7 +281,6 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
     const ActP16 a = carve_p16(smem, nblk);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane >> 4, t = lane & 15;
-    const RowSel sel = row16_selectors(lane);
     constexpr int NP = (EPI == EPI_SILU_MUL) ? 2 : 1;
     const int nq = (p.nrows + 3) >> 2;
     // waves [0, tw) of a workgroup own row quads, the others only help with the activation prologue (a 16-lane row per chain
@@ -327,8 +305,8 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
     set_row();
     auto issue = [&](i32x4& w, float& s) __attribute__((always_inline)) {
         int b = 16 * lg + t;
-        b = b < nblk ? b : nblk - 1;                        // short last group: the surplus lanes reload its last block (unused)
-        w = __builtin_nontemporal_load((const i32x4*)wrow + b);
+        w = __builtin_nontemporal_load((const i32x4*)wrow + b);   // P16T: chunk t of group lg = byte t of its 16 blocks (rows padded to whole groups)
+        b = b < nblk ? b : nblk - 1;                        // short last group: the surplus lanes reload its last scale (unused)
         s = __builtin_nontemporal_load(srow + b);
         if (++lg == G) {
             lg = 0;
@@ -365,10 +343,8 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
 
     float acc = 0.0f, gres = 0.0f, gsel = 0.0f, usel = 0.0f;
     int cq = q0, cpass = 0, cg = 0;                         // compute cursor
-    // one group in two halves with the slot's refill between them: prep() uses up the loaded registers (transpose, scale product),
-    // so the next load can land in the same registers and hipcc has no old value to copy out of the way
+    // one group in two halves with the slot's refill between them: prep() takes the scale product out of the loaded registers
     auto prep = [&](i32x4& x, float s, int g) __attribute__((always_inline)) {
-        row16_transpose(x, sel);
         int bd = 16 * g + t;
         bd = bd < nblk ? bd : nblk - 1;
         return p16_scale_product(a.d16[bd], s);             // lane t carries the scale product of block 16*g + t
@@ -500,7 +476,6 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_f32q4_p16_kernel(GemvParams 
     const ActF32P16 a = carve_f32_p16(smem, nblk);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int r = lane >> 4, t = lane & 15;
-    const RowSel sel = row16_selectors(lane);
     const int nq = (p.nrows + 3) >> 2;
     int q0 = wave < tw ? (blockIdx.x * tw + wave) * per : nq;
     if (q0 > nq) q0 = nq;
@@ -540,8 +515,8 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_f32q4_p16_kernel(GemvParams 
     set_row();
     auto issue = [&](i32x4& w, float& s) __attribute__((always_inline)) {
         int b = 16 * lg + t;
+        w = __builtin_nontemporal_load((const i32x4*)wrow + b);   // P16T copy
         b = b < nblk ? b : nblk - 1;
-        w = __builtin_nontemporal_load((const i32x4*)wrow + b);
         s = __builtin_nontemporal_load(srow + b);
         if (++lg == G) { lg = 0; ++lq; set_row(); }
     };
@@ -563,7 +538,7 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_f32q4_p16_kernel(GemvParams 
     float acc = 0.0f;
     int cq = q0, cg = 0;
     auto prep = [&](i32x4& x, float s) __attribute__((always_inline)) {
-        row16_transpose(x, sel);
+        (void)x;
         return p16_scale_product(0.0625f, s);               // s/16 (exact), pinned here so that the slot's registers are free for the refill
     };
     auto compute = [&](const i32x4& x, float s16, int g, bool can_be_short) __attribute__((always_inline)) {
@@ -1000,7 +975,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_i8q4_p16_kernel(GemmP16Params p)
     const int nblk = p.K / QB, G = nblk >> 4;                  // host: nblk % 16 == 0
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane >> 4, t = lane & 15;
-    const RowSel sel = row16_selectors(lane);
     const int m0 = blockIdx.y * MT;
     constexpr int NP = (EPI == EPI_SILU_MUL) ? 2 : 1;
     i32x2* pts = (i32x2*)smem;                                 // [MT][G*64] pair-word images
@@ -1044,7 +1018,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_i8q4_p16_kernel(GemmP16Params p)
             const int gn = g + 1 < G ? g + 1 : g;              // branch-free: the last group is requested twice
             wn = __builtin_nontemporal_load((const i32x4*)wrow + 16 * gn + t);
             sn = __builtin_nontemporal_load(srow + 16 * gn + t);
-            row16_transpose(x, sel);
             float sp[MT];
 #pragma unroll
             for (int m = 0; m < MT; m++) sp[m] = p16_scale_product(ds[m * nblk + 16 * g + t], sc);

@@ -1068,6 +1068,7 @@ struct JWeight {
     float* tiled_scales = nullptr;
     uint8_t* t16 = nullptr;          // Q4 only: resident copy in T16 order (jh_t16.h) for the reference-order MFMA GEMV
     float* t16_scales = nullptr;
+    uint8_t* p16t = nullptr;         // Q4 only: resident copy in P16T order (jh_p16.h), what every other reference-order GEMV / GEMM reads
 };
 struct jh_model {
     jh_config c;
@@ -1369,11 +1370,40 @@ int ensure_gateup_t16(jh_model* m, int li, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
-// every T16 operand a reference-order session of this shard will touch (allocation must not happen inside a graph capture)
+// P16T copy of a Q4 weight (jh_p16.h: byte t of the 16 blocks of a group in one 16-byte chunk), made once
+int ensure_p16t(JWeight& W, hipStream_t st) {
+    if (W.p16t || !W.data || W.dtype != JH_DT_Q4) return JH_OK;
+    const int nblk = W.cols / QB;
+    const size_t rb = p16t_row_bytes(W.cols);
+    if (hipMalloc((void**)&W.p16t, (size_t)W.rows * rb + 64) != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc P16T weight copy");
+    const long long threads = (long long)W.rows * (long long)(rb / 16);
+    hipLaunchKernelGGL(p16t_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const uint8_t*)W.data, W.rows, nblk, W.cols / 2, W.p16t);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+// the reference-order kernels' view of a weight: P16T nibbles + the checkpoint's scales
+int use_p16t(GemvParams& p, const JWeight& W) {
+    if (!W.p16t) return set_err(JH_ERR_INVALID, "reference-order GEMV: the weight has no P16T copy (ensure_strict_operands)");
+    p.w = W.p16t; p.ldb = (int)p16t_row_bytes(W.cols);
+    return JH_OK;
+}
+// every operand copy a reference-order session of this shard will touch (allocation must not happen inside a graph capture)
 int ensure_strict_operands(jh_session* s, hipStream_t st) {
     if (!s->strict || s->strict_legacy) return JH_OK;
     jh_model* m = s->m;
-    for (int li = m->c.layer_start; li < m->c.layer_end; li++) JHCHK(ensure_gateup_t16(m, li, st));
+    for (int li = m->c.layer_start; li < m->c.layer_end; li++) {
+        JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+        JHCHK(ensure_p16t(m->qkv[(size_t)li], st));
+        JHCHK(ensure_p16t(W[JH_W_O], st));
+        JHCHK(ensure_p16t(W[JH_W_DOWN], st));
+        if (t16_gateup_ok(m, li)) JHCHK(ensure_gateup_t16(m, li, st));
+        {   // the M-row prompt GEMM (gemm_i8q4_p16_kernel) reads gate / up in P16T order
+            JHCHK(ensure_p16t(W[JH_W_GATE], st));
+            JHCHK(ensure_p16t(W[JH_W_UP], st));
+        }
+    }
+    JWeight* lm = m->global_w[JH_W_LMHEAD].data ? &m->global_w[JH_W_LMHEAD] : &m->global_w[JH_W_EMBED];   // (lm_head_weight)
+    if (lm->data && m->global_w[JH_W_FINALNORM].data) JHCHK(ensure_p16t(*lm, st));
     return JH_OK;
 }
 
@@ -1529,7 +1559,7 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st))); }
         else if (s->strict && s->strict_legacy) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_STORE>(p, st)));
-        else if (s->strict) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_STORE>(p, s->p16_depth, st)));
+        else if (s->strict) { JHCHK(use_p16t(p, F)); JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_STORE>(p, s->p16_depth, st))); }
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
         JHCHK(trace_sync("qkv", st));
     }
@@ -1561,8 +1591,10 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
             if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
             else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
         } else if (!resid && s->tp_push) {
+            if (s->strict) JHCHK(use_p16t(p, W[JH_W_O]));
             JHCHK(tp_push_gemv(s, p, s->cfg_o, st));
         } else if (s->strict) {
+            JHCHK(use_p16t(p, W[JH_W_O]));
             if (resid) JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
             else JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_STORE>(p, s->p16_depth, st)));
         } else if (!resid) {
@@ -1607,7 +1639,12 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
             p.w = m->gateup[(size_t)li].t16; p.ws = m->gateup[(size_t)li].t16_scales; p.w2 = nullptr; p.ws2 = nullptr;
             JHCHK((launch_gemv_t16<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
         }
-        else if (s->strict) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->p16_depth, st)));
+        else if (s->strict) {
+            JHCHK(use_p16t(p, W[JH_W_GATE]));
+            if (!W[JH_W_UP].p16t) return set_err(JH_ERR_INVALID, "reference-order GEMV: up projection has no P16T copy");
+            p.w2 = W[JH_W_UP].p16t;
+            JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->p16_depth, st)));
+        }
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
         JHCHK(trace_sync("gateup", st));
     }
@@ -1626,8 +1663,10 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
             if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
             else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
         } else if (!resid && s->tp_push) {
+            if (s->strict) JHCHK(use_p16t(p, W[JH_W_DOWN]));
             JHCHK(tp_push_gemv(s, p, s->cfg_down, st));
         } else if (s->strict) {
+            JHCHK(use_p16t(p, W[JH_W_DOWN]));
             if (resid) JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
             else JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_STORE>(p, s->p16_depth, st)));
         } else if (resid) {
@@ -1994,7 +2033,8 @@ int rows_act_p16_launch(jh_session* s, const float* x, int ldx, const float* nw,
 template <int EPI>
 int gemm_p16_launch(jh_session* s, const JWeight& W, const JWeight* W2, int N, int K, int rows, float* out, int ldc, const float* resid, int ldr,
                     hipStream_t st) {
-    GemmP16Params g{(const uint8_t*)W.data, W.scales, W2 ? (const uint8_t*)W2->data : nullptr, W2 ? W2->scales : nullptr, K / 2, K / QB, N, K, rows,
+    if (!W.p16t || (W2 && !W2->p16t)) return set_err(JH_ERR_INVALID, "reference-order GEMM: the weight has no P16T copy (ensure_strict_operands)");
+    GemmP16Params g{W.p16t, W.scales, W2 ? W2->p16t : nullptr, W2 ? W2->scales : nullptr, (int)p16t_row_bytes(K), K / QB, N, K, rows,
                     (const uint8_t*)s->pb_aq, s->pb_ad, K, K / QB, out, ldc, resid, ldr};
     static const int nw_env = env_int("JH_P16_GEMM_WAVES", 16), mt_env = env_int("JH_P16_GEMM_MT", 0);
     const int nq = (N + 3) / 4;
@@ -2173,6 +2213,7 @@ int lmhead_launch(jh_session* s, hipStream_t st) {
     } else if (s->strict && s->strict_legacy) {
         JHCHK(launch_gemv_f32q4_strict(p, &grid, st));
     } else if (s->strict) {
+        JHCHK(use_p16t(p, *w));
         JHCHK((launch_gemv_f32q4_p16<PRO_RMS_F32>(p, &grid, st)));
     } else {
         JHCHK((launch_gemv_f32q4<PRO_RMS_F32>(p, s->cfg_lm, &grid, st)));
@@ -2252,10 +2293,11 @@ int jh_model_destroy(jh_model* m) {
         if (w.scales) hipFree(w.scales);
         if (w.tiled) hipFree(w.tiled);
         if (w.tiled_scales) hipFree(w.tiled_scales);
+        if (w.p16t) hipFree(w.p16t);
     }
-    for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); }
+    for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); if (w.p16t) hipFree(w.p16t); }
     for (auto& w : m->gateup) { if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); if (w.t16) hipFree(w.t16); if (w.t16_scales) hipFree(w.t16_scales); }
-    for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); }
+    for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.p16t) hipFree(w.p16t); }
     if (m->rope) hipFree(m->rope);
     delete m;
     return JH_OK;
@@ -2327,6 +2369,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
             f.dtype = dtype; f.rows = (int)tot; f.cols = E;
         }
         if (f.tiled) { hipFree(f.tiled); hipFree(f.tiled_scales); f.tiled = nullptr; f.tiled_scales = nullptr; }
+        if (f.p16t) { hipFree(f.p16t); f.p16t = nullptr; }
         const size_t row0 = which == JH_W_Q ? 0 : (which == JH_W_K ? (size_t)A : (size_t)(A + KV));
         uint8_t* dd = (uint8_t*)f.data + row0 * row_bytes;
         float* ds = f.scales ? f.scales + row0 * (E / QB) : nullptr;
@@ -2340,6 +2383,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     if (w->data) hipFree(w->data);
     if (w->scales) hipFree(w->scales);
     if (w->tiled) { hipFree(w->tiled); hipFree(w->tiled_scales); w->tiled = nullptr; w->tiled_scales = nullptr; }
+    if (w->p16t) { hipFree(w->p16t); w->p16t = nullptr; }
     if (layer >= 0 && (which == JH_W_GATE || which == JH_W_UP)) {
         JWeight& gu = m->gateup[(size_t)layer];
         if (gu.tiled) { hipFree(gu.tiled); hipFree(gu.tiled_scales); gu.tiled = nullptr; gu.tiled_scales = nullptr; }
@@ -2367,10 +2411,12 @@ int64_t jh_model_tiled_bytes(jh_model* m) {
     auto add = [&](const JWeight& w) {
         if (w.tiled) b += (int64_t)(tiled_w_bytes(w) + (w.tiled_scales ? tiled_s_bytes(w) : 0));
         if (w.t16) b += (int64_t)(t16_w_bytes(w.rows, w.cols) + t16_s_bytes(w.rows, w.cols));
+        if (w.p16t) b += (int64_t)((size_t)w.rows * p16t_row_bytes(w.cols));
     };
     for (const JWeight& w : m->layer_w) add(w);
     for (const JWeight& w : m->qkv) add(w);
     for (const JWeight& w : m->gateup) add(w);
+    for (const JWeight& w : m->global_w) add(w);
     return b;
 }
 
@@ -2654,6 +2700,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
     const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
     const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
     const int nl = c.layer_end - c.layer_start;
+    JHCHK(ensure_strict_operands(s, st));
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, s->max_ctx / 2, 0, 0);
     s->attn_variant = attn_variant_for(s, s->max_ctx / 2);
     const bool p16 = s->strict && !s->strict_legacy;   // reference-order kernels (jh_p16.h) when the session is in that mode
@@ -2672,7 +2719,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                 p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
                 p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
                 p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
-                if (p16) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_STORE>(p, s->p16_depth, st)));
+                if (p16) { JHCHK(use_p16t(p, F)); JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_STORE>(p, s->p16_depth, st))); }
                 else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
             } else if (which == 1) {
                 JHCHK(attn_launch(s, li - c.layer_start, st, false));
@@ -2680,6 +2727,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                 p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = s->x1;
                 p.K = A; p.ldb = A / 2; p.ldbf = A / QB; p.x = s->attf; p.resid = s->x;
                 if (p16) {
+                    JHCHK(use_p16t(p, W[JH_W_O]));
                     JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
                 } else if (s->direct_max > 0) {
                     p.part_o = s->part_o; p.part_ml = s->part_ml; p.st = s->st; p.direct_max = s->direct_max;
@@ -2699,12 +2747,12 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                     p.w = m->gateup[(size_t)li].t16; p.ws = m->gateup[(size_t)li].t16_scales; p.w2 = nullptr; p.ws2 = nullptr;
                     JHCHK((launch_gemv_t16<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
                 }
-                else if (p16) JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->p16_depth, st)));
+                else if (p16) { JHCHK(use_p16t(p, W[JH_W_GATE])); p.w2 = W[JH_W_UP].p16t; JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->p16_depth, st))); }
                 else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_SILU_MUL>(p, s->cfg_gateup, st)));
             } else if (which == 4) {
                 p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = s->x1;
                 p.K = H; p.ldb = H / 2; p.ldbf = H / QB; p.x = s->hf; p.resid = s->x;
-                if (p16) JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
+                if (p16) { JHCHK(use_p16t(p, W[JH_W_DOWN])); JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st))); }
                 else JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_down, st)));
             } else if (which >= 5 && which <= 8) {
                 // the same GEMVs fed a pre-quantized activation row (PRO_Q8): what the fused prologue costs
@@ -2815,6 +2863,7 @@ static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in,
     jh_model* m = s->m;
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = s->stream;
+    JHCHK(ensure_strict_operands(s, st));   // (no-op unless a reference-order session is missing an operand copy)
     const int E = m->c.embedding_length;
     const JWeight& emb = m->global_w[JH_W_EMBED];
     if (tokens && !emb.data) return set_err(JH_ERR_INVALID, "forward: this shard has no embedding table");
