@@ -28,10 +28,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6290.0  # what a float4 copy reaches on this part (MI355X_MICROARCH.md: 79 % of peak): roofline.frac_of_achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense BF16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
 MFMA_I8_PEAK_TOPS = 5000.0       # dense I8 MFMA ~ 2x the BF16 rate (MI355X_MICROARCH.md: >= 3944 TOPS measured)
 DOMINANT_KERNEL = "gemv_i8q4_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV, fused RMSNorm+Q8 prologue, SiLU*up epilogue)"
+DOMINANT_KERNEL_REF_ORDER = ("gemv_t16_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV in the reference's summation order: block pair sums on "
+                             "v_mfma_i32_16x16x32_i8 with a one-hot activation operand, cvt + fma chains on the VALU; jh_t16.h)")
 
 
 def _profiled(config):
@@ -90,7 +93,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-strict", action="store_true")     # skip the reference-order leg (strict_tokens_per_s)
-    ap.add_argument("--reference-order", action="store_true")   # `value` / `roofline` = the reference-order path (bit-exact ids); the fast kernels move to fast_tokens_per_s
+    # `value` / `roofline` = the REFERENCE-ORDER path (ids and logits bit-identical to the Panama-order oracle: the path that meets
+    # BASELINE north_star's parity bar); the order-free kernels are reported beside it as fast_tokens_per_s.  --fast-order prints the
+    # line the other way round (value = order-free kernels, strict_tokens_per_s = reference order), as rounds 1-3 did.
+    ap.add_argument("--fast-order", action="store_true")
+    ap.add_argument("--reference-order", action="store_true")   # (default now; kept so that older command lines still parse)
     ap.add_argument("--cpu-steps", type=int, default=256)   # ~12 s of CPU work at the reference path's ~21 tok/s
     ap.add_argument("--parity-steps", type=int, default=256)   # free-running strict-order ids compared with the oracle
     ap.add_argument("--probe-iters", type=int, default=3)
@@ -350,7 +357,7 @@ def run_single(args, cfg):
         ss.close()
         strict = {"tokens_per_s": round(args.steps / sdt, 2), "ms_per_step": round(sdt / args.steps * 1e3, 4), "prefill_ms": round(sprompt_ms, 2),
                   "event_ms_per_token": round(sev_ms, 4), "kernels_per_token": skernels, "kernels": sprobe,
-                  "note": "reference-order kernels (jh_p16.h): bit-identical ids and logits vs the Panama-order oracle "
+                  "note": "reference-order kernels (jh_t16.h, jh_p16.h): bit-identical ids and logits vs the Panama-order oracle "
                           "(parity_full_size.strict_order), same K steps, same bracket as `value`"}
     wbytes = S.weight_bytes(cfg)
     kvb = S.kv_bytes_per_position(cfg)
@@ -375,14 +382,16 @@ def run_single(args, cfg):
                    "prefill_tokens_per_s": round(prompt.size / prompt_ms * 1e3, 1)},
         "roofline": ({"bound": "hbm", "kernel": DOMINANT_KERNEL,
                       "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                      "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "frac_of_achievable": round(dom["GBps"] / HBM_ACHIEVABLE_GBS, 4), "traffic": traffic,
                       "bytes_per_launch": dom["bytes"], "us_per_launch": dom["us"], "us_per_launch_rocprof": us_rocprof,
                       "profile": prof} if is_q4 else
                      {"bound": "hbm", "kernel": "whole decode step (per-kernel probe is JQ4-only)",
                       "achieved": round(bytes_per_token * tps / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(bytes_per_token * tps / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}),
+                      "frac": round(bytes_per_token * tps / 1e9 / HBM_PEAK_GBS, 4),
+                      "frac_of_achievable": round(bytes_per_token * tps / 1e9 / HBM_ACHIEVABLE_GBS, 4), "traffic": None}),
         "token_roofline": {"bytes_per_token": int(bytes_per_token), "achieved_GBps": round(bytes_per_token * tps / 1e9, 1),
                            "frac_of_8TBps": round(bytes_per_token * tps / 1e9 / HBM_PEAK_GBS, 4),
+                           "frac_of_achievable": round(bytes_per_token * tps / 1e9 / HBM_ACHIEVABLE_GBS, 4),
                            "event_ms_per_token": round(ev_ms, 4)},
         "prefill_mfma": {"rows": int(prompt.size), "flops": prefill_flops, "achieved_TFLOPs": round(prefill_tflops, 1),
                          "peak_TFLOPs": mfma_peak, "frac": round(prefill_tflops / mfma_peak, 4),
@@ -398,13 +407,14 @@ def run_single(args, cfg):
         ro = (prof or {}).get("reference_order") or {}
         fresh = bool(prof and prof.get("matches_this_build"))
         gu = strict["kernels"]["gate_up"]
-        strict["roofline"] = {"bound": "hbm", "kernel": "gemv_i8q4_p16_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV in the reference's summation order)",
+        strict["roofline"] = {"bound": "hbm", "kernel": DOMINANT_KERNEL_REF_ORDER,
                               "achieved": gu["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gu["GBps"] / HBM_PEAK_GBS, 4),
+                              "frac_of_achievable": round(gu["GBps"] / HBM_ACHIEVABLE_GBS, 4),
                               "traffic": ro.get("traffic_bytes_per_launch") if fresh else None, "bytes_per_launch": gu["bytes"], "us_per_launch": gu["us"],
                               "us_per_launch_rocprof": ro.get("us_per_launch_rocprof") if fresh else None}
         out["strict_tokens_per_s"] = strict["tokens_per_s"]
         out["strict_order"] = strict
-        if args.reference_order:   # the path with bit-exact ids as the headline of this line
+        if not args.fast_order:   # the path with bit-exact ids is the headline of this line
             out["fast_tokens_per_s"] = out["value"]
             out["fast_roofline"] = out["roofline"]
             out["value"], out["ms_per_step"] = strict["tokens_per_s"], strict["ms_per_step"]
@@ -416,11 +426,14 @@ def run_single(args, cfg):
             tr = out["token_roofline"]
             tr["achieved_GBps"] = round(tr["bytes_per_token"] * out["value"] / 1e9, 1)
             tr["frac_of_8TBps"] = round(tr["achieved_GBps"] / HBM_PEAK_GBS, 4)
+            tr["frac_of_achievable"] = round(tr["achieved_GBps"] / HBM_ACHIEVABLE_GBS, 4)
             tr["event_ms_per_token"] = strict["event_ms_per_token"]
     host_w = None
     if not args.no_cpu_baseline:
         host_w = ST.to_host(w)
-        out["cpu_baseline"] = cpu_baseline(cfg, host_w, 8, args.cpu_steps)
+        # the metric's own workload: the same prompt.size-row prompt (one row at a time on the CPU, ~6 s for 129 rows of the 8B
+        # model), then decode positions prompt.size ... prompt.size + cpu_steps - 1
+        out["cpu_baseline"] = cpu_baseline(cfg, host_w, int(prompt.size), args.cpu_steps)
     if not args.no_parity and not is_q4:
         host_w = host_w or ST.to_host(w)
         # the BF16 oracle streams 14 GB per row on the host cores: a bounded sample (8-row prompt, 16 teacher-forced + 16 free steps)

@@ -285,4 +285,221 @@ __global__ __launch_bounds__(NT) void gemv_t16_kernel(GemvParams p, int tiles_pe
     tile_end();
 }
 
+// ================================================================================================ prompt rows (M > 1)
+// AbstractModel.batchForward in reference order on the matrix pipe.  The reference's batch GEMM (GemmerI8Q4_512 tiles,
+// PTO:852-1043) keeps ONE 16-lane accumulator per output whatever the tile, so a prompt row's result does not depend on how many
+// rows are processed together: every (prompt row, weight row) pair is the GEMV's chain.  Per (prompt row m, 16-row weight tile,
+// block) the only ordered work is 16 x 16 fmas; the pair sums come from ONE MFMA.  With M rows the converts of the integer form
+// would equal the fmas in VALU work, so this kernel uses the F16 MFMA with F32 output instead: int8 codes (|a| <= 127) and
+// nib - 8 are exact in f16, their products and the two-term sums exact in f32 whatever the matrix pipe's internal order --
+// D[t][j] IS (float)(lo_t*a[t] + hi_t*a[t+16]), and the chain step is the reference's own  acc = fma(da*sb, D, acc)  (no 1/16
+// trick here: nib - 8 is unpacked exactly, 0x6400|nib = 1024+nib then a packed f16 add of -1032).
+// Operands: weights in T16 order (the GEMV's copy; a weight tile is unpacked once per block and serves MT prompt rows, and is
+// fetched from HBM once: the row tiles of a weight slice are neighbours in the launch order on ONE XCD, so all but the first
+// hit in its L2); activations as ready-made one-hot selector operands [row][block][16 entries x 16 B] (rows_act_t16_kernel),
+// staged through LDS in chunks of KC blocks (double-buffered) for the waves of the workgroup.
+//   workgroup = CW waves x 2 tiles (CW * 32 weight rows) x MT = 8 prompt rows; 256 threads (up to 256 VGPRs: 64 accumulators).
+struct RowsT16Params {
+    const float* x; int ldx;          // [rows][ldx] F32
+    const float* nw; float eps;       // PRO_RMS_Q8
+    int K;
+    i32x4* asel;                      // out: [rows][nblk][16] one-hot selector entries, 8 halves each (k slots 0-3: a[t] at slot t&3; 4-7: a[t+16])
+    float* ad;                        // out: [nblk][ad_stride] block scales (d = max/127), row-minor so that a row tile's scales are contiguous
+    int ad_stride;
+};
+template <int PRO, int UM>
+__global__ __launch_bounds__(P16_THREADS) void rows_act_t16_kernel(RowsT16Params rp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nblk = rp.K / QB;
+    const ActT16 a = carve_t16(smem, nblk);
+    GemvParams p{};
+    p.x = rp.x + (size_t)blockIdx.x * rp.ldx; p.nw = rp.nw; p.eps = rp.eps; p.K = rp.K;
+    ActRegsP16<UM> ar;
+    stage_issue_p16<PRO, UM, P16_THREADS>(p, ar);
+    stage_finish_t16<PRO, UM, P16_THREADS>(p, a, ar);          // the GEMV's own prologue: int8 selector table + d/16 in LDS
+    i32x4* dst = rp.asel + (size_t)blockIdx.x * nblk * 16;
+    for (int i = threadIdx.x; i < nblk * 16; i += P16_THREADS) {
+        const int b = i >> 4, t = i & 15, y = t & 3;
+        const i32x2 e = *(const i32x2*)(a.sel + (size_t)b * T16_SEL_STRIDE + t * 8);
+        const int lo = (int)(int8_t)(e.x >> (8 * y)), hi = (int)(int8_t)(e.y >> (8 * y));
+        const _Float16 hl = (_Float16)lo, hh = (_Float16)hi;   // exact: |code| <= 127
+        const unsigned ul = (unsigned)__builtin_bit_cast(unsigned short, hl) << (16 * (y & 1));
+        const unsigned uh = (unsigned)__builtin_bit_cast(unsigned short, hh) << (16 * (y & 1));
+        i32x4 v = {0, 0, 0, 0};
+        v[y >> 1] = (int)ul;
+        v[2 + (y >> 1)] = (int)uh;
+        dst[i] = v;
+    }
+    for (int b = threadIdx.x; b < nblk; b += P16_THREADS) rp.ad[(size_t)b * rp.ad_stride + blockIdx.x] = a.d16[b] * 16.0f;   // d (x16: exact)
+}
+
+struct GemmT16Params {
+    const i32x4* w; const f32x4t* ws;      // T16 copy of the weight (mode 1 for EPI_SILU_MUL)
+    int ntiles, K, M;
+    const i32x4* asel; const float* ad; int ad_stride;   // rows_act_t16_kernel's output
+    float* out; int ldc;                   // [M][ldc]
+    const float* resid; int ldr;           // EPI_RESID
+    int nslices, nrt;                      // weight slices of 2*CW tiles, row tiles of MT rows
+};
+constexpr int GT16_KC = 16;                // blocks per staged activation chunk
+constexpr int GT16_ENTRY = 272;            // bytes per (row, block) in LDS: 16 entries x 16 B + 16 zero bytes (the inactive lanes' operand)
+constexpr int GT16_SKEW = 2;               // the MFMAs run this many prompt rows ahead of the chains that read them
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+static inline size_t lds_bytes_gemm_t16(int MT) { return (size_t)2 * MT * GT16_KC * GT16_ENTRY + (size_t)2 * MT * GT16_KC * 4; }
+
+// 8 nibbles of one dword -> the MFMA B operand of its lane: halves 0-3 = lo nibbles - 8 (elements 4g..4g+3), 4-7 = hi nibbles - 8
+__device__ __forceinline__ f16x8 nib8_to_f16(int w) {
+    const unsigned u = (unsigned)w, u4 = u >> 4;
+    const unsigned m = 0x000F000Fu, k = 0x64006400u;           // 0x6400 = 1024.0: |nib has ulp 1 there
+    const unsigned l01 = (__builtin_amdgcn_perm(0u, u, 0x0C010C00u) & m) | k, l23 = (__builtin_amdgcn_perm(0u, u, 0x0C030C02u) & m) | k;
+    const unsigned h01 = (__builtin_amdgcn_perm(0u, u4, 0x0C010C00u) & m) | k, h23 = (__builtin_amdgcn_perm(0u, u4, 0x0C030C02u) & m) | k;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 c = {(_Float16)-1032.0f, (_Float16)-1032.0f};     // 1024 + nib - 1032 = nib - 8, exact
+    const h2 a0 = __builtin_bit_cast(h2, l01) + c, a1 = __builtin_bit_cast(h2, l23) + c, a2 = __builtin_bit_cast(h2, h01) + c, a3 = __builtin_bit_cast(h2, h23) + c;
+    f16x8 r;
+    r[0] = a0[0]; r[1] = a0[1]; r[2] = a1[0]; r[3] = a1[1]; r[4] = a2[0]; r[5] = a2[1]; r[6] = a3[0]; r[7] = a3[1];
+    return r;
+}
+// acc = fma(s, d, acc) as a plain C fma (hipcc must see the MFMA -> VALU hazard on d), fenced so that the SLP vectoriser cannot
+// pack neighbouring chains into v_pk_fma_f32 (measured slower here: 577 vs 535 us on the 8B gate|up prompt GEMM)
+__device__ __forceinline__ void fma_c(float& acc, float s, float d) {
+    acc = __builtin_fmaf(s, d, acc);
+    asm volatile("" : "+v"(acc));
+}
+
+template <int EPI, int MT, int CW>
+__global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_t16_kernel(GemmT16Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KC = GT16_KC, NT = CW * 64;
+    const int nblk = p.K / QB, nq = nblk >> 2, nchunks = nblk / KC;   // host: nblk % KC == 0
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    // launch order: block x runs on XCD x & 7 (observed placement; only speed depends on it).  The row tiles of one weight slice are
+    // consecutive on one XCD: the first fetches the slice from HBM, the others find it in that XCD's L2.
+    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+    const int rt = kx % p.nrt, slice = (kx / p.nrt) * 8 + xcd;
+    if (slice >= p.nslices) return;
+    const int m0 = rt * MT;
+    int tA = slice * (2 * CW) + 2 * wave, tB = tA + 1;
+    const bool okA = tA < p.ntiles, okB = tB < p.ntiles;
+    tA = okA ? tA : p.ntiles - 1; tB = okB ? tB : p.ntiles - 1;
+    char* selbuf = smem;                                        // [2][MT][KC][272]
+    float* dabuf = (float*)(smem + (size_t)2 * MT * KC * GT16_ENTRY);   // [2][KC][MT]
+    // zero words (the operand of the 48 lanes that are not (t, t/4)): written once, never overwritten by the staging
+    for (int i = threadIdx.x; i < 2 * MT * KC; i += NT) *(i32x4*)(selbuf + (size_t)i * GT16_ENTRY + 256) = i32x4{0, 0, 0, 0};
+    auto stage = [&](int c, int buf) __attribute__((always_inline)) {   // activation chunk c -> LDS buffer buf
+        for (int i = threadIdx.x; i < MT * KC * 16; i += NT) {
+            const int e = i & 15, mb = i >> 4, kb = mb % KC, m = mb / KC;
+            int mm = m0 + m;
+            mm = mm < p.M ? mm : p.M - 1;                        // rows past M replicate the last row (never stored)
+            const i32x4 v = p.asel[((size_t)mm * nblk + (size_t)c * KC + kb) * 16 + e];
+            *(i32x4*)(selbuf + ((size_t)(buf * MT + m) * KC + kb) * GT16_ENTRY + e * 16) = v;
+        }
+        for (int i = threadIdx.x; i < MT * KC; i += NT) {
+            const int m = i % MT, kb = i / MT;
+            int mm = m0 + m;
+            mm = mm < p.M ? mm : p.M - 1;
+            dabuf[(buf * KC + kb) * MT + m] = p.ad[(size_t)(c * KC + kb) * p.ad_stride + mm];
+        }
+    };
+    const char* asel_lane = selbuf + (((j >> 2) == g) ? j * 16 : 256);
+    const i32x4* wA = p.w + (size_t)tA * nq * 64 + lane;
+    const i32x4* wB = p.w + (size_t)tB * nq * 64 + lane;
+    const f32x4t* sA = p.ws + (size_t)tA * nq * 16 + j;
+    const f32x4t* sB = p.ws + (size_t)tB * nq * 16 + j;
+    float acc[MT][2][4];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[m][u][i] = 0.f;
+    stage(0, 0);
+    i32x4 wa = wA[0], wb = wB[0];                               // (default cache policy: the sibling row tiles re-read these lines from L2)
+    f32x4t sa = sA[0], sb = sB[0];
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage(c + 1, buf ^ 1);             // lands while this chunk is consumed; the barrier below publishes it
+        // the selector operands (and block scales) of block kb+1 are read from LDS while block kb's MFMAs and chains run: an LDS
+        // round trip per (row, block) in front of its MFMA would otherwise be the critical path (two waves per SIMD do not hide it)
+        f16x8 av[2][MT];
+        f32x4t dav[2][MT / 4];
+        auto read_block = [&](int kb, f16x8 (&a)[MT], f32x4t (&dv)[MT / 4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) a[m] = *(const f16x8*)(asel_lane + ((size_t)(buf * MT + m) * KC + kb) * GT16_ENTRY);
+#pragma unroll
+            for (int h = 0; h < MT / 4; h++) dv[h] = *(const f32x4t*)(dabuf + (buf * KC + kb) * MT + 4 * h);
+        };
+        read_block(0, av[0], dav[0]);
+#pragma unroll
+        for (int qq = 0; qq < KC / 4; qq++) {
+            const int q = c * (KC / 4) + qq;
+            const i32x4 wa_c = wa, wb_c = wb;
+            const f32x4t sa_c = sa, sb_c = sb;
+            const int qn = q + 1 < nq ? q + 1 : q;              // branch-free prefetch of the next q step (the last one twice)
+            wa = wA[(size_t)qn * 64]; wb = wB[(size_t)qn * 64];
+            sa = sA[(size_t)qn * 16]; sb = sB[(size_t)qn * 16];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int kb = 4 * qq + d, cb = kb & 1;
+                if (kb + 1 < KC) read_block(kb + 1, av[cb ^ 1], dav[cb ^ 1]);
+                const f16x8 bA = nib8_to_f16(wa_c[d]), bB = nib8_to_f16(wb_c[d]);
+                // the MFMAs of prompt rows m+1, m+2 are issued before the chains of row m read their results (SK + 1 result sets): the
+                // matrix pipe runs beside the VALU instead of in front of it
+                constexpr int SK = GT16_SKEW;
+                f32x4t dA[SK + 1], dB[SK + 1];
+                auto pair = [&](int m, f32x4t& ra, f32x4t& rb) __attribute__((always_inline)) {
+                    const f32x4t z = {0.f, 0.f, 0.f, 0.f};
+                    ra = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[cb][m], bA, z, 0, 0, 0);
+                    rb = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[cb][m], bB, z, 0, 0, 0);
+                };
+#pragma unroll
+                for (int m = 0; m < SK; m++) pair(m, dA[m], dB[m]);
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    const int cur = m % (SK + 1);
+                    if (m + SK < MT) pair(m + SK, dA[(m + SK) % (SK + 1)], dB[(m + SK) % (SK + 1)]);
+                    const float da = dav[cb][m >> 2][m & 3];
+                    const float s0 = mul1(da, sa_c[d]), s1 = mul1(da, sb_c[d]);   // afr[blk] * bfr[blk] (PTO:819): the reference's own product
+                    fma_c(acc[m][0][0], s0, dA[cur][0]); fma_c(acc[m][0][1], s0, dA[cur][1]); fma_c(acc[m][0][2], s0, dA[cur][2]); fma_c(acc[m][0][3], s0, dA[cur][3]);
+                    fma_c(acc[m][1][0], s1, dB[cur][0]); fma_c(acc[m][1][1], s1, dB[cur][1]); fma_c(acc[m][1][2], s1, dB[cur][2]); fma_c(acc[m][1][3], s1, dB[cur][3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // halving tree per (prompt row, tile): (t, t+8) = lanes l, l^32; (t, t+4) = l, l^16; registers (i, i+2); (0, 1).  Every lane group
+    // ends with the 16 row sums; group g stores prompt rows m = g and g + 4.
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int tile = u ? tB : tA;
+        const bool ok = u ? okB : okA;
+        float mine0 = 0.f, mine1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            float a0 = acc[m][u][0], a1 = acc[m][u][1], a2 = acc[m][u][2], a3 = acc[m][u][3];
+            a0 = a0 + __shfl_xor(a0, 32); a1 = a1 + __shfl_xor(a1, 32); a2 = a2 + __shfl_xor(a2, 32); a3 = a3 + __shfl_xor(a3, 32);
+            a0 = a0 + __shfl_xor(a0, 16); a1 = a1 + __shfl_xor(a1, 16); a2 = a2 + __shfl_xor(a2, 16); a3 = a3 + __shfl_xor(a3, 16);
+            const float r = (a0 + a2) + (a1 + a3);
+            if ((m & 3) == g) { if (m < 4) mine0 = r; else mine1 = r; }
+        }
+#pragma unroll
+        for (int h = 0; h < MT / 4; h++) {
+            const int mrow = m0 + g + 4 * h;
+            float v = h ? mine1 : mine0;
+            if (EPI == EPI_SILU_MUL) {
+                const float up = dpp_f<0x128>(v);               // row_ror:8: the up row of the lane's hidden unit (tile = 8 gate + 8 up rows)
+                v = silu_ref(v) * up;                           // MLPBlock.java:132-142
+                if (ok && mrow < p.M && j < 8) p.out[(size_t)mrow * p.ldc + (size_t)tile * 8 + j] = v;
+            } else {
+                const int row = tile * 16 + j;
+                if (EPI == EPI_RESID && ok && mrow < p.M) v = v + p.resid[(size_t)mrow * p.ldr + row];   // TransformerBlock.java:185,203
+                if (ok && mrow < p.M) p.out[(size_t)mrow * p.ldc + row] = v;
+            }
+        }
+    }
+}
+
 }  // namespace jh

@@ -1142,6 +1142,8 @@ struct jh_session {
     float *pb_att_o = nullptr, *pb_att_ml = nullptr;   // key-range split partials of the MFMA prefill attention
     struct TPPush* tp_push = nullptr;                  // set while a tensor-parallel token graph is captured: o-proj / down push their partials
     float* p16_scores_b = nullptr;                     // reference-order prefill: score rows of a whole chunk [rows][n_heads][p16_sc_stride]
+    uint8_t* pb_sel = nullptr;                         // reference-order prefill on the MFMA (gemm_t16_kernel): one-hot selector operands of a chunk's rows
+    float* pb_sad = nullptr;                           // ... and their block scales [nblk][PB_MAX_ROWS]
     uint8_t* tile_w = nullptr;                         // TILED_TRANSIENT: scratch for ONE weight in MFMA order (+ its scales)
     float* tile_s = nullptr;
     size_t tile_w_bytes = 0, tile_s_bytes = 0;
@@ -1370,6 +1372,20 @@ int ensure_gateup_t16(jh_model* m, int li, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
+// T16 copy (mode 0: tile u = rows 16u..16u+15) of a Q4 weight: the operand of the reference-order prompt GEMM on the MFMA
+bool t16_weight_ok(const JWeight& W) { return W.data && W.dtype == JH_DT_Q4 && W.rows % 16 == 0 && W.cols % 512 == 0; }
+int ensure_t16(JWeight& W, hipStream_t st) {
+    if (W.t16 || !t16_weight_ok(W)) return JH_OK;
+    const int nblk = W.cols / QB, ntiles = W.rows / 16;
+    hipError_t e = hipMalloc((void**)&W.t16, t16_w_bytes(W.rows, W.cols));
+    if (e == hipSuccess) e = hipMalloc((void**)&W.t16_scales, t16_s_bytes(W.rows, W.cols));
+    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc T16 weight copy");
+    const long long threads = (long long)ntiles * (nblk / 4) * 16;
+    hipLaunchKernelGGL(t16_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const i32x4*)W.data, (const float*)W.scales,
+                       (const i32x4*)nullptr, (const float*)nullptr, nblk, ntiles, 0, (i32x4*)W.t16, (f32x4t*)W.t16_scales);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
 // P16T copy of a Q4 weight (jh_p16.h: byte t of the 16 blocks of a group in one 16-byte chunk), made once
 int ensure_p16t(JWeight& W, hipStream_t st) {
     if (W.p16t || !W.data || W.dtype != JH_DT_Q4) return JH_OK;
@@ -1387,6 +1403,7 @@ int use_p16t(GemvParams& p, const JWeight& W) {
     p.w = W.p16t; p.ldb = (int)p16t_row_bytes(W.cols);
     return JH_OK;
 }
+bool prefill_t16_ok(jh_session* s);
 // every operand copy a reference-order session of this shard will touch (allocation must not happen inside a graph capture)
 int ensure_strict_operands(jh_session* s, hipStream_t st) {
     if (!s->strict || s->strict_legacy) return JH_OK;
@@ -1397,7 +1414,12 @@ int ensure_strict_operands(jh_session* s, hipStream_t st) {
         JHCHK(ensure_p16t(W[JH_W_O], st));
         JHCHK(ensure_p16t(W[JH_W_DOWN], st));
         if (t16_gateup_ok(m, li)) JHCHK(ensure_gateup_t16(m, li, st));
-        {   // the M-row prompt GEMM (gemm_i8q4_p16_kernel) reads gate / up in P16T order
+        if (prefill_t16_ok(s)) {   // prompt rows through gemm_t16_kernel: every projection in T16 order
+            JHCHK(ensure_t16(m->qkv[(size_t)li], st));
+            JHCHK(ensure_t16(W[JH_W_O], st));
+            JHCHK(ensure_t16(W[JH_W_DOWN], st));
+        }
+        if (!t16_gateup_ok(m, li) || !prefill_t16_ok(s)) {   // the p16 forms of gate / up (decode GEMV, M-row prompt GEMM) read P16T order
             JHCHK(ensure_p16t(W[JH_W_GATE], st));
             JHCHK(ensure_p16t(W[JH_W_UP], st));
         }
@@ -1704,6 +1726,14 @@ bool prefill_p16_ok(jh_session* s) {
     const int hs = c.head_size, A = c.n_heads * hs, group = c.n_heads / c.n_kv_heads;
     if (c.embedding_length % 512 || c.hidden_length % 512 || A % 512 || c.hidden_length > 32768 || c.embedding_length > 32768 || A > 32768) return false;
     return (hs == 128 || hs == 64) && (group == 1 || group == 2 || group == 4 || group == 8);
+}
+// ... and through the F16-MFMA form of that GEMM (jh_t16.h: gemm_t16_kernel) when every projection has whole T16 tiles
+bool prefill_t16_ok(jh_session* s) {
+    static const int enabled = env_int("JH_T16_PREFILL", 1);
+    const jh_config& c = s->m->c;
+    if (!enabled || !prefill_p16_ok(s)) return false;                 // E, H, A are multiples of 512 (whole chunks of 16 blocks)
+    const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    return (A + 2 * KV) % 16 == 0 && c.embedding_length % 16 == 0 && c.hidden_length % 8 == 0 && t16_shape_ok(c.embedding_length);
 }
 bool prefill_batch_ok(jh_session* s) {
     const jh_config& c = s->m->c;
@@ -2057,6 +2087,35 @@ int gemm_p16_launch(jh_session* s, const JWeight& W, const JWeight* W2, int N, i
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
+// ---- the same GEMMs on the F16 MFMA (jh_t16.h): activations as one-hot selector operands, weights in T16 order
+template <int PRO>
+int rows_act_t16_launch(jh_session* s, const float* x, int ldx, const float* nw, float eps, int K, int rows, hipStream_t st) {
+    RowsT16Params rp{x, ldx, nw, eps, K, (i32x4*)s->pb_sel, s->pb_sad, PB_MAX_ROWS};
+    const size_t lds = lds_bytes_t16(K);
+#define JH_ACT(UMV)                                                                                   \
+    {                                                                                                 \
+        JHCHK(allow_lds((rows_act_t16_kernel<PRO, UMV>), lds));                                       \
+        hipLaunchKernelGGL((rows_act_t16_kernel<PRO, UMV>), dim3(rows), dim3(P16_THREADS), lds, st, rp); \
+    }
+    if (K <= 8192) JH_ACT(2) else if (K <= 16384) JH_ACT(4) else JH_ACT(8)
+#undef JH_ACT
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+template <int EPI>
+int gemm_t16_launch(jh_session* s, const uint8_t* w, const float* ws, int ntiles, int K, int rows, float* out, int ldc, const float* resid, int ldr,
+                    hipStream_t st) {
+    if (!w || !ws) return set_err(JH_ERR_INVALID, "reference-order GEMM: the weight has no T16 copy (ensure_strict_operands)");
+    constexpr int MT = 8, CW = 4;                      // 4 waves x 2 tiles = 128 weight rows x 8 prompt rows per workgroup
+    const int nslices = (ntiles + 2 * CW - 1) / (2 * CW), nrt = (rows + MT - 1) / MT;
+    GemmT16Params g{(const i32x4*)w, (const f32x4t*)ws, ntiles, K, rows, (const i32x4*)s->pb_sel, s->pb_sad, PB_MAX_ROWS, out, ldc, resid, ldr, nslices, nrt};
+    const size_t lds = lds_bytes_gemm_t16(MT);
+    JHCHK(allow_lds((gemm_t16_kernel<EPI, MT, CW>), lds));
+    const int grid = ((nslices + 7) / 8) * 8 * nrt;
+    hipLaunchKernelGGL((gemm_t16_kernel<EPI, MT, CW>), dim3(grid), dim3(CW * 64), lds, st, g);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
 int prefill_attn_p16_launch(jh_session* s, int rel, int rows, int start_pos, hipStream_t st) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
@@ -2107,12 +2166,34 @@ int prefill_layers_p16(jh_session* s, int rows, int start_pos, hipStream_t st) {
     const jh_config& c = m->c;
     const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
     const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    const bool t16 = prefill_t16_ok(s);
+    if (t16 && !s->pb_sel) {
+        size_t kmax = E > H ? E : H;
+        if ((size_t)A > kmax) kmax = A;
+        hipError_t e = hipMalloc((void**)&s->pb_sel, (size_t)PB_MAX_ROWS * (kmax / QB) * 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&s->pb_sad, (size_t)(kmax / QB) * PB_MAX_ROWS * 4);
+        if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc prompt selector operands");
+    }
     for (int li = c.layer_start; li < c.layer_end; li++) {
         const int rel = li - c.layer_start;
         JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
         JWeight& F = m->qkv[(size_t)li];
         if (!F.data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data || !W[JH_W_NORM1].data || !W[JH_W_NORM2].data)
             return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": weights not set");
+        if (t16) {   // pair sums on the F16 MFMA (gemm_t16_kernel): same chains, same bits
+            const JWeight& GU = m->gateup[(size_t)li];
+            JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, s->pb_x, E, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
+            JHCHK((gemm_t16_launch<EPI_STORE>(s, F.t16, F.t16_scales, (A + 2 * KV) / 16, E, rows, s->pb_qkv, A + 2 * KV, nullptr, 0, st)));
+            JHCHK(prefill_attn_p16_launch(s, rel, rows, start_pos, st));
+            JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_att, A, nullptr, 0.f, A, rows, st)));
+            JHCHK((gemm_t16_launch<EPI_RESID>(s, W[JH_W_O].t16, W[JH_W_O].t16_scales, E / 16, A, rows, s->pb_x1, E, s->pb_x, E, st)));
+            JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, s->pb_x1, E, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
+            JHCHK((gemm_t16_launch<EPI_SILU_MUL>(s, GU.t16, GU.t16_scales, H / 8, E, rows, s->pb_g, H, nullptr, 0, st)));
+            JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_g, H, nullptr, 0.f, H, rows, st)));
+            JHCHK((gemm_t16_launch<EPI_RESID>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rows, s->pb_x, E, s->pb_x1, E, st)));
+            JHCHK(trace_sync("prefill layer (reference order, MFMA)", st));
+            continue;
+        }
         JHCHK((rows_act_p16_launch<PRO_RMS_Q8>(s, s->pb_x, E, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
         JHCHK((gemm_p16_launch<EPI_STORE>(s, F, nullptr, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, 0, st)));
         JHCHK(prefill_attn_p16_launch(s, rel, rows, start_pos, st));
@@ -2294,8 +2375,10 @@ int jh_model_destroy(jh_model* m) {
         if (w.tiled) hipFree(w.tiled);
         if (w.tiled_scales) hipFree(w.tiled_scales);
         if (w.p16t) hipFree(w.p16t);
+        if (w.t16) hipFree(w.t16);
+        if (w.t16_scales) hipFree(w.t16_scales);
     }
-    for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); if (w.p16t) hipFree(w.p16t); }
+    for (auto& w : m->qkv) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); if (w.p16t) hipFree(w.p16t); if (w.t16) hipFree(w.t16); if (w.t16_scales) hipFree(w.t16_scales); }
     for (auto& w : m->gateup) { if (w.tiled) hipFree(w.tiled); if (w.tiled_scales) hipFree(w.tiled_scales); if (w.t16) hipFree(w.t16); if (w.t16_scales) hipFree(w.t16_scales); }
     for (auto& w : m->global_w) { if (w.data) hipFree(w.data); if (w.scales) hipFree(w.scales); if (w.p16t) hipFree(w.p16t); }
     if (m->rope) hipFree(m->rope);
@@ -2370,6 +2453,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
         }
         if (f.tiled) { hipFree(f.tiled); hipFree(f.tiled_scales); f.tiled = nullptr; f.tiled_scales = nullptr; }
         if (f.p16t) { hipFree(f.p16t); f.p16t = nullptr; }
+        if (f.t16) { hipFree(f.t16); hipFree(f.t16_scales); f.t16 = nullptr; f.t16_scales = nullptr; }
         const size_t row0 = which == JH_W_Q ? 0 : (which == JH_W_K ? (size_t)A : (size_t)(A + KV));
         uint8_t* dd = (uint8_t*)f.data + row0 * row_bytes;
         float* ds = f.scales ? f.scales + row0 * (E / QB) : nullptr;
@@ -2384,6 +2468,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     if (w->scales) hipFree(w->scales);
     if (w->tiled) { hipFree(w->tiled); hipFree(w->tiled_scales); w->tiled = nullptr; w->tiled_scales = nullptr; }
     if (w->p16t) { hipFree(w->p16t); w->p16t = nullptr; }
+    if (w->t16) { hipFree(w->t16); hipFree(w->t16_scales); w->t16 = nullptr; w->t16_scales = nullptr; }
     if (layer >= 0 && (which == JH_W_GATE || which == JH_W_UP)) {
         JWeight& gu = m->gateup[(size_t)layer];
         if (gu.tiled) { hipFree(gu.tiled); hipFree(gu.tiled_scales); gu.tiled = nullptr; gu.tiled_scales = nullptr; }
@@ -2598,7 +2683,7 @@ int jh_session_destroy(jh_session* s) {
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
-    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start, (void*)s->pb_att_o, (void*)s->pb_att_ml, (void*)s->tile_w, (void*)s->tile_s, (void*)s->p16_scores_b}) if (b) hipFree(b);
+    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start, (void*)s->pb_att_o, (void*)s->pb_att_ml, (void*)s->tile_w, (void*)s->tile_s, (void*)s->p16_scores_b, (void*)s->pb_sel, (void*)s->pb_sad}) if (b) hipFree(b);
     for (auto& kv : s->pb_graphs) hipGraphExecDestroy(kv.second);
     for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
     if (s->ev0) hipEventDestroy(s->ev0);

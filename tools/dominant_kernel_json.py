@@ -45,9 +45,9 @@ if fetch:
     rec["ratio_to_algorithmic"] = rec["traffic_bytes_per_launch"] / algo
 
 
-# the same kernel of the reference-order path (jh_p16.h): gemv_i8q4_p16_kernel<PRO_RMS_Q8=1, EPI_SILU_MUL=2, ...>
-def is_gateup_p16(name):
-    return re.match(r"gemv_i8q4_p16_kernel<1, 2,", name) is not None
+# the same kernel of the reference-order path (jh_t16.h / jh_p16.h)
+def is_gateup_p16(name):   # gemv_t16_kernel<PRO_RMS_Q8=1, EPI_SILU_MUL=2, ...> (jh_t16.h), or the p16 form where the shape rules T16 out
+    return re.match(r"gemv_t16_kernel<1, 2,", name) is not None or re.match(r"gemv_i8q4_p16_kernel<1, 2,", name) is not None
 
 
 t16 = [r for r in rows(prefix + "_kernel_trace_stats.md") if is_gateup_p16(r[0])]
