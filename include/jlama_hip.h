@@ -69,6 +69,13 @@ const char* jh_source_hash(void);
 int jh_abi_config_layout(int32_t* out, int n);
 /* Block until all work queued by this thread's stream has finished. */
 int jh_synchronize(void);
+/* Process options.  The library reads NO tuning knob from the process environment (a JVM host would inherit whatever its launcher
+ * exported); an option exists only after the host sets it here.  The one exception is a documented handful that jh_init copies
+ * from the environment once: JH_TRACE, JH_NO_GRAPH, JH_STRICT_ORDER, JH_TILED_COPY (auto|resident|transient), JH_TP_LOUD.
+ * Everything else is a constant chosen by the launch planners; names and meanings of the test / tuning options are listed in
+ * tools/README.md.  No reference counterpart (the reference has no such switches). */
+int jh_set_option(const char* name, int32_t value);
+int jh_clear_options(void);
 
 /* ------------------------------------------------------------------ Tier 1: TensorOperations */
 

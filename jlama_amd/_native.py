@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "lib", "libjlamahip.so")
 SRC = os.path.join(HERE, "csrc", "jlama_hip.hip")
-HDRS = [os.path.join(HERE, "csrc", "jh_kernels.h"), os.path.join(HERE, "csrc", "jh_p16.h"), os.path.join(HERE, "csrc", "jh_strict.h"),
+HDRS = [os.path.join(HERE, "csrc", "jh_kernels.h"), os.path.join(HERE, "csrc", "jh_p16.h"),
         os.path.join(HERE, "csrc", "jh_t16.h"),
         os.path.join(ROOT, "include", "jlama_hip.h")]
 
@@ -83,6 +83,8 @@ _PROTOS = {
     "jh_preferred_working_qtype": (_i, []),
     "jh_last_error": (C.c_char_p, []),
     "jh_synchronize": (_i, []),
+    "jh_set_option": (_i, [C.c_char_p, _i]),
+    "jh_clear_options": (_i, []),
     "jh_register_tensor": (_l, [_p, _l]),
     "jh_unregister_tensor": (_i, [_l]),
     "jh_gemm_q8_q4": (_i, [_l, _l, _p, _p, _i, _p, _p, _i, _p, _i] + [_i] * 9),
@@ -201,6 +203,29 @@ def check(rc):
 def ptr(a):
     """void* of a numpy array (or None)."""
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def set_option(name, value):
+    """Explicit process option (include/jlama_hip.h: jh_set_option); the library does not read tuning knobs from the environment."""
+    if isinstance(value, str) and name == "JH_TILED_COPY":
+        value = {"resident": 1, "transient": 2}.get(value, 0)
+    check(lib().jh_set_option(name.encode(), int(value)))
+
+
+def clear_options():
+    check(lib().jh_clear_options())
+
+
+def options_from_env(prefix="JH_"):
+    """tools/ only: forward every JH_* environment variable with an integer value as an explicit option (the sweeps drive the
+    planners this way).  The product never does this."""
+    for k, v in os.environ.items():
+        if k.startswith(prefix):
+            try:
+                set_option(k, int(v))
+            except ValueError:
+                if k == "JH_TILED_COPY":
+                    set_option(k, {"resident": 1, "transient": 2}.get(v, 0))
 
 
 def init(device=0):

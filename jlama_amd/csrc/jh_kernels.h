@@ -2392,58 +2392,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
     for (int i = tid; i < GROUP * HS; i += NT) p.outf[(size_t)kvh * GROUP * HS + i] = oloc[i];
 }
 
-// Merge the slices of attn_decode_kernel (combine_kernel mode): w_s = l_s*exp(m_s - M) / sum_s(l_s*exp(m_s - M)),
-// o = sum_s w_s*o_s in slice order.  One workgroup per kv head.  The in-kernel alternative (write-through publish +
-// ticket + last-arriver combine) costs ~4.1 us of dependent round trips; a kernel edge costs 1.55 us.
-template <int HS, int GROUP>
-__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
-    __shared__ float wts[GROUP * 64];
-    const int kvh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = p.st->pos + 1;
-    int S = (n + 31) / 32, cap = p.max_splits;
-    if (p.mid_max && n <= p.mid_max && p.mid_splits < cap) cap = p.mid_splits;
-    if (S > cap) S = cap;
-    for (int gi = wave; gi < GROUP; gi += 4) {
-        const float* pr = p.part_ml + ((size_t)(kvh * GROUP + gi) * p.part_stride) * 2;
-        float m = -INFINITY;
-        for (int s = lane; s < S; s += 64) m = fmaxf(m, pr[2 * s]);
-        m = wave_max(m);
-        float L = 0.0f;
-        for (int s = lane; s < S; s += 64) {
-            const float w = pr[2 * s + 1] * (float)exp((double)(pr[2 * s] - m));
-            wts[gi * 64 + s] = w;
-            L += w;
-        }
-        L = wave_sum(L);
-        for (int s = lane; s < S; s += 64) wts[gi * 64 + s] = wts[gi * 64 + s] / L;
-    }
-    constexpr int CS = 16, EPT = (GROUP * HS + 255) / 256;   // slices loaded per batch (all in flight), elements per thread
-    float pv[EPT][CS];
-#pragma unroll
-    for (int e = 0; e < EPT; e++) {
-        int i = tid + e * 256;
-        i = i < GROUP * HS ? i : GROUP * HS - 1;
-        const int gi = i / HS, d = i - gi * HS;
-        const float* pb = p.part_o + (size_t)(kvh * GROUP + gi) * p.part_stride * HS + d;
-#pragma unroll
-        for (int s = 0; s < CS; s++) pv[e][s] = pb[(size_t)(s < S ? s : S - 1) * HS];   // branch-free: one round trip
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < EPT; e++) {
-        const int i = tid + e * 256;
-        if (i >= GROUP * HS) break;
-        const int gi = i / HS, d = i - gi * HS;
-        const float* pb = p.part_o + (size_t)(kvh * GROUP + gi) * p.part_stride * HS + d;
-        float o = 0.0f;
-#pragma unroll
-        for (int s = 0; s < CS; s++)
-            if (s < S) o = fmaf(pv[e][s], wts[gi * 64 + s], o);
-        for (int s = CS; s < S; s++) o = fmaf(pb[(size_t)s * HS], wts[gi * 64 + s], o);
-        p.outf[(size_t)kvh * GROUP * HS + i] = o;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ batched prefill
 // AbstractModel.batchForward (core/model/AbstractModel.java:295-312) for a chunk of B <= 256 prompt rows: the
 // projections run as MFMA GEMMs over all rows (gemm_q8q4_mfma_kernel), the per-row work between them is below.

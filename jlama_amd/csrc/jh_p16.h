@@ -705,16 +705,13 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (arrays of HIP's float4 class type end up in scratch)
-template <int HS, int RU, bool FUSED = false>
+template <int HS, int RU>
 __device__ __forceinline__ void p16_av_load_tile(const AttnParams& p, f32x4 (&vreg)[RU], int tile, int n, int KV, int kvh, int d0, int vr, int vc) {
 #pragma unroll
     for (int u = 0; u < RU; u++) {
         int tt = tile * (32 * RU) + vr + 32 * u;
         tt = tt < n ? tt : n - 1;
         const float* vrow = kv_row(p, 1, tt, KV) + (size_t)kvh * HS + d0;
-        // one launch for scores + values: the page row of the NEW position is being written by another workgroup of this very
-        // launch, so it is taken from the q|k|v row (the same bits)
-        if (FUSED && tt == n - 1) vrow = p.qkv + (size_t)p.n_heads * HS + KV + (size_t)kvh * HS + d0;
         vreg[u] = ((const f32x4*)vrow)[vc];
     }
 }
@@ -726,12 +723,8 @@ __device__ __forceinline__ void p16_av_store_tile(float* vt, const f32x4 (&vreg)
 // RU = V rows per thread and tile, i.e. TP = 32 * RU positions per V tile in LDS (host: 2, 4, 8 or 16 -- the smallest that holds
 // the session's max_ctx, at most 512 positions): a context of up to TP positions is ONE tile, requested at kernel start and
 // landing while the softmax runs.
-// FUSED (decode at short contexts, <= 512 positions): the scores of the head are computed HERE, by every workgroup of the head for
-// itself (each reads the K rows of the whole context once more -- L2 hits, 16-lane dots exactly as attn_p16_scores_kernel), and
-// workgroup (0, first head of the kv group) writes the new K / V page rows: one launch per layer less; the score row never
-// leaves LDS.  Long contexts keep the two launches (a workgroup cannot ingest the whole K of a long context in time).
 constexpr int P16_AV_TPMAX = 512;
-template <int HS, int RU, bool FUSED = false>
+template <int HS, int RU>
 __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams p, const float* scores, int sc_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 32 * RU;   // columns per workgroup, positions per tile
@@ -748,72 +741,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     const int vr = tid >> 3, vc = tid & 7;
     f32x4 vreg[RU];
     float m = -INFINITY;
-    if constexpr (FUSED) {
-        constexpr int half = HS / 2, NC = HS / 16, RP = NT / 16, PB = 2;
-        float* qs = w + p.w_cap;                               // roped q of this head, then the roped new k row
-        float* knew = qs + HS;
-        const int l = tid & 15, prow = tid >> 4, A = p.n_heads * HS;
-        float kvv[PB][NC];
-        auto load_k = [&](int tb) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < PB; u++) {
-                int tt = tb + u * RP;
-                tt = tt < n ? tt : n - 1;
-                const float* krow = kv_row(p, 0, tt, KV) + (size_t)kvh * HS + l;
-#pragma unroll
-                for (int c = 0; c < NC; c++) kvv[u][c] = krow[16 * c];
-            }
-        };
-        load_k(prow);                                          // K rows first (their addresses need the position only) ...
-        p16_av_load_tile<HS, RU, true>(p, vreg, 0, n, KV, kvh, d0, vr, vc);   // ... then the V tile, in flight across scores + softmax
-        const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
-        const bool owner = blockIdx.x == 0 && h == kvh * group;
-        for (int i = tid; i < 2 * half; i += NT) {
-            const int gi = i / half, d = i - gi * half;
-            const float c = rf[2 * d], sn = rf[2 * d + 1];
-            if (gi == 0) {
-                const float* qh = p.qkv + (size_t)h * HS;
-                const float q0 = qh[d], q1 = qh[d + half];
-                const float r0 = q0 * c - q1 * sn, r1 = q0 * sn + q1 * c;   // contraction off: mul, mul, sub / add as in Java
-                qs[d] = r0; qs[d + half] = r1;
-                if (p.tap_q && blockIdx.x == 0) { p.tap_q[(size_t)h * HS + d] = r0; p.tap_q[(size_t)h * HS + d + half] = r1; }
-            } else {
-                const float* kh = p.qkv + A + (size_t)kvh * HS;
-                const float k0 = kh[d], k1 = kh[d + half];
-                const float r0 = k0 * c - k1 * sn, r1 = k0 * sn + k1 * c;
-                knew[d] = r0; knew[d + half] = r1;
-                if (owner) {   // K is stored post-RoPE (CausalSelfAttention.java:273-286 rotates the page row in place)
-                    float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
-                    kdst[d] = r0; kdst[d + half] = r1;
-                }
-            }
-        }
-        if (owner)
-            for (int d = tid; d < HS; d += NT) ((float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS)[d] = p.qkv[A + KV + (size_t)kvh * HS + d];
-        __syncthreads();
-        float q[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) q[c] = qs[16 * c + l];
-        for (int tb = prow; tb < n; tb += RP * PB) {
-            if (tb != prow) load_k(tb);
-#pragma unroll
-            for (int u = 0; u < PB; u++) {
-                const int tt = tb + u * RP;
-                if (tt >= n) break;                             // uniform per 16-lane row
-                if (tt == pos) {
-#pragma unroll
-                    for (int c = 0; c < NC; c++) kvv[u][c] = knew[16 * c + l];   // the page row is being written just now
-                }
-                float acc = 0.0f;
-#pragma unroll
-                for (int c = 0; c < NC; c++) acc = fmaf(q[c], kvv[u][c], acc);   // GemmerF32 (PTO:1086-1102): lane l, steps of 16
-                acc = row16_tree_sum(acc);
-                if (l == 0) w[tt] = acc * p.scale;              // ops.scale after the dot (:332)
-            }
-        }
-        __syncthreads();
-        for (int tt = tid; tt < n; tt += NT) m = fmaxf(m, w[tt]);
-    } else {
+    {
         p16_av_load_tile<HS, RU>(p, vreg, 0, n, KV, kvh, d0, vr, vc);   // in flight across the softmax
         const float* srow = scores + (size_t)h * sc_stride;
         for (int tt = tid; tt < n; tt += NT) {
@@ -854,7 +782,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
         if (tile > 0) {                     // contexts beyond one tile: plain copy per tile (the register array must not be
             __syncthreads();                // loop-carried: hipcc then keeps it in scratch); the previous tile has been consumed
             f32x4 vnext[RU];
-            p16_av_load_tile<HS, RU, FUSED>(p, vnext, tile, n, KV, kvh, d0, vr, vc);
+            p16_av_load_tile<HS, RU>(p, vnext, tile, n, KV, kvh, d0, vr, vc);
             p16_av_store_tile<RU>(vt, vnext, vr, vc);
         }
         __syncthreads();                    // tile (and, first time round, the normalised weights) visible

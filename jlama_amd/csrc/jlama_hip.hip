@@ -16,7 +16,6 @@
 #include <vector>
 
 #include "jh_kernels.h"
-#include "jh_strict.h"
 #include "jh_t16.h"
 
 using namespace jh;
@@ -100,9 +99,35 @@ const void* reg_ptr(int64_t id) {
     return it == g_reg.end() ? nullptr : it->second.ptr;
 }
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
+// Process options.  The library does NOT read tuning knobs from the process environment (a Java host would inherit whatever its
+// launcher exported): an option exists only after jh_set_option() -- the host's explicit decision, used by tests and tools/ -- with
+// one exception, the documented handful that jh_init copies from the environment ONCE (JH_ENV_OPTIONS below).  Everything else is
+// a constant chosen by the launch planners.
+std::mutex g_opt_mu;
+std::map<std::string, int> g_opts;
+int opt_int(const char* name, int dflt) {
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    auto it = g_opts.find(name);
+    return it == g_opts.end() ? dflt : it->second;
+}
+// JH_TRACE=1          synchronize + report after every launch (debugging)
+// JH_NO_GRAPH=1       decode without hipGraph replay (debugging)
+// JH_STRICT_ORDER=0   new sessions start with the order-free kernels instead of the reference-order ones (jh_session_set_strict)
+// JH_TILED_COPY=auto|resident|transient   where the order-free prefill GEMM's MFMA-ordered weight operand lives
+// JH_TP_LOUD=1        a tensor-parallel meeting that times out is an error instead of a (reported) fall-back to the event loop
+const char* const JH_ENV_OPTIONS[] = {"JH_TRACE", "JH_NO_GRAPH", "JH_STRICT_ORDER", "JH_TILED_COPY", "JH_TP_LOUD"};
+void options_from_environment_once() {
+    static bool done = false;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (done) return;
+    done = true;
+    for (const char* name : JH_ENV_OPTIONS) {
+        const char* v = getenv(name);
+        if (!v || !*v || g_opts.count(name)) continue;
+        int val = atoi(v);
+        if (!strcmp(name, "JH_TILED_COPY")) val = !strcmp(v, "resident") ? 1 : !strcmp(v, "transient") ? 2 : 0;
+        g_opts[name] = val;
+    }
 }
 
 template <typename K>
@@ -114,7 +139,7 @@ int allow_lds(K kernel, size_t bytes) {
 std::mutex g_capture_mu;   // one hipGraph capture at a time per process (captures are rare; concurrent ones from different host threads are fragile)
 int g_trace = -1;
 int trace_sync(const char* what, hipStream_t st) {
-    if (g_trace < 0) g_trace = env_int("JH_TRACE", 0);
+    if (g_trace < 0) g_trace = opt_int("JH_TRACE", 0);
     if (!g_trace) return JH_OK;
     fprintf(stderr, "[jh] %s ...", what);
     fflush(stderr);
@@ -278,7 +303,7 @@ int launch_gemm_q8q4_lds(const MfmaQ4Params& g, int mtiles, float* ws, size_t ws
     const int nblk = g.k / QB;
     const int cgroups = g.n / (32 * CW * CT), gg = (cgroups + 7) / 8;
     int Z = 1;
-    const int z_env = env_int("JH_GEMM_Z", 0);
+    const int z_env = opt_int("JH_GEMM_Z", 0);
     while (Z < 8 && (long long)mtiles * cgroups * Z < (long long)g_cu_count * 2 && nblk % (16 * S * Z) == 0 &&
            ws && (size_t)(2 * Z) * g.m * g.n * 4 <= ws_bytes) Z *= 2;
     if (z_env > 0 && nblk % (8 * S * z_env) == 0 && (z_env == 1 || (ws && (size_t)z_env * g.m * g.n * 4 <= ws_bytes))) Z = z_env;
@@ -302,16 +327,16 @@ int launch_gemm_q8q4_lds(const MfmaQ4Params& g, int mtiles, float* ws, size_t ws
 int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = false, float* ws = nullptr, size_t ws_bytes = 0) {
     const int mt = (g.m + 31) / 32;
     const int nblk = g.k / QB;
-    if (nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024 && (tiled || (g.lda % 16) == 0) && (tiled || !env_int("JH_GEMM_FAT", 0))) {
+    if (nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024 && (tiled || (g.lda % 16) == 0) && true) {
         // one 32x32 output tile per wave; split K over S waves until the chip has >= ~8 waves per CU; CW column tiles per
         // workgroup share the A tile through L1 (S*CW <= 8 waves: several workgroups per CU keep the CUs evenly loaded)
         // gemm_q8q4_lds_kernel (A through LDS, K split over the waves of a workgroup) for the GEMMs with enough work per column
         // group -- gate|up and down: 71 vs 78 us and 45 vs 56 us at M = 129, 96 vs 102 and 54 vs 67 at M = 256 -- the tile kernel
         // below for q|k|v and the o-projection (21 vs 30 us).  JH_GEMM_LDS = 0 / 1 forces one of them.
-        const int lds_env = env_int("JH_GEMM_LDS", -1);   // read per call: the tests flip it within one process
+        const int lds_env = opt_int("JH_GEMM_LDS", -1);   // read per call: the tests flip it within one process
         const bool lds_auto = (long long)(g.n / 32) * nblk >= (long long)896 * 64;
         if (tiled && (lds_env > 0 || (lds_env < 0 && lds_auto))) {
-            const int cw_l = env_int("JH_GEMM_LDS_CW", 4), ct_l = env_int("JH_GEMM_LDS_CT", 1), s_l = env_int("JH_GEMM_LDS_S", 2);
+            const int cw_l = opt_int("JH_GEMM_LDS_CW", 4), ct_l = opt_int("JH_GEMM_LDS_CT", 1), s_l = opt_int("JH_GEMM_LDS_S", 2);
             int CWL = cw_l, CTL = ct_l > 2 ? 2 : ct_l, SL = s_l;
             while (CTL > 1 && g.n % (32 * CWL * CTL)) CTL >>= 1;
             while (CWL > 1 && g.n % (32 * CWL * CTL)) CWL >>= 1;
@@ -319,7 +344,7 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
             while (SL > 1 && (size_t)nblk * 128 + (size_t)SL * 8192 > 150 * 1024) SL >>= 1;   // scale slice + the A rings of the SL K slices
             const bool lds_fits = (size_t)nblk * 128 + (size_t)SL * 8192 <= 150 * 1024;
             if (!lds_fits) CWL = -1;   // no instantiation below matches: the tile kernel takes it
-            if (CWL == 4 && CTL == 1 && SL == 2 && env_int("JH_GEMM_LDS_PK", 0)) return launch_gemm_q8q4_lds<4, 1, 2, true>(g, mt, ws, ws_bytes, st);
+            if (CWL == 4 && CTL == 1 && SL == 2 && opt_int("JH_GEMM_LDS_PK", 0)) return launch_gemm_q8q4_lds<4, 1, 2, true>(g, mt, ws, ws_bytes, st);
 #define JH_LDS(CV, TV, SV) if (CWL == CV && CTL == TV && SL == SV) return launch_gemm_q8q4_lds<CV, TV, SV>(g, mt, ws, ws_bytes, st);
             JH_LDS(4, 1, 1) JH_LDS(4, 1, 2) JH_LDS(4, 1, 4) JH_LDS(2, 1, 2) JH_LDS(2, 1, 4) JH_LDS(2, 1, 8) JH_LDS(4, 2, 1) JH_LDS(4, 2, 2) JH_LDS(2, 2, 2)
             JH_LDS(1, 1, 4) JH_LDS(1, 1, 8) JH_LDS(2, 1, 1) JH_LDS(1, 1, 1) JH_LDS(1, 1, 2)
@@ -328,7 +353,7 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
         const long long tiles = (long long)mt * (g.n / 32);
         int S = 1;
         while (S < 8 && tiles * S < (long long)g_cu_count * 8 && nblk % (16 * S) == 0) S *= 2;   // nblk/S stays a multiple of 8
-        static const int cw_env = env_int("JH_GEMM_CW", 0), s_env = env_int("JH_GEMM_S", 0);
+        static const int cw_env = opt_int("JH_GEMM_CW", 0), s_env = opt_int("JH_GEMM_S", 0);
         if (s_env > 0 && nblk % (8 * s_env) == 0) S = s_env;
         int CW = 1;
         if (tiled) {
@@ -400,7 +425,7 @@ int launch_gemm_bf16_tile_mc(MfmaBf16TileParams g, int S, hipStream_t st) {
     const int tiles = g.n / 32, grid = (tiles + CWB - 1) / CWB;
     g.nsplit = S;
     // A through LDS (gemm_bf16_lds_kernel) when the K range of a workgroup row divides into double chunks of 4 slices
-    const int lds_env = env_int("JH_BF16_LDS", 1);
+    const int lds_env = opt_int("JH_BF16_LDS", 1);
     if (lds_env && (tiles % CWB) == 0 && ((g.k / 16 / S) % 8) == 0) {
         const size_t lds = (size_t)2 * MT * 4 * 1024;
         JHCHK(allow_lds((gemm_bf16_lds_kernel<MT, CWB>), lds));
@@ -422,14 +447,14 @@ int launch_gemm_bf16_tile(const MfmaBf16TileParams& g, hipStream_t st) {
     const int mt = (g.m + 31) / 32, tiles = g.n / 32, nks = g.k / 16;
     // waves per workgroup (column tiles sharing the A fragments through L1) vs workgroups: want >= ~2 workgroups per CU
     // before splitting K, because the split's reduce pass moves S*M*N*8 bytes
-    static const int cwb_env = env_int("JH_BF16_CWB", 0), s_env = env_int("JH_BF16_S", 0);
+    static const int cwb_env = opt_int("JH_BF16_CWB", 0), s_env = opt_int("JH_BF16_S", 0);
     int cwb = 8;
     while (cwb > 1 && ((tiles % cwb) != 0 || tiles / cwb < g_cu_count * 2)) cwb >>= 1;
     if (cwb < 4 && tiles % 4 == 0 && nks >= 512) cwb = 4;      // long K, few tiles: measured best (tools/gemm_bench.py)
     if (cwb < 2 && tiles % 2 == 0) cwb = 2;
     if (cwb_env > 0 && tiles % cwb_env == 0) cwb = cwb_env;
     int S = 1;
-    const bool lds_kernel = env_int("JH_BF16_LDS", 1) != 0 && nks % 8 == 0;
+    const bool lds_kernel = opt_int("JH_BF16_LDS", 1) != 0 && nks % 8 == 0;
     if (lds_kernel && cwb_env <= 0) {
         // gemm_bf16_lds_kernel (tools/bf16_exp.sh sweeps, profiles/r02i_*): the waves of a workgroup share the staged A chunk, so
         // 4 column tiles per workgroup (8 when the A chunk is 7-8 row tiles); K split until the launch has a workgroup per CU and
@@ -507,6 +532,7 @@ int jh_init(int device, int64_t* out_info) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) return set_err(JH_ERR_NO_DEVICE, "no HIP device (hipGetDeviceCount)");
     if (device < 0 || device >= n) return set_err(JH_ERR_INVALID, "device ordinal out of range");
+    options_from_environment_once();
     g_default_device = device;
     if (tctx.device != device) {
         tctx.device = -1;  // re-create the per-thread stream on the new device
@@ -524,6 +550,17 @@ int jh_init(int device, int64_t* out_info) {
         out_info[2] = n;
         out_info[3] = (int64_t)prop.maxSharedMemoryPerMultiProcessor;
     }
+    return JH_OK;
+}
+int jh_set_option(const char* name, int32_t value) {
+    if (!name || !*name) return set_err(JH_ERR_INVALID, "set_option: null name");
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    g_opts[name] = value;
+    return JH_OK;
+}
+int jh_clear_options(void) {
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    g_opts.clear();
     return JH_OK;
 }
 const char* jh_name(void) { return "HIP CDNA4 (gfx950) Operations"; }
@@ -642,7 +679,7 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
     JHCHK(dev_buf(4, r_elems * 4, &dR));
 
     bool fast = (m == 1) && q4 && (aoffset % QB == 0) && (boffset % 16 == 0) && (ldb % 16 == 0) &&
-                !env_int("JH_TIER1_GENERIC", 0);
+                !opt_int("JH_TIER1_GENERIC", 0);
     if (fast) {
         GemvParams p;
         memset(&p, 0, sizeof(p));
@@ -653,8 +690,8 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         p.w = dB + (size_t)ldb * n0 + boffset;
         p.ws = dBf + (size_t)ldbf * n0 + (boffset * 2) / QB;
         p.out = (float*)dR + cmin;
-        LaunchCfg cfg{env_int("JH_GEMV_R", 0), env_int("JH_GEMV_WAVES", 0), 0, env_int("JH_GEMV_PIPE", -1)};
-        LaunchCfg cfgf{env_int("JH_GEMV_R", 0), 8, g_cu_count * 2, 1};
+        LaunchCfg cfg{opt_int("JH_GEMV_R", 0), opt_int("JH_GEMV_WAVES", 0), 0, opt_int("JH_GEMV_PIPE", -1)};
+        LaunchCfg cfgf{opt_int("JH_GEMV_R", 0), 8, g_cu_count * 2, 1};
         if (kind == G_Q8Q4) {
             p.aq = (const int8_t*)dA + aoffset;
             p.ad = (const float*)dAf + aoffset / QB;
@@ -666,7 +703,7 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         }
     }
     if (!fast && kind == G_Q8Q4 && m >= 2 && m <= 256 && (n % 32) == 0 && (aoffset % QB) == 0 && (boffset % 16) == 0 && (lda % 16) == 0 &&
-        (ldb % 16) == 0 && !env_int("JH_TIER1_GENERIC", 0)) {
+        (ldb % 16) == 0 && !opt_int("JH_TIER1_GENERIC", 0)) {
         // batched I8 x Q4 GEMM on the matrix cores (prefill shape), exact integer block sums
         MfmaQ4Params g;
         g.a = (const int8_t*)dA + aoffset; g.af = (const float*)dAf + aoffset / QB;
@@ -677,7 +714,7 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
         else if (rcm != JH_ERR_UNSUPPORTED) return rcm;
     }
     if (!fast && kind == G_BF16 && m >= 2 && m <= 256 && (k % MG_KS) == 0 && (n % 32) == 0 && (aoffset % 8) == 0 && (boffset % 8) == 0 &&
-        (lda % 8) == 0 && (ldb % 8) == 0 && !env_int("JH_TIER1_GENERIC", 0)) {
+        (lda % 8) == 0 && (ldb % 8) == 0 && !opt_int("JH_TIER1_GENERIC", 0)) {
         // batched BF16 GEMM on the matrix cores (prefill shape)
         MfmaGemmParams g;
         g.a = (const uint16_t*)dA + aoffset; g.w = (const uint16_t*)dB + boffset; g.c = (float*)dR;
@@ -1121,7 +1158,6 @@ struct jh_session {
     // graphs exist per attention variant (0: PRE=8 row steps prefetched, 1: PRE=2 for short contexts, 2: long contexts -- more slices)
     int attn_variant = 0;
     int graphs_version = 0;   // jh_model::weights_version the cached graphs were captured against
-    int attn_combine = 0;   // 1: slices merged by attn_combine_kernel after the kernel edge (0: in-kernel ticket + last arriver)
     hipGraph_t graph[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
     hipGraphExec_t exec[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
     hipGraph_t row_graph[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};   // this shard's layers only: single-row forward (pipeline stages)
@@ -1154,7 +1190,6 @@ struct jh_session {
     std::vector<hipGraph_t> pb_graph_src;
     int prefill_batch_min = 4;
     int strict = 0;           // jh_session_set_strict: reference-order kernels (jh_p16.h)
-    int strict_legacy = 0;    // JH_STRICT_LEGACY=1: the first, byte-granular implementation of them (jh_strict.h), kept as a cross-check
     // temperature sampling inside the device loop: exp((l - max)/T) of every logit, the caller's uniforms, the picked id; the
     // decode graphs of this mode are captured per temperature (a kernel argument)
     float* prob = nullptr;
@@ -1192,29 +1227,6 @@ namespace {
 
 bool is_global_slot(int which) { return which == JH_W_EMBED || which == JH_W_LMHEAD || which == JH_W_FINALNORM; }
 
-// ---- reference-order launchers, first implementation (jh_strict.h): 4 waves x 4 output rows per workgroup
-template <int PRO, int EPI>
-int launch_gemv_i8q4_strict(const GemvParams& p, hipStream_t st) {
-    const size_t lds = lds_bytes_i8(p.K);
-    int grid = (p.nrows + 15) / 16;
-    if (grid < 1) grid = 1;
-    JHCHK(allow_lds((gemv_i8q4_strict_kernel<PRO, EPI>), lds));
-    hipLaunchKernelGGL((gemv_i8q4_strict_kernel<PRO, EPI>), dim3(grid), dim3(256), lds, st, p);
-    HIPCHK(hipGetLastError());
-    return JH_OK;
-}
-int launch_gemv_f32q4_strict(const GemvParams& p, int* grid_out, hipStream_t st) {
-    const size_t lds = lds_bytes_f32_strict(p.K);
-    int grid = (p.nrows + 15) / 16;
-    if (grid > 2048) grid = 2048;   // argmax partial buffers hold 4096 entries
-    if (grid < 1) grid = 1;
-    if (grid_out) *grid_out = grid;
-    JHCHK(allow_lds((gemv_f32q4_strict_kernel<PRO_RMS_F32>), lds));
-    hipLaunchKernelGGL((gemv_f32q4_strict_kernel<PRO_RMS_F32>), dim3(grid), dim3(256), lds, st, p);
-    HIPCHK(hipGetLastError());
-    return JH_OK;
-}
-
 // ---- reference-order launchers (jh_p16.h).  A wave serves 4 weight rows ("row quad"); the plan gives every CU the same
 // number of row quads: one 512-thread workgroup per CU, `tw` of its 8 waves own `per` row quads each (the others help
 // with the activation prologue only -- a 16-lane row per chain caps the useful waves at rows / 4).
@@ -1244,15 +1256,7 @@ template <int PRO, int EPI, int D>
 int launch_gemv_i8q4_p16_d(const GemvParams& p, const P16Plan& pl, bool wide, hipStream_t st) {
     const size_t lds = lds_bytes_p16(p.K);
     constexpr int UM_LO = (PRO == PRO_RMS_Q8) ? 2 : 4;
-    if constexpr (PRO == PRO_RMS_Q8 && EPI == EPI_SILU_MUL && D <= 4) {
-        if (wide && p.K <= 8192) {   // 16 waves: twice the row quads in flight per CU (gate|up has more than 8 per CU)
-            JHCHK(allow_lds((gemv_i8q4_p16_kernel<PRO, EPI, D, 1, 1024>), lds));
-            hipLaunchKernelGGL((gemv_i8q4_p16_kernel<PRO, EPI, D, 1, 1024>), dim3(pl.grid), dim3(1024), lds, st, p, pl.per, pl.tw);
-            HIPCHK(hipGetLastError());
-            g_last_gemv_grid = pl.grid;
-            return JH_OK;
-        }
-    }
+    (void)wide;
     if (p.K <= UM_LO * 4096) {
         JHCHK(allow_lds((gemv_i8q4_p16_kernel<PRO, EPI, D, UM_LO>), lds));
         hipLaunchKernelGGL((gemv_i8q4_p16_kernel<PRO, EPI, D, UM_LO>), dim3(pl.grid), dim3(P16_THREADS), lds, st, p, pl.per, pl.tw);
@@ -1270,16 +1274,11 @@ template <int PRO, int EPI>
 int launch_gemv_i8q4_p16(const GemvParams& p, int depth, hipStream_t st) {
     // more than 8 row quads per CU (gate|up): two workgroups per CU, so that every SIMD has 3-4 waves to issue from -- the kernel
     // is as much VALU- as HBM-bound, and a wave alone issues one instruction per ~4 cycles
-    static const int wgs_big = env_int("JH_P16_WGS_BIG", 1);   // measured on 8B gate|up: 22.2 us with two workgroups per CU, 21.3 with one
-    static const int waves_big = env_int("JH_P16_WAVES_BIG", 8);   // 16: one 1024-thread workgroup per CU for gate|up
-    const int q_cu = ((p.nrows + 3) / 4 + g_cu_count - 1) / g_cu_count;
-    const bool wide = PRO == PRO_RMS_Q8 && EPI == EPI_SILU_MUL && q_cu > 8 && waves_big >= 16 && p.K <= 8192;
-    const P16Plan pl = p16_plan(p.nrows, q_cu > 8 && wgs_big > 1 && !wide ? wgs_big : 1, wide ? 16 : 8);
+    const P16Plan pl = p16_plan(p.nrows, 1, 8);
+    const bool wide = false;
     // ring depth by bytes in flight per CU (tw waves x D KiB): ~32 KiB is what a CU sustains; deeper rings only cost registers
     // (measured: q|k|v and gate|up with 6-7 task waves 4 > 8, the o- and down-projections with 4 task waves 8 / 7 > 4)
     if (pl.tw >= 6 && depth > 4) depth = 4;
-    static const int wide_d = env_int("JH_P16_WIDE_D", 4);
-    if (wide && depth > wide_d) depth = wide_d;
     switch (p16_depth_for(p.K, depth)) {
         case 8: return launch_gemv_i8q4_p16_d<PRO, EPI, 8>(p, pl, wide, st);
         case 7: return launch_gemv_i8q4_p16_d<PRO, EPI, 7>(p, pl, wide, st);
@@ -1305,11 +1304,9 @@ int launch_gemv_f32q4_p16_d(const GemvParams& p, const P16Plan& pl, hipStream_t 
 }
 template <int PRO>
 int launch_gemv_f32q4_p16(const GemvParams& p, int* grid_out, hipStream_t st) {
-    static const int gx = env_int("JH_P16_LM_GRIDX", 2);
-    const P16Plan pl = p16_plan(p.nrows, gx > 0 && gx <= 16 ? gx : 2);   // argmax partial buffers hold 4096 entries
+    const P16Plan pl = p16_plan(p.nrows, 2);   // two workgroups per CU; the argmax partial buffers hold 4096 entries
     if (grid_out) *grid_out = pl.grid;
-    static const int lm_d = env_int("JH_P16_LM_D", 8);
-    switch (p16_depth_for(p.K, lm_d)) {
+    switch (p16_depth_for(p.K, 8)) {
         case 8: return launch_gemv_f32q4_p16_d<PRO, 8>(p, pl, st);
         case 7: return launch_gemv_f32q4_p16_d<PRO, 7>(p, pl, st);
         case 4: return launch_gemv_f32q4_p16_d<PRO, 4>(p, pl, st);
@@ -1350,7 +1347,7 @@ int launch_gemv_t16(const GemvParams& p, hipStream_t st) {
 }
 // gate|up of layer li in T16 order (tile u = gate rows 8u..8u+7, up rows 8u..8u+7): made once, before any graph capture
 bool t16_gateup_ok(const jh_model* m, int li) {
-    static const int enabled = env_int("JH_T16", 1);
+    static const int enabled = opt_int("JH_T16", 1);
     const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     const JWeight &G = W[JH_W_GATE], &U = W[JH_W_UP];
     return enabled && G.data && U.data && G.dtype == JH_DT_Q4 && U.dtype == JH_DT_Q4 && G.rows == U.rows && G.cols == U.cols &&
@@ -1406,7 +1403,7 @@ int use_p16t(GemvParams& p, const JWeight& W) {
 bool prefill_t16_ok(jh_session* s);
 // every operand copy a reference-order session of this shard will touch (allocation must not happen inside a graph capture)
 int ensure_strict_operands(jh_session* s, hipStream_t st) {
-    if (!s->strict || s->strict_legacy) return JH_OK;
+    if (!s->strict) return JH_OK;
     jh_model* m = s->m;
     for (int li = m->c.layer_start; li < m->c.layer_end; li++) {
         JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
@@ -1463,33 +1460,23 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     p.outf = s->attf;
     p.tap_q = tap ? s->tapq : nullptr;
     p.dbg = dbg;
-    p.combine_kernel = (s->attn_combine && s->direct_max == 0 && p.max_splits <= 64) ? 1 : 0;
-    if (s->strict && !s->strict_legacy) {
+    p.combine_kernel = 0;   // (slices merged after the kernel edge: measured slower than the in-kernel last arriver, removed)
+    if (s->strict) {
         // reference order in two launches (jh_p16.h): scores of every position slice, then softmax + the value chains
         const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
         const size_t lds_av = lds_bytes_attn_p16(s->max_ctx);
         if (lds_av > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "reference-order attention: the score row of max_ctx positions must fit in LDS");
         const dim3 grid_s(s->p16_att_splits, c.n_kv_heads), grid_v(hs / 32, c.n_heads);
         const int ru = p16_av_rows(s->max_ctx);
-        // contexts of <= 512 positions (the "short" graph variant) can run scores + softmax + values in ONE launch per layer
-        // (JH_P16_ATTN_FUSED=1).  Measured and left off: every workgroup of a head then ingests the head's whole K, which costs
-        // what the launch saves -- 8B 484.5 vs 488.0 tok/s, 1B 1,444 vs 1,503 (profiles/r03s_*)
-        static const int fused_env = env_int("JH_P16_ATTN_FUSED", 0);
-        const bool fused = fused_env && s->attn_variant == 1;
         p.w_cap = (s->max_ctx + 63) & ~63;
 #define JH_P16_AV(HSV, RV)                                                                                                      \
     if (hs == HSV && ru == RV) {                                                                                               \
-        if (fused) {                                                                                                           \
-            JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV, true>), lds_av));                                                     \
-            hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV, true>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
-        } else {                                                                                                               \
-            JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                           \
-            hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
-        }                                                                                                                      \
+        JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                               \
+        hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
     }
 #define JH_P16_ATTN(HSV, GV)                                                                                                   \
     if (hs == HSV && group == GV) {                                                                                            \
-        if (!fused) hipLaunchKernelGGL((attn_p16_scores_kernel<HSV, GV>), grid_s, dim3(P16_ATT_THREADS), 0, st, p, s->p16_scores, s->p16_sc_stride); \
+        hipLaunchKernelGGL((attn_p16_scores_kernel<HSV, GV>), grid_s, dim3(P16_ATT_THREADS), 0, st, p, s->p16_scores, s->p16_sc_stride); \
         HIPCHK(hipGetLastError());                                                                                             \
         JH_P16_AV(HSV, 2) JH_P16_AV(HSV, 4) JH_P16_AV(HSV, 8) JH_P16_AV(HSV, 16)                                                \
         HIPCHK(hipGetLastError());                                                                                             \
@@ -1499,14 +1486,6 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
 #undef JH_P16_ATTN
 #undef JH_P16_AV
         return set_err(JH_ERR_UNSUPPORTED, "attention: head_size must be 64 or 128 and heads/kv_heads in {1,2,4,8}");
-    }
-    if (s->strict) {
-        const size_t lds_s = lds_bytes_attn_strict(c.head_size, s->max_ctx);
-        if (lds_s > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "strict attention: the score row of max_ctx positions must fit in LDS");
-        JHCHK(allow_lds(attn_strict_kernel, lds_s));
-        hipLaunchKernelGGL(attn_strict_kernel, dim3(c.n_heads), dim3(256), lds_s, st, p);
-        HIPCHK(hipGetLastError());
-        return JH_OK;
     }
     const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
     const int most = s->long_splits > s->max_splits ? s->long_splits : s->max_splits;
@@ -1524,10 +1503,6 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
             hipLaunchKernelGGL((attn_decode_kernel<HSV, GV, 8>), grid, block, lds, st, p); \
         }                                                                                  \
         HIPCHK(hipGetLastError());                                                         \
-        if (p.combine_kernel) {                                                            \
-            hipLaunchKernelGGL((attn_combine_kernel<HSV, GV>), dim3(c.n_kv_heads), dim3(256), 0, st, p); \
-            HIPCHK(hipGetLastError());                                                     \
-        }                                                                                  \
         return JH_OK;                                                                      \
     }
     JH_ATTN(128, 4) JH_ATTN(128, 8) JH_ATTN(64, 4) JH_ATTN(128, 1) JH_ATTN(128, 2) JH_ATTN(64, 1) JH_ATTN(64, 2) JH_ATTN(64, 8)
@@ -1580,7 +1555,6 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
         p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st))); }
-        else if (s->strict && s->strict_legacy) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_STORE>(p, st)));
         else if (s->strict) { JHCHK(use_p16t(p, F)); JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_STORE>(p, s->p16_depth, st))); }
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
         JHCHK(trace_sync("qkv", st));
@@ -1609,9 +1583,6 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
             p.ldb = A * 2;
             if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
             else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
-        } else if (s->strict && s->strict_legacy) {
-            if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
-            else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
         } else if (!resid && s->tp_push) {
             if (s->strict) JHCHK(use_p16t(p, W[JH_W_O]));
             JHCHK(tp_push_gemv(s, p, s->cfg_o, st));
@@ -1621,12 +1592,6 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
             else JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_STORE>(p, s->p16_depth, st)));
         } else if (!resid) {
             JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_STORE>(p, s->cfg_o, st)));
-        } else if (s->direct_max > 0) {
-            // short contexts: the attention slices are combined here, under the weight prefetch
-            p.part_o = s->part_o; p.part_ml = s->part_ml; p.st = s->st; p.direct_max = s->direct_max;
-            p.direct_chunk = s->direct_chunk; p.part_stride = s->part_stride; p.head_size = hs; p.n_heads = c.n_heads;
-            p.tap_att = tap ? s->attf : nullptr;
-            JHCHK((launch_gemv_i8q4<PRO_ATTN_Q8, EPI_RESID>(p, s->cfg_o, st)));
         } else {
             JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_o, st)));
         }
@@ -1655,7 +1620,6 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
         p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
         p.out = s->hf;   // silu(gate)*up, F32; the down projection's prologue quantizes it (MLPBlock.java:144)
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, g_cu_count * 4, nullptr, st))); }
-        else if (s->strict && s->strict_legacy) JHCHK((launch_gemv_i8q4_strict<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
         else if (s->strict && t16_gateup_ok(m, li)) {
             JHCHK(ensure_gateup_t16(m, li, st));   // (already there unless a weight was just replaced; never inside a capture: ensure_strict_operands)
             p.w = m->gateup[(size_t)li].t16; p.ws = m->gateup[(size_t)li].t16_scales; p.w2 = nullptr; p.ws2 = nullptr;
@@ -1681,9 +1645,6 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
             p.ldb = H * 2;
             if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
             else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
-        } else if (s->strict && s->strict_legacy) {
-            if (resid) JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_RESID>(p, st)));
-            else JHCHK((launch_gemv_i8q4_strict<PRO_QUANT_Q8, EPI_STORE>(p, st)));
         } else if (!resid && s->tp_push) {
             if (s->strict) JHCHK(use_p16t(p, W[JH_W_DOWN]));
             JHCHK(tp_push_gemv(s, p, s->cfg_down, st));
@@ -1720,16 +1681,16 @@ constexpr int PF_MAX_SPLIT = 8;    // key-range splits of the MFMA prefill atten
 
 // reference-order sessions: prompt rows through the M-row p16 GEMM (jh_p16.h) -- whole groups of 16 Q blocks in every K
 bool prefill_p16_ok(jh_session* s) {
-    static const int enabled = env_int("JH_P16_PREFILL", 1);
+    static const int enabled = opt_int("JH_P16_PREFILL", 1);
     const jh_config& c = s->m->c;
-    if (!enabled || !s->strict || s->strict_legacy || c.weight_dtype != JH_DT_Q4) return false;
+    if (!enabled || !s->strict || c.weight_dtype != JH_DT_Q4) return false;
     const int hs = c.head_size, A = c.n_heads * hs, group = c.n_heads / c.n_kv_heads;
     if (c.embedding_length % 512 || c.hidden_length % 512 || A % 512 || c.hidden_length > 32768 || c.embedding_length > 32768 || A > 32768) return false;
     return (hs == 128 || hs == 64) && (group == 1 || group == 2 || group == 4 || group == 8);
 }
 // ... and through the F16-MFMA form of that GEMM (jh_t16.h: gemm_t16_kernel) when every projection has whole T16 tiles
 bool prefill_t16_ok(jh_session* s) {
-    static const int enabled = env_int("JH_T16_PREFILL", 1);
+    static const int enabled = opt_int("JH_T16_PREFILL", 1);
     const jh_config& c = s->m->c;
     if (!enabled || !prefill_p16_ok(s)) return false;                 // E, H, A are multiples of 512 (whole chunks of 16 blocks)
     const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs;
@@ -1782,7 +1743,7 @@ int prefill_alloc(jh_session* s) {
 }
 // The prefill GEMM wants both operands in MFMA order (gemm_q8q4_tile_kernel, TILED): possible when K % 128 == 0
 bool prefill_tiled(jh_session* s, int K) {
-    static const int enabled = env_int("JH_PREFILL_TILED", 1);
+    static const int enabled = opt_int("JH_PREFILL_TILED", 1);
     const int nblk = K / QB;
     if (s->m->c.weight_dtype == JH_DT_BF16) return enabled && (K % 32) == 0;
     return enabled && s->m->c.weight_dtype == JH_DT_Q4 && nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024;
@@ -1801,11 +1762,10 @@ static size_t tiled_w_bytes(const JWeight& W) { return W.dtype == JH_DT_BF16 ? (
 static size_t tiled_s_bytes(const JWeight& W) { return W.dtype == JH_DT_BF16 ? 0 : (size_t)W.rows * (W.cols / QB) * 4; }
 int tiled_mode_for(jh_model* m) {
     if (m->tiled_mode != TILED_UNSET) return m->tiled_mode;
-    const char* e = getenv("JH_TILED_COPY");
-    const std::string v = e ? e : "auto";
+    const int want = opt_int("JH_TILED_COPY", 0);   // 0 auto, 1 resident, 2 transient
     int mode = TILED_RESIDENT;
-    if (v == "transient") mode = TILED_TRANSIENT;
-    else if (v != "resident") {
+    if (want == 2) mode = TILED_TRANSIENT;
+    else if (want != 1) {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < (size_t)m->weight_bytes + tot / 4) mode = TILED_TRANSIENT;
         (void)hipGetLastError();
@@ -2066,7 +2026,7 @@ int gemm_p16_launch(jh_session* s, const JWeight& W, const JWeight* W2, int N, i
     if (!W.p16t || (W2 && !W2->p16t)) return set_err(JH_ERR_INVALID, "reference-order GEMM: the weight has no P16T copy (ensure_strict_operands)");
     GemmP16Params g{W.p16t, W.scales, W2 ? W2->p16t : nullptr, W2 ? W2->scales : nullptr, (int)p16t_row_bytes(K), K / QB, N, K, rows,
                     (const uint8_t*)s->pb_aq, s->pb_ad, K, K / QB, out, ldc, resid, ldr};
-    static const int nw_env = env_int("JH_P16_GEMM_WAVES", 16), mt_env = env_int("JH_P16_GEMM_MT", 0);
+    static const int nw_env = opt_int("JH_P16_GEMM_WAVES", 16), mt_env = opt_int("JH_P16_GEMM_MT", 0);
     const int nq = (N + 3) / 4;
     // MT activation images of K + K/8 bytes each in LDS.  16 would fit for K <= 8192 and halves the weight-unpack share, but it
     // costs occupancy (116 VGPRs in the gate|up kernel, 74-147 KB of LDS: one workgroup per CU) and rounds 129 rows up to 144:
@@ -2238,10 +2198,10 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     while (bound < start_pos + rows) bound *= 2;
     const bool attn_mfma = prefill_attn_mfma(s, start_pos, rows);
     if (!attn_mfma && !prefill_chunk_fits(s, 0, bound)) bound = start_pos + rows;
-    static const int use_graph = env_int("JH_PREFILL_GRAPH", 1);
+    static const int use_graph = opt_int("JH_PREFILL_GRAPH", 1);
     if (p16) {
         JHCHK(prefill_layers_p16(s, rows, start_pos, st));   // positions are launch arguments here: launched directly, no graph
-    } else if (use_graph && !env_int("JH_TRACE", 0)) {
+    } else if (use_graph && !opt_int("JH_TRACE", 0)) {
         drop_stale_graphs(s);
         const uint64_t key = (uint64_t)rows | ((uint64_t)(attn_mfma ? 1 : 0) << 16) | ((uint64_t)bound << 32);
         auto it = s->pb_graphs.find(key);
@@ -2291,8 +2251,6 @@ int lmhead_launch(jh_session* s, hipStream_t st) {
     if (w->dtype == JH_DT_BF16) {
         p.ldb = p.K * 2;
         JHCHK((launch_gemv_bf16<PROB_RMS_F32, EPI_STORE, true>(p, 4096, &grid, st)));   // F32 x BF16 (GemmerF32BF16)
-    } else if (s->strict && s->strict_legacy) {
-        JHCHK(launch_gemv_f32q4_strict(p, &grid, st));
     } else if (s->strict) {
         JHCHK(use_p16t(p, *w));
         JHCHK((launch_gemv_f32q4_p16<PRO_RMS_F32>(p, &grid, st)));
@@ -2553,12 +2511,11 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     s->page_elems = page_elems;
     HIPCHK(hipMalloc(&s->pages_dev, s->pages_host.size() * sizeof(float*)));
     HIPCHK(hipMemcpy(s->pages_dev, s->pages_host.data(), s->pages_host.size() * sizeof(float*), hipMemcpyHostToDevice));
-    s->attn_combine = env_int("JH_ATTN_COMBINE_KERNEL", 0);   // measured slower than the in-kernel last arriver
-    s->max_splits = env_int("JH_ATTN_SPLITS", 16);
+    s->max_splits = opt_int("JH_ATTN_SPLITS", 16);
     if (s->max_splits < 1) s->max_splits = 1;
     s->chunk_cap = (max_ctx + s->max_splits - 1) / s->max_splits;
     if (s->chunk_cap < 32) s->chunk_cap = 32;
-    { const int dc = env_int("JH_ATTN_DIRECT_CHUNK", 128); if (s->chunk_cap < dc) s->chunk_cap = dc; }
+    if (s->chunk_cap < 128) s->chunk_cap = 128;
     HIPCHK(hipMalloc(&s->x, (size_t)E * 4));
     HIPCHK(hipMalloc(&s->x1, (size_t)E * 4));
     HIPCHK(hipMalloc(&s->qkv, (size_t)(A + 2 * KV) * 4));
@@ -2570,19 +2527,17 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     HIPCHK(hipMalloc(&s->amax_i, 4096 * 4));
     // long contexts (> long_min rows) are bandwidth-bound and want the whole chip: up to long_splits slices (mid_splits up to
     // mid_max rows) -- 8100 rows: 518 vs 464 tok/s with 32 instead of 16, 4096 rows: 560 vs 537 with 24; <= 1024 rows lose with more than 16
-    s->long_splits = env_int("JH_ATTN_LONG_SPLITS", 32);
-    s->long_min = env_int("JH_ATTN_LONG_MIN", 2048);
-    s->mid_splits = env_int("JH_ATTN_MID_SPLITS", 24);
-    s->mid_max = env_int("JH_ATTN_MID_MAX", 6144);
+    s->long_splits = opt_int("JH_ATTN_LONG_SPLITS", 32);
+    s->long_min = opt_int("JH_ATTN_LONG_MIN", 2048);
+    s->mid_splits = opt_int("JH_ATTN_MID_SPLITS", 24);
+    s->mid_max = opt_int("JH_ATTN_MID_MAX", 6144);
     if (s->long_splits > 64) s->long_splits = 64;
     if (s->long_splits <= s->max_splits) s->long_splits = 0;   // no separate tier
     s->part_stride = s->max_splits > 4 ? s->max_splits : 4;
     if (s->long_splits > s->part_stride) s->part_stride = s->long_splits;
     // "direct" attention: contexts of up to 4 slices x 128 rows are combined by the o-projection's prologue
-    s->direct_chunk = env_int("JH_ATTN_DIRECT_CHUNK", 128);
-    s->direct_max = env_int("JH_ATTN_DIRECT", 0) ? 4 * s->direct_chunk : 0;   // measured slower on MI355X: off by default
-    if (s->direct_max) s->long_splits = 0;
-    if (c.n_heads * 4 > 512 || (A / 8) > 2 * 512) s->direct_max = 0;   // prologue limits (PRO_ATTN_Q8)
+    s->direct_chunk = 128;
+    s->direct_max = 0;   // ("direct" mode -- the o-projection's prologue combining the attention slices -- measured slower, DESIGN.md 3: removed)
     HIPCHK(hipMalloc(&s->part_o, (size_t)c.n_heads * s->part_stride * c.head_size * 4));
     HIPCHK(hipMalloc(&s->part_ml, (size_t)c.n_heads * s->part_stride * 2 * 4));
     HIPCHK(hipMemset(s->part_o, 0, (size_t)c.n_heads * s->part_stride * c.head_size * 4));
@@ -2596,14 +2551,14 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     JHCHK(ensure_out_tokens(s, 1024));
     const int cu = g_cu_count;
     // launch plans: see launch_gemv_i8q4 (env overrides are for tuning sweeps only)
-    s->cfg_qkv = LaunchCfg{env_int("JH_QKV_R", 0), env_int("JH_QKV_WAVES", 0), cu * env_int("JH_QKV_GRIDX", 1), env_int("JH_QKV_PIPE", -1)};
-    s->cfg_o = LaunchCfg{env_int("JH_O_R", 0), env_int("JH_O_WAVES", 0), cu * env_int("JH_O_GRIDX", 1), env_int("JH_O_PIPE", -1)};
-    s->cfg_gateup = LaunchCfg{env_int("JH_GATEUP_R", 0), env_int("JH_GATEUP_WAVES", 0), cu * env_int("JH_GATEUP_GRIDX", 1), env_int("JH_GATEUP_PIPE", -1)};
-    s->cfg_down = LaunchCfg{env_int("JH_DOWN_R", 0), env_int("JH_DOWN_WAVES", 0), cu * env_int("JH_DOWN_GRIDX", 1), env_int("JH_DOWN_PIPE", -1)};
-    s->cfg_lm = LaunchCfg{env_int("JH_LM_R", 2), env_int("JH_LM_WAVES", 8), cu * env_int("JH_LM_GRIDX", 2), 1};   // tools/sweep_lm.py
+    s->cfg_qkv = LaunchCfg{opt_int("JH_QKV_R", 0), opt_int("JH_QKV_WAVES", 0), cu * opt_int("JH_QKV_GRIDX", 1), opt_int("JH_QKV_PIPE", -1)};
+    s->cfg_o = LaunchCfg{opt_int("JH_O_R", 0), opt_int("JH_O_WAVES", 0), cu * opt_int("JH_O_GRIDX", 1), opt_int("JH_O_PIPE", -1)};
+    s->cfg_gateup = LaunchCfg{opt_int("JH_GATEUP_R", 0), opt_int("JH_GATEUP_WAVES", 0), cu * opt_int("JH_GATEUP_GRIDX", 1), opt_int("JH_GATEUP_PIPE", -1)};
+    s->cfg_down = LaunchCfg{opt_int("JH_DOWN_R", 0), opt_int("JH_DOWN_WAVES", 0), cu * opt_int("JH_DOWN_GRIDX", 1), opt_int("JH_DOWN_PIPE", -1)};
+    s->cfg_lm = LaunchCfg{opt_int("JH_LM_R", 2), opt_int("JH_LM_WAVES", 8), cu * opt_int("JH_LM_GRIDX", 2), 1};   // tools/sweep_lm.py
     if (s->cfg_lm.grid_cap > 4096) s->cfg_lm.grid_cap = 4096;
-    s->prefill_batch_min = env_int("JH_PREFILL_BATCH_MIN", 4);   // chunks of fewer rows go row by row; 0 disables batching
-    s->prefill_attn_mfma_min = env_int("JH_PREFILL_ATTN_MFMA_MIN", 384);   // -1: always the per-row kernel; 0: always the MFMA kernel
+    s->prefill_batch_min = opt_int("JH_PREFILL_BATCH_MIN", 4);   // chunks of fewer rows go row by row; 0 disables batching
+    s->prefill_attn_mfma_min = opt_int("JH_PREFILL_ATTN_MFMA_MIN", 384);   // -1: always the per-row kernel; 0: always the MFMA kernel
     s->graphs_version = m->weights_version;
     HIPCHK(hipMalloc(&s->eos_dev, (1 + JH_MAX_EOS) * sizeof(int)));
     HIPCHK(hipMemset(s->eos_dev, 0, (1 + JH_MAX_EOS) * sizeof(int)));
@@ -2611,12 +2566,11 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     memset(s->st_host, 0, 2 * sizeof(DecodeState));
     HIPCHK(hipEventCreateWithFlags(&s->ev_chunk[0], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&s->ev_chunk[1], hipEventDisableTiming));
-    s->strict = env_int("JH_STRICT_ORDER", 0) ? 1 : 0;
-    s->strict_legacy = env_int("JH_STRICT_LEGACY", 0) ? 1 : 0;
-    s->p16_depth = env_int("JH_P16_D", 8);   // upper bound of the prefetch depth (p16_depth_for)
+    s->strict = opt_int("JH_STRICT_ORDER", 0) ? 1 : 0;
+    s->p16_depth = opt_int("JH_P16_D", 8);   // upper bound of the prefetch depth (p16_depth_for)
     // reference-order attention: one slice of the context per 16 positions of max_ctx, at least 16, at most 256 (the slices that
     // lie beyond the current position return at once)
-    s->p16_att_splits = env_int("JH_P16_ATT_SPLITS", 0);
+    s->p16_att_splits = opt_int("JH_P16_ATT_SPLITS", 0);
     if (s->p16_att_splits <= 0) s->p16_att_splits = (max_ctx + 15) / 16;
     if (s->p16_att_splits < 16) s->p16_att_splits = 16;
     if (s->p16_att_splits > 256) s->p16_att_splits = 256;
@@ -2788,8 +2742,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
     JHCHK(ensure_strict_operands(s, st));
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, s->max_ctx / 2, 0, 0);
     s->attn_variant = attn_variant_for(s, s->max_ctx / 2);
-    const bool p16 = s->strict && !s->strict_legacy;   // reference-order kernels (jh_p16.h) when the session is in that mode
-    if (s->strict && s->strict_legacy) return set_err(JH_ERR_UNSUPPORTED, "kernel_bench: not for the legacy strict kernels");
+    const bool p16 = s->strict != 0;   // reference-order kernels (jh_t16.h / jh_p16.h) when the session is in that mode
     int launches = 0;
     for (int it = -1; it < iters; it++) {
         if (it == 0) HIPCHK(hipEventRecord(s->ev0, st));
@@ -2814,10 +2767,6 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                 if (p16) {
                     JHCHK(use_p16t(p, W[JH_W_O]));
                     JHCHK((launch_gemv_i8q4_p16<PRO_QUANT_Q8, EPI_RESID>(p, s->p16_depth, st)));
-                } else if (s->direct_max > 0) {
-                    p.part_o = s->part_o; p.part_ml = s->part_ml; p.st = s->st; p.direct_max = s->direct_max;
-                    p.direct_chunk = s->direct_chunk; p.part_stride = s->part_stride; p.head_size = hs; p.n_heads = c.n_heads;
-                    JHCHK((launch_gemv_i8q4<PRO_ATTN_Q8, EPI_RESID>(p, s->cfg_o, st)));
                 } else {
                     JHCHK((launch_gemv_i8q4<PRO_QUANT_Q8, EPI_RESID>(p, s->cfg_o, st)));
                 }
@@ -2977,7 +2926,7 @@ static int forward_impl(jh_session* s, const int32_t* tokens, const float* x_in,
             HIPCHK(hipMemcpyAsync(s->x, x_in + (size_t)i * E, (size_t)E * 4, x_in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         }
         HIPCHK(hipGetLastError());
-        if (s->tap_layer < 0 && !env_int("JH_NO_GRAPH", 0)) {
+        if (s->tap_layer < 0 && !opt_int("JH_NO_GRAPH", 0)) {
             // the layers read the position from the device-resident state, so ONE captured graph serves every row:
             // a pipeline stage pays 1 launch per tick instead of 5 per layer
             const int v = attn_variant_for(s, start_pos + i);
@@ -3152,9 +3101,8 @@ static int build_graph(jh_session* s, int v, float temperature = 0.0f) {
     }
     s->graph[v] = g;
     HIPCHK(hipGraphInstantiate(&s->exec[v], g, nullptr, nullptr, 0));
-    static const int p16_fused = env_int("JH_P16_ATTN_FUSED", 0);
-    const bool p16_two_launch_attn = s->strict && !s->strict_legacy && !(p16_fused && v == 1);
-    const int per_layer = 5 + (p16_two_launch_attn || (!s->strict && s->attn_combine && s->direct_max == 0 && s->max_splits <= 64) ? 1 : 0);
+    const bool p16_two_launch_attn = s->strict != 0;
+    const int per_layer = 5 + (p16_two_launch_attn ? 1 : 0);
     s->kernels_per_token = (c.layer_end - c.layer_start) * per_layer + (has_out ? 2 : 0);
     return JH_OK;
 }
@@ -3195,7 +3143,7 @@ static int decode_n_async_impl(jh_session* s, int32_t first_token, int start_pos
         }
         HIPCHK(hipMemcpyAsync(s->u_dev, u, (size_t)n * 4, hipMemcpyHostToDevice, st));
     }
-    const bool use_graph = !env_int("JH_NO_GRAPH", 0);
+    const bool use_graph = !opt_int("JH_NO_GRAPH", 0);
     if (use_graph) {   // capture the graph variants this call needs before the timed region (a capture costs milliseconds)
         for (int v = 0; v < N_ATTN_VARIANTS; v++)
             if (attn_variant_in_range(s, v, start_pos, start_pos + n - 1)) JHCHK(build_graph(s, v, temperature));
@@ -3452,7 +3400,7 @@ namespace {
 // row, publish] -> count the token.  Nothing in it depends on the host: the position / token / sequence number are device words.
 int tp_build_graph(jh_tp_group* g, int k, int v) {
     jh_session* s = g->sh[k];
-    const int strict_key = s->strict * 2 + s->strict_legacy;
+    const int strict_key = s->strict;
     if (g->graphs_strict != strict_key || g->graphs_version != s->m->weights_version) {
         for (int vv = 0; vv < N_ATTN_VARIANTS; vv++)
             for (size_t j = 0; j < g->sh.size(); j++) {
@@ -3482,7 +3430,7 @@ int tp_build_graph(jh_tp_group* g, int k, int v) {
     }
     // the o-proj / down GEMVs push their partial rows and raise the flags themselves (EPI_TP) where a kernel for it exists;
     // otherwise (grid == 0: BF16 model, first-generation strict kernels) a scatter launch follows the GEMV
-    const int tp_fuse = env_int("JH_TP_FUSE", 1);
+    const int tp_fuse = opt_int("JH_TP_FUSE", 1);
     TPPush push[2];
     for (int r = 0; r < 2; r++) push[r] = TPPush{(float* const*)(g->peers[k] + (size_t)r * N), (unsigned* const*)(g->peers_f[k] + (size_t)r * N), g->seq[k], N, 0, L, 0};
     auto meet = [&](int r, int li, const float* resid, float* out) {
@@ -3557,7 +3505,7 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
     HIPCHK(hipSetDevice(s0->m->device));
     JHCHK(ensure_out_tokens(s0, n));
     const int E = s0->m->c.embedding_length;
-    static const int tp_graph = env_int("JH_TP_GRAPH", 1);
+    static const int tp_graph = opt_int("JH_TP_GRAPH", 1);
     if (tp_graph && g->graph_ok) {
         // ---- one graph replay per shard and token, the shards meet in kernels (tp_build_graph)
         for (int v = 0; v < N_ATTN_VARIANTS; v++)
@@ -3614,7 +3562,7 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
                 HIPCHK(hipMemset(g->mail[k], 0, sizeof(TPMail)));
             }
             g->graph_ok = false;
-            if (env_int("JH_TP_GRAPH_STRICT", 0))
+            if (opt_int("JH_TP_LOUD", 0))
                 return set_err(JH_ERR_HIP, "tp_group_decode_n: a shard waited for a peer that never arrived (streams serialised on one hardware queue?)");
             return jh_tp_group_decode_n(g, first_token, start_pos, n, out_tokens);
         }
@@ -3704,7 +3652,7 @@ int jh_tp_rank_create(jh_session* shard, int rank, int n_ranks, jh_tp_group** ou
     if (!ok) { (void)hipGetLastError(); jh_tp_group_destroy(g); return set_err(JH_ERR_OOM, "tp_rank_create: buffers"); }
     g->slots_of[k] = g->slots[k]; g->flags_of[k] = g->flags[k]; g->mail_of[k] = g->mail[k];
     {   // waits of a rank are bounded by seconds, not the group's 50 ms: the ranks start their graphs independently
-        const unsigned bound = (unsigned)env_int("JH_TP_RANK_WAIT_TICKS", 300000000);   // 3 s of the 100 MHz wall clock
+        const unsigned bound = 300000000u;   // 3 s of the 100 MHz wall clock
         HIPCHK(hipMemcpy((char*)g->seq[k] + 8, &bound, 4, hipMemcpyHostToDevice));
     }
     HIPCHK(hipDeviceSynchronize());

@@ -44,3 +44,12 @@ def oracle():
     from oracle import oracle as O
     O.lib()
     return O
+
+
+@pytest.fixture(autouse=True)
+def _clear_library_options(request):
+    """Options set through jh_set_option (the library reads no tuning knob from the environment) live for one test only."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from jlama_amd import _native as N
+        N.clear_options()

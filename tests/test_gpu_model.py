@@ -20,6 +20,8 @@ import os
 import numpy as np
 import pytest
 
+from jlama_amd import _native as _N
+
 pytestmark = pytest.mark.gpu
 FLIP_ROW = 5e-2   # one tipped Q8 code moves a row of a single-layer model by about one code step of its scale
 
@@ -137,14 +139,14 @@ def test_decode_paths_agree(gpu, oracle):
         b.append(tok)
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(la, s2.logits())
-    os.environ["JH_NO_GRAPH"] = "1"
+    _N.set_option("JH_NO_GRAPH", "1")
     try:
         s3 = hm.session(128)
         s3.batch_forward(prompt, 0)
         s3.sample()
         c = s3.decode_n(first, prompt.size, n)
     finally:
-        del os.environ["JH_NO_GRAPH"]
+        _N.clear_options()
     np.testing.assert_array_equal(a, c)
     ms, k = s1.decode_stats()
     assert ms > 0 and k == cfg["n_layers"] * 5 + 2
@@ -163,12 +165,12 @@ def test_attention_split_combine_long_context(gpu, oracle):
     want = os_.forward(prompt, 0)[-1]
     outs = []
     for splits in ("1", "4", "16"):
-        os.environ["JH_ATTN_SPLITS"] = splits
+        _N.set_option("JH_ATTN_SPLITS", splits)
         try:
             hs = hm.session(1400)
             got = hs.batch_forward(prompt, 0)[-1]
         finally:
-            del os.environ["JH_ATTN_SPLITS"]
+            _N.clear_options()
         assert _rel(got, want) <= TRUNK_TOL, (splits, _rel(got, want))
         outs.append(got)
     assert _rel(outs[0], outs[2]) <= TRUNK_TOL
@@ -302,10 +304,10 @@ def test_batched_prefill_matches_row_path_and_oracle(gpu, oracle, monkeypatch, d
     hm, om, _ = _pair(cfg, 21, oracle)
     prompt = S.prompt_tokens(cfg, n=300, seed=22)
     want = om.session().forward(prompt, 0)
-    monkeypatch.setenv("JH_PREFILL_BATCH_MIN", "0")
+    _N.set_option("JH_PREFILL_BATCH_MIN", "0")
     s_row = hm.session(512)
     rows = s_row.forward(prompt, 0)
-    monkeypatch.delenv("JH_PREFILL_BATCH_MIN")
+    _N.clear_options()
     s_bat = hm.session(512)
     bat = s_bat.forward(prompt, 0)
     assert bat.shape == rows.shape == want.shape
@@ -346,12 +348,12 @@ def test_prefill_without_a_resident_second_copy_of_the_weights(gpu, oracle, monk
     if dtype == "BF16":
         cfg["weight_dtype"] = N.DT_BF16
     prompt = S.prompt_tokens(cfg, n=300, seed=22)
-    monkeypatch.setenv("JH_TILED_COPY", "resident")
+    _N.set_option("JH_TILED_COPY", "resident")
     hm, om, _ = _pair(cfg, 21, oracle)
     s1 = hm.session(512)
     res = s1.forward(prompt, 0)
     assert hm.tiled_bytes() > 0.8 * sum(r * c for r, c in S.layer_shapes(cfg).values()) * cfg["n_layers"] * (0.625 if dtype == "Q4" else 2.0)
-    monkeypatch.setenv("JH_TILED_COPY", "transient")
+    _N.set_option("JH_TILED_COPY", "transient")
     hm2, _, _ = _pair(cfg, 21, oracle)
     s2 = hm2.session(512)
     tra = s2.forward(prompt, 0)
@@ -528,7 +530,7 @@ def test_decode_attention_long_slices(gpu, oracle):
         ref_toks.append(tok)
         ref_margin.append(float(top2[1] - top2[0]))
     for splits in ("4", "2"):
-        os.environ["JH_ATTN_SPLITS"] = splits
+        _N.set_option("JH_ATTN_SPLITS", splits)
         try:
             hs = hm.session(800)
             got = hs.batch_forward(prompt, 0)
@@ -541,7 +543,7 @@ def test_decode_attention_long_slices(gpu, oracle):
                 assert g == ref_toks[i] or ref_margin[i] <= LOGIT_TOL, (splits, i, g, ref_toks[i])
                 toks.append(ref_toks[i])
         finally:
-            del os.environ["JH_ATTN_SPLITS"]
+            _N.clear_options()
 
 
 @pytest.mark.parametrize("rows", [129, 37, 264])
@@ -555,13 +557,13 @@ def test_prefill_ragged_last_row_tile(gpu, oracle, monkeypatch, rows):
     hm, om, _ = _pair(cfg, 37, oracle)
     prompt = S.prompt_tokens(cfg, n=rows, seed=38)
     want = om.session().forward(prompt, 0)
-    monkeypatch.setenv("JH_PREFILL_BATCH_MIN", "0")
+    _N.set_option("JH_PREFILL_BATCH_MIN", "0")
     row = hm.session(512).forward(prompt, 0)
-    monkeypatch.delenv("JH_PREFILL_BATCH_MIN")
+    _N.clear_options()
     got = [hm.session(512).forward(prompt, 0)]
-    monkeypatch.setenv("JH_GEMM_LDS", "1")
+    _N.set_option("JH_GEMM_LDS", "1")
     got.append(hm.session(512).forward(prompt, 0))
-    monkeypatch.setenv("JH_GEMM_LDS", "0")
+    _N.set_option("JH_GEMM_LDS", "0")
     got.append(hm.session(512).forward(prompt, 0))
     for g in got:
         assert g.shape == want.shape and _rel(g, want) <= TRUNK_TOL and _rel(g, row) <= TRUNK_TOL
@@ -583,11 +585,11 @@ def test_decode_attention_slice_tiers(gpu, oracle, monkeypatch):
     base.batch_forward(prompt, 0)
     for k, v in (("JH_ATTN_SPLITS", "2"), ("JH_ATTN_LONG_MIN", "100"), ("JH_ATTN_LONG_SPLITS", "8"), ("JH_ATTN_MID_SPLITS", "4"),
                  ("JH_ATTN_MID_MAX", "150")):
-        monkeypatch.setenv(k, v)
+        _N.set_option(k, v)
     tier = hm.session(256)          # variant 1 up to 64 rows, 0 up to 100, 2 beyond: <= 4 slices up to 150 rows, <= 8 after
     tier2 = hm.session(256)
     for k in ("JH_ATTN_SPLITS", "JH_ATTN_LONG_MIN", "JH_ATTN_LONG_SPLITS", "JH_ATTN_MID_SPLITS", "JH_ATTN_MID_MAX"):
-        monkeypatch.delenv(k)
+        _N.clear_options()
     tier.batch_forward(prompt, 0)
     tier2.batch_forward(prompt, 0)
     tb, lb = base.sample(0.0, 0.5, want_logits=True)
@@ -630,15 +632,15 @@ def test_prefill_gemm_lds_kernel_equals_tile_kernel(gpu, oracle, monkeypatch, sh
     hm, om, _ = _pair(cfg, 27, oracle)
     prompt = S.prompt_tokens(cfg, n=300, seed=28)
     want = om.session().forward(prompt, 0)
-    monkeypatch.setenv("JH_GEMM_LDS", "0")
+    _N.set_option("JH_GEMM_LDS", "0")
     tile = hm.session(512).forward(prompt, 0)
     cw, ct, sk = shape.split(",")
-    monkeypatch.setenv("JH_GEMM_LDS", "1")
-    monkeypatch.setenv("JH_GEMM_LDS_CW", cw)
-    monkeypatch.setenv("JH_GEMM_LDS_CT", ct)
-    monkeypatch.setenv("JH_GEMM_LDS_S", sk)
+    _N.set_option("JH_GEMM_LDS", "1")
+    _N.set_option("JH_GEMM_LDS_CW", cw)
+    _N.set_option("JH_GEMM_LDS_CT", ct)
+    _N.set_option("JH_GEMM_LDS_S", sk)
     lds = hm.session(512).forward(prompt, 0)
-    monkeypatch.setenv("JH_GEMM_Z", "2")
+    _N.set_option("JH_GEMM_Z", "2")
     ldz = hm.session(512).forward(prompt, 0)
     for got in (lds, ldz):
         assert _rel(got, want) <= TRUNK_TOL and _rel(got, tile) <= TRUNK_TOL
@@ -660,10 +662,10 @@ def test_blockwise_mfma_prefill_attention(gpu, oracle, monkeypatch, cfgname, mfm
     hm, om, _ = _pair(cfg, 23, oracle)
     prompt = S.prompt_tokens(cfg, n=300, seed=24)
     want = om.session().forward(prompt, 0)
-    monkeypatch.setenv("JH_PREFILL_BATCH_MIN", "0")
+    _N.set_option("JH_PREFILL_BATCH_MIN", "0")
     rows = hm.session(512).forward(prompt, 0)                 # decode kernels, one position at a time
-    monkeypatch.delenv("JH_PREFILL_BATCH_MIN")
-    monkeypatch.setenv("JH_PREFILL_ATTN_MFMA_MIN", mfma_min)
+    _N.clear_options()
+    _N.set_option("JH_PREFILL_ATTN_MFMA_MIN", mfma_min)
     s = hm.session(512)
     bat = s.forward(prompt, 0)
     assert _rel(bat, want) <= TRUNK_TOL and _rel(bat, rows) <= TRUNK_TOL
@@ -698,9 +700,9 @@ def test_blockwise_prefill_attention_is_exact_in_isolation(gpu, oracle, monkeypa
     cfg.update(n_layers=1, context_length=1024)
     hm, om, _ = _pair(cfg, 29, oracle)
     prompt = S.prompt_tokens(cfg, n=699, seed=30)
-    monkeypatch.setenv("JH_PREFILL_ATTN_MFMA_MIN", "-1")
+    _N.set_option("JH_PREFILL_ATTN_MFMA_MIN", "-1")
     ref = hm.session(800).forward(prompt, 0)
-    monkeypatch.setenv("JH_PREFILL_ATTN_MFMA_MIN", "0")
+    _N.set_option("JH_PREFILL_ATTN_MFMA_MIN", "0")
     got = hm.session(800).forward(prompt, 0)
     # one layer: the outputs differ only through the attention rows (then one Q8 step); most rows see no code flip
     rel = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
@@ -1132,8 +1134,8 @@ def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, monkeypatch, s
     slot themselves (EPI_TP); "-unfused" keeps the separate scatter launch (JH_TP_FUSE=0), "strict" runs the reference-order
     kernels -- every combination must give the hand loop's bits."""
     import torch
-    monkeypatch.setenv("JH_TP_FUSE", "0" if mode.endswith("unfused") else "1")
-    monkeypatch.setenv("JH_TP_GRAPH_STRICT", "1")      # a wait that times out is an error here, not a silent fall-back to the event loop
+    _N.set_option("JH_TP_FUSE", "0" if mode.endswith("unfused") else "1")
+    _N.set_option("JH_TP_LOUD", "1")      # a wait that times out is an error here, not a silent fall-back to the event loop
     strict = mode.startswith("strict")
     from jlama_amd import distributed as D, synthetic as S
     from jlama_amd.model import HipLlamaModel, HipTPGroup

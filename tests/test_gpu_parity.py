@@ -1,7 +1,7 @@
 """GPU parity, the two instruments that take the Q8 quantizer's step function out of the comparison:
 
 1. STRICT ORDER (jh_session_set_strict): every float accumulation of the decode path in the reference's Panama-512 order
-   (jlama_amd/csrc/jh_strict.h).  With identical summation order there is no noise floor to hide behind: stage taps of
+   (jlama_amd/csrc/jh_t16.h, jh_p16.h).  With identical summation order there is no noise floor to hide behind: stage taps of
    EVERY layer, logits and greedy ids must equal the oracle BIT FOR BIT.
 2. PER-LAYER TEACHER FORCING of the fast kernels: layer l of the oracle is fed the GPU's own `input_emb` tap of layer l
    (all positions), so each layer is compared in isolation -- no cascade from earlier layers.  Within ONE layer the fast
@@ -13,6 +13,8 @@
 """
 import numpy as np
 import pytest
+
+from jlama_amd import _native as _N
 
 pytestmark = pytest.mark.gpu
 
@@ -185,11 +187,11 @@ def test_reference_order_prefill_in_batches_is_the_row_path_bit_for_bit(gpu, ora
     cfg = dict(S.SMALL)
     hm, om, w = _pair(cfg, 3, oracle)
     prompt = S.prompt_tokens(cfg, n=300, seed=19)
-    monkeypatch.setenv("JH_PREFILL_BATCH_MIN", "0")            # rows one at a time
+    _N.set_option("JH_PREFILL_BATCH_MIN", "0")            # rows one at a time
     s_row = hm.session(512)
     s_row.set_strict(True)
     rows = s_row.forward(prompt, 0)
-    monkeypatch.delenv("JH_PREFILL_BATCH_MIN")
+    _N.clear_options()
     s_bat = hm.session(512)
     s_bat.set_strict(True)
     bat = s_bat.forward(prompt, 0)

@@ -4,6 +4,7 @@ from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
 from jlama_amd.model import HipLlamaModel
 cfg = dict(S.LLAMA3_8B); cfg["n_layers"] = 2
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 m = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
 names = ["entry", "loads issued", "rope done", "scores", "softmax", "PV", "reduced", "published", "ticket", "combined"]
 for env in ({},):

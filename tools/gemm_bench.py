@@ -2,6 +2,7 @@ import os, sys, ctypes as C
 sys.path.insert(0, os.getcwd())
 from jlama_amd import _native as N
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 for kind, name, bpw in ((2, "I8xQ4t", 0.625), (3, "BF16t", 2.0), (0, "I8xQ4", 0.625), (1, "BF16", 2.0)):
     shapes = ((129, 4096, 4096), (129, 28672, 4096), (129, 4096, 14336), (256, 28672, 4096), (32, 28672, 4096))
     if os.environ.get("GB_MODEL_SHAPES"):

@@ -8,6 +8,7 @@ from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
 from jlama_amd.model import HipLlamaModel
 cfg = dict(getattr(S, os.environ.get("MS_CONFIG", "LLAMA3_8B")))
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 model = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
 prompt = S.prompt_tokens(cfg, n=128, seed=1234)
 steps = int(os.environ.get("MS_STEPS", "128"))

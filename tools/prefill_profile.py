@@ -6,6 +6,7 @@ from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
 from jlama_amd.model import HipLlamaModel
 cfg = dict(getattr(S, os.environ.get("PF_CFG", "LLAMA3_8B"))); cfg["n_layers"] = int(os.environ.get("PF_LAYERS", "8"))
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 m = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
 prompt = S.prompt_tokens(cfg, n=int(os.environ.get("PF_ROWS", "128")), seed=1)
 s = m.session(prompt.size + 8)

@@ -21,6 +21,7 @@ def main():
     cfg = dict(getattr(S, config))
     torch.cuda.set_device(0)
     N.init(0)
+    N.options_from_env()   # tools only: JH_* environment variables become explicit library options
     w = ST.make_weights(cfg, seed=0, device="cuda")
     model = HipLlamaModel(cfg, w)
     prompt = S.prompt_tokens(cfg, n=128, seed=1234)

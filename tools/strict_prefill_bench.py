@@ -9,6 +9,7 @@ from jlama_amd.model import HipLlamaModel
 name = os.environ.get("TP_CONFIG", "LLAMA3_8B")
 cfg = dict(getattr(S, name))
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 w = ST.make_weights(cfg, seed=0, device=torch.device("cuda", 0))
 model = HipLlamaModel(cfg, w)
 prompt = S.prompt_tokens(cfg, n=128, seed=1234)

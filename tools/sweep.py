@@ -8,6 +8,7 @@ from jlama_amd.model import HipLlamaModel
 cfgname = os.environ.get("SWEEP_CFG", "LLAMA3_8B")
 cfg = dict(getattr(S, cfgname)); cfg["n_layers"] = int(os.environ.get("SWEEP_LAYERS", "8"))
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 w = ST.make_weights(cfg, seed=0, device="cuda", need_embed=True, need_head=True)
 m = HipLlamaModel(cfg, w)
 names = ["qkv", "attn", "oproj", "gateup", "down"]

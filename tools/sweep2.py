@@ -6,6 +6,7 @@ from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
 from jlama_amd.model import HipLlamaModel
 cfg = dict(getattr(S, os.environ.get("SWEEP_CFG", "LLAMA3_8B"))); cfg["n_layers"] = int(os.environ.get("SWEEP_LAYERS", "8"))
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 m = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
 names = ["qkv", "attn", "oproj", "gateup", "down", "qkv_preq", "oproj_preq", "gateup_preq", "down_preq"]
 def run(env, k, ctx=512):

@@ -6,6 +6,7 @@ from jlama_amd.model import HipLlamaModel
 import torch
 cfg = dict(S.LLAMA3_8B); cfg["n_layers"] = 1
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 m = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
 def run(env):
     for k, v in env.items(): os.environ[k] = str(v)

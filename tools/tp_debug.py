@@ -7,6 +7,7 @@ cfg = dict(getattr(S, os.environ.get("TP_CONFIG", "LLAMA32_1B")))
 if os.environ.get("TP_LAYERS"):
     cfg["n_layers"] = int(os.environ["TP_LAYERS"])
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 w = S.make_weights(cfg, seed=0)
 prompt = S.prompt_tokens(cfg, n=16, seed=3)
 size = int(os.environ.get("TP_SIZE", "2"))

@@ -10,6 +10,7 @@ from jlama_amd import _native as N, distributed as D, synthetic as S
 from jlama_amd.model import HipLlamaModel, HipTPGroup
 cfg = dict(getattr(S, os.environ.get("TP_CONFIG", "LLAMA32_1B")))
 N.init(0)
+N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 w = S.make_weights(cfg, seed=0)
 prompt = S.prompt_tokens(cfg, n=16, seed=3)
 steps = 64
