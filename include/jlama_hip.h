@@ -283,9 +283,20 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
  *   decode_n: every rank calls it with the same (first_token, start_pos, n) after the prompt rows (jh_tp_attn / jh_tp_ffn /
  *   jh_tp_finish_layer with the host's all-reduce, as before): one captured graph per token and rank, partial rows pushed into
  *   every rank's slot by the o-proj / down GEMVs, shard-ordered sums, sampled id through mailboxes -- no collective library on
- *   the data path, nothing on the host inside a token.  out_tokens (HOST [n]) is filled on rank 0 only.  Destroy with
- *   jh_tp_group_destroy. */
+ *   the data path, nothing on the host inside a token.  out_tokens (HOST [n]) is filled on rank 0 only.  A rank returns only
+ *   after rank 0's publish of the LAST token has reached its mailbox, so back-to-back calls need no barrier between them; a
+ *   meeting that times out disconnects the group (destroy and re-create it on every rank).  Destroy with jh_tp_group_destroy. */
 int jh_tp_rank_create(jh_session* shard, int rank, int n_ranks, jh_tp_group** out);
+/* Status of a tensor-parallel group (either host): out[0] = what the last decode_n ran on (1: one captured graph per shard and
+ * token with in-kernel meetings, 2: the event-ordered host loop, 0: nothing yet), out[1] = meetings that timed out so far (a
+ * time-out moves a one-process group to the host loop for good and is reported on stderr; JH_TP_LOUD=1 makes it an error; a rank
+ * of the process-per-shard host is disconnected by it), out[2] = 1 while the graph path is in use, out[3] = 1 when the o-proj /
+ * down GEMVs push their partial rows themselves (0: separate scatter launches), out[4] = flag words polled per producer launch,
+ * out[5] = connected (ranks).  Returns the number of words available (6); at most n are written. */
+int jh_tp_group_status(jh_tp_group* g, int32_t* out, int n);
+/* One word every rank of a process-per-shard group must agree on before the first jh_tp_rank_decode_n (kernel family, CU count,
+ * push mode, shard shape: what the flag-polling protocol depends on); the host all-gathers and compares them. */
+int jh_tp_rank_signature(jh_tp_group* g, int64_t* out);
 int jh_tp_rank_handles(jh_tp_group* g, void* out192);
 int jh_tp_rank_connect(jh_tp_group* g, const void* all_handles);
 int jh_tp_rank_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int n, int32_t* out_tokens);

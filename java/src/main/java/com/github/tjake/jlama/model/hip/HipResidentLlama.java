@@ -153,6 +153,9 @@ public final class HipResidentLlama implements AutoCloseable {
         /** The same loop at temperature > 0 (AbstractModel.java:471-489): softmax((l - max) / T), inverse CDF against
          *  uniforms[i] -- the caller draws them (the reference: ThreadLocalRandom.nextFloat() per token, :594). */
         public int[] decodeSampled(int firstToken, int position, int maxTokens, float temperature, float[] uniforms) {
+            // the native side copies maxTokens floats and cannot see the array's length
+            if (uniforms == null || uniforms.length < maxTokens)
+                throw new IllegalArgumentException("decodeSampled: " + maxTokens + " tokens need as many uniforms, got " + (uniforms == null ? 0 : uniforms.length));
             try (Arena a = Arena.ofConfined()) {
                 MemorySegment out = a.allocate(JAVA_INT, maxTokens);
                 MemorySegment u = a.allocateFrom(JAVA_FLOAT, uniforms);

@@ -110,6 +110,14 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
     private static final MethodHandle jh_tp_rank_connect = h("jh_tp_rank_connect", JAVA_INT, sig("pp"));
     // int jh_tp_rank_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int n, int32_t* out_tokens)
     private static final MethodHandle jh_tp_rank_decode_n = h("jh_tp_rank_decode_n", JAVA_INT, sig("piiip"));
+    // int jh_tp_group_status(jh_tp_group* g, int32_t* out, int n)
+    private static final MethodHandle jh_tp_group_status = h("jh_tp_group_status", JAVA_INT, sig("ppi"));
+    // int jh_tp_rank_signature(jh_tp_group* g, int64_t* out)
+    private static final MethodHandle jh_tp_rank_signature = h("jh_tp_rank_signature", JAVA_INT, sig("pp"));
+    // int jh_set_option(const char* name, int32_t value)
+    private static final MethodHandle jh_set_option = h("jh_set_option", JAVA_INT, sig("pi"));
+    // int jh_clear_options(void)
+    private static final MethodHandle jh_clear_options = h("jh_clear_options", JAVA_INT, sig(""));
     // int64_t jh_model_tiled_bytes(jh_model* m)
     private static final MethodHandle jh_model_tiled_bytes = h("jh_model_tiled_bytes", JAVA_LONG, sig("p"));
     // int jh_pipeline_peer_access(jh_pipeline* p, int32_t* out, int n)
@@ -257,6 +265,22 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
 
     public static int jh_tp_rank_decode_n(MemorySegment g, int first_token, int start_pos, int n, MemorySegment out_tokens) {
         try { return (int) jh_tp_rank_decode_n.invokeExact(g, first_token, start_pos, n, out_tokens); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_tp_group_status(MemorySegment g, MemorySegment out, int n) {
+        try { return (int) jh_tp_group_status.invokeExact(g, out, n); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_tp_rank_signature(MemorySegment g, MemorySegment out) {
+        try { return (int) jh_tp_rank_signature.invokeExact(g, out); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_set_option(MemorySegment name, int value) {
+        try { return (int) jh_set_option.invokeExact(name, value); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static int jh_clear_options() {
+        try { return (int) jh_clear_options.invokeExact(); } catch (Throwable t) { throw rethrow(t); }
     }
 
     public static long jh_model_tiled_bytes(MemorySegment m) {

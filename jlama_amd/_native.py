@@ -83,6 +83,8 @@ _PROTOS = {
     "jh_preferred_working_qtype": (_i, []),
     "jh_last_error": (C.c_char_p, []),
     "jh_synchronize": (_i, []),
+    "jh_tp_group_status": (_i, [_p, _p, _i]),
+    "jh_tp_rank_signature": (_i, [_p, _p]),
     "jh_set_option": (_i, [C.c_char_p, _i]),
     "jh_clear_options": (_i, []),
     "jh_register_tensor": (_l, [_p, _l]),

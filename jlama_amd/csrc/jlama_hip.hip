@@ -3238,6 +3238,11 @@ struct jh_tp_group {
     std::vector<hipGraphExec_t> exec[N_ATTN_VARIANTS];
     int graphs_strict = -1, graphs_version = -1;
     bool graph_ok = true;                      // false after a wait timed out once: this group stays on the event-ordered loop
+    int timeouts = 0;                          // meetings that ran into their bound so far (jh_tp_group_status)
+    int last_mode = 0;                         // what the last decode_n ran on: 1 graph replay per shard and token, 2 event-ordered host loop
+    int fused_push = -1, flags_per_launch = 0; // launch plan of the pushing GEMVs as captured (EPI_TP or scatter kernel; flag words polled per producer)
+    bool fresh_graphs = true;                  // the first replay after a capture uploads the graphs: its waits get a longer bound
+    int plan_flags[2] = {-1, -1};              // flag words per producer launch (0 = scatter kernel) of the o-proj / down meeting: one plan for ALL shards
     // one process per shard (jh_tp_rank_*): only shard `local` lives here, the others' slot / flag / mailbox buffers are mapped
     // through hipIpc handles (slots_of / flags_of / mail_of[j] = shard j's buffer as addressable from this process)
     int local = -1;
@@ -3409,9 +3414,11 @@ int tp_build_graph(jh_tp_group* g, int k, int v) {
             }
         g->graphs_strict = strict_key;
         g->graphs_version = s->m->weights_version;
+        g->plan_flags[0] = g->plan_flags[1] = -1;
     }
     if (g->exec[v][k]) return JH_OK;
     JHCHK(ensure_strict_operands(s, s->stream));
+    g->fresh_graphs = true;
     const int N = (int)g->sh.size();
     const jh_config& c = s->m->c;
     const int E = c.embedding_length, L = c.n_layers;
@@ -3436,6 +3443,15 @@ int tp_build_graph(jh_tp_group* g, int k, int v) {
     auto meet = [&](int r, int li, const float* resid, float* out) {
         const float* slots = g->slots[k] + (size_t)r * N * E;
         const unsigned* flags = g->flags[k] + (size_t)r * N * TP_MAX_FLAGS;
+        // the consumer polls as many flag words per producer as ITS OWN GEMV launch raised: every shard must have planned the same
+        // launch (same kernel family, CU count, push mode) or the sums would read slots before the last producer workgroup stored
+        if (g->plan_flags[r] < 0) g->plan_flags[r] = push[r].grid;
+        else if (g->plan_flags[r] != push[r].grid && rc == JH_OK)
+            rc = set_err(JH_ERR_INVALID, "tensor-parallel group: shard " + std::to_string(k) + " planned " + std::to_string(push[r].grid) +
+                                             " flag words per launch where an earlier shard planned " + std::to_string(g->plan_flags[r]) +
+                                             " (different kernel mode or CU count between the shards)");
+        g->fused_push = push[r].grid > 0 ? 1 : 0;
+        g->flags_per_launch = push[r].grid > 0 ? push[r].grid : g->nwg;
         if (push[r].grid > 0) {
             hipLaunchKernelGGL(tp_sum_wait_all_kernel, eg, eb, 0, st, slots, flags, N, E, push[r].grid, TP_MAX_FLAGS, g->seq[k], li, L, resid, out);
         } else {
@@ -3515,6 +3531,10 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
             jh_session* s = g->sh[k];
             HIPCHK(hipSetDevice(s->m->device));
             HIPCHK(hipStreamSynchronize(s->stream));            // counters below are read on the host
+            // the first replay after a capture uploads every shard's graph: its waits are bounded by 2 s instead of 50 ms, so that a
+            // slow upload (or a descheduled host thread between the per-shard launches) is not mistaken for a missing peer
+            const unsigned bound = g->fresh_graphs ? 200000000u : 0u;
+            HIPCHK(hipMemcpy((char*)g->seq[k] + 8, &bound, 4, hipMemcpyHostToDevice));
         }
         for (int k = 0; k < N; k++) {
             jh_session* s = g->sh[k];
@@ -3562,10 +3582,15 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
                 HIPCHK(hipMemset(g->mail[k], 0, sizeof(TPMail)));
             }
             g->graph_ok = false;
+            g->timeouts++;
             if (opt_int("JH_TP_LOUD", 0))
                 return set_err(JH_ERR_HIP, "tp_group_decode_n: a shard waited for a peer that never arrived (streams serialised on one hardware queue?)");
+            fprintf(stderr, "[jlama-hip] tensor-parallel group: a meeting timed out (%d so far); this group continues on the event-ordered host loop "
+                            "(jh_tp_group_status reports it; JH_TP_LOUD=1 makes it an error)\n", g->timeouts);
             return jh_tp_group_decode_n(g, first_token, start_pos, n, out_tokens);
         }
+        g->last_mode = 1;
+        g->fresh_graphs = false;
         HIPCHK(hipSetDevice(s0->m->device));
         DecodeState hs;
         HIPCHK(hipMemcpy(&hs, s0->st, sizeof(hs), hipMemcpyDeviceToHost));
@@ -3573,6 +3598,7 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
         HIPCHK(hipMemcpy(out_tokens, s0->out_tokens, (size_t)s0->generated * sizeof(int), hipMemcpyDeviceToHost));
         return JH_OK;
     }
+    g->last_mode = 2;
     for (int k = 0; k < N; k++) {   // row of the first token on every shard; shard 0's step counter starts at 0
         jh_session* s = g->sh[k];
         const JWeight& emb = s->m->global_w[JH_W_EMBED];
@@ -3737,12 +3763,22 @@ int jh_tp_rank_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int 
     }
     HIPCHK(hipGetLastError());
     for (int i = 0; i < n; i++) HIPCHK(hipGraphLaunch(g->exec[attn_variant_for(s, start_pos + i)][k], s->stream));
+    // A rank k > 0 meets rank 0 for the last time in the final layer's meeting, BEFORE rank 0's LM head / finish / publish of the
+    // last token: without this wait it could return, and a later call could write its mailbox {first_token, seq} from the host
+    // while that publish (same sequence number) is still in flight and then overwrites token and position.  One more wait on the
+    // mailbox for the sequence number of that publish (this rank's counter after its n bumps): the call returns only once it landed.
+    if (k > 0) hipLaunchKernelGGL(tp_wait_token_kernel, dim3(1), dim3(1), 0, s->stream, (const TPMail*)g->mail[k], g->seq[k], s->st);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     unsigned w2[2] = {0, 0};
     HIPCHK(hipMemcpy(w2, g->seq[k], sizeof(w2), hipMemcpyDeviceToHost));
     if (w2[1]) {
-        HIPCHK(hipMemset((char*)g->seq[k] + 4, 0, 4));
-        return set_err(JH_ERR_HIP, "tp_rank_decode_n: this rank waited for a peer that never arrived (is every rank decoding the same steps?)");
+        // sequence numbers, flags and mailboxes have diverged across the ranks: clearing only the error word would leave every later
+        // call broken in silence.  The group is dead until it is re-created and re-connected.
+        g->connected = false;
+        g->timeouts++;
+        return set_err(JH_ERR_HIP, "tp_rank_decode_n: this rank waited for a peer that never arrived (is every rank decoding the same steps?); "
+                                   "the group is disconnected -- destroy and re-create it on every rank");
     }
     if (k == 0) {
         DecodeState hs;
@@ -3750,6 +3786,28 @@ int jh_tp_rank_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int 
         s->generated = hs.step < n ? hs.step : n;
         HIPCHK(hipMemcpy(out_tokens, s->out_tokens, (size_t)s->generated * sizeof(int), hipMemcpyDeviceToHost));
     }
+    return JH_OK;
+}
+
+int jh_tp_group_status(jh_tp_group* g, int32_t* out, int n) {
+    if (!g || !out || n <= 0) return set_err(JH_ERR_INVALID, "tp_group_status: bad argument");
+    const int32_t v[6] = {g->last_mode, g->timeouts, g->graph_ok ? 1 : 0, g->fused_push, g->flags_per_launch, g->connected ? 1 : 0};
+    for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
+    return 6;
+}
+// What the meeting protocol of a rank depends on besides the model shape: every rank must poll the flag count the producers raise
+// and agree on push vs scatter mode -- both follow from (kernel family, CU count, push option, shard shape), which this folds into
+// one word.  The host compares the words of all ranks before the first jh_tp_rank_decode_n (distributed.tp_generate_ipc does).
+int jh_tp_rank_signature(jh_tp_group* g, int64_t* out) {
+    if (!g || g->local < 0 || !out) return set_err(JH_ERR_INVALID, "tp_rank_signature: bad argument");
+    const jh_session* s = g->sh[g->local];
+    const jh_config& c = s->m->c;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; };
+    mix((uint64_t)g_cu_count); mix((uint64_t)s->strict); mix((uint64_t)opt_int("JH_TP_FUSE", 1)); mix((uint64_t)c.weight_dtype);
+    mix((uint64_t)c.embedding_length); mix((uint64_t)c.n_layers); mix((uint64_t)(c.n_heads * c.head_size)); mix((uint64_t)c.hidden_length);
+    mix((uint64_t)g->sh.size());
+    *out = (int64_t)(h & 0x7fffffffffffffffull);
     return JH_OK;
 }
 

@@ -411,6 +411,12 @@ def tp_generate_ipc(dist, engine, rank, size, prompt, n_gen, cfg, device, dtype)
     gathered = [torch.empty_like(mine) for _ in range(size)]
     dist.all_gather(gathered, mine)
     tpr.connect(b"".join(bytes(g.cpu().numpy().tobytes()) for g in gathered))
+    # the meeting protocol assumes one launch plan on every rank (flag words per producer, push vs scatter): compare the signatures
+    sig = torch.tensor([tpr.signature()], dtype=torch.int64, device=xdev)
+    sigs = [torch.empty_like(sig) for _ in range(size)]
+    dist.all_gather(sigs, sig)
+    if len({int(x.item()) for x in sigs}) != 1:
+        raise RuntimeError(f"tensor-parallel ranks disagree on the launch plan (kernel mode / CU count / push option): {[int(x.item()) for x in sigs]}")
     dist.barrier()                                   # every rank has mapped every buffer before anyone stores into one
     ids = tpr.decode_n(first, len(prompt), n_gen - 1) if n_gen > 1 else np.zeros(0, np.int32)
     dist.barrier()                                   # nobody unmaps while a peer's last graph may still be storing
@@ -547,10 +553,13 @@ def one_process_tp_leg(cfg, devices, prompt, steps):
     t0 = time.perf_counter()
     ids = grp.decode_n(first, n_prompt, steps)
     dt = time.perf_counter() - t0
+    st = grp.status()                                        # which loop actually ran the timed steps, and whether a meeting ever timed out
     grp.close()
     return {"shards": n, "devices": list(devices), "single_stream_tokens_per_s": round(len(ids) / dt, 2), "steps": int(len(ids)),
-            "prompt_rows": n_prompt, "first_ids": [int(t) for t in ids[:8]],
-            "note": "one-process tensor-parallel group, one head-split shard per device; 2 meetings per layer over xGMI peer stores"}
+            "prompt_rows": n_prompt, "first_ids": [int(t) for t in ids[:8]], "loop": st["mode"], "meeting_timeouts": st["timeouts"],
+            "gemv_push": st["gemv_push"], "flags_per_launch": st["flags_per_launch"],
+            "note": "one-process tensor-parallel group, one head-split shard per device; 2 meetings per layer over xGMI peer stores "
+                    "(`loop` says which host loop the timed steps ran on)"}
 
 
 def multi_gpu_extras(args, cfg, gate_up_probe, device_index=0):
@@ -617,6 +626,13 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         dev_sync = lambda: None
     tok_group = dist.new_group() if world > 1 else None   # the sampled id's way back: its own communicator (see _grp)
+    # every rank contributes a one: what the communicator actually spans (rccl_ranks_seen in the line) and which device each rank drives
+    _seen = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(_seen)
+    ranks_seen = int(_seen.item())
+    _devs = [torch.zeros(1, dtype=torch.int32, device=device) for _ in range(world)]
+    dist.all_gather(_devs, torch.tensor([local], dtype=torch.int32, device=device))
+    rank_devices = [int(d.item()) for d in _devs]
     L, E = cfg["n_layers"], cfg["embedding_length"]
     ls, le = layer_range(rank, world, L)
     prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
@@ -746,6 +762,7 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
                "scaling_detail": f"fixed total of {total} tokens; value = throughput of {n_sess} sessions in flight (one per GPU), the "
                                  "batch-1 single-stream rate is single_stream_tokens_per_s",
                "single_stream_tokens_per_s": round(single_steps / dt1, 2), "vs_baseline": None,
+               "rccl_ranks_seen": ranks_seen, "rank_devices": rank_devices,
                "dtype": "i8xq4->f32", "data": "synthetic",
                "config": {"workload": f"{args.config} JQ4, {prompt.size}-row prefill + {steps_per_session} greedy decode steps x {n_sess} "
                                       f"sessions in flight", "parallelism": f"layer-sharded pp{world} ({L // world} layers/GPU), RCCL send/recv of [1,E] F32",

@@ -360,6 +360,13 @@ class HipTPGroup:
         N.check(N.lib().jh_tp_group_decode_n(self.h, int(first_token), int(start_pos), int(n), N.ptr(out)))
         return out[:self.sessions[0].decode_generated()]   # fewer than n only after a stop token (set_eos on shard 0's session)
 
+    def status(self):
+        """What the last decode_n ran on and whether any meeting timed out (include/jlama_hip.h: jh_tp_group_status)."""
+        out = (C.c_int32 * 6)()
+        N.check(N.lib().jh_tp_group_status(self.h, out, 6))
+        return {"mode": {0: "none", 1: "graph replay per shard and token, in-kernel meetings", 2: "event-ordered host loop"}[out[0]],
+                "timeouts": out[1], "graph_path_in_use": bool(out[2]), "gemv_push": out[3], "flags_per_launch": out[4]}
+
     def close(self):
         if self.h:
             N.lib().jh_tp_group_destroy(self.h)
@@ -397,6 +404,17 @@ class HipTPRank:
         assert len(all_handles) == self.n * self.HANDLE_BYTES
         buf = (C.c_ubyte * len(all_handles)).from_buffer_copy(all_handles)
         N.check(N.lib().jh_tp_rank_connect(self.h, buf))
+
+    def signature(self):
+        """The word every rank must agree on before decode_n (kernel family, CU count, push mode, shard shape)."""
+        v = C.c_int64()
+        N.check(N.lib().jh_tp_rank_signature(self.h, C.byref(v)))
+        return v.value
+
+    def status(self):
+        out = (C.c_int32 * 6)()
+        N.check(N.lib().jh_tp_group_status(self.h, out, 6))
+        return {"timeouts": out[1], "gemv_push": out[3], "flags_per_launch": out[4], "connected": bool(out[5])}
 
     def decode_n(self, first_token, start_pos, n):
         out = np.empty(n, dtype=np.int32)
