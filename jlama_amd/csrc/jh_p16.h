@@ -833,243 +833,6 @@ static inline int p16_av_rows(int max_ctx) {   // RU: the whole context in one t
 }
 static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)p16_av_rows(max_ctx) * 32 * 32 + 16 + (size_t)((max_ctx + 63) & ~63) + 2 * 128) * 4; }
 
-// ------------------------------------------------------------------------------------------------ decode attention in ONE launch
-// The two launches above cost a kernel boundary (~1.7 us) and a second cold start (V loads, the score row through global memory)
-// per layer.  Here the same workgroups do both halves and meet in the kernel: workgroup (kv head, part), NPART = GROUP * HS/32
-// parts per kv head, first computes the scores of position slice `part` for the GROUP heads of its kv head (exactly
-// attn_p16_scores_kernel), publishes them write-through, draws a ticket on the kv head's counter, waits until the NPART tickets of
-// this launch are drawn, and then is the (head part / (HS/32), 32-column slice part % (HS/32)) worker of attn_p16_av_kernel -- its
-// V tile was requested at kernel start and landed while the scores were taken.  Only the 16 (Llama-3: GROUP 4 x 4 slices)
-// workgroups of one kv head meet, and launch order puts them on one XCD (block x -> XCD x % 8, kv head = x % n_kv_heads: with
-// 8 kv heads one XCD per head); correctness does not depend on the placement (sc1 stores / sc1 loads / agent-scope ticket, the
-// order-free attention kernel's publish pattern).  The tickets only grow (round = ticket / NPART), nothing is reset.
-// A wait is bounded (50 us of the 100 MHz clock): when the workgroups of a kv head are not all resident -- many sessions' launches
-// side by side can fill the chip with waiting workgroups -- the waiter computes the scores of its head itself (same bits) instead
-// of spinning on.  Decode only (one query row): a batched launch has rows x NPART workgroups per kv head, not co-resident.
-template <int HS, int GROUP, int RU>
-__global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnParams p, float* scores, int sc_stride, unsigned* tickets) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = P16_ATT_THREADS, half = HS / 2, NC = HS / 16, RP = NT / 16, DW = 32, TP = 32 * RU, NCS = HS / DW, NPART = GROUP * NCS;
-    const int kvh = blockIdx.x % p.n_kv_heads, part = blockIdx.x / p.n_kv_heads;
-    const int pos = p.st->pos, n = pos + 1;
-    const int KV = p.n_kv_heads * HS, A = p.n_heads * HS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = tid & 15, prow = tid >> 4;
-    const int gi2 = part / NCS, h = kvh * GROUP + gi2, d0 = (part % NCS) * DW;   // phase 2: this workgroup's head and column slice
-    float* vt = (float*)smem;              // [TP][DW] V tile
-    float* redf = vt + (size_t)TP * DW;    // [16]
-    float* w = redf + 16;                  // [n, padded to 64] scores -> softmax weights
-    float* qs = w + p.w_cap;               // [GROUP][HS] roped q of the group's heads
-    float* knew = qs + GROUP * HS;         // [HS] roped new k row
-    __shared__ int sh_fallback;
-    // ---- requests that need the position only: the K rows of this slice's first passes, then the V tile of phase 2
-    const int chunk = (((n + NPART - 1) / NPART) + RP - 1) / RP * RP;   // whole passes per slice
-    const int t0 = part * chunk;
-    const int t1 = t0 + chunk < n ? t0 + chunk : n;                   // (t0 >= n: an empty slice; the workgroup still meets and does phase 2)
-    constexpr int PB = 2;
-    float kv[PB][NC];
-    auto load_k = [&](int tb) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < PB; u++) {
-            int tt = tb + u * RP;
-            tt = tt < n ? tt : n - 1;
-            const float* krow = kv_row(p, 0, tt, KV) + (size_t)kvh * HS + l;
-#pragma unroll
-            for (int c = 0; c < NC; c++) kv[u][c] = krow[16 * c];
-        }
-    };
-    load_k(t0 + prow);
-    const int vr = tid >> 3, vc = tid & 7;
-    f32x4 vreg[RU];
-    auto load_v = [&](f32x4 (&vv)[RU], int tile) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < RU; u++) {
-            int tt = tile * TP + vr + 32 * u;
-            tt = tt < n ? tt : n - 1;
-            const float* vrow = kv_row(p, 1, tt, KV) + (size_t)kvh * HS + d0;
-            // the page row of the NEW position is being written by another workgroup of this very launch: take it from the q|k|v row
-            if (tt == n - 1) vrow = p.qkv + (size_t)A + KV + (size_t)kvh * HS + d0;
-            vv[u] = ((const f32x4*)vrow)[vc];
-        }
-    };
-    load_v(vreg, 0);
-    // ---- RoPE of the group's q heads and of the new k row; the slice that owns `pos` writes the KV page rows
-    const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
-    const bool owner = pos >= t0 && pos < t1;
-    for (int i = tid; i < (GROUP + 1) * half; i += NT) {
-        const int gi = i / half, d = i - gi * half;
-        const float c = rf[2 * d], sn = rf[2 * d + 1];
-        if (gi < GROUP) {
-            const float* qh = p.qkv + (size_t)(kvh * GROUP + gi) * HS;
-            const float q0 = qh[d], q1 = qh[d + half];
-            const float r0 = q0 * c - q1 * sn, r1 = q0 * sn + q1 * c;   // contraction off: mul, mul, sub / add as in Java
-            qs[gi * HS + d] = r0; qs[gi * HS + d + half] = r1;
-            if (p.tap_q && part == 0) {
-                p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d] = r0;
-                p.tap_q[(size_t)(kvh * GROUP + gi) * HS + d + half] = r1;
-            }
-        } else {
-            const float* kh = p.qkv + A + (size_t)kvh * HS;
-            const float k0 = kh[d], k1 = kh[d + half];
-            const float r0 = k0 * c - k1 * sn, r1 = k0 * sn + k1 * c;
-            knew[d] = r0; knew[d + half] = r1;
-            if (owner) {   // K is stored post-RoPE (CausalSelfAttention.java:273-286 rotates the page row in place)
-                float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
-                kdst[d] = r0; kdst[d + half] = r1;
-            }
-        }
-    }
-    if (owner)
-        for (int d = tid; d < HS; d += NT) ((float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS)[d] = p.qkv[A + KV + (size_t)kvh * HS + d];
-    __syncthreads();
-    // ---- phase 1: scaled scores of this slice for the GROUP heads (GemmerF32's 16-lane dot, PTO:1086-1102), published write-through
-    {
-        float q[GROUP][NC];
-#pragma unroll
-        for (int gi = 0; gi < GROUP; gi++)
-#pragma unroll
-            for (int c = 0; c < NC; c++) q[gi][c] = qs[gi * HS + 16 * c + l];
-        for (int tb = t0 + prow; tb < t1; tb += RP * PB) {
-            if (tb != t0 + prow) load_k(tb);
-#pragma unroll
-            for (int u = 0; u < PB; u++) {
-                const int tt = tb + u * RP;
-                if (tt >= t1) break;   // uniform per 16-lane row; the DPP tree below stays inside the row
-                if (tt == pos) {
-#pragma unroll
-                    for (int c = 0; c < NC; c++) kv[u][c] = knew[16 * c + l];   // the page row is being written just now
-                }
-#pragma unroll
-                for (int gi = 0; gi < GROUP; gi++) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < NC; c++) acc = fmaf(q[gi][c], kv[u][c], acc);
-                    acc = row16_tree_sum(acc);
-                    if (l == 0) st_sc1(scores + (size_t)(kvh * GROUP + gi) * sc_stride + tt, acc * p.scale);   // ops.scale after the dot (:332)
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores (the V tile has landed too)
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned tk = __hip_atomic_fetch_add(&tickets[kvh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = (tk / NPART + 1u) * NPART;    // all NPART tickets of THIS launch (rounds never overlap: launches are stream-ordered)
-        const long long tstart = wall_clock64();
-        int fb = 0;
-        while ((int)(__hip_atomic_load(&tickets[kvh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            if (wall_clock64() - tstart > 5000) { fb = 1; break; }   // 50 us: the kv head's workgroups are not all resident
-            __builtin_amdgcn_s_sleep(1);
-        }
-        sh_fallback = fb;
-    }
-    __syncthreads();
-    // ---- phase 2: softmax of head h's score row, then the value chains of its 32 columns (attn_p16_av_kernel)
-    float m = -INFINITY;
-    if (!sh_fallback) {
-        const float* srow = scores + (size_t)h * sc_stride;
-        for (int tt = tid; tt < n; tt += NT) {
-            const float sv = ld_sc1(srow + tt);
-            w[tt] = sv;
-            m = fmaxf(m, sv);
-        }
-    } else {
-        // the same scores, computed here for head h alone over the whole context (K rows re-read through L2)
-        float qh[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) qh[c] = qs[gi2 * HS + 16 * c + l];
-        for (int tt = prow; tt < n; tt += RP) {
-            float kk[NC];
-            const float* krow = kv_row(p, 0, tt, KV) + (size_t)kvh * HS + l;
-#pragma unroll
-            for (int c = 0; c < NC; c++) kk[c] = (tt == pos) ? knew[16 * c + l] : krow[16 * c];
-            float acc = 0.0f;
-#pragma unroll
-            for (int c = 0; c < NC; c++) acc = fmaf(qh[c], kk[c], acc);
-            acc = row16_tree_sum(acc);
-            if (l == 0) w[tt] = acc * p.scale;
-        }
-        __syncthreads();
-        for (int tt = tid; tt < n; tt += NT) m = fmaxf(m, w[tt]);
-    }
-    m = wave_max(m);
-    if (lane == 0) redf[wave] = m;
-    __syncthreads();
-    m = redf[0];
-    for (int i = 1; i < NT / 64; i++) m = fmaxf(m, redf[i]);
-    for (int tt = tid; tt < n; tt += NT) w[tt] = (float)exp((double)(w[tt] - m));   // (float)FastMath.exp(x - max)
-    p16_av_store_tile<RU>(vt, vreg, vr, vc);                        // tile 0 into LDS while lane 0 sums
-    __syncthreads();
-    if (tid == 0) {
-        float sum = 0.0f;                   // VectorMath.java:80-85: one float accumulator, index order
-        int tt = 0;
-        for (; tt + 16 <= n; tt += 16) {
-            const float4 e0 = *(const float4*)(w + tt), e1 = *(const float4*)(w + tt + 4);
-            const float4 e2 = *(const float4*)(w + tt + 8), e3 = *(const float4*)(w + tt + 12);
-            sum += e0.x; sum += e0.y; sum += e0.z; sum += e0.w;
-            sum += e1.x; sum += e1.y; sum += e1.z; sum += e1.w;
-            sum += e2.x; sum += e2.y; sum += e2.z; sum += e2.w;
-            sum += e3.x; sum += e3.y; sum += e3.z; sum += e3.w;
-        }
-        for (; tt < n; tt++) sum += w[tt];
-        redf[8] = sum;
-    }
-    __syncthreads();
-    const float sum = redf[8];
-    for (int tt = tid; tt < n; tt += NT) w[tt] = w[tt] / sum;
-    float acc = 0.0f;
-    const int ntiles = (n + TP - 1) / TP;
-    for (int tile = 0; tile < ntiles; tile++) {
-        if (tile > 0) {
-            __syncthreads();                // the previous tile has been consumed
-            f32x4 vnext[RU];
-            load_v(vnext, tile);
-            p16_av_store_tile<RU>(vt, vnext, vr, vc);
-        }
-        __syncthreads();                    // tile (and, first time round, the normalised weights) visible
-        if (tid < DW) {
-            const int tbase = tile * TP, cnt = n - tbase < TP ? n - tbase : TP;
-            float va[16], vb[16];
-            float4 wa[4], wb[4];
-            auto ldchunk = [&](int i0, float (&v)[16], float4 (&ww)[4]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int jj = 0; jj < 16; jj++) v[jj] = vt[(i0 + jj) * DW + tid];
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) ww[jj] = *(const float4*)(w + tbase + i0 + 4 * jj);
-            };
-            auto dochunk = [&](int i0, const float (&v)[16], const float4 (&ww)[4]) __attribute__((always_inline)) {
-                if (i0 + 16 <= cnt) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        acc = fmaf(v[4 * jj + 0], ww[jj].x, acc);
-                        acc = fmaf(v[4 * jj + 1], ww[jj].y, acc);
-                        acc = fmaf(v[4 * jj + 2], ww[jj].z, acc);
-                        acc = fmaf(v[4 * jj + 3], ww[jj].w, acc);
-                    }
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        if (i0 + 4 * jj + 0 < cnt) acc = fmaf(v[4 * jj + 0], ww[jj].x, acc);
-                        if (i0 + 4 * jj + 1 < cnt) acc = fmaf(v[4 * jj + 1], ww[jj].y, acc);
-                        if (i0 + 4 * jj + 2 < cnt) acc = fmaf(v[4 * jj + 2], ww[jj].z, acc);
-                        if (i0 + 4 * jj + 3 < cnt) acc = fmaf(v[4 * jj + 3], ww[jj].w, acc);
-                    }
-                }
-            };
-            ldchunk(0, va, wa);
-            for (int i0 = 0; i0 < cnt; i0 += 32) {
-                if (i0 + 16 < cnt) ldchunk(i0 + 16, vb, wb);
-                dochunk(i0, va, wa);
-                if (i0 + 32 < cnt) ldchunk(i0 + 32, va, wa);
-                if (i0 + 16 < cnt) dochunk(i0 + 16, vb, wb);
-            }
-        }
-    }
-    if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
-}
-static inline size_t lds_bytes_attn_p16_fused(int max_ctx, int hs, int group) {
-    return ((size_t)p16_av_rows(max_ctx) * 32 * 32 + 16 + (size_t)((max_ctx + 63) & ~63) + (size_t)(group + 1) * hs) * 4;
-}
-
 // ------------------------------------------------------------------------------------------------ prompt rows in reference order
 // AbstractModel.batchForward (AbstractModel.java:295-312) with every GEMM output summed exactly like the M = 1 kernels above: the
 // reference's Gemmer tiles (PTO:852-1043) keep one 16-lane accumulator per output and walk K in ascending blocks whatever the

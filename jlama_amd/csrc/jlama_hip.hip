@@ -1200,7 +1200,6 @@ struct jh_session {
     hipGraph_t graph_s[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
     hipGraphExec_t exec_s[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
     float* p16_scores = nullptr;   // [n_heads][p16_sc_stride] scaled attention scores between the two reference-order attention launches
-    unsigned* p16_tickets = nullptr;   // [n_kv_heads] tickets of attn_p16_fused_kernel (only grow)
     int p16_sc_stride = 0, p16_att_splits = 16, p16_depth = 8;
     // stop tokens (jh_session_set_eos): device copy for finish_token_kernel + host-side feeding control
     int* eos_dev = nullptr;   // fixed buffer [count, id0, id1, ...] read by finish_token_kernel: changing the list re-captures nothing
@@ -1427,7 +1426,6 @@ int ensure_strict_operands(jh_session* s, hipStream_t st) {
     return JH_OK;
 }
 
-bool p16_attn_fused(const jh_session*) { return opt_int("JH_P16_ATTN_SPLIT", 0) == 0; }   // option 1: the two-launch form (scores, then softmax + values)
 int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg = nullptr) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
@@ -1471,22 +1469,6 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
         const dim3 grid_s(s->p16_att_splits, c.n_kv_heads), grid_v(hs / 32, c.n_heads);
         const int ru = p16_av_rows(s->max_ctx);
         p.w_cap = (s->max_ctx + 63) & ~63;
-        // one launch (attn_p16_fused_kernel: the workgroups of a kv head meet in the kernel) unless the option says two
-        const size_t lds_f = lds_bytes_attn_p16_fused(s->max_ctx, hs, group);
-        if (p16_attn_fused(s) && lds_f <= 158 * 1024) {
-            const dim3 grid_f(c.n_kv_heads * group * (hs / 32));
-#define JH_P16_FUSED(HSV, GV, RV)                                                                                              \
-    if (hs == HSV && group == GV && ru == RV) {                                                                                \
-        JHCHK(allow_lds((attn_p16_fused_kernel<HSV, GV, RV>), lds_f));                                                         \
-        hipLaunchKernelGGL((attn_p16_fused_kernel<HSV, GV, RV>), grid_f, dim3(P16_ATT_THREADS), lds_f, st, p, s->p16_scores, s->p16_sc_stride, s->p16_tickets); \
-        HIPCHK(hipGetLastError());                                                                                             \
-        return JH_OK;                                                                                                          \
-    }
-#define JH_P16_FUSED_G(HSV, GV) JH_P16_FUSED(HSV, GV, 2) JH_P16_FUSED(HSV, GV, 4) JH_P16_FUSED(HSV, GV, 8) JH_P16_FUSED(HSV, GV, 16)
-            JH_P16_FUSED_G(128, 4) JH_P16_FUSED_G(128, 8) JH_P16_FUSED_G(64, 4) JH_P16_FUSED_G(128, 1) JH_P16_FUSED_G(128, 2) JH_P16_FUSED_G(64, 1) JH_P16_FUSED_G(64, 2) JH_P16_FUSED_G(64, 8)
-#undef JH_P16_FUSED_G
-#undef JH_P16_FUSED
-        }
 #define JH_P16_AV(HSV, RV)                                                                                                      \
     if (hs == HSV && ru == RV) {                                                                                               \
         JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                               \
@@ -2597,8 +2579,6 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     JHCHK(ensure_out_tokens(s, max_ctx));
     s->p16_sc_stride = (max_ctx + 63) & ~63;
     HIPCHK(hipMalloc(&s->p16_scores, (size_t)c.n_heads * s->p16_sc_stride * 4));
-    HIPCHK(hipMalloc(&s->p16_tickets, (size_t)c.n_kv_heads * 4));
-    HIPCHK(hipMemset(s->p16_tickets, 0, (size_t)c.n_kv_heads * 4));
     if (s->strict && c.weight_dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "JH_STRICT_ORDER: strict-order kernels exist for JQ4 models only");
     if (!s->strict && prefill_batch_ok(s)) {
         // the MFMA-ordered weight copies of the prefill GEMM are made here, once per model, not inside the first prompt
@@ -2666,7 +2646,6 @@ int jh_session_destroy(jh_session* s) {
     if (s->st_host) hipHostFree(s->st_host);
     if (s->eos_dev) hipFree(s->eos_dev);
     if (s->p16_scores) hipFree(s->p16_scores);
-    if (s->p16_tickets) hipFree(s->p16_tickets);
     if (s->prob) hipFree(s->prob);
     if (s->u_dev) hipFree(s->u_dev);
     if (s->pick) hipFree(s->pick);
@@ -3122,7 +3101,7 @@ static int build_graph(jh_session* s, int v, float temperature = 0.0f) {
     }
     s->graph[v] = g;
     HIPCHK(hipGraphInstantiate(&s->exec[v], g, nullptr, nullptr, 0));
-    const bool p16_two_launch_attn = s->strict != 0 && !(p16_attn_fused(s) && lds_bytes_attn_p16_fused(s->max_ctx, c.head_size, c.n_heads / c.n_kv_heads) <= 158 * 1024);
+    const bool p16_two_launch_attn = s->strict != 0;
     const int per_layer = 5 + (p16_two_launch_attn ? 1 : 0);
     s->kernels_per_token = (c.layer_end - c.layer_start) * per_layer + (has_out ? 2 : 0);
     return JH_OK;
