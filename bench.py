@@ -421,7 +421,18 @@ def run_single(args, cfg):
             out["roofline"] = strict["roofline"]
             out["config"]["kernels_per_token"] = strict["kernels_per_token"]
             out["config"]["prefill_ms_fast_kernels"] = out["config"]["prefill_ms"]
+            out["config"]["prefill_tokens_per_s_fast_kernels"] = out["config"]["prefill_tokens_per_s"]
             out["config"]["prefill_ms"] = strict["prefill_ms"]
+            out["config"]["prefill_tokens_per_s"] = round(prompt.size / strict["prefill_ms"] * 1e3, 1)
+            del out["config"]["prefill_cold_ms"]
+            # the reference-order prompt GEMMs run on the F16 MFMA (gemm_t16_kernel): same projection flops over ITS prefill time
+            pm = out["prefill_mfma"]
+            out["prefill_mfma_fast_kernels"] = dict(pm)
+            so_tflops = prefill_flops / (strict["prefill_ms"] * 1e-3) / 1e12
+            pm.update({"achieved_TFLOPs": round(so_tflops, 1), "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "frac": round(so_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                       "hbm_bound_frac": round(min(1.0, 2.0 * prompt.size * HBM_PEAK_GBS * 1e9 / (bytes_per_weight * MFMA_BF16_PEAK_TFLOPS * 1e12)), 3),
+                       "note": "reference-order prompt: projection GEMMs (2*rows*weights flops) over the whole prefill time against the dense F16 MFMA "
+                               "peak; every (row, weight row, block) still pays 16 ordered fmas on the VALU (jh_t16.h), which bounds it far below"})
             out["config"]["workload"] += " -- REFERENCE ORDER (every float accumulation in the Panama provider's order; ids and logits bit-identical)"
             tr = out["token_roofline"]
             tr["achieved_GBps"] = round(tr["bytes_per_token"] * out["value"] / 1e9, 1)

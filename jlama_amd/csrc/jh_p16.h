@@ -48,8 +48,9 @@ __device__ __forceinline__ int perm_b(int hi_src, int lo_src, int sel) {   // se
     return (int)__builtin_amdgcn_perm((unsigned)hi_src, (unsigned)lo_src, (unsigned)sel);
 }
 
-// P16T copy of a Q4 weight: row stride G * 256 bytes (G = groups of 16 blocks, the last one zero-padded); inside a group byte
-// 16t + c = byte t of block c (= nibble pair t: elements t and t+16 of block 16g + c).  One thread per output 16-byte chunk.
+// P16T copy of a Q4 weight: row stride G * 256 bytes (G = groups of 16 blocks, the last one zero-padded); inside a group the 16-byte
+// chunk t holds nibble pair t (elements t and t+16) of the group's 16 blocks, four blocks per dword in the nibble order below.
+// One thread per output 16-byte chunk.
 __global__ __launch_bounds__(256) void p16t_pack_kernel(const uint8_t* __restrict__ w, int nrows, int nblk, int ldb, uint8_t* __restrict__ out) {
     const int G = (nblk + 15) >> 4;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -59,11 +60,19 @@ __global__ __launch_bounds__(256) void p16t_pack_kernel(const uint8_t* __restric
     const int g = (int)(rg % G);
     const long long row = rg / G;
     const uint8_t* src = w + (size_t)row * ldb + (size_t)g * 256 + t;
+    // dword d of the chunk = nibble pair t of blocks 4d..4d+3 (b0..b3), nibble positions (from bit 0):
+    //   [lo_b1, lo_b0, hi_b1, hi_b0, lo_b3, lo_b2, hi_b3, hi_b2]
+    // so that  x & 0xF0F0F0F0         = bytes [lo_b0, hi_b0, lo_b2, hi_b2] * 16  (one op)
+    //          (x << 4) & 0xF0F0F0F0  = bytes [lo_b1, hi_b1, lo_b3, hi_b3] * 16  (two ops)
+    // are the v_dot4 operands of the four blocks as they stand (against pair words placed in the low / high half): no byte shuffle
     i32x4 v = {0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-        const int byte = (16 * g + c < nblk) ? (int)src[c * 16] : 0;
-        v[c >> 2] |= byte << (8 * (c & 3));
+        const unsigned byte = (16 * g + c < nblk) ? (unsigned)src[c * 16] : 0u;
+        const unsigned lo = byte & 15u, hi = byte >> 4;
+        const int b = c & 3;
+        const int plo = (b == 0) ? 4 : (b == 1) ? 0 : (b == 2) ? 20 : 16;   // bit position of the low nibble; the high one sits 8 bits above
+        v[c >> 2] |= (int)((lo << plo) | (hi << (plo + 8)));
     }
     ((i32x4*)out)[idx] = v;
 }
@@ -92,26 +101,30 @@ template <int N> __device__ __forceinline__ float cvt_sbyte(int x) {
     else asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(f) : "v"(x));
     return f;
 }
-// 4 blocks' nibbles (byte t of each) -> int8 16*(nib-8): low nibbles (element t) / high nibbles (element t+16)
+// 8 nibbles of a dword -> int8 16*(nib-8): the nibbles at even positions (needs the shift) / at odd positions.
+// T16 dwords (jh_t16.h): even = low nibbles (elements 4g..), odd = high nibbles (elements 16+4g..).
+// P16T dwords: odd = [lo_b0, hi_b0, lo_b2, hi_b2] ("E"), even = [lo_b1, hi_b1, lo_b3, hi_b3] ("O") of blocks b0..b3.
 __device__ __forceinline__ int nib_lo16(int x) { return ((x << 4) & (int)0xF0F0F0F0) ^ (int)0x80808080; }
 __device__ __forceinline__ int nib_hi16(int x) { return (x & (int)0xF0F0F0F0) ^ (int)0x80808080; }
 
 // ------------------------------------------------------------------------------------------------ activation row in LDS
 struct ActP16 {
-    i32x2* pt;     // [ceil(nblk/4)][16 lanes]: the 4 pair words (a[b*32+t] & 0xff) | (a[b*32+16+t] & 0xff) << 8 of blocks 4j..4j+3
+    i32x4* pt;     // [ceil(nblk/4)][16 lanes]: the pair words pw = (a[b*32+t] & 0xff) | (a[b*32+16+t] & 0xff) << 8 of blocks 4j..4j+3, one
+                   // per dword: blocks 4j, 4j+1 in the LOW half, 4j+2, 4j+3 in the HIGH half (the other half zero) -- the v_dot4
+                   // partners of the P16T weight bytes
     float* d16;    // [nblk] activation block scale / 16
     double* red;   // [32] reduction scratch
 };
 __device__ __forceinline__ ActP16 carve_p16(char* smem, int nblk) {
     ActP16 a;
-    a.pt = (i32x2*)smem;
+    a.pt = (i32x4*)smem;
     a.d16 = (float*)(a.pt + ((nblk + 15) >> 4) * 64);   // whole groups: the reads of a short last group stay inside the table
     a.red = (double*)(a.d16 + ((nblk + 1) & ~1));
     return a;
 }
 static inline size_t lds_bytes_p16(int K) {
     const size_t nblk = (size_t)K / QB;
-    return ((nblk + 15) / 16) * 512 + ((nblk + 1) & ~(size_t)1) * 4 + 32 * 8;
+    return ((nblk + 15) / 16) * 1024 + ((nblk + 1) & ~(size_t)1) * 4 + 32 * 8;
 }
 
 // Quantize 8 consecutive values held by one lane (Panama quantizeQ8_512, PTO:1684-1723, exactly as quad_quantize_store) and file
@@ -142,11 +155,12 @@ __device__ __forceinline__ void quad_quantize_store_p16(const float (&y)[8], int
     const int w0 = perm_b(hi_dw, lo_dw, 0x05010400);   // [lo0, hi0, lo1, hi1]
     const int w1 = perm_b(hi_dw, lo_dw, 0x07030602);   // [lo2, hi2, lo3, hi3]
     const int t0 = (sub & 1) * 8 + (lower ? 0 : 4);
-    uint16_t* dst = (uint16_t*)a.pt + ((size_t)((blk >> 2) * 16 + t0)) * 4 + (blk & 3);
-    dst[0] = (uint16_t)(w0 & 0xffff);
-    dst[4] = (uint16_t)((unsigned)w0 >> 16);
-    dst[8] = (uint16_t)(w1 & 0xffff);
-    dst[12] = (uint16_t)((unsigned)w1 >> 16);
+    unsigned* dst = (unsigned*)a.pt + ((size_t)((blk >> 2) * 16 + t0)) * 4 + (blk & 3);   // dword (blk & 3) of entries t0..t0+3
+    const int sh = (blk & 2) ? 16 : 0;                                                     // blocks 4j+2, 4j+3: the high half
+    dst[0] = ((unsigned)w0 & 0xffffu) << sh;
+    dst[4] = ((unsigned)w0 >> 16) << sh;
+    dst[8] = ((unsigned)w1 & 0xffffu) << sh;
+    dst[12] = ((unsigned)w1 >> 16) << sh;
     if (sub == 0) a.d16[blk] = d * 0.0625f;
 }
 
@@ -208,29 +222,28 @@ __device__ __forceinline__ void stage_finish_p16(const GemvParams& p, const ActP
 }
 
 // ------------------------------------------------------------------------------------------------ I8 x Q4 GEMV, reference order
-// one group of 16 blocks: 4 dwords x (byte t of 4 consecutive blocks)
+// one group of 16 blocks: 4 dwords x (nibble pair t of 4 consecutive blocks)
 // Four steps' pair sums at once: 4 x v_dot4_i32_i8 (the non-accumulating VOP3P form: hipcc only emits v_dot4c + a zeroing move) followed
 // by their 4 converts.  Inside one asm block on purpose: a DOT result needs 3 wait states before a VALU read, which hipcc cannot
-// know about asm -- here every convert sits 4 instructions behind its dot.
-__device__ __forceinline__ void dot4x4_cvt(int a01, int a23, int w0, int w1, int w2, int w3, float& f0, float& f1, float& f2, float& f3) {
+// know about asm -- here every convert sits 4 instructions behind its dot.  e / o: the weight bytes of blocks (b0, b2) / (b1, b3);
+// pp: their pair words (b0, b1 in the low half, b2, b3 in the high half): the zero half of a pair word blanks the other block.
+__device__ __forceinline__ void dot4x4_cvt(const i32x4 pp, int e, int o, float& f0, float& f1, float& f2, float& f3) {
     int i0, i1, i2, i3;
-    asm("v_dot4_i32_i8 %4, %8, %10, 0\n\t"
-        "v_dot4_i32_i8 %5, %8, %11, 0\n\t"
-        "v_dot4_i32_i8 %6, %9, %12, 0\n\t"
-        "v_dot4_i32_i8 %7, %9, %13, 0\n\t"
+    asm("v_dot4_i32_i8 %4, %8, %12, 0\n\t"
+        "v_dot4_i32_i8 %5, %9, %13, 0\n\t"
+        "v_dot4_i32_i8 %6, %10, %12, 0\n\t"
+        "v_dot4_i32_i8 %7, %11, %13, 0\n\t"
         "v_cvt_f32_i32_e32 %0, %4\n\t"
         "v_cvt_f32_i32_e32 %1, %5\n\t"
         "v_cvt_f32_i32_e32 %2, %6\n\t"
         "v_cvt_f32_i32_e32 %3, %7"
         : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)
-        : "v"(a01), "v"(a23), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+        : "v"(pp.x), "v"(pp.y), "v"(pp.z), "v"(pp.w), "v"(e), "v"(o));
 }
 struct Quad4 { float f0, f1, f2, f3; };
-__device__ __forceinline__ Quad4 p16_quad_sums(int x, const i32x2 pp) {   // (float) pair sums of 4 consecutive blocks (x16)
-    const int lo = nib_lo16(x), hi = nib_hi16(x);
+__device__ __forceinline__ Quad4 p16_quad_sums(int x, const i32x4 pp) {   // (float) pair sums of 4 consecutive blocks (x16)
     Quad4 q;
-    dot4x4_cvt(pp.x, pp.y, perm_b(hi, lo, 0x0C0C0400), perm_b(hi, lo, 0x05010C0C), perm_b(hi, lo, 0x0C0C0602), perm_b(hi, lo, 0x07030C0C),
-               q.f0, q.f1, q.f2, q.f3);
+    dot4x4_cvt(pp, nib_hi16(x), nib_lo16(x), q.f0, q.f1, q.f2, q.f3);   // 3 bit ops, no byte shuffle: the P16T nibble order is the operand order
     return q;
 }
 template <int K4, bool FULL>
@@ -245,7 +258,7 @@ __device__ __forceinline__ void p16_quad_chain(const Quad4& q, float pscale, int
 // convert of the group in front of it (hundreds of live registers, spills).  Blocks past a short last group hold clamped
 // copies: their sums are computed and dropped.
 template <bool FULL>
-__device__ __forceinline__ void p16_group_i8(const i32x4& x, const i32x2* pt, float pscale, int nb, float& acc) {
+__device__ __forceinline__ void p16_group_i8(const i32x4& x, const i32x4* pt, float pscale, int nb, float& acc) {
     const Quad4 q0 = p16_quad_sums(x.x, pt[0]);
     __builtin_amdgcn_sched_barrier(0);
     const Quad4 q1 = p16_quad_sums(x.y, pt[16]);
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
         return p16_scale_product(a.d16[bd], s);             // lane t carries the scale product of block 16*g + t
     };
     auto compute = [&](const i32x4& x, float pscale, int g, bool can_be_short) __attribute__((always_inline)) {
-        const i32x2* pt = a.pt + (size_t)(4 * g) * 16 + t;
+        const i32x4* pt = a.pt + (size_t)(4 * g) * 16 + t;
         const int nb = nblk - 16 * g;
         if (can_be_short && nb < 16) p16_group_i8<false>(x, pt, pscale, nb, acc);
         else p16_group_i8<true>(x, pt, pscale, 16, acc);
@@ -433,11 +446,11 @@ struct QuadW { float wl0, wl1, wl2, wl3, wh0, wh1, wh2, wh3; float2 a0, a1, a2, 
 // dequantized weights (float)(nib-8)*s of 4 consecutive blocks for this lane's element pair, and the matching activation pairs
 template <int K4>
 __device__ __forceinline__ QuadW p16_quad_deq(int x, const float2* af, float s16) {
-    const int lo = nib_lo16(x), hi = nib_hi16(x);
+    const int e = nib_hi16(x), o = nib_lo16(x);   // P16T: e = [lo_b0, hi_b0, lo_b2, hi_b2], o = [lo_b1, hi_b1, lo_b3, hi_b3] (x16)
     QuadW q;
     q.a0 = af[(4 * K4 + 0) * 16]; q.a1 = af[(4 * K4 + 1) * 16]; q.a2 = af[(4 * K4 + 2) * 16]; q.a3 = af[(4 * K4 + 3) * 16];
-    const float l0 = cvt_sbyte<0>(lo), l1 = cvt_sbyte<1>(lo), l2 = cvt_sbyte<2>(lo), l3 = cvt_sbyte<3>(lo);
-    const float h0 = cvt_sbyte<0>(hi), h1 = cvt_sbyte<1>(hi), h2 = cvt_sbyte<2>(hi), h3 = cvt_sbyte<3>(hi);
+    const float l0 = cvt_sbyte<0>(e), h0 = cvt_sbyte<1>(e), l2 = cvt_sbyte<2>(e), h2 = cvt_sbyte<3>(e);
+    const float l1 = cvt_sbyte<0>(o), h1 = cvt_sbyte<1>(o), l3 = cvt_sbyte<2>(o), h3 = cvt_sbyte<3>(o);
     q.wl0 = mul_bcast<4 * K4 + 0>(s16, l0); q.wh0 = mul_bcast<4 * K4 + 0>(s16, h0);
     q.wl1 = mul_bcast<4 * K4 + 1>(s16, l1); q.wh1 = mul_bcast<4 * K4 + 1>(s16, h1);
     q.wl2 = mul_bcast<4 * K4 + 2>(s16, l2); q.wh2 = mul_bcast<4 * K4 + 2>(s16, h2);
@@ -707,8 +720,11 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (arrays of HIP's float4 class type end up in scratch)
 template <int HS, int RU>
 __device__ __forceinline__ void p16_av_load_tile(const AttnParams& p, f32x4 (&vreg)[RU], int tile, int n, int KV, int kvh, int d0, int vr, int vc) {
+    // 32-row groups that lie wholly behind the context are neither requested nor filed (wave-uniform: a session sized for 512
+    // positions otherwise moves 16 groups for a 130-position context); inside the last group rows past n are clamped copies
 #pragma unroll
     for (int u = 0; u < RU; u++) {
+        if (tile * (32 * RU) + 32 * u >= n) continue;
         int tt = tile * (32 * RU) + vr + 32 * u;
         tt = tt < n ? tt : n - 1;
         const float* vrow = kv_row(p, 1, tt, KV) + (size_t)kvh * HS + d0;
@@ -716,9 +732,10 @@ __device__ __forceinline__ void p16_av_load_tile(const AttnParams& p, f32x4 (&vr
     }
 }
 template <int RU>
-__device__ __forceinline__ void p16_av_store_tile(float* vt, const f32x4 (&vreg)[RU], int vr, int vc) {
+__device__ __forceinline__ void p16_av_store_tile(float* vt, const f32x4 (&vreg)[RU], int vr, int vc, int tile, int n) {
 #pragma unroll
-    for (int u = 0; u < RU; u++) ((f32x4*)(vt + (size_t)(vr + 32 * u) * 32))[vc] = vreg[u];
+    for (int u = 0; u < RU; u++)
+        if (tile * (32 * RU) + 32 * u < n) ((f32x4*)(vt + (size_t)(vr + 32 * u) * 32))[vc] = vreg[u];
 }
 // RU = V rows per thread and tile, i.e. TP = 32 * RU positions per V tile in LDS (host: 2, 4, 8 or 16 -- the smallest that holds
 // the session's max_ctx, at most 512 positions): a context of up to TP positions is ONE tile, requested at kernel start and
@@ -756,7 +773,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     m = redf[0];
     for (int i = 1; i < NT / 64; i++) m = fmaxf(m, redf[i]);
     for (int tt = tid; tt < n; tt += NT) w[tt] = (float)exp((double)(w[tt] - m));   // (float)FastMath.exp(x - max)
-    p16_av_store_tile<RU>(vt, vreg, vr, vc);                        // tile 0 lands in LDS while lane 0 sums
+    p16_av_store_tile<RU>(vt, vreg, vr, vc, 0, n);                  // tile 0 lands in LDS while lane 0 sums
     __syncthreads();
     if (tid == 0) {
         float sum = 0.0f;                   // VectorMath.java:80-85: one float accumulator, index order
@@ -783,7 +800,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
             __syncthreads();                // loop-carried: hipcc then keeps it in scratch); the previous tile has been consumed
             f32x4 vnext[RU];
             p16_av_load_tile<HS, RU>(p, vnext, tile, n, KV, kvh, d0, vr, vc);
-            p16_av_store_tile<RU>(vt, vnext, vr, vc);
+            p16_av_store_tile<RU>(vt, vnext, vr, vc, tile, n);
         }
         __syncthreads();                    // tile (and, first time round, the normalised weights) visible
         if (tid < DW) {
@@ -834,151 +851,10 @@ static inline int p16_av_rows(int max_ctx) {   // RU: the whole context in one t
 static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)p16_av_rows(max_ctx) * 32 * 32 + 16 + (size_t)((max_ctx + 63) & ~63) + 2 * 128) * 4; }
 
 // ------------------------------------------------------------------------------------------------ prompt rows in reference order
-// AbstractModel.batchForward (AbstractModel.java:295-312) with every GEMM output summed exactly like the M = 1 kernels above: the
-// reference's Gemmer tiles (PTO:852-1043) keep one 16-lane accumulator per output and walk K in ascending blocks whatever the
-// tile, so a prompt row's result does not depend on how many rows are processed together -- and neither does it here: each
-// (prompt row, weight row) pair owns a 16-lane chain fed in the same block order by the same instructions.  What batching buys
-// is the weight side: a group of 16 blocks is loaded, transposed and unpacked ONCE and then serves MT prompt rows (the GEMV
-// spends a third of its VALU work there), and the activation prologue runs once per row instead of once per workgroup.
-//   rows_act_p16_kernel   one workgroup per prompt row: the GEMVs' own prologue code (RMSNorm + Q8 / plain Q8, pair-word layout),
-//                         LDS image copied to global memory [rows][G*512 B] + block scales [rows][nblk]
-//   gemm_i8q4_p16_kernel  workgroup = 8 row quads (32 weight rows) x MT prompt rows, the MT activation images resident in LDS
-//   rows_rope_kv_p16_kernel  K (post-RoPE) and V rows of the whole chunk into the KV pages, before any row's scores are taken
-struct RowsP16Params {
-    const float* x; int ldx;          // [rows][ldx] F32
-    const float* nw; float eps;       // PRO_RMS_Q8
-    int K;
-    uint8_t* apt; float* ad16;        // out: pair-word images [rows][pt_stride bytes], block scales / 16 [rows][d_stride]
-    int pt_stride, d_stride;
-};
-template <int PRO, int UM>
-__global__ __launch_bounds__(P16_THREADS) void rows_act_p16_kernel(RowsP16Params rp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nblk = rp.K / QB, G = (nblk + 15) >> 4;
-    const ActP16 a = carve_p16(smem, nblk);
-    GemvParams p{};
-    p.x = rp.x + (size_t)blockIdx.x * rp.ldx; p.nw = rp.nw; p.eps = rp.eps; p.K = rp.K;
-    ActRegsP16<UM> ar;
-    stage_issue_p16<PRO, UM>(p, ar);
-    stage_finish_p16<PRO, UM>(p, a, ar);
-    i32x4* dst = (i32x4*)(rp.apt + (size_t)blockIdx.x * rp.pt_stride);
-    const i32x4* src = (const i32x4*)a.pt;
-    for (int i = threadIdx.x; i < G * 32; i += P16_THREADS) dst[i] = src[i];
-    for (int i = threadIdx.x; i < nblk; i += P16_THREADS) rp.ad16[(size_t)blockIdx.x * rp.d_stride + i] = a.d16[i];
-}
-
-struct GemmP16Params {
-    const uint8_t* w; const float* ws;       // Q4 weight [nrows][K/2] + scales [nrows][K/32]
-    const uint8_t* w2; const float* ws2;     // EPI_SILU_MUL: the up projection (w = gate)
-    int ldb, ldbf, nrows, K, M;
-    const uint8_t* apt; const float* ad16;   // activation images of the M prompt rows (rows_act_p16_kernel)
-    int pt_stride, d_stride;
-    float* out; int ldc;                     // [M][ldc]
-    const float* resid; int ldr;             // EPI_RESID
-};
-// the 4 chained steps of blocks 4*K4 .. 4*K4+3 of a group for MT prompt rows: the weight bytes are unpacked once (2 bit ops + 4
-// perms), every row then pays pair-word read + 4 dots + 4 converts + 4 chained fmacs
-template <int K4, int MT>
-__device__ __forceinline__ void p16_quad_rows(int xk, const i32x2* pt_q, int row_stride, const float (&sp)[MT], float (&acc)[MT]) {
-    const int lo = nib_lo16(xk), hi = nib_hi16(xk);
-    const int w0 = perm_b(hi, lo, 0x0C0C0400), w1 = perm_b(hi, lo, 0x05010C0C), w2 = perm_b(hi, lo, 0x0C0C0602), w3 = perm_b(hi, lo, 0x07030C0C);
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-        const i32x2 pp = pt_q[(size_t)m * row_stride];
-        float f0, f1, f2, f3;
-        dot4x4_cvt(pp.x, pp.y, w0, w1, w2, w3, f0, f1, f2, f3);
-        fmac_bcast<4 * K4 + 0>(acc[m], sp[m], f0);
-        fmac_bcast<4 * K4 + 1>(acc[m], sp[m], f1);
-        fmac_bcast<4 * K4 + 2>(acc[m], sp[m], f2);
-        fmac_bcast<4 * K4 + 3>(acc[m], sp[m], f3);
-    }
-}
-// NW = waves (= row quads) per workgroup: they share the MT activation images in LDS; 16 waves put four on every SIMD, which this
-// VALU-bound body (pair-word reads, DPP operands, 3-wait-state dots) needs to keep the SIMDs issuing
-template <int EPI, int MT, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_i8q4_p16_kernel(GemmP16Params p) {
-    static_assert(MT <= 16, "one prompt row per lane of a 16-lane row in the epilogue");
-    constexpr int NT = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nblk = p.K / QB, G = nblk >> 4;                  // host: nblk % 16 == 0
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane >> 4, t = lane & 15;
-    const int m0 = blockIdx.y * MT;
-    constexpr int NP = (EPI == EPI_SILU_MUL) ? 2 : 1;
-    i32x2* pts = (i32x2*)smem;                                 // [MT][G*64] pair-word images
-    float* ds = (float*)(pts + (size_t)MT * G * 64);           // [MT][nblk] block scales / 16
-    const int row_stride = G * 64;
-    {
-        const int n16 = G * 32;                                // 16-byte chunks per image
-        for (int i = threadIdx.x; i < MT * n16; i += NT) {
-            const int m = i / n16, j = i - m * n16;
-            int mm = m0 + m;
-            mm = mm < p.M ? mm : p.M - 1;                      // rows past M replicate the last row (never stored)
-            ((i32x4*)pts)[i] = ((const i32x4*)(p.apt + (size_t)mm * p.pt_stride))[j];
-        }
-        for (int i = threadIdx.x; i < MT * nblk; i += NT) {
-            const int m = i / nblk, j = i - m * nblk;
-            int mm = m0 + m;
-            mm = mm < p.M ? mm : p.M - 1;
-            ds[i] = p.ad16[(size_t)mm * p.d_stride + j];
-        }
-    }
-    const int quad = blockIdx.x * NW + wave;
-    int row = 4 * quad + r;
-    const bool row_ok = row < p.nrows;
-    row = row_ok ? row : p.nrows - 1;
-    __syncthreads();
-    float gres[MT];
-#pragma unroll
-    for (int m = 0; m < MT; m++) gres[m] = 0.0f;
-#pragma unroll
-    for (int pass = 0; pass < NP; pass++) {
-        const uint8_t* wrow = ((NP == 2 && pass) ? p.w2 : p.w) + (size_t)row * p.ldb;
-        const float* srow = ((NP == 2 && pass) ? p.ws2 : p.ws) + (size_t)row * p.ldbf;
-        float acc[MT];
-#pragma unroll
-        for (int m = 0; m < MT; m++) acc[m] = 0.0f;
-        i32x4 wn = __builtin_nontemporal_load((const i32x4*)wrow + t);
-        float sn = __builtin_nontemporal_load(srow + t);
-        for (int g = 0; g < G; g++) {
-            i32x4 x = wn;
-            const float sc = sn;
-            const int gn = g + 1 < G ? g + 1 : g;              // branch-free: the last group is requested twice
-            wn = __builtin_nontemporal_load((const i32x4*)wrow + 16 * gn + t);
-            sn = __builtin_nontemporal_load(srow + 16 * gn + t);
-            float sp[MT];
-#pragma unroll
-            for (int m = 0; m < MT; m++) sp[m] = p16_scale_product(ds[m * nblk + 16 * g + t], sc);
-            const i32x2* pq = pts + (size_t)(4 * g) * 16 + t;
-            p16_quad_rows<0, MT>(x.x, pq, row_stride, sp, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            p16_quad_rows<1, MT>(x.y, pq + 16, row_stride, sp, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            p16_quad_rows<2, MT>(x.z, pq + 32, row_stride, sp, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            p16_quad_rows<3, MT>(x.w, pq + 48, row_stride, sp, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // every lane of a 16-lane row ends with the finished sums; lane t keeps prompt row m0 + t
-        float mine = 0.0f, gate = 0.0f;
-#pragma unroll
-        for (int m = 0; m < MT; m++) {
-            const float res = row16_tree_sum(acc[m]);
-            if (NP == 2 && pass == 0) gres[m] = res;
-            else if (t == m) { mine = res; gate = gres[m]; }
-        }
-        if (NP == 2 && pass == 0) continue;
-        const int mrow = m0 + t;
-        if (t < MT && mrow < p.M && row_ok) {
-            float v = mine;
-            if (EPI == EPI_SILU_MUL) v = silu_ref(gate) * mine;                          // MLPBlock.java:132-142
-            if (EPI == EPI_RESID) v = v + p.resid[(size_t)mrow * p.ldr + row];           // TransformerBlock.java:185,203
-            p.out[(size_t)mrow * p.ldc + row] = v;
-        }
-    }
-}
-static inline size_t lds_bytes_gemm_p16(int K, int MT) { return (size_t)MT * ((size_t)(K / QB / 16) * 512 + (size_t)(K / QB) * 4); }
-
+// AbstractModel.batchForward (AbstractModel.java:295-312): the projections of a prompt chunk run on the F16 MFMA (jh_t16.h:
+// rows_act_t16_kernel + gemm_t16_kernel, bit-identical to the GEMVs here by construction); this file keeps the attention side:
+//   rows_rope_kv_p16_kernel  K (post-RoPE) and V rows of the whole chunk into the KV pages, before any row's scores are taken,
+//   then attn_p16_scores_kernel / attn_p16_av_kernel with the prompt row as blockIdx.z.
 template <int HS>
 __global__ __launch_bounds__(128) void rows_rope_kv_p16_kernel(AttnParams p) {
     constexpr int half = HS / 2;

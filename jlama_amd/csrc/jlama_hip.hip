@@ -1416,7 +1416,7 @@ int ensure_strict_operands(jh_session* s, hipStream_t st) {
             JHCHK(ensure_t16(W[JH_W_O], st));
             JHCHK(ensure_t16(W[JH_W_DOWN], st));
         }
-        if (!t16_gateup_ok(m, li) || !prefill_t16_ok(s)) {   // the p16 forms of gate / up (decode GEMV, M-row prompt GEMM) read P16T order
+        if (!t16_gateup_ok(m, li)) {   // the p16 form of the gate|up decode GEMV reads P16T order
             JHCHK(ensure_p16t(W[JH_W_GATE], st));
             JHCHK(ensure_p16t(W[JH_W_UP], st));
         }
@@ -1699,7 +1699,7 @@ bool prefill_t16_ok(jh_session* s) {
 bool prefill_batch_ok(jh_session* s) {
     const jh_config& c = s->m->c;
     if (s->prefill_batch_min <= 0 || s->tap_layer >= 0) return false;
-    if (s->strict) return prefill_p16_ok(s);
+    if (s->strict) return prefill_t16_ok(s);
     if (c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16) return false;
     const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
     if (c.embedding_length % 64 || c.hidden_length % 64 || A % 64 || (A + 2 * KV) % 32) return false;
@@ -2004,49 +2004,8 @@ int prefill_layers(jh_session* s, int rows, int nkeys_bound, bool attn_mfma, hip
     }
     return JH_OK;
 }
-// ---- the same chunk in reference order (jh_p16.h): activation images per row, M-row p16 GEMMs, KV rows of the whole chunk, then
-// scores / softmax + value chains of every row in one launch each
-template <int PRO>
-int rows_act_p16_launch(jh_session* s, const float* x, int ldx, const float* nw, float eps, int K, int rows, hipStream_t st) {
-    RowsP16Params rp{x, ldx, nw, eps, K, (uint8_t*)s->pb_aq, s->pb_ad, K, K / QB};
-    const size_t lds = lds_bytes_p16(K);
-#define JH_ACT(UMV)                                                                                   \
-    {                                                                                                 \
-        JHCHK(allow_lds((rows_act_p16_kernel<PRO, UMV>), lds));                                       \
-        hipLaunchKernelGGL((rows_act_p16_kernel<PRO, UMV>), dim3(rows), dim3(P16_THREADS), lds, st, rp); \
-    }
-    if (K <= 8192) JH_ACT(2) else if (K <= 16384) JH_ACT(4) else JH_ACT(8)
-#undef JH_ACT
-    HIPCHK(hipGetLastError());
-    return JH_OK;
-}
-template <int EPI>
-int gemm_p16_launch(jh_session* s, const JWeight& W, const JWeight* W2, int N, int K, int rows, float* out, int ldc, const float* resid, int ldr,
-                    hipStream_t st) {
-    if (!W.p16t || (W2 && !W2->p16t)) return set_err(JH_ERR_INVALID, "reference-order GEMM: the weight has no P16T copy (ensure_strict_operands)");
-    GemmP16Params g{W.p16t, W.scales, W2 ? W2->p16t : nullptr, W2 ? W2->scales : nullptr, (int)p16t_row_bytes(K), K / QB, N, K, rows,
-                    (const uint8_t*)s->pb_aq, s->pb_ad, K, K / QB, out, ldc, resid, ldr};
-    static const int nw_env = opt_int("JH_P16_GEMM_WAVES", 16), mt_env = opt_int("JH_P16_GEMM_MT", 0);
-    const int nq = (N + 3) / 4;
-    // MT activation images of K + K/8 bytes each in LDS.  16 would fit for K <= 8192 and halves the weight-unpack share, but it
-    // costs occupancy (116 VGPRs in the gate|up kernel, 74-147 KB of LDS: one workgroup per CU) and rounds 129 rows up to 144:
-    // measured on the 8B prompt 68.8 ms with MT = 16 where it fits, 59.9 ms with 8 everywhere (profiles/r03l_*)
-    int mt = K <= 16384 ? 8 : 4;
-    if (mt_env == 16 && K <= 8192) mt = 16;
-    else if (mt_env > 0 && mt_env < mt) mt = mt_env;
-    const int nw = nw_env >= 16 ? 16 : 8;
-    const int gx = (nq + nw - 1) / nw;
-#define JH_GEMM(MTV, NWV)                                                                                         \
-    if (mt == MTV && nw == NWV) {                                                                                 \
-        const size_t lds = lds_bytes_gemm_p16(K, MTV);                                                            \
-        JHCHK(allow_lds((gemm_i8q4_p16_kernel<EPI, MTV, NWV>), lds));                                             \
-        hipLaunchKernelGGL((gemm_i8q4_p16_kernel<EPI, MTV, NWV>), dim3(gx, (rows + MTV - 1) / MTV), dim3(NWV * 64), lds, st, g); \
-    }
-    JH_GEMM(16, 16) JH_GEMM(8, 16) JH_GEMM(4, 16) JH_GEMM(16, 8) JH_GEMM(8, 8) JH_GEMM(4, 8)
-#undef JH_GEMM
-    HIPCHK(hipGetLastError());
-    return JH_OK;
-}
+// ---- the same chunk in reference order: one-hot selector operands per row + T16 GEMMs on the F16 MFMA (jh_t16.h), KV rows of the
+// whole chunk, then scores / softmax + value chains of every row in one launch each (jh_p16.h)
 // ---- the same GEMMs on the F16 MFMA (jh_t16.h): activations as one-hot selector operands, weights in T16 order
 template <int PRO>
 int rows_act_t16_launch(jh_session* s, const float* x, int ldx, const float* nw, float eps, int K, int rows, hipStream_t st) {
@@ -2154,16 +2113,7 @@ int prefill_layers_p16(jh_session* s, int rows, int start_pos, hipStream_t st) {
             JHCHK(trace_sync("prefill layer (reference order, MFMA)", st));
             continue;
         }
-        JHCHK((rows_act_p16_launch<PRO_RMS_Q8>(s, s->pb_x, E, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
-        JHCHK((gemm_p16_launch<EPI_STORE>(s, F, nullptr, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, 0, st)));
-        JHCHK(prefill_attn_p16_launch(s, rel, rows, start_pos, st));
-        JHCHK((rows_act_p16_launch<PRO_QUANT_Q8>(s, s->pb_att, A, nullptr, 0.f, A, rows, st)));
-        JHCHK((gemm_p16_launch<EPI_RESID>(s, W[JH_W_O], nullptr, E, A, rows, s->pb_x1, E, s->pb_x, E, st)));
-        JHCHK((rows_act_p16_launch<PRO_RMS_Q8>(s, s->pb_x1, E, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
-        JHCHK((gemm_p16_launch<EPI_SILU_MUL>(s, W[JH_W_GATE], &W[JH_W_UP], H, E, rows, s->pb_g, H, nullptr, 0, st)));
-        JHCHK((rows_act_p16_launch<PRO_QUANT_Q8>(s, s->pb_g, H, nullptr, 0.f, H, rows, st)));
-        JHCHK((gemm_p16_launch<EPI_RESID>(s, W[JH_W_DOWN], nullptr, E, H, rows, s->pb_x, E, s->pb_x1, E, st)));
-        JHCHK(trace_sync("prefill layer (reference order)", st));
+        return set_err(JH_ERR_UNSUPPORTED, "reference-order prompt chunk: the model's shapes do not fit the T16 GEMM (rows go one at a time)");
     }
     return JH_OK;
 }
