@@ -1345,6 +1345,9 @@ int launch_gemv_t16(const GemvParams& p, hipStream_t st) {
     g_last_gemv_grid = grid;
     return JH_OK;
 }
+int tiled_mode_for(jh_model* m);
+// the order-free sessions use the MFMA gate|up GEMV as well (option JH_FAST_GATEUP_T16=0: their own VALU kernel, for comparisons)
+bool fast_gateup_t16(jh_model* m) { return opt_int("JH_FAST_GATEUP_T16", 1) != 0 && tiled_mode_for(m) == TILED_RESIDENT; }   // (a second copy: not under JH_TILED_COPY=transient)
 // gate|up of layer li in T16 order (tile u = gate rows 8u..8u+7, up rows 8u..8u+7): made once, before any graph capture
 bool t16_gateup_ok(const jh_model* m, int li) {
     static const int enabled = opt_int("JH_T16", 1);
@@ -1403,8 +1406,15 @@ int use_p16t(GemvParams& p, const JWeight& W) {
 bool prefill_t16_ok(jh_session* s);
 // every operand copy a reference-order session of this shard will touch (allocation must not happen inside a graph capture)
 int ensure_strict_operands(jh_session* s, hipStream_t st) {
-    if (!s->strict) return JH_OK;
     jh_model* m = s->m;
+    if (m->c.weight_dtype != JH_DT_Q4) return JH_OK;
+    if (!s->strict) {
+        // the order-free sessions take the gate|up GEMV from jh_t16.h too (it is the faster kernel -- and bit-exact): its T16 copy only
+        if (fast_gateup_t16(m))
+            for (int li = m->c.layer_start; li < m->c.layer_end; li++)
+                if (t16_gateup_ok(m, li)) JHCHK(ensure_gateup_t16(m, li, st));
+        return JH_OK;
+    }
     for (int li = m->c.layer_start; li < m->c.layer_end; li++) {
         JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
         JHCHK(ensure_p16t(m->qkv[(size_t)li], st));
@@ -1620,7 +1630,7 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
         p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
         p.out = s->hf;   // silu(gate)*up, F32; the down projection's prologue quantizes it (MLPBlock.java:144)
         if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, g_cu_count * 4, nullptr, st))); }
-        else if (s->strict && t16_gateup_ok(m, li)) {
+        else if (t16_gateup_ok(m, li) && (s->strict || fast_gateup_t16(m))) {
             JHCHK(ensure_gateup_t16(m, li, st));   // (already there unless a weight was just replaced; never inside a capture: ensure_strict_operands)
             p.w = m->gateup[(size_t)li].t16; p.ws = m->gateup[(size_t)li].t16_scales; p.w2 = nullptr; p.ws2 = nullptr;
             JHCHK((launch_gemv_t16<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
@@ -2726,7 +2736,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
                 p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
                 p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
                 p.out = s->hf;
-                if (p16 && t16_gateup_ok(m, li)) {
+                if (t16_gateup_ok(m, li) && (p16 || fast_gateup_t16(m))) {
                     JHCHK(ensure_gateup_t16(m, li, st));
                     p.w = m->gateup[(size_t)li].t16; p.ws = m->gateup[(size_t)li].t16_scales; p.w2 = nullptr; p.ws2 = nullptr;
                     JHCHK((launch_gemv_t16<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
