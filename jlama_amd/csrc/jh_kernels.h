@@ -2024,13 +2024,9 @@ struct AttnParams {
     float* outf;           // [A] attention output, ticket mode only (the o-projection then quantizes it)
     float* tap_q;          // roped q [A] (tap), may be null
     long long* dbg;        // optional phase timestamps (wall_clock64, 100 MHz) of workgroups with kvh == 0: [split][16]
-    int combine_kernel;    // 1: slices only publish (plain stores); attn_combine_kernel merges them after the kernel edge
-    // reference-order prefill (jh_p16.h, batch != 0): blockIdx.z = prompt row, at position batch_pos0 + z, q|k|v row z at
-    // qkv + z*ldqkv, its output row at outf + z*ldo, its score rows at scores + z*sc_batch; the KV rows of the whole chunk were
-    // written before (rows_rope_kv_p16_kernel), nothing is written to the pages here
-    int batch, batch_pos0, ldqkv, ldo;
-    long long sc_batch;
-    int w_cap;             // attn_p16_av_kernel<.., FUSED>: capacity (floats, multiple of 64) of its score row in LDS; q / new-k rows sit behind it
+    // reference-order prompt chunks (jh_p16.h, rows_*_p16_kernel): prompt row z sits at position batch_pos0 + z, its q|k|v row at
+    // qkv + z*ldqkv, its output row at outf + z*ldo
+    int batch_pos0, ldqkv, ldo;
 };
 #define JH_ATT_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && blockIdx.y == 0) p.dbg[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
@@ -2300,7 +2296,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(AttnParams p) 
     JH_ATT_STAMP(6);   // slice reduced
 
     float* my_o = p.part_o + ((size_t)(kvh * GROUP) * p.part_stride + split) * HS;   // + gi*part_stride*HS + d
-    if (direct || p.combine_kernel) {
+    if (direct) {
         // publish the slice and finish: the o-projection's prologue (direct mode) or attn_combine_kernel merges the
         // slices after the kernel boundary (= visibility, no write-through stores, no ticket)
         for (int i = tid; i < GROUP * HS; i += NT) {

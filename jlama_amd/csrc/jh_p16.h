@@ -633,10 +633,8 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
     __shared__ float qs[GROUP * HS];
     __shared__ float knew[HS];
     constexpr int NT = P16_ATT_THREADS, half = HS / 2, NC = HS / 16, RP = NT / 16;   // RP positions per pass
-    const int z = blockIdx.z;                                   // prompt row of a batched (prefill) launch, 0 in decode
-    const int pos = p.batch ? p.batch_pos0 + z : p.st->pos, n = pos + 1;
-    const float* qkv_row = p.qkv + (size_t)z * p.ldqkv;
-    scores += (size_t)z * p.sc_batch;
+    const int pos = p.st->pos, n = pos + 1;
+    const float* qkv_row = p.qkv;
     const int kvh = blockIdx.y, split = blockIdx.x, S = gridDim.x;
     const int chunk = (((n + S - 1) / S) + RP - 1) / RP * RP;   // whole passes per slice
     const int t0 = split * chunk;
@@ -662,7 +660,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
     // ---- RoPE of the group's q heads and of the new k row (table row pos + 2*kvHead: CausalSelfAttention.java:247-286); every
     // slice rotates them locally, bit-identically; the slice that owns `pos` writes the KV page rows
     const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
-    const bool owner = !p.batch && (pos >= t0 && pos < t1);
+    const bool owner = pos >= t0 && pos < t1;
     for (int i = tid; i < (GROUP + 1) * half; i += NT) {
         const int gi = i / half, d = i - gi * half;
         const float c = rf[2 * d], s = rf[2 * d + 1];
@@ -746,9 +744,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 32 * RU;   // columns per workgroup, positions per tile
     const int h = blockIdx.y, group = p.n_heads / p.n_kv_heads, kvh = h / group, d0 = blockIdx.x * DW;
-    const int z = blockIdx.z;                                   // prompt row of a batched (prefill) launch, 0 in decode
-    const int pos = p.batch ? p.batch_pos0 + z : p.st->pos, n = pos + 1;
-    scores += (size_t)z * p.sc_batch;
+    const int pos = p.st->pos, n = pos + 1;
     const int KV = p.n_kv_heads * HS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* vt = (float*)smem;              // [TP][DW] V tile
@@ -842,7 +838,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
             }
         }
     }
-    if (tid < DW) p.outf[(size_t)z * p.ldo + (size_t)h * HS + d0 + tid] = acc;
+    if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
 }
 static inline int p16_av_rows(int max_ctx) {   // RU: the whole context in one tile when it fits
     const int want = ((max_ctx + 63) & ~63) / 32;
@@ -852,15 +848,27 @@ static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)p16_av_ro
 
 // ------------------------------------------------------------------------------------------------ prompt rows in reference order
 // AbstractModel.batchForward (AbstractModel.java:295-312): the projections of a prompt chunk run on the F16 MFMA (jh_t16.h:
-// rows_act_t16_kernel + gemm_t16_kernel, bit-identical to the GEMVs here by construction); this file keeps the attention side:
-//   rows_rope_kv_p16_kernel  K (post-RoPE) and V rows of the whole chunk into the KV pages, before any row's scores are taken,
-//   then attn_p16_scores_kernel / attn_p16_av_kernel with the prompt row as blockIdx.z.
+// rows_act_t16_kernel + gemm_t16_kernel, bit-identical to the GEMVs here by construction); this file keeps the attention side.
+// Every (row, head) of CausalSelfAttention.java:314-356 is the computation the two decode kernels above do for one row -- the
+// same 16-lane dot per score, the same float sum of the exponentials in index order, the same fma chain per output element --
+// but laid out so that the rows of a chunk share what they read:
+//   chain          = (row r of an 8-row tile, query head gi of the kv head's group): NCH = 8 * GROUP chains per (tile, kv head)
+//   sT             = [tile][kv head][position j][chain] floats: scores, then exponentials (one 4*NCH-byte line per position)
+//   rows_rope_kv   K (post-RoPE) and V rows of the whole chunk into the KV pages, q rotated in place, before any score is taken
+//   rows_scores    a K row in registers serves all NCH chains (the decode kernel reads it once per row)
+//   rows_max / rows_exp / rows_sum   softMax (VectorMath.java:69-90): max, (float)exp(double), then ONE float accumulator per chain
+//                  in index order -- a lane per chain, 4*NCH bytes per step coalesced
+//   rows_av        a V tile in LDS serves the 8 rows x GROUP heads of the tile (8 waves, a row each; lane = column pair): every
+//                  lane runs GROUP * HS/64 fma chains over the positions, weights = e / sum broadcast from LDS
+constexpr int P16_ROWS_TILE = 8;      // prompt rows per tile
+constexpr int P16_ROWS_TJ = 64;       // positions per LDS tile / per scores workgroup
+
 template <int HS>
 __global__ __launch_bounds__(128) void rows_rope_kv_p16_kernel(AttnParams p) {
     constexpr int half = HS / 2;
-    const int z = blockIdx.x, kvh = blockIdx.y, pos = p.batch_pos0 + z;
+    const int z = blockIdx.x, kvh = blockIdx.y, pos = p.batch_pos0 + z, group = p.n_heads / p.n_kv_heads;
     const int KV = p.n_kv_heads * HS, A = p.n_heads * HS;
-    const float* qkv_row = p.qkv + (size_t)z * p.ldqkv;
+    float* qkv_row = const_cast<float*>(p.qkv) + (size_t)z * p.ldqkv;
     const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
     const float* kh = qkv_row + A + (size_t)kvh * HS;
     float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
@@ -869,9 +877,230 @@ __global__ __launch_bounds__(128) void rows_rope_kv_p16_kernel(AttnParams p) {
         const float k0 = kh[d], k1 = kh[d + half];
         const float r0 = k0 * c - k1 * s, r1 = k0 * s + k1 * c;   // as attn_p16_scores_kernel (CausalSelfAttention.java:273-286)
         kdst[d] = r0; kdst[d + half] = r1;
+        for (int gi = 0; gi < group; gi++) {                       // the group's query heads use the same table row (:247-266)
+            float* qh = qkv_row + (size_t)(kvh * group + gi) * HS;
+            const float q0 = qh[d], q1 = qh[d + half];
+            qh[d] = q0 * c - q1 * s; qh[d + half] = q0 * s + q1 * c;
+        }
     }
     float* vdst = (float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS;
     for (int d = threadIdx.x; d < HS; d += 128) vdst[d] = qkv_row[A + KV + (size_t)kvh * HS + d];
+}
+
+// grid (position slices of 64, kv heads, row tiles).  A 16-lane row owns positions j0 + prow + 16u (u = 0..3), K rows in
+// registers; the chains' q vectors come from LDS in GemmerF32's lane order.  Pairs (row, position) beyond the row's context
+// are computed like the others and never read.
+template <int HS, int GROUP>
+__global__ __launch_bounds__(256) void rows_scores_p16_kernel(AttnParams p, int rows, float* sT, int sc_stride) {
+    constexpr int NCH = P16_ROWS_TILE * GROUP, NC = HS / 16, NR = (NCH + 15) / 16, PU = P16_ROWS_TJ / 16;
+    __shared__ __attribute__((aligned(16))) float qs[NCH * 16 * NC];   // [chain][lane l][step c] = q[16c + l]
+    const int ztile = blockIdx.z, kvh = blockIdx.y, j0 = blockIdx.x * P16_ROWS_TJ, z0 = ztile * P16_ROWS_TILE;
+    const int zlast = z0 + P16_ROWS_TILE - 1 < rows - 1 ? z0 + P16_ROWS_TILE - 1 : rows - 1;
+    const int nmax = p.batch_pos0 + zlast + 1;
+    if (j0 >= nmax) return;
+    const int KV = p.n_kv_heads * HS;
+    const int tid = threadIdx.x, l = tid & 15, prow = tid >> 4;
+    float kv[PU][NC];
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        int tt = j0 + prow + 16 * u;
+        tt = tt < nmax ? tt : nmax - 1;
+        const float* krow = kv_row(p, 0, tt, KV) + (size_t)kvh * HS + l;
+#pragma unroll
+        for (int c = 0; c < NC; c++) kv[u][c] = krow[16 * c];
+    }
+    for (int i = tid; i < NCH * HS; i += 256) {
+        const int chain = i / HS, d = i - chain * HS, r = chain / GROUP, gi = chain - r * GROUP, z = z0 + r;
+        const float v = z < rows ? p.qkv[(size_t)z * p.ldqkv + (size_t)(kvh * GROUP + gi) * HS + d] : 0.0f;
+        qs[(chain * 16 + (d & 15)) * NC + (d >> 4)] = v;
+    }
+    __syncthreads();
+    float res[PU][NR];
+#pragma unroll
+    for (int u = 0; u < PU; u++)
+#pragma unroll
+        for (int cb = 0; cb < NR; cb++) res[u][cb] = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < NR; cb++) {
+#pragma unroll 2
+        for (int ci = 0; ci < (NCH - cb * 16 < 16 ? NCH - cb * 16 : 16); ci++) {   // (not unrolled further: 8 q registers per chain in flight)
+            const int chain = cb * 16 + ci;
+            float q[NC];
+#pragma unroll
+            for (int c4 = 0; c4 < NC / 4; c4++) {
+                const f32x4 t = *(const f32x4*)(qs + (chain * 16 + l) * NC + 4 * c4);
+                q[4 * c4] = t.x; q[4 * c4 + 1] = t.y; q[4 * c4 + 2] = t.z; q[4 * c4 + 3] = t.w;
+            }
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NC; c++) acc = fmaf(q[c], kv[u][c], acc);   // GemmerF32 (PTO:1086-1102): lane l, steps of 16
+                acc = row16_tree_sum(acc);                                      // every lane of the row holds the sum
+                if (l == ci) res[u][cb] = acc;
+            }
+        }
+    }
+    float* out = sT + ((size_t)(ztile * p.n_kv_heads + kvh) * sc_stride) * NCH;
+#pragma unroll
+    for (int u = 0; u < PU; u++) {
+        const int tt = j0 + prow + 16 * u;
+        if (tt >= nmax) continue;
+#pragma unroll
+        for (int cb = 0; cb < NR; cb++)
+            if (cb * 16 + l < NCH) out[(size_t)tt * NCH + cb * 16 + l] = res[u][cb] * p.scale;   // ops.scale after the dot (:332)
+    }
+}
+
+// grid (row tiles * kv heads): maximum of every chain's score row
+template <int GROUP>
+__global__ __launch_bounds__(256) void rows_max_p16_kernel(int rows, int pos0, int n_kv, const float* sT, int sc_stride, float* mx) {
+    constexpr int NCH = P16_ROWS_TILE * GROUP, JL = 256 / NCH;
+    __shared__ float red[256];
+    const int unit = blockIdx.x, ztile = unit / n_kv;
+    const int tid = threadIdx.x, chain = tid % NCH, jl = tid / NCH, z = ztile * P16_ROWS_TILE + chain / GROUP;
+    const int n = z < rows ? pos0 + z + 1 : 0;
+    const float* src = sT + (size_t)unit * sc_stride * NCH + chain;
+    float m = -INFINITY;
+    for (int j = jl; j < n; j += JL) m = fmaxf(m, src[(size_t)j * NCH]);
+    red[tid] = m;
+    __syncthreads();
+    if (tid < NCH) {
+        for (int i = 1; i < JL; i++) m = fmaxf(m, red[i * NCH + tid]);
+        mx[(size_t)unit * NCH + tid] = m;
+    }
+}
+// grid (1024-element slices of a unit's lines, row tiles * kv heads): e = (float)FastMath.exp(x - max) in place (VectorMath.java:76-79)
+template <int GROUP>
+__global__ __launch_bounds__(256) void rows_exp_p16_kernel(int rows, int pos0, int n_kv, float* sT, int sc_stride, const float* mx) {
+    constexpr int NCH = P16_ROWS_TILE * GROUP;
+    const int unit = blockIdx.y, ztile = unit / n_kv, z0 = ztile * P16_ROWS_TILE;
+    const int zlast = z0 + P16_ROWS_TILE - 1 < rows - 1 ? z0 + P16_ROWS_TILE - 1 : rows - 1;
+    const int nmax = pos0 + zlast + 1;
+    const int e0 = (blockIdx.x * 256 + threadIdx.x) * 4;   // element of the unit: position e0 / NCH, chains e0 % NCH .. + 3
+    const int j = e0 / NCH, c0 = e0 - j * NCH;
+    if (j >= nmax) return;
+    f32x4* ptr = (f32x4*)(sT + (size_t)unit * sc_stride * NCH + e0);
+    const f32x4 s = *ptr, m = *(const f32x4*)(mx + (size_t)unit * NCH + c0);
+    f32x4 e;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int z = z0 + (c0 + i) / GROUP;
+        e[i] = (z < rows && j <= pos0 + z) ? (float)exp((double)(s[i] - m[i])) : 0.0f;
+    }
+    *ptr = e;
+}
+// one wave per (row tile, kv head): lane = chain, one float accumulator in index order (VectorMath.java:80-85)
+template <int GROUP>
+__global__ __launch_bounds__(64) void rows_sum_p16_kernel(int rows, int pos0, int n_kv, const float* sT, int sc_stride, float* sums) {
+    constexpr int NCH = P16_ROWS_TILE * GROUP;
+    const int unit = blockIdx.x, ztile = unit / n_kv, lane = threadIdx.x;
+    if (lane >= NCH) return;
+    const int z = ztile * P16_ROWS_TILE + lane / GROUP;
+    const int n = z < rows ? pos0 + z + 1 : 0;
+    const float* src = sT + (size_t)unit * sc_stride * NCH + lane;
+    float sum = 0.0f;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = src[(size_t)(j + i) * NCH];
+#pragma unroll
+        for (int i = 0; i < 8; i++) sum += e[i];
+    }
+    for (; j < n; j++) sum += src[(size_t)j * NCH];
+    sums[(size_t)unit * NCH + lane] = sum;
+}
+
+// grid (row tiles * kv heads), 8 waves: wave w = row w of the tile.  LDS: two V tiles [TJ][HS] and two weight tiles [TJ][NCH];
+// the next tiles are requested before the current ones are consumed and filed after, one barrier per tile.
+constexpr int P16_ROWS_AV_THREADS = 64 * P16_ROWS_TILE;
+static inline size_t lds_bytes_rows_av_p16(int hs, int group) { return (size_t)2 * P16_ROWS_TJ * (hs + P16_ROWS_TILE * group) * 4; }
+template <int HS, int GROUP>
+__global__ __launch_bounds__(P16_ROWS_AV_THREADS) void rows_av_p16_kernel(AttnParams p, int rows, const float* eT, int sc_stride, const float* sums) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = P16_ROWS_AV_THREADS, TJ = P16_ROWS_TJ, NCH = P16_ROWS_TILE * GROUP, DPL = HS / 64;
+    constexpr int VU = TJ * HS / 4 / NT;                    // 16-byte V loads per thread and tile
+    constexpr int PN4 = TJ * NCH / 4, PU = (PN4 + NT - 1) / NT;   // 16-byte weight loads per tile / per thread
+    const int unit = blockIdx.x, ztile = unit / p.n_kv_heads, kvh = unit - ztile * p.n_kv_heads, z0 = ztile * P16_ROWS_TILE;
+    const int zlast = z0 + P16_ROWS_TILE - 1 < rows - 1 ? z0 + P16_ROWS_TILE - 1 : rows - 1;
+    const int nmax = p.batch_pos0 + zlast + 1;
+    const int KV = p.n_kv_heads * HS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, z = z0 + w;
+    const int n = z < rows ? p.batch_pos0 + z + 1 : 0;
+    float* vt = (float*)smem;                               // [2][TJ][HS]
+    float* pt = vt + 2 * TJ * HS;                           // [2][TJ][NCH]
+    const float* esrc = eT + (size_t)unit * sc_stride * NCH;
+    const f32x4 sum4 = *(const f32x4*)(sums + (size_t)unit * NCH + (tid * 4) % NCH);   // NT * 4 is a multiple of NCH: the same chains every tile
+    f32x4 vreg[VU], preg[PU];
+    auto request = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < VU; u++) {
+            const int idx = tid + NT * u, pr = idx / (HS / 4), c4 = idx - pr * (HS / 4);
+            int tt = tile * TJ + pr;
+            tt = tt < nmax ? tt : nmax - 1;
+            vreg[u] = *(const f32x4*)(kv_row(p, 1, tt, KV) + (size_t)kvh * HS + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int idx = tid + NT * u;
+            if (idx < PN4) preg[u] = *(const f32x4*)(esrc + (size_t)tile * TJ * NCH + 4 * idx);   // lines up to sc_stride exist
+        }
+    };
+    auto file = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < VU; u++) *(f32x4*)(vt + (size_t)buf * TJ * HS + 4 * (tid + NT * u)) = vreg[u];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const int idx = tid + NT * u;
+            if (idx < PN4) {
+                f32x4 wv;
+                wv.x = preg[u].x / sum4.x; wv.y = preg[u].y / sum4.y; wv.z = preg[u].z / sum4.z; wv.w = preg[u].w / sum4.w;   // VectorMath.java:86-89
+                *(f32x4*)(pt + (size_t)buf * TJ * NCH + 4 * idx) = wv;
+            }
+        }
+    };
+    float acc[GROUP][DPL];
+#pragma unroll
+    for (int gi = 0; gi < GROUP; gi++)
+#pragma unroll
+        for (int k = 0; k < DPL; k++) acc[gi][k] = 0.0f;
+    const int ntiles = (nmax + TJ - 1) / TJ;
+    request(0);
+    file(0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) request(tile + 1);
+        const int cnt = n - tile * TJ < TJ ? n - tile * TJ : TJ;   // this row's positions in the tile (<= 0: none)
+        const float* vb = vt + (size_t)buf * TJ * HS + lane * DPL;
+        const float* pb = pt + (size_t)buf * TJ * NCH + w * GROUP;
+        auto step = [&](int jj) __attribute__((always_inline)) {
+            float v[DPL], pw[GROUP];
+#pragma unroll
+            for (int k = 0; k < DPL; k++) v[k] = vb[jj * HS + k];
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++) pw[gi] = pb[jj * NCH + gi];
+#pragma unroll
+            for (int gi = 0; gi < GROUP; gi++)
+#pragma unroll
+                for (int k = 0; k < DPL; k++) acc[gi][k] = fmaf(v[k], pw[gi], acc[gi][k]);   // saxpy per position (PTO:2648-2698)
+        };
+        int jj = 0;
+        for (; jj + 8 <= cnt; jj += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) step(jj + i);
+        }
+        for (; jj < cnt; jj++) step(jj);
+        if (tile + 1 < ntiles) file(buf ^ 1);
+        __syncthreads();
+    }
+    if (z < rows) {
+#pragma unroll
+        for (int gi = 0; gi < GROUP; gi++)
+#pragma unroll
+            for (int k = 0; k < DPL; k++) p.outf[(size_t)z * p.ldo + (size_t)(kvh * GROUP + gi) * HS + lane * DPL + k] = acc[gi][k];
+    }
 }
 
 }  // namespace jh

@@ -1470,7 +1470,6 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     p.outf = s->attf;
     p.tap_q = tap ? s->tapq : nullptr;
     p.dbg = dbg;
-    p.combine_kernel = 0;   // (slices merged after the kernel edge: measured slower than the in-kernel last arriver, removed)
     if (s->strict) {
         // reference order in two launches (jh_p16.h): scores of every position slice, then softmax + the value chains
         const int group = c.n_heads / c.n_kv_heads, hs = c.head_size;
@@ -1478,7 +1477,6 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
         if (lds_av > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "reference-order attention: the score row of max_ctx positions must fit in LDS");
         const dim3 grid_s(s->p16_att_splits, c.n_kv_heads), grid_v(hs / 32, c.n_heads);
         const int ru = p16_av_rows(s->max_ctx);
-        p.w_cap = (s->max_ctx + 63) & ~63;
 #define JH_P16_AV(HSV, RV)                                                                                                      \
     if (hs == HSV && ru == RV) {                                                                                               \
         JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                               \
@@ -2063,31 +2061,32 @@ int prefill_attn_p16_launch(jh_session* s, int rel, int rows, int start_pos, hip
     p.n_heads = c.n_heads; p.n_kv_heads = c.n_kv_heads; p.head_size = hs; p.kv_head_offset = m->kv_head_offset;
     p.st = s->st; p.scale = m->attention_scale;
     p.outf = s->pb_att;
-    p.batch = 1; p.batch_pos0 = start_pos; p.ldqkv = A + 2 * KV; p.ldo = A;
-    p.sc_batch = (long long)c.n_heads * s->p16_sc_stride;
-    const size_t lds_av = lds_bytes_attn_p16(s->max_ctx);
-    if (lds_av > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "reference-order attention: the score row of max_ctx positions must fit in LDS");
-    const dim3 grid_s(s->p16_att_splits, c.n_kv_heads, rows), grid_v(hs / 32, c.n_heads, rows);
-    const int ru = p16_av_rows(s->max_ctx);
+    p.batch_pos0 = start_pos; p.ldqkv = A + 2 * KV; p.ldo = A;
+    // score lines [row tile][kv head][position][8 rows x group] (jh_p16.h "prompt rows in reference order")
+    const int ztiles = (rows + P16_ROWS_TILE - 1) / P16_ROWS_TILE, units = ztiles * c.n_kv_heads, nch = P16_ROWS_TILE * group;
+    const int nmax = start_pos + rows, stride = s->p16_sc_stride;
+    float* sT = s->p16_scores_b;
+    float* mx = sT + (size_t)PB_MAX_ROWS * c.n_heads * stride;
+    float* sums = mx + (size_t)PB_MAX_ROWS * c.n_heads;
+    const dim3 grid_s((nmax + P16_ROWS_TJ - 1) / P16_ROWS_TJ, c.n_kv_heads, ztiles);
+    const dim3 grid_e(((size_t)nmax * nch + 1023) / 1024, units);
+    const size_t lds_av = lds_bytes_rows_av_p16(hs, group);
     if (hs == 128) hipLaunchKernelGGL((rows_rope_kv_p16_kernel<128>), dim3(rows, c.n_kv_heads), dim3(128), 0, st, p);
     else hipLaunchKernelGGL((rows_rope_kv_p16_kernel<64>), dim3(rows, c.n_kv_heads), dim3(128), 0, st, p);
     HIPCHK(hipGetLastError());
-#define JH_P16_AVB(HSV, RV)                                                                                                     \
-    if (hs == HSV && ru == RV) {                                                                                               \
-        JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                               \
-        hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores_b, s->p16_sc_stride); \
-    }
 #define JH_P16_ATTNB(HSV, GV)                                                                                                  \
     if (hs == HSV && group == GV) {                                                                                            \
-        hipLaunchKernelGGL((attn_p16_scores_kernel<HSV, GV>), grid_s, dim3(P16_ATT_THREADS), 0, st, p, s->p16_scores_b, s->p16_sc_stride); \
-        HIPCHK(hipGetLastError());                                                                                             \
-        JH_P16_AVB(HSV, 2) JH_P16_AVB(HSV, 4) JH_P16_AVB(HSV, 8) JH_P16_AVB(HSV, 16)                                            \
+        hipLaunchKernelGGL((rows_scores_p16_kernel<HSV, GV>), grid_s, dim3(256), 0, st, p, rows, sT, stride);                  \
+        hipLaunchKernelGGL((rows_max_p16_kernel<GV>), dim3(units), dim3(256), 0, st, rows, start_pos, c.n_kv_heads, (const float*)sT, stride, mx); \
+        hipLaunchKernelGGL((rows_exp_p16_kernel<GV>), grid_e, dim3(256), 0, st, rows, start_pos, c.n_kv_heads, sT, stride, (const float*)mx); \
+        hipLaunchKernelGGL((rows_sum_p16_kernel<GV>), dim3(units), dim3(64), 0, st, rows, start_pos, c.n_kv_heads, (const float*)sT, stride, sums); \
+        JHCHK(allow_lds((rows_av_p16_kernel<HSV, GV>), lds_av));                                                               \
+        hipLaunchKernelGGL((rows_av_p16_kernel<HSV, GV>), dim3(units), dim3(P16_ROWS_AV_THREADS), lds_av, st, p, rows, (const float*)sT, stride, (const float*)sums); \
         HIPCHK(hipGetLastError());                                                                                             \
         return JH_OK;                                                                                                          \
     }
     JH_P16_ATTNB(128, 4) JH_P16_ATTNB(128, 8) JH_P16_ATTNB(64, 4) JH_P16_ATTNB(128, 1) JH_P16_ATTNB(128, 2) JH_P16_ATTNB(64, 1) JH_P16_ATTNB(64, 2) JH_P16_ATTNB(64, 8)
 #undef JH_P16_ATTNB
-#undef JH_P16_AVB
     return set_err(JH_ERR_UNSUPPORTED, "attention: head_size must be 64 or 128 and heads/kv_heads in {1,2,4,8}");
 }
 int prefill_layers_p16(jh_session* s, int rows, int start_pos, hipStream_t st) {
@@ -2136,7 +2135,7 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     const bool p16 = s->strict != 0;                      // reference order: prefill_batch_ok() admitted the session via prefill_p16_ok()
     if (!p16) JHCHK(ensure_all_tiled(s, st));
     if (p16 && !s->p16_scores_b) {
-        const hipError_t e = hipMalloc(&s->p16_scores_b, (size_t)PB_MAX_ROWS * c.n_heads * s->p16_sc_stride * 4);
+        const hipError_t e = hipMalloc(&s->p16_scores_b, (size_t)PB_MAX_ROWS * c.n_heads * ((size_t)s->p16_sc_stride + 2) * 4);   // score lines + maxima + sums
         if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc score rows of a prompt chunk");
     }
     const int E = c.embedding_length;

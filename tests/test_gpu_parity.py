@@ -178,8 +178,9 @@ def test_strict_order_real_shapes(gpu, oracle, name):
 
 
 def test_reference_order_prefill_in_batches_is_the_row_path_bit_for_bit(gpu, oracle, monkeypatch):
-    """Reference-order sessions run prompts through the M-row p16 GEMM (jh_p16.h: gemm_i8q4_p16_kernel + batched scores / value
-    launches).  Every (prompt row, weight row) pair keeps its own 16-lane chain fed in the same order, so the rows, the KV
+    """Reference-order sessions run prompts in chunks (jh_t16.h: gemm_t16_kernel on the F16 MFMA; jh_p16.h: rows_*_p16_kernel, the
+    attention of 8-row tiles).  Every (prompt row, weight row) pair keeps its own 16-lane chain fed in the same order, every
+    (row, head) its own score dots, float sum and value chains, so the rows, the KV
     pages they leave behind and everything decoded afterwards must equal the one-position-at-a-time path bit for bit --
     across a chunk boundary (300 rows = 256 + 44), a ragged last row tile, KV context pages, and a continuation at
     start_pos > 0."""

@@ -1,5 +1,6 @@
-"""Reference-order (Panama-512 summation order) prompt processing: the M-row p16 GEMM path against the one-position-at-a-time path,
-full-size model, the metric's 129-row prompt.  Usage: [TP_CONFIG=LLAMA3_8B] python tools/strict_prefill_bench.py"""
+"""Reference-order (Panama-512 summation order) prompt processing: the batched path (gemm_t16_kernel + rows_*_p16_kernel) against
+the one-position-at-a-time path, full-size model, the metric's 129-row prompt (SPB_ROWS=n for another length; SPB_SKIP_ROWS=1
+times the batched path only).  Usage: [TP_CONFIG=LLAMA3_8B] python tools/strict_prefill_bench.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,15 +13,14 @@ N.init(0)
 N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 w = ST.make_weights(cfg, seed=0, device=torch.device("cuda", 0))
 model = HipLlamaModel(cfg, w)
-prompt = S.prompt_tokens(cfg, n=128, seed=1234)
+nrows = int(os.environ.get("SPB_ROWS", "129"))
+prompt = S.prompt_tokens(cfg, n=nrows - 1, seed=1234)
 res = {}
 modes = (("batched", None),) if os.environ.get("SPB_SKIP_ROWS") else (("batched", None), ("row by row", "0"))
 for mode, env in modes:
-    if env is None:
-        os.environ.pop("JH_PREFILL_BATCH_MIN", None)
-    else:
-        os.environ["JH_PREFILL_BATCH_MIN"] = env
-    s = model.session(512)
+    if env is not None:
+        N.set_option("JH_PREFILL_BATCH_MIN", env)
+    s = model.session(max(512, nrows + 64))
     s.set_strict(True)
     s.batch_forward(prompt, 0); s.synchronize()          # warm (allocations)
     t0 = time.perf_counter()
@@ -31,6 +31,9 @@ for mode, env in modes:
     res[mode] = (out, tok, logits)
     print(f"{name} reference order, {prompt.size}-row prompt, {mode}: {dt * 1e3:8.2f} ms", flush=True)
     s.close()
+    if env is not None:
+        N.clear_options()
+        N.options_from_env()
 if len(res) < 2:
     sys.exit(0)
 a, b = res["batched"], res["row by row"]
