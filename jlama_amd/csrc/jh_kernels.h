@@ -15,12 +15,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include "jh_seqsum.h"
 
 namespace jh {
 
 constexpr int QB = 32;  // Q4/Q8 block size (Q4ByteBufferTensor.java:36, Q8ByteBufferTensor.java:39)
 using i32x4 = int __attribute__((ext_vector_type(4)));
 using i32x2 = int __attribute__((ext_vector_type(2)));
+using f32x4 = float __attribute__((ext_vector_type(4)));   // native vector (arrays of HIP's float4 class type end up in scratch)
 
 // ------------------------------------------------------------------------------------------------ helpers
 // 64-lane reductions entirely on the VALU's DPP path: quad_perm / row_half_mirror / row_mirror inside a 16-lane row,
@@ -1894,8 +1896,8 @@ __global__ void embed_kernel(const void* table, const float* scales, int dtype, 
 // ---- temperature sampling inside the device loop (AbstractModel.sample, core/model/AbstractModel.java:471-489):
 //   v_i = (float)exp((logit_i - max) / T) in double;  sum = float running sum over i in INDEX ORDER;  acc += v_i / sum until
 //   acc >= u -> token i (V-1 if never).  The exponentials are independent (sample_exp_kernel, whole chip); the two float
-//   accumulations are sequential by definition -- one lane walks the V values through LDS chunks (sample_pick_kernel), which
-//   costs ~0.3-0.5 ms at V = 128256 and keeps a T > 0 generation at one graph replay per token, no host round trip.
+//   accumulations are defined by their index order -- sample_pick_kernel below reproduces them bit for bit -- and a T > 0
+//   generation stays at one graph replay per token, no host round trip.
 __global__ __launch_bounds__(256) void sample_exp_kernel(const float* logits, int V, const float* partv, int nparts, float temperature, float* prob) {
     __shared__ float red[4];
     float m = -INFINITY;
@@ -1907,48 +1909,184 @@ __global__ __launch_bounds__(256) void sample_exp_kernel(const float* logits, in
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < V) prob[i] = (float)exp(((double)logits[i] - maxv) / (double)temperature);
 }
-constexpr int SAMPLE_CHUNK = 8192;
-__global__ __launch_bounds__(1024) void sample_pick_kernel(const float* prob, int V, const float* u, const DecodeState* st, int* tok_out) {
-    __shared__ __attribute__((aligned(16))) float buf[SAMPLE_CHUNK];
-    __shared__ float sh_sum;
-    __shared__ int sh_pick;
+// The two accumulations, exactly, by 1024 lanes (jh_seqsum.h).  The values are taken in windows of 1024 x SAMPLE_E: a lane owns
+// SAMPLE_E consecutive values (coalesced 16-byte loads, transposed through LDS), adds them to the two reference values of the
+// running sum's binade (2 float adds per value), a scan composes the lanes' parity -> increment maps, and the first lane whose
+// partial sum leaves the binade (or reaches u) walks its own values with plain adds; the lanes behind it redo their maps in the
+// new binade from registers.  V / (1024 E) windows + one scan per binade crossing instead of 128256 dependent adds.
+//   sample_exp_kernel (chip) -> sample_sum_kernel (1 workgroup) -> sample_norm_kernel (chip: v / sum) -> sample_pick_kernel (1 workgroup)
+constexpr int SAMPLE_T_DEFAULT = 1024, SAMPLE_E_DEFAULT = 16, SAMPLE_T_MAX = 1024;
+struct SeqShared {
+    SeqStep tot[SAMPLE_T_MAX / 64];
+    int first[SAMPLE_T_MAX / 64];
+    int m_end;
+    float s;
+    int pick;
+};
+static inline size_t lds_bytes_sample(int t, int e) { return (size_t)t * e * 4; }
+// inclusive scan of the lanes' maps over a wave: row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31
+// carry the row totals over (lanes without a source receive the identity map {0, 0})
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ SeqStep seq_dpp(SeqStep h) {
+    SeqStep o;
+    o.d0 = __builtin_amdgcn_update_dpp(0, h.d0, CTRL, ROW_MASK, 0xf, false);
+    o.d1 = __builtin_amdgcn_update_dpp(0, h.d1, CTRL, ROW_MASK, 0xf, false);
+    return o;
+}
+__device__ __forceinline__ SeqStep seq_wave_scan(SeqStep h) {
+    h = seq_compose(seq_dpp<0x111, 0xf>(h), h);
+    h = seq_compose(seq_dpp<0x112, 0xf>(h), h);
+    h = seq_compose(seq_dpp<0x114, 0xf>(h), h);
+    h = seq_compose(seq_dpp<0x118, 0xf>(h), h);
+    h = seq_compose(seq_dpp<0x142, 0xa>(h), h);
+    h = seq_compose(seq_dpp<0x143, 0xc>(h), h);
+    return h;
+}
+// s = sum of val[0..V) in index order; pick = first i with s >= u (then s is the sum up to i), else -1.  xt: SAMPLE_T * SAMPLE_E floats of LDS.
+// (tools/seqsum_lab.hip: 1024 x 16 and 512 x 16 are the fastest shapes; more values per lane lengthen every walk,
+// fewer lanes lengthen every window)
+template <int SAMPLE_T, int SAMPLE_E>
+__device__ __forceinline__ void seq_pass(const float* __restrict__ val, int V, float u, SeqShared& sh, float* xt, float& s_out, int& pick_out) {
+    constexpr int G = SAMPLE_E / 4;                             // 16-byte groups per lane and window
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 g4[G];
+    auto request = [&](int wpos) __attribute__((always_inline)) {   // window [wpos, wpos + T*E): group j*T + tid of the window
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            const int e = wpos + 4 * (j * SAMPLE_T + tid);
+            if (e + 4 <= V) g4[j] = *(const f32x4*)(val + e);
+            else {
+                g4[j].x = e < V ? val[e] : 0.0f; g4[j].y = e + 1 < V ? val[e + 1] : 0.0f;       // + 0: the sum stays as it is
+                g4[j].z = e + 2 < V ? val[e + 2] : 0.0f; g4[j].w = 0.0f;
+            }
+        }
+    };
+    // LDS slot of window group g: g ^ ((g >> 3) & 3) -- the lanes' own groups G*tid + i then spread over all banks
+    auto slot = [](int g) __attribute__((always_inline)) { return g ^ ((g >> 3) & 3); };
+    float s = 0.0f;
+    int pick = -1;
+    request(0);
+    for (int wpos = 0; wpos < V && pick < 0; wpos += SAMPLE_T * SAMPLE_E) {
+        float x[SAMPLE_E];
+#pragma unroll
+        for (int j = 0; j < G; j++) *(f32x4*)(xt + 4 * slot(j * SAMPLE_T + tid)) = g4[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            const f32x4 t = *(const f32x4*)(xt + 4 * slot(G * tid + j));
+            x[4 * j] = t.x; x[4 * j + 1] = t.y; x[4 * j + 2] = t.z; x[4 * j + 3] = t.w;
+        }
+        if (wpos + SAMPLE_T * SAMPLE_E < V) request(wpos + SAMPLE_T * SAMPLE_E);   // in flight across this window's scans
+        auto lane_map = [&](int k, bool live) __attribute__((always_inline)) {
+            SeqStep h{0, 0};
+            if (live) {
+                SeqRef ref = seq_ref_begin(k);
+#pragma unroll
+                for (int i = 0; i < SAMPLE_E; i++) seq_ref_add(ref, x[i]);
+                h = seq_ref_end(ref, k);
+            }
+            return h;
+        };
+        // the reference's own loop over this lane's values, from the exact sum w in front of them
+        auto walk = [&](float& w, int& pk) __attribute__((always_inline)) {
+            const int e0 = wpos + tid * SAMPLE_E;
+#pragma unroll
+            for (int i = 0; i < SAMPLE_E; i++) {
+                if (pk < 0) {
+                    w += x[i];
+                    if (w >= u && e0 + i < V) pk = e0 + i;
+                }
+            }
+        };
+        int lo = 0;                                             // lanes below lo are behind the running sum already
+        while (true) {
+            const int k = seq_k(s), m_in = seq_m(s), th = seq_threshold(u, k);
+            const SeqStep h = seq_wave_scan(lane_map(k, tid >= lo));
+            if (lane == 63) sh.tot[wave] = h;
+            __syncthreads();                                    // (also: every lane has read its window values from xt)
+            SeqStep t = lane < SAMPLE_T / 64 ? sh.tot[lane & (SAMPLE_T / 64 - 1)] : SeqStep{0, 0};
+            t = seq_wave_scan(t);                               // lanes 0..15: the waves' totals up to and including wave `lane`
+            SeqStep pre{0, 0};
+            if (wave > 0) { pre.d0 = __builtin_amdgcn_readlane(t.d0, wave - 1); pre.d1 = __builtin_amdgcn_readlane(t.d1, wave - 1); }
+            const int m_wave = seq_apply(m_in, pre);            // the sum in front of this wave
+            const int m = seq_apply(m_wave, h);
+            const unsigned long long hit = __ballot(tid >= lo && m >= th);
+            if (lane == 0) sh.first[wave] = hit ? wave : 0x7fffffff;
+            if (lane == 63 && wave == SAMPLE_T / 64 - 1) sh.m_end = m;
+            __syncthreads();
+            int we = 0x7fffffff;
+#pragma unroll
+            for (int w = 0; w < SAMPLE_T / 64; w++) we = we < sh.first[w] ? we : sh.first[w];
+            if (we == 0x7fffffff) {
+                s = seq_value(sh.m_end, k);
+                break;
+            }
+            if (wave == we) {
+                // this wave holds the first lane that leaves the binade (or reaches u): it settles ALL its lanes among itself --
+                // walk that lane, redo the maps of the lanes behind it in the new binade, scan, next such lane, ... -- no barrier
+                int kk = k, mw = m_wave, wlo = lo > wave * 64 ? lo - wave * 64 : 0, pk = -1;
+                unsigned long long hh = hit;
+                SeqStep hs = h;
+                float sw = 0.0f;
+                while (true) {
+                    const int te = __builtin_ctzll(hh);         // uniform
+                    int m_before = seq_apply(mw, hs);           // behind this lane ...
+                    m_before = __shfl_up(m_before, 1);          // ... so in front of the next one
+                    if (lane == wlo) m_before = mw;             // (lanes below wlo hold identity maps: lane wlo starts at mw)
+                    float w = seq_value(m_before, kk);
+                    int p1 = -1;
+                    if (lane == te) walk(w, p1);
+                    sw = __shfl(w, te);
+                    pk = __shfl(p1, te);
+                    if (pk >= 0 || te == 63) break;
+                    wlo = te + 1;
+                    kk = seq_k(sw);
+                    mw = seq_m(sw);
+                    const int th2 = seq_threshold(u, kk);
+                    hs = seq_wave_scan(lane_map(kk, lane >= wlo));
+                    hh = __ballot(lane >= wlo && seq_apply(mw, hs) >= th2);
+                    if (!hh) {
+                        sw = seq_value(__builtin_amdgcn_readlane(seq_apply(mw, hs), 63), kk);
+                        break;
+                    }
+                }
+                if (lane == 0) { sh.s = sw; sh.pick = pk; }
+            }
+            __syncthreads();
+            s = sh.s;
+            pick = sh.pick;
+            if (pick >= 0) break;
+            lo = (we + 1) * 64;
+            if (lo >= SAMPLE_T) break;
+        }
+    }
+    s_out = s;
+    pick_out = pick;
+}
+template <int SAMPLE_T, int SAMPLE_E>
+__global__ __launch_bounds__(SAMPLE_T) void sample_sum_kernel(const float* prob, int V, const DecodeState* st, float* sum_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ SeqShared sh;
     if (st->done) return;
-    const int tid = threadIdx.x;
-    float sum = 0.0f;
-    for (int base = 0; base < V; base += SAMPLE_CHUNK) {
-        const int cnt = V - base < SAMPLE_CHUNK ? V - base : SAMPLE_CHUNK;
-        for (int i = tid; i < cnt; i += 1024) buf[i] = prob[base + i];
-        __syncthreads();
-        if (tid == 0) {
-            int i = 0;
-            for (; i + 8 <= cnt; i += 8) {
-                const float4 a = *(const float4*)(buf + i), b = *(const float4*)(buf + i + 4);
-                sum += a.x; sum += a.y; sum += a.z; sum += a.w;
-                sum += b.x; sum += b.y; sum += b.z; sum += b.w;
-            }
-            for (; i < cnt; i++) sum += buf[i];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) { sh_sum = sum; sh_pick = -1; }
-    __syncthreads();
-    sum = sh_sum;
-    const float uu = u[st->step];
-    float acc = 0.0f;
-    for (int base = 0; base < V; base += SAMPLE_CHUNK) {
-        const int cnt = V - base < SAMPLE_CHUNK ? V - base : SAMPLE_CHUNK;
-        for (int i = tid; i < cnt; i += 1024) buf[i] = prob[base + i] / sum;
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 0; i < cnt; i++) {
-                acc += buf[i];
-                if (acc >= uu) { sh_pick = base + i; break; }
-            }
-        }
-        __syncthreads();
-        if (sh_pick >= 0) break;   // uniform: read after the barrier
-    }
-    if (tid == 0) *tok_out = sh_pick >= 0 ? sh_pick : V - 1;
+    float sum;
+    int pick;
+    seq_pass<SAMPLE_T, SAMPLE_E>(prob, V, INFINITY, sh, (float*)smem, sum, pick);   // AbstractModel.java:475-480
+    if (threadIdx.x == 0) *sum_out = sum;
+}
+__global__ __launch_bounds__(256) void sample_norm_kernel(float* prob, int V, const DecodeState* st, const float* sum) {
+    if (st->done) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < V) prob[i] = prob[i] / *sum;                              // :481-483
+}
+template <int SAMPLE_T, int SAMPLE_E>
+__global__ __launch_bounds__(SAMPLE_T) void sample_pick_kernel(const float* prob, int V, const float* u, const DecodeState* st, int* tok_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ SeqShared sh;
+    if (st->done) return;
+    float acc;
+    int pick;
+    seq_pass<SAMPLE_T, SAMPLE_E>(prob, V, u[st->step], sh, (float*)smem, acc, pick);   // :484-489
+    if (threadIdx.x == 0) *tok_out = pick >= 0 ? pick : V - 1;
 }
 
 __global__ void finish_token_kernel(const float* partv, const int* parti, int nparts, DecodeState* st,

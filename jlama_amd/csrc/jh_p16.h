@@ -715,7 +715,6 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnPa
     }
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector (arrays of HIP's float4 class type end up in scratch)
 template <int HS, int RU>
 __device__ __forceinline__ void p16_av_load_tile(const AttnParams& p, f32x4 (&vreg)[RU], int tile, int n, int KV, int kvh, int d0, int vr, int vc) {
     // 32-row groups that lie wholly behind the context are neither requested nor filed (wave-uniform: a session sized for 512

@@ -2227,7 +2227,13 @@ int finish_launch(jh_session* s, hipStream_t st, int do_embed, float temperature
     if (temperature != 0.0f) {   // AbstractModel.java:471-489 on the device: exponentials, then the two sequential float accumulations
         hipLaunchKernelGGL(sample_exp_kernel, dim3((V + 255) / 256), dim3(256), 0, st, (const float*)s->logits, V, (const float*)s->amax_v, s->lm_grid,
                            temperature, s->prob);
-        hipLaunchKernelGGL(sample_pick_kernel, dim3(1), dim3(1024), 0, st, (const float*)s->prob, V, (const float*)s->u_dev, (const DecodeState*)s->st, s->pick);
+        float* sum = s->prob + (((size_t)V + 3) & ~(size_t)3);
+        const size_t lds = lds_bytes_sample(SAMPLE_T_DEFAULT, SAMPLE_E_DEFAULT);
+        JHCHK(allow_lds((sample_sum_kernel<SAMPLE_T_DEFAULT, SAMPLE_E_DEFAULT>), lds));
+        JHCHK(allow_lds((sample_pick_kernel<SAMPLE_T_DEFAULT, SAMPLE_E_DEFAULT>), lds));
+        hipLaunchKernelGGL((sample_sum_kernel<SAMPLE_T_DEFAULT, SAMPLE_E_DEFAULT>), dim3(1), dim3(SAMPLE_T_DEFAULT), lds, st, (const float*)s->prob, V, (const DecodeState*)s->st, sum);
+        hipLaunchKernelGGL(sample_norm_kernel, dim3((V + 255) / 256), dim3(256), 0, st, s->prob, V, (const DecodeState*)s->st, (const float*)sum);
+        hipLaunchKernelGGL((sample_pick_kernel<SAMPLE_T_DEFAULT, SAMPLE_E_DEFAULT>), dim3(1), dim3(SAMPLE_T_DEFAULT), lds, st, (const float*)s->prob, V, (const float*)s->u_dev, (const DecodeState*)s->st, s->pick);
     }
     hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(256), 0, st, (const float*)s->amax_v, (const int*)s->amax_i, s->lm_grid,
                        s->st, s->out_tokens, (const void*)e.data, (const float*)e.scales, e.dtype, m->c.embedding_length, s->x,
@@ -3090,7 +3096,7 @@ static int decode_n_async_impl(jh_session* s, int32_t first_token, int start_pos
     hipStream_t st = s->stream;
     const bool sampled = temperature != 0.0f;
     if (sampled) {
-        if (!s->prob) HIPCHK(hipMalloc(&s->prob, (size_t)m->c.vocab_size * 4));
+        if (!s->prob) HIPCHK(hipMalloc(&s->prob, ((size_t)m->c.vocab_size + 8) * 4));   // exponentials, then their float sum
         if (!s->pick) HIPCHK(hipMalloc(&s->pick, 64));
         if (s->u_cap < n) {
             HIPCHK(hipStreamSynchronize(st));
