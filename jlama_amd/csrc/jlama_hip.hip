@@ -3216,7 +3216,48 @@ struct jh_tp_group {
     std::vector<unsigned*> flags_of;
     std::vector<TPMail*> mail_of;
     std::vector<void*> ipc_open;               // mappings to close
+    // shards that share ONE device (loopback runs): each gets a stream with its own CU mask for the life of the group -- a hardware
+    // queue of its own (the runtime multiplexes plain streams over a few queues; two shards on one queue cannot meet inside
+    // kernels) and CUs no other shard's spinning kernel can occupy
+    std::vector<hipStream_t> masked, unmasked;
 };
+static void tp_mask_streams(jh_tp_group* g) {
+    const size_t N = g->sh.size();
+    g->masked.assign(N, nullptr);
+    g->unmasked.assign(N, nullptr);
+    if (!opt_int("JH_TP_CU_MASK", 1)) return;
+    for (size_t k = 0; k < N; k++) {
+        if (!g->sh[k] || g->masked[k]) continue;
+        const int dev = g->sh[k]->m->device;
+        std::vector<size_t> same;
+        for (size_t j = 0; j < N; j++) if (g->sh[j] && g->sh[j]->m->device == dev) same.push_back(j);
+        if (same.size() < 2) continue;
+        hipDeviceProp_t prop;
+        if (hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); continue; }
+        const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
+        for (size_t i = 0; i < same.size(); i++) {
+            std::vector<uint32_t> mask((size_t)words, 0u);
+            for (int cu = 0; cu < cus; cu++) if ((size_t)cu % same.size() == i) mask[cu >> 5] |= 1u << (cu & 31);
+            hipStream_t ns = nullptr;
+            if (hipExtStreamCreateWithCUMask(&ns, (uint32_t)words, mask.data()) != hipSuccess) { (void)hipGetLastError(); continue; }
+            jh_session* s = g->sh[same[i]];
+            hipStreamSynchronize(s->stream);
+            g->unmasked[same[i]] = s->stream;
+            g->masked[same[i]] = ns;
+            s->stream = ns;
+        }
+    }
+}
+static void tp_unmask_streams(jh_tp_group* g) {
+    for (size_t k = 0; k < g->masked.size() && k < g->sh.size(); k++) {
+        if (!g->masked[k] || !g->sh[k]) continue;
+        hipSetDevice(g->sh[k]->m->device);
+        hipStreamSynchronize(g->masked[k]);
+        g->sh[k]->stream = g->unmasked[k];
+        hipStreamDestroy(g->masked[k]);
+        g->masked[k] = nullptr;
+    }
+}
 // memory that kernels of several devices meet in: fine-grained (coherent at system scope inside a kernel) where the runtime
 // offers it, plain device memory otherwise (enough when all shards share one device)
 static hipError_t tp_shared_malloc(void** p, size_t bytes) {
@@ -3246,6 +3287,7 @@ int jh_tp_group_destroy(jh_tp_group* g) {
         if (k < g->evB.size() && g->evB[k]) hipEventDestroy(g->evB[k]);
         if (k < g->evTok.size() && g->evTok[k]) hipEventDestroy(g->evTok[k]);
     }
+    tp_unmask_streams(g);
     for (void* p : g->ipc_open) hipIpcCloseMemHandle(p);
     if (g->mails_dev) {
         if (g->sh[0]) hipSetDevice(g->sh[0]->m->device);
@@ -3321,6 +3363,7 @@ int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** ou
             return set_err(JH_ERR_HIP, "tp_group_create: mailbox table upload");
         }
     }
+    tp_mask_streams(g);
     *out = g;
     return JH_OK;
 }

@@ -4,8 +4,9 @@ import sys
 import pytest
 
 # The tensor-parallel loopback tests run several shards' streams side by side on ONE device, kernels of one stream waiting for
-# kernels of another: each stream needs its own hardware queue (the runtime multiplexes streams over GPU_MAX_HW_QUEUES = 4 by
-# default; the tests that depend on it also retry with fresh streams).  Read when HIP initialises, so it is set before anything imports torch.
+# kernels of another: each stream needs its own hardware queue.  The one-process group makes sure of that itself (CU-masked
+# streams, jh_tp_group_create); the raised queue count keeps the other multi-stream tests (pipeline stages, concurrent sessions)
+# off shared queues.  Read when HIP initialises, so it is set before anything imports torch.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 try:   # torch bundles its own HIP runtime: when a test mixes torch.cuda with libjlamahip.so, torch must be loaded first
