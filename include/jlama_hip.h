@@ -260,6 +260,15 @@ int jh_tp_attn(jh_session* s, int layer, float* partial_out_dev);  /* norm, q|k|
 int jh_tp_ffn(jh_session* s, int layer, const float* reduced_attn_dev, float* partial_out_dev);  /* x1 = x + reduced; norm, gate/up, SiLU*up, down partial */
 int jh_tp_finish_layer(jh_session* s, const float* reduced_ffn_dev);  /* x = x1 + reduced */
 int jh_session_get_row(jh_session* s, float* out, int to_device);   /* the session's current row x [E] */
+/* The same halves over a CHUNK of prompt rows (AbstractModel.batchForward on a shard, AbstractModel.java:295-312: the reducer then
+ * sums [rows, E] once per half-layer instead of [E] once per row).  jh_tp_rows_max: rows a chunk may hold (256), 0 if this shard's
+ * shapes have no batched path (then feed rows with jh_tp_set_row).  partial / reduced buffers are [n, E] F32, row-major, device. */
+int jh_tp_rows_max(jh_session* s);
+int jh_tp_set_rows(jh_session* s, const int32_t* tokens, const float* x_dev, int n, int start_pos);  /* rows = embedding rows of tokens (host ids) or x_dev [n, E] */
+int jh_tp_attn_rows(jh_session* s, int layer, float* partial_out_dev);
+int jh_tp_ffn_rows(jh_session* s, int layer, const float* reduced_attn_dev, float* partial_out_dev);
+int jh_tp_finish_layer_rows(jh_session* s, const float* reduced_ffn_dev);
+int jh_tp_finish_rows(jh_session* s, float* rows_out_dev);   /* after the last layer: last row -> current row (sample reads it); rows_out_dev [n, E] optional */
 
 /* ---- One-process tensor-parallel group: N head-split shard sessions (one per device; loopback on one device allowed)
  * driven by one host thread with no host synchronisation inside a layer.  The two reductions of a layer

@@ -140,6 +140,18 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
     private static final MethodHandle jh_tp_ffn = h("jh_tp_ffn", JAVA_INT, sig("pipp"));
     // int jh_tp_finish_layer(jh_session* s, const float* reduced_ffn_dev)
     private static final MethodHandle jh_tp_finish_layer = h("jh_tp_finish_layer", JAVA_INT, sig("pp"));
+    // int jh_tp_rows_max(jh_session* s)
+    private static final MethodHandle jh_tp_rows_max = h("jh_tp_rows_max", JAVA_INT, sig("p"));
+    // int jh_tp_set_rows(jh_session* s, const int32_t* tokens, const float* x_dev, int n, int start_pos)
+    private static final MethodHandle jh_tp_set_rows = h("jh_tp_set_rows", JAVA_INT, sig("pppii"));
+    // int jh_tp_attn_rows(jh_session* s, int layer, float* partial_out_dev)
+    private static final MethodHandle jh_tp_attn_rows = h("jh_tp_attn_rows", JAVA_INT, sig("pip"));
+    // int jh_tp_ffn_rows(jh_session* s, int layer, const float* reduced_attn_dev, float* partial_out_dev)
+    private static final MethodHandle jh_tp_ffn_rows = h("jh_tp_ffn_rows", JAVA_INT, sig("pipp"));
+    // int jh_tp_finish_layer_rows(jh_session* s, const float* reduced_ffn_dev)
+    private static final MethodHandle jh_tp_finish_layer_rows = h("jh_tp_finish_layer_rows", JAVA_INT, sig("pp"));
+    // int jh_tp_finish_rows(jh_session* s, float* rows_out_dev)
+    private static final MethodHandle jh_tp_finish_rows = h("jh_tp_finish_rows", JAVA_INT, sig("pp"));
     // int jh_tp_group_create(jh_session* const* shards, int n_shards, jh_tp_group** out)
     private static final MethodHandle jh_tp_group_create = h("jh_tp_group_create", JAVA_INT, sig("pip"));
     // int jh_tp_group_destroy(jh_tp_group* g)
@@ -325,6 +337,24 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
 
     public static int jh_tp_finish_layer(MemorySegment s, MemorySegment reduced_ffn_dev) {
         try { return (int) jh_tp_finish_layer.invokeExact(s, reduced_ffn_dev); } catch (Throwable t) { throw rethrow(t); }
+    }
+    public static int jh_tp_rows_max(MemorySegment s) {
+        try { return (int) jh_tp_rows_max.invokeExact(s); } catch (Throwable t) { throw rethrow(t); }
+    }
+    public static int jh_tp_set_rows(MemorySegment s, MemorySegment tokens, MemorySegment x_dev, int n, int start_pos) {
+        try { return (int) jh_tp_set_rows.invokeExact(s, tokens, x_dev, n, start_pos); } catch (Throwable t) { throw rethrow(t); }
+    }
+    public static int jh_tp_attn_rows(MemorySegment s, int layer, MemorySegment partial_out_dev) {
+        try { return (int) jh_tp_attn_rows.invokeExact(s, layer, partial_out_dev); } catch (Throwable t) { throw rethrow(t); }
+    }
+    public static int jh_tp_ffn_rows(MemorySegment s, int layer, MemorySegment reduced_attn_dev, MemorySegment partial_out_dev) {
+        try { return (int) jh_tp_ffn_rows.invokeExact(s, layer, reduced_attn_dev, partial_out_dev); } catch (Throwable t) { throw rethrow(t); }
+    }
+    public static int jh_tp_finish_layer_rows(MemorySegment s, MemorySegment reduced_ffn_dev) {
+        try { return (int) jh_tp_finish_layer_rows.invokeExact(s, reduced_ffn_dev); } catch (Throwable t) { throw rethrow(t); }
+    }
+    public static int jh_tp_finish_rows(MemorySegment s, MemorySegment rows_out_dev) {
+        try { return (int) jh_tp_finish_rows.invokeExact(s, rows_out_dev); } catch (Throwable t) { throw rethrow(t); }
     }
 
     public static int jh_tp_group_create(MemorySegment shards, int n_shards, MemorySegment out) {

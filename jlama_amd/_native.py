@@ -158,6 +158,12 @@ _PROTOS = {
     "jh_tp_attn": (_i, [_p, _i, _p]),
     "jh_tp_ffn": (_i, [_p, _i, _p, _p]),
     "jh_tp_finish_layer": (_i, [_p, _p]),
+    "jh_tp_rows_max": (_i, [_p]),
+    "jh_tp_set_rows": (_i, [_p, _p, _p, _i, _i]),
+    "jh_tp_attn_rows": (_i, [_p, _i, _p]),
+    "jh_tp_ffn_rows": (_i, [_p, _i, _p, _p]),
+    "jh_tp_finish_layer_rows": (_i, [_p, _p]),
+    "jh_tp_finish_rows": (_i, [_p, _p]),
     "jh_session_get_row": (_i, [_p, _p, _i]),
     "jh_set_tap_layer": (_i, [_p, _i]),
     "jh_get_tap": (_i, [_p, _i, _p, _i]),

@@ -1749,11 +1749,11 @@ __global__ void tp_scatter_kernel(const float* part, float* const* dst, int n_ds
 }
 // ... and every shard sums the N slots locally, in shard order 0..N-1 (the lock-step order: results never depend on which
 // peer arrived first)
-__global__ void tp_sum_kernel(const float* slots, int n, int E, float* out) {
+__global__ void tp_sum_kernel(const float* slots, int n, int E, float* out, size_t stride) {   // stride: floats between two shards' slots
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E) return;
     float v = slots[i];
-    for (int k = 1; k < n; k++) v = v + slots[(size_t)k * E + i];
+    for (int k = 1; k < n; k++) v = v + slots[k * stride + i];
     out[i] = v;
 }
 // ---- the same reduction without the host in it: every shard replays ONE captured graph per token, the shards meet in kernels.

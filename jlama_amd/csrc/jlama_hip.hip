@@ -1189,6 +1189,7 @@ struct jh_session {
     std::map<uint64_t, hipGraphExec_t> pb_graphs;   // captured layer loops, key = rows | key-count bucket << 32
     std::vector<hipGraph_t> pb_graph_src;
     int prefill_batch_min = 4;
+    int tp_rows = 0, tp_pos0 = 0, tp_last_token = 0;   // chunk of prompt rows a tensor-parallel host is walking through the layers (jh_tp_set_rows)
     int strict = 0;           // jh_session_set_strict: reference-order kernels (jh_p16.h)
     // temperature sampling inside the device loop: exp((l - max)/T) of every logit, the caller's uniforms, the picked id; the
     // decode graphs of this mode are captured per temperature (a kernel argument)
@@ -1975,39 +1976,55 @@ int prefill_attn_launch(jh_session* s, int rel, int nkeys_bound, int rows, bool 
     return set_err(JH_ERR_UNSUPPORTED, "prefill attention: unsupported head geometry");
 }
 // the layer loop of one chunk (also what the prefill graphs capture)
-int prefill_layers(jh_session* s, int rows, int nkeys_bound, bool attn_mfma, hipStream_t st) {
+// One layer of a prompt chunk is two halves (a tensor-parallel shard's partial results are reduced between them): `resid` non-null
+// adds the residual in the GEMM's epilogue (a whole model), null stores the bare projection (a shard's partial rows).
+int prefill_weights_set(jh_session* s, int li) {
+    jh_model* m = s->m;
+    JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    if (!m->qkv[(size_t)li].data || !W[JH_W_Q].data || !W[JH_W_K].data || !W[JH_W_V].data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data ||
+        !W[JH_W_DOWN].data || !W[JH_W_NORM1].data || !W[JH_W_NORM2].data)
+        return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": weights not set");
+    return JH_OK;
+}
+// preAttentionNorm + maybeQuantize, q|k|v projections, attention, maybeQuantize(valueBatch) + output projection
+// (CausalSelfAttention.java:161-171, 364-376; residual TransformerBlock.java:185): rows of s->pb_x -> out
+int prefill_attn_half(jh_session* s, int li, int rows, int nkeys_bound, bool attn_mfma, float* out, const float* resid, hipStream_t st) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
-    const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
-    const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    const int E = c.embedding_length, hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    JHCHK(prefill_weights_set(s, li));
+    JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
+    JHCHK(prefill_gemm(s, m->qkv[(size_t)li], A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, st));
+    JHCHK(prefill_attn_launch(s, li - c.layer_start, nkeys_bound, rows, attn_mfma, st));
+    JHCHK((rows_quant_launch<ROWS_QUANT>(s, s->pb_att, A, nullptr, 0, nullptr, 0.f, A, rows, st)));
+    return prefill_gemm(s, W[JH_W_O], E, A, rows, out, E, resid, st);
+}
+// preFFNorm + maybeQuantize, gate / up, SiLU*up + maybeQuantize, down (MLPBlock.java:117-158; residual TransformerBlock.java:203): rows of x1 -> out
+int prefill_ffn_half(jh_session* s, int li, int rows, const float* x1, float* out, const float* resid, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int E = c.embedding_length, H = c.hidden_length;
+    JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    JHCHK((rows_quant_launch<ROWS_RMS>(s, x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
+    if (gateup_fusable(s, li)) {   // one GEMM for gate|up: out[:, :H] = gate, out[:, H:] = up
+        const uint8_t* tw = nullptr;
+        const float* ts = nullptr;
+        JHCHK(gateup_operand(s, li, st, &tw, &ts));
+        JHCHK(prefill_gemm_operand(s, W[JH_W_GATE].dtype, tw, ts, 2 * H, E, rows, s->pb_g, 2 * H, nullptr, st));
+        JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, 2 * H, s->pb_g + H, 2 * H, nullptr, 0.f, H, rows, st)));
+    } else {
+        JHCHK(prefill_gemm(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, st));
+        JHCHK(prefill_gemm(s, W[JH_W_UP], H, E, rows, s->pb_u, H, nullptr, st));
+        JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, st)));
+    }
+    return prefill_gemm(s, W[JH_W_DOWN], E, H, rows, out, E, resid, st);
+}
+int prefill_layers(jh_session* s, int rows, int nkeys_bound, bool attn_mfma, hipStream_t st) {
+    const jh_config& c = s->m->c;
     for (int li = c.layer_start; li < c.layer_end; li++) {
-        const int rel = li - c.layer_start;
-        JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
-        JWeight& F = m->qkv[(size_t)li];
-        if (!F.data || !W[JH_W_Q].data || !W[JH_W_K].data || !W[JH_W_V].data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data ||
-            !W[JH_W_DOWN].data || !W[JH_W_NORM1].data || !W[JH_W_NORM2].data)
-            return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": weights not set");
-        // preAttentionNorm + maybeQuantize, q|k|v projections (CausalSelfAttention.java:161-171)
-        JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
-        JHCHK(prefill_gemm(s, F, A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, st));
-        JHCHK(prefill_attn_launch(s, rel, nkeys_bound, rows, attn_mfma, st));
-        // maybeQuantize(valueBatch) + output projection + residual (:364-376, TransformerBlock.java:185)
-        JHCHK((rows_quant_launch<ROWS_QUANT>(s, s->pb_att, A, nullptr, 0, nullptr, 0.f, A, rows, st)));
-        JHCHK(prefill_gemm(s, W[JH_W_O], E, A, rows, s->pb_x1, E, s->pb_x, st));
-        // preFFNorm + maybeQuantize, gate / up, SiLU*up + maybeQuantize, down + residual (MLPBlock.java:117-158)
-        JHCHK((rows_quant_launch<ROWS_RMS>(s, s->pb_x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
-        if (gateup_fusable(s, li)) {   // one GEMM for gate|up: out[:, :H] = gate, out[:, H:] = up
-            const uint8_t* tw = nullptr;
-            const float* ts = nullptr;
-            JHCHK(gateup_operand(s, li, st, &tw, &ts));
-            JHCHK(prefill_gemm_operand(s, W[JH_W_GATE].dtype, tw, ts, 2 * H, E, rows, s->pb_g, 2 * H, nullptr, st));
-            JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, 2 * H, s->pb_g + H, 2 * H, nullptr, 0.f, H, rows, st)));
-        } else {
-            JHCHK(prefill_gemm(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, st));
-            JHCHK(prefill_gemm(s, W[JH_W_UP], H, E, rows, s->pb_u, H, nullptr, st));
-            JHCHK((rows_quant_launch<ROWS_SILU_MUL>(s, s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, st)));
-        }
-        JHCHK(prefill_gemm(s, W[JH_W_DOWN], E, H, rows, s->pb_x, E, s->pb_x1, st));
+        JHCHK(prefill_attn_half(s, li, rows, nkeys_bound, attn_mfma, s->pb_x1, s->pb_x, st));
+        JHCHK(prefill_ffn_half(s, li, rows, s->pb_x1, s->pb_x, s->pb_x1, st));
         JHCHK(trace_sync("prefill layer", st));
     }
     return JH_OK;
@@ -2089,40 +2106,58 @@ int prefill_attn_p16_launch(jh_session* s, int rel, int rows, int start_pos, hip
 #undef JH_P16_ATTNB
     return set_err(JH_ERR_UNSUPPORTED, "attention: head_size must be 64 or 128 and heads/kv_heads in {1,2,4,8}");
 }
-int prefill_layers_p16(jh_session* s, int rows, int start_pos, hipStream_t st) {
-    jh_model* m = s->m;
-    const jh_config& c = m->c;
-    const int E = c.embedding_length, H = c.hidden_length, hs = c.head_size;
-    const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
-    const bool t16 = prefill_t16_ok(s);
-    if (t16 && !s->pb_sel) {
+// the two halves of a layer in reference order: pair sums on the F16 MFMA (gemm_t16_kernel), same chains and bits as the GEMVs
+int prefill_p16_operands(jh_session* s) {
+    const jh_config& c = s->m->c;
+    if (!prefill_t16_ok(s))
+        return set_err(JH_ERR_UNSUPPORTED, "reference-order prompt chunk: the model's shapes do not fit the T16 GEMM (rows go one at a time)");
+    if (!s->pb_sel) {
+        const size_t E = c.embedding_length, H = c.hidden_length, A = (size_t)c.n_heads * c.head_size;
         size_t kmax = E > H ? E : H;
-        if ((size_t)A > kmax) kmax = A;
+        if (A > kmax) kmax = A;
         hipError_t e = hipMalloc((void**)&s->pb_sel, (size_t)PB_MAX_ROWS * (kmax / QB) * 256);
         if (e == hipSuccess) e = hipMalloc((void**)&s->pb_sad, (size_t)(kmax / QB) * PB_MAX_ROWS * 4);
         if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc prompt selector operands");
     }
+    if (!s->p16_scores_b) {
+        const hipError_t e = hipMalloc(&s->p16_scores_b, (size_t)PB_MAX_ROWS * c.n_heads * ((size_t)s->p16_sc_stride + 2) * 4);   // score lines + maxima + sums
+        if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc score rows of a prompt chunk");
+    }
+    return JH_OK;
+}
+int prefill_attn_half_p16(jh_session* s, int li, int rows, int start_pos, float* out, const float* resid, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int E = c.embedding_length, hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    JWeight& F = m->qkv[(size_t)li];
+    JHCHK(prefill_weights_set(s, li));
+    JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, s->pb_x, E, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
+    JHCHK((gemm_t16_launch<EPI_STORE>(s, F.t16, F.t16_scales, (A + 2 * KV) / 16, E, rows, s->pb_qkv, A + 2 * KV, nullptr, 0, st)));
+    JHCHK(prefill_attn_p16_launch(s, li - c.layer_start, rows, start_pos, st));
+    JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_att, A, nullptr, 0.f, A, rows, st)));
+    if (resid) return gemm_t16_launch<EPI_RESID>(s, W[JH_W_O].t16, W[JH_W_O].t16_scales, E / 16, A, rows, out, E, resid, E, st);
+    return gemm_t16_launch<EPI_STORE>(s, W[JH_W_O].t16, W[JH_W_O].t16_scales, E / 16, A, rows, out, E, nullptr, 0, st);
+}
+int prefill_ffn_half_p16(jh_session* s, int li, int rows, const float* x1, float* out, const float* resid, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int E = c.embedding_length, H = c.hidden_length;
+    JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    const JWeight& GU = m->gateup[(size_t)li];
+    JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, x1, E, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
+    JHCHK((gemm_t16_launch<EPI_SILU_MUL>(s, GU.t16, GU.t16_scales, H / 8, E, rows, s->pb_g, H, nullptr, 0, st)));
+    JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_g, H, nullptr, 0.f, H, rows, st)));
+    if (resid) return gemm_t16_launch<EPI_RESID>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rows, out, E, resid, E, st);
+    return gemm_t16_launch<EPI_STORE>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rows, out, E, nullptr, 0, st);
+}
+int prefill_layers_p16(jh_session* s, int rows, int start_pos, hipStream_t st) {
+    const jh_config& c = s->m->c;
+    JHCHK(prefill_p16_operands(s));
     for (int li = c.layer_start; li < c.layer_end; li++) {
-        const int rel = li - c.layer_start;
-        JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
-        JWeight& F = m->qkv[(size_t)li];
-        if (!F.data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data || !W[JH_W_NORM1].data || !W[JH_W_NORM2].data)
-            return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": weights not set");
-        if (t16) {   // pair sums on the F16 MFMA (gemm_t16_kernel): same chains, same bits
-            const JWeight& GU = m->gateup[(size_t)li];
-            JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, s->pb_x, E, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
-            JHCHK((gemm_t16_launch<EPI_STORE>(s, F.t16, F.t16_scales, (A + 2 * KV) / 16, E, rows, s->pb_qkv, A + 2 * KV, nullptr, 0, st)));
-            JHCHK(prefill_attn_p16_launch(s, rel, rows, start_pos, st));
-            JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_att, A, nullptr, 0.f, A, rows, st)));
-            JHCHK((gemm_t16_launch<EPI_RESID>(s, W[JH_W_O].t16, W[JH_W_O].t16_scales, E / 16, A, rows, s->pb_x1, E, s->pb_x, E, st)));
-            JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, s->pb_x1, E, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
-            JHCHK((gemm_t16_launch<EPI_SILU_MUL>(s, GU.t16, GU.t16_scales, H / 8, E, rows, s->pb_g, H, nullptr, 0, st)));
-            JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_g, H, nullptr, 0.f, H, rows, st)));
-            JHCHK((gemm_t16_launch<EPI_RESID>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rows, s->pb_x, E, s->pb_x1, E, st)));
-            JHCHK(trace_sync("prefill layer (reference order, MFMA)", st));
-            continue;
-        }
-        return set_err(JH_ERR_UNSUPPORTED, "reference-order prompt chunk: the model's shapes do not fit the T16 GEMM (rows go one at a time)");
+        JHCHK(prefill_attn_half_p16(s, li, rows, start_pos, s->pb_x1, s->pb_x, st));
+        JHCHK(prefill_ffn_half_p16(s, li, rows, s->pb_x1, s->pb_x, s->pb_x1, st));
+        JHCHK(trace_sync("prefill layer (reference order, MFMA)", st));
     }
     return JH_OK;
 }
@@ -2134,10 +2169,6 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     JHCHK(prefill_alloc(s));
     const bool p16 = s->strict != 0;                      // reference order: prefill_batch_ok() admitted the session via prefill_p16_ok()
     if (!p16) JHCHK(ensure_all_tiled(s, st));
-    if (p16 && !s->p16_scores_b) {
-        const hipError_t e = hipMalloc(&s->p16_scores_b, (size_t)PB_MAX_ROWS * c.n_heads * ((size_t)s->p16_sc_stride + 2) * 4);   // score lines + maxima + sums
-        if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc score rows of a prompt chunk");
-    }
     const int E = c.embedding_length;
     if (tokens) {
         const JWeight& emb = m->global_w[JH_W_EMBED];
@@ -2972,6 +3003,91 @@ int jh_tp_finish_layer(jh_session* s, const float* reduced_ffn_dev) {
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
+// ---- the same halves over a chunk of prompt rows (AbstractModel.batchForward on a head-split shard: the reducer then sums
+// [rows, E], CausalSelfAttention.java:378 / MLPBlock.java:160): one meeting per half-layer and chunk instead of one per row
+int jh_tp_rows_max(jh_session* s) {
+    if (!s) return 0;
+    return prefill_batch_ok(s) ? PB_MAX_ROWS : 0;
+}
+int jh_tp_set_rows(jh_session* s, const int32_t* tokens, const float* x_dev, int n, int start_pos) {
+    if (!s || (!tokens && !x_dev) || n <= 0 || n > PB_MAX_ROWS || start_pos < 0 || start_pos + n > s->max_ctx)
+        return set_err(JH_ERR_INVALID, "tp_set_rows: bad argument (at most 256 rows per chunk)");
+    if (!prefill_batch_ok(s)) return set_err(JH_ERR_UNSUPPORTED, "tp_set_rows: this shard's shapes have no batched path (jh_tp_rows_max == 0): feed rows with jh_tp_set_row");
+    if (!s->strict && !prefill_chunk_fits(s, start_pos, n))
+        return set_err(JH_ERR_UNSUPPORTED, "tp_set_rows: the score rows of this chunk do not fit the per-row attention kernel (feed these rows with jh_tp_set_row)");
+    JHCHK(check_positions(s, start_pos + n - 1));
+    jh_model* m = s->m;
+    const JWeight& emb = m->global_w[JH_W_EMBED];
+    if (tokens) {
+        if (!emb.data) return set_err(JH_ERR_INVALID, "tp_set_rows: this shard has no embedding table");
+        for (int i = 0; i < n; i++)
+            if (tokens[i] < 0 || tokens[i] >= m->c.vocab_size) return set_err(JH_ERR_INVALID, "tp_set_rows: token id out of range");
+    }
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = s->stream;
+    JHCHK(ensure_strict_operands(s, st));
+    JHCHK(prefill_alloc(s));
+    if (s->strict) JHCHK(prefill_p16_operands(s));
+    else JHCHK(ensure_all_tiled(s, st));
+    const int E = m->c.embedding_length;
+    if (tokens) {
+        HIPCHK(hipMemcpyAsync(s->pb_tok, tokens, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(256), 0, st, (const void*)emb.data, (const float*)emb.scales, emb.dtype,
+                           (const int*)s->pb_tok, E, s->pb_x);
+    } else {
+        HIPCHK(hipMemcpyAsync(s->pb_x, x_dev, (size_t)n * E * 4, hipMemcpyDeviceToDevice, st));
+    }
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, st, s->pb_start, start_pos);
+    HIPCHK(hipGetLastError());
+    s->tp_rows = n;
+    s->tp_pos0 = start_pos;
+    s->tp_last_token = tokens ? tokens[n - 1] : 0;
+    return JH_OK;
+}
+int jh_tp_attn_rows(jh_session* s, int layer, float* partial_out_dev) {
+    if (!s || !partial_out_dev || layer < s->m->c.layer_start || layer >= s->m->c.layer_end || s->tp_rows <= 0)
+        return set_err(JH_ERR_INVALID, "tp_attn_rows: bad argument (jh_tp_set_rows first)");
+    HIPCHK(hipSetDevice(s->m->device));
+    const int rows = s->tp_rows, pos0 = s->tp_pos0;
+    if (s->strict) return prefill_attn_half_p16(s, layer, rows, pos0, partial_out_dev, nullptr, s->stream);
+    int bound = 1024;
+    while (bound < pos0 + rows) bound *= 2;
+    const bool attn_mfma = prefill_attn_mfma(s, pos0, rows);
+    if (!attn_mfma && !prefill_chunk_fits(s, 0, bound)) bound = pos0 + rows;
+    return prefill_attn_half(s, layer, rows, bound, attn_mfma, partial_out_dev, nullptr, s->stream);
+}
+int jh_tp_ffn_rows(jh_session* s, int layer, const float* reduced_attn_dev, float* partial_out_dev) {
+    if (!s || !reduced_attn_dev || !partial_out_dev || layer < s->m->c.layer_start || layer >= s->m->c.layer_end || s->tp_rows <= 0)
+        return set_err(JH_ERR_INVALID, "tp_ffn_rows: bad argument (jh_tp_set_rows first)");
+    HIPCHK(hipSetDevice(s->m->device));
+    const int cnt = s->tp_rows * s->m->c.embedding_length;
+    // residual (TransformerBlock.java:185) after the reduction: x1 = x + sum_shards(o-proj partial), every row of the chunk
+    hipLaunchKernelGGL(add_rows_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s->stream, (const float*)s->pb_x, reduced_attn_dev, s->pb_x1, cnt);
+    HIPCHK(hipGetLastError());
+    if (s->strict) return prefill_ffn_half_p16(s, layer, s->tp_rows, s->pb_x1, partial_out_dev, nullptr, s->stream);
+    return prefill_ffn_half(s, layer, s->tp_rows, s->pb_x1, partial_out_dev, nullptr, s->stream);
+}
+int jh_tp_finish_layer_rows(jh_session* s, const float* reduced_ffn_dev) {
+    if (!s || !reduced_ffn_dev || s->tp_rows <= 0) return set_err(JH_ERR_INVALID, "tp_finish_layer_rows: bad argument");
+    HIPCHK(hipSetDevice(s->m->device));
+    const int cnt = s->tp_rows * s->m->c.embedding_length;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s->stream, (const float*)s->pb_x1, reduced_ffn_dev, s->pb_x, cnt);   // :203
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+// after the last layer: the chunk's last row becomes the session's current row (what sample() reads); rows_out_dev (optional) gets all rows
+int jh_tp_finish_rows(jh_session* s, float* rows_out_dev) {
+    if (!s || s->tp_rows <= 0) return set_err(JH_ERR_INVALID, "tp_finish_rows: no chunk in flight");
+    HIPCHK(hipSetDevice(s->m->device));
+    const int E = s->m->c.embedding_length, rows = s->tp_rows;
+    hipStream_t st = s->stream;
+    HIPCHK(hipMemcpyAsync(s->x, s->pb_x + (size_t)(rows - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, s->tp_pos0 + rows - 1, s->tp_last_token, 0);
+    if (rows_out_dev) HIPCHK(hipMemcpyAsync(rows_out_dev, s->pb_x, (size_t)rows * E * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipGetLastError());
+    s->tp_rows = 0;
+    return JH_OK;
+}
 int jh_session_get_row(jh_session* s, float* out, int to_device) {
     if (!s || !out) return set_err(JH_ERR_INVALID, "get_row: null");
     HIPCHK(hipSetDevice(s->m->device));
@@ -3220,6 +3336,9 @@ struct jh_tp_group {
     // queue of its own (the runtime multiplexes plain streams over a few queues; two shards on one queue cannot meet inside
     // kernels) and CUs no other shard's spinning kernel can occupy
     std::vector<hipStream_t> masked, unmasked;
+    // prompt chunks (jh_tp_group_forward): per shard [256 rows][E] partial / reduced rows, [2 rounds][N][256][E] slots + pointer tables
+    std::vector<float*> part_rows, red_rows, slots_rows;
+    std::vector<float**> peers_rows;
 };
 static void tp_mask_streams(jh_tp_group* g) {
     const size_t N = g->sh.size();
@@ -3286,6 +3405,14 @@ int jh_tp_group_destroy(jh_tp_group* g) {
         if (k < g->evA.size() && g->evA[k]) hipEventDestroy(g->evA[k]);
         if (k < g->evB.size() && g->evB[k]) hipEventDestroy(g->evB[k]);
         if (k < g->evTok.size() && g->evTok[k]) hipEventDestroy(g->evTok[k]);
+    }
+    for (size_t k = 0; k < g->part_rows.size(); k++) {
+        if (!g->sh[k]) continue;
+        hipSetDevice(g->sh[k]->m->device);
+        if (g->part_rows[k]) hipFree(g->part_rows[k]);
+        if (k < g->red_rows.size() && g->red_rows[k]) hipFree(g->red_rows[k]);
+        if (k < g->slots_rows.size() && g->slots_rows[k]) hipFree(g->slots_rows[k]);
+        if (k < g->peers_rows.size() && g->peers_rows[k]) hipFree(g->peers_rows[k]);
     }
     tp_unmask_streams(g);
     for (void* p : g->ipc_open) hipIpcCloseMemHandle(p);
@@ -3387,7 +3514,7 @@ int tp_group_layers(jh_tp_group* g, int pos) {
             jh_session* s = g->sh[j];
             HIPCHK(hipSetDevice(s->m->device));
             for (int k = 0; k < N; k++) if (k != j) HIPCHK(hipStreamWaitEvent(s->stream, g->evA[k], 0));
-            hipLaunchKernelGGL(tp_sum_kernel, eg, eb, 0, s->stream, (const float*)g->slots[j], N, E, g->red[j]);
+            hipLaunchKernelGGL(tp_sum_kernel, eg, eb, 0, s->stream, (const float*)g->slots[j], N, E, g->red[j], (size_t)E);
             hipLaunchKernelGGL(add_rows_kernel, eg, eb, 0, s->stream, (const float*)s->x, (const float*)g->red[j], s->x1, E);   // TransformerBlock.java:185
             HIPCHK(hipGetLastError());
             JHCHK(layer_ffn_launch(s, li, s->stream, false, g->part[j], nullptr));
@@ -3399,7 +3526,7 @@ int tp_group_layers(jh_tp_group* g, int pos) {
             jh_session* s = g->sh[j];
             HIPCHK(hipSetDevice(s->m->device));
             for (int k = 0; k < N; k++) if (k != j) HIPCHK(hipStreamWaitEvent(s->stream, g->evB[k], 0));
-            hipLaunchKernelGGL(tp_sum_kernel, eg, eb, 0, s->stream, (const float*)(g->slots[j] + (size_t)N * E), N, E, g->red[j]);
+            hipLaunchKernelGGL(tp_sum_kernel, eg, eb, 0, s->stream, (const float*)(g->slots[j] + (size_t)N * E), N, E, g->red[j], (size_t)E);
             hipLaunchKernelGGL(add_rows_kernel, eg, eb, 0, s->stream, (const float*)s->x1, (const float*)g->red[j], s->x, E);   // :203
             HIPCHK(hipGetLastError());
         }
@@ -3498,14 +3625,92 @@ int tp_build_graph(jh_tp_group* g, int k, int v) {
     return JH_OK;
 }
 }  // namespace
+namespace {
+int tp_group_rows_alloc(jh_tp_group* g) {
+    const size_t N = g->sh.size();
+    if (g->part_rows.size() == N) return JH_OK;
+    const size_t RE = (size_t)PB_MAX_ROWS * g->sh[0]->m->c.embedding_length;
+    g->part_rows.assign(N, nullptr); g->red_rows.assign(N, nullptr); g->slots_rows.assign(N, nullptr); g->peers_rows.assign(N, nullptr);
+    for (size_t k = 0; k < N; k++) {
+        HIPCHK(hipSetDevice(g->sh[k]->m->device));
+        if (hipMalloc(&g->part_rows[k], RE * 4) != hipSuccess || hipMalloc(&g->red_rows[k], RE * 4) != hipSuccess ||
+            tp_shared_malloc((void**)&g->slots_rows[k], 2 * N * RE * 4) != hipSuccess || hipMalloc(&g->peers_rows[k], 2 * N * sizeof(float*)) != hipSuccess) {
+            g->part_rows.clear();
+            return set_err(JH_ERR_OOM, "tp_group_forward: buffers for a chunk of prompt rows");
+        }
+    }
+    for (size_t k = 0; k < N; k++) {   // shard k's slot on shard j, round r:  slots_rows[j] + (r*N + k)*RE
+        std::vector<float*> h(2 * N);
+        for (size_t r = 0; r < 2; r++)
+            for (size_t j = 0; j < N; j++) h[r * N + j] = g->slots_rows[j] + (r * N + k) * RE;
+        HIPCHK(hipSetDevice(g->sh[k]->m->device));
+        HIPCHK(hipMemcpy(g->peers_rows[k], h.data(), h.size() * sizeof(float*), hipMemcpyHostToDevice));
+    }
+    return JH_OK;
+}
+// one chunk of prompt rows through all layers: the shards' partial [rows, E] results meet once per half-layer (event-ordered;
+// sums in shard order like the row loop)
+int tp_group_rows(jh_tp_group* g, const int32_t* tokens, int rows, int start_pos) {
+    const int N = (int)g->sh.size();
+    const int E = g->sh[0]->m->c.embedding_length, L = g->sh[0]->m->c.n_layers, cnt = rows * E;
+    const size_t RE = (size_t)PB_MAX_ROWS * E;
+    const dim3 eg((cnt + 255) / 256), eb(256);
+    JHCHK(tp_group_rows_alloc(g));
+    for (jh_session* s : g->sh) JHCHK(jh_tp_set_rows(s, tokens, nullptr, rows, start_pos));
+    for (int li = 0; li < L; li++) {
+        for (int k = 0; k < N; k++) {
+            jh_session* s = g->sh[k];
+            JHCHK(jh_tp_attn_rows(s, li, g->part_rows[k]));
+            hipLaunchKernelGGL(tp_scatter_kernel, eg, eb, 0, s->stream, (const float*)g->part_rows[k], (float* const*)g->peers_rows[k], N, cnt);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(g->evA[k], s->stream));
+        }
+        for (int j = 0; j < N; j++) {
+            jh_session* s = g->sh[j];
+            HIPCHK(hipSetDevice(s->m->device));
+            for (int k = 0; k < N; k++) if (k != j) HIPCHK(hipStreamWaitEvent(s->stream, g->evA[k], 0));
+            hipLaunchKernelGGL(tp_sum_kernel, eg, eb, 0, s->stream, (const float*)g->slots_rows[j], N, cnt, g->red_rows[j], RE);
+            HIPCHK(hipGetLastError());
+            JHCHK(jh_tp_ffn_rows(s, li, g->red_rows[j], g->part_rows[j]));
+            hipLaunchKernelGGL(tp_scatter_kernel, eg, eb, 0, s->stream, (const float*)g->part_rows[j], (float* const*)(g->peers_rows[j] + N), N, cnt);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(g->evB[j], s->stream));
+        }
+        for (int j = 0; j < N; j++) {
+            jh_session* s = g->sh[j];
+            HIPCHK(hipSetDevice(s->m->device));
+            for (int k = 0; k < N; k++) if (k != j) HIPCHK(hipStreamWaitEvent(s->stream, g->evB[k], 0));
+            hipLaunchKernelGGL(tp_sum_kernel, eg, eb, 0, s->stream, (const float*)(g->slots_rows[j] + (size_t)N * RE), N, cnt, g->red_rows[j], RE);
+            HIPCHK(hipGetLastError());
+            JHCHK(jh_tp_finish_layer_rows(s, g->red_rows[j]));
+        }
+    }
+    for (jh_session* s : g->sh) JHCHK(jh_tp_finish_rows(s, nullptr));
+    return JH_OK;
+}
+}  // namespace
 int jh_tp_group_forward(jh_tp_group* g, const int32_t* tokens, int n, int start_pos) {
     if (!g || !tokens || n <= 0 || start_pos < 0) return set_err(JH_ERR_INVALID, "tp_group_forward: bad argument");
     for (jh_session* s : g->sh) {
         if (start_pos + n > s->max_ctx) return set_err(JH_ERR_INVALID, "tp_group_forward: position beyond a shard's max_ctx");
         JHCHK(check_positions(s, start_pos + n - 1));
     }
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; i++)
         if (tokens[i] < 0 || tokens[i] >= g->sh[0]->m->c.vocab_size) return set_err(JH_ERR_INVALID, "tp_group_forward: token id out of range");
+    // chunks of >= prefill_batch_min rows go through the layers together (one meeting per half-layer and chunk, the reducer's
+    // [batch, E] of CausalSelfAttention.java:378 / MLPBlock.java:160) when every shard has the batched path; the rest row by row
+    int done = 0;
+    bool rows_ok = true;
+    for (jh_session* s : g->sh) rows_ok = rows_ok && prefill_batch_ok(s);
+    while (rows_ok && n - done >= g->sh[0]->prefill_batch_min) {
+        const int rows = n - done < PB_MAX_ROWS ? n - done : PB_MAX_ROWS;
+        bool fits = true;
+        for (jh_session* s : g->sh) fits = fits && (s->strict || prefill_chunk_fits(s, start_pos + done, rows));
+        if (!fits) break;
+        JHCHK(tp_group_rows(g, tokens + done, rows, start_pos + done));
+        done += rows;
+    }
+    for (int i = done; i < n; i++) {
         for (jh_session* s : g->sh) JHCHK(jh_tp_set_row(s, tokens[i], nullptr, start_pos + i));
         JHCHK(tp_group_layers(g, start_pos + i));
     }

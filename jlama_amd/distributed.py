@@ -313,6 +313,25 @@ class TPEngine:
     def sample(self):                               # rank 0: greedy token of the current row
         raise NotImplementedError
 
+    # the same halves over a chunk of prompt rows ([rows, E] buffers); rows_max() == 0: this engine feeds rows one at a time
+    def rows_max(self):
+        return 0
+
+    def set_rows(self, tokens, pos):
+        raise NotImplementedError
+
+    def attn_rows(self, layer, partial):
+        raise NotImplementedError
+
+    def ffn_rows(self, layer, reduced, partial):
+        raise NotImplementedError
+
+    def finish_layer_rows(self, reduced):
+        raise NotImplementedError
+
+    def finish_rows(self):                          # the chunk's last row becomes the current row
+        raise NotImplementedError
+
     def stream_context(self):                       # the stream the halves AND the all-reduces are ordered on
         import contextlib
         return contextlib.nullcontext()
@@ -351,6 +370,24 @@ class HipTPEngine(TPEngine):
     def sample(self):
         return self.s.sample(0.0, 0.5)   # synchronises the session stream (the row, incl. its last all-reduce, is complete)
 
+    def rows_max(self):
+        return self.s.tp_rows_max()
+
+    def set_rows(self, tokens, pos):
+        self.s.tp_set_rows(tokens, pos)
+
+    def attn_rows(self, layer, partial):
+        self.s.tp_attn_rows(layer, partial.data_ptr())
+
+    def ffn_rows(self, layer, reduced, partial):
+        self.s.tp_ffn_rows(layer, reduced.data_ptr(), partial.data_ptr())
+
+    def finish_layer_rows(self, reduced):
+        self.s.tp_finish_layer_rows(reduced.data_ptr())
+
+    def finish_rows(self):
+        self.s.tp_finish_rows()
+
 
 def tp_forward_row(dist, engine, token, pos, layers, buf):
     """One row through all layers on every shard: 2 all-reduces (sum) per layer.  buf: [E] float32 on the engine's device."""
@@ -364,6 +401,40 @@ def tp_forward_row(dist, engine, token, pos, layers, buf):
             engine.finish_layer(buf)
 
 
+TP_ROWS_MIN = 4   # shorter pieces of a prompt go row by row (as jh_forward does below prefill_batch_min)
+
+
+def tp_forward_prompt(dist, engine, prompt, start_pos, layers, cfg, device, dtype, buf):
+    """The prompt rows through all layers on every shard.  Engines with a batched path take chunks of up to rows_max() rows: the
+    partial [rows, E] results are all-reduced ONCE per half-layer and chunk (what the reference's reducer sees in batchForward,
+    CausalSelfAttention.java:378 / MLPBlock.java:160) instead of once per row; the rest goes row by row (tp_forward_row).  Every
+    rank must take the same path: the chunk size is the minimum over the ranks."""
+    import torch
+    n, E = len(prompt), cfg["embedding_length"]
+    cap = torch.tensor([int(engine.rows_max())], dtype=torch.int32, device=device)
+    dist.all_reduce(cap, op=dist.ReduceOp.MIN)
+    cap = int(cap.item())
+    done = 0
+    if cap >= TP_ROWS_MIN:
+        rows_buf = torch.empty((min(cap, n), E), dtype=dtype, device=device)
+        while n - done >= TP_ROWS_MIN:
+            rows = min(cap, n - done)
+            part = rows_buf[:rows]
+            with engine.stream_context():
+                engine.set_rows(np.asarray(prompt[done:done + rows], dtype=np.int32), start_pos + done)
+                for li in range(*layers):
+                    engine.attn_rows(li, part)
+                    dist.all_reduce(part, op=dist.ReduceOp.SUM)
+                    engine.ffn_rows(li, part, part)
+                    dist.all_reduce(part, op=dist.ReduceOp.SUM)
+                    engine.finish_layer_rows(part)
+                engine.finish_rows()
+            done += rows
+    for i in range(done, n):
+        tp_forward_row(dist, engine, int(prompt[i]), start_pos + i, layers, buf)
+    return {"rows_per_chunk": cap if cap >= TP_ROWS_MIN else 1, "rows_batched": done}
+
+
 def tp_generate(dist, engine, rank, prompt, n_gen, cfg, device, dtype):
     """Greedy generation with every rank holding a head-split shard: rows are fed one position at a time
     (batchForwardSlow order), rank 0 samples (Coordinator.java:184) and broadcasts the token id."""
@@ -372,10 +443,8 @@ def tp_generate(dist, engine, rank, prompt, n_gen, cfg, device, dtype):
     tok = torch.zeros(1, dtype=torch.int32, device=device)
     layers = (0, cfg["n_layers"])
     out = []
-    pos = 0
-    for t in prompt:
-        tp_forward_row(dist, engine, int(t), pos, layers, buf)
-        pos += 1
+    tp_forward_prompt(dist, engine, prompt, 0, layers, cfg, device, dtype, buf)
+    pos = len(prompt)
     for _ in range(n_gen):
         with engine.stream_context():
             if rank == 0:
@@ -397,8 +466,7 @@ def tp_generate_ipc(dist, engine, rank, size, prompt, n_gen, cfg, device, dtype)
     from .model import HipTPRank
     buf = torch.empty(cfg["embedding_length"], dtype=dtype, device=device)
     layers = (0, cfg["n_layers"])
-    for pos, t in enumerate(prompt):
-        tp_forward_row(dist, engine, int(t), pos, layers, buf)
+    tp_forward_prompt(dist, engine, prompt, 0, layers, cfg, device, dtype, buf)
     tok = torch.zeros(1, dtype=torch.int32, device=device)
     with engine.stream_context():
         if rank == 0:

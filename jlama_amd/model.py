@@ -134,6 +134,26 @@ class HipSession:
     def tp_finish_layer(self, reduced_ptr):
         N.check(N.lib().jh_tp_finish_layer(self.h, C.c_void_p(reduced_ptr)))
 
+    # the same halves over a chunk of prompt rows ([rows, E] partial / reduced buffers)
+    def tp_rows_max(self):
+        return int(N.lib().jh_tp_rows_max(self.h))
+
+    def tp_set_rows(self, tokens, pos):
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        N.check(N.lib().jh_tp_set_rows(self.h, N.ptr(tokens), None, int(tokens.size), int(pos)))
+
+    def tp_attn_rows(self, layer, partial_ptr):
+        N.check(N.lib().jh_tp_attn_rows(self.h, layer, C.c_void_p(partial_ptr)))
+
+    def tp_ffn_rows(self, layer, reduced_ptr, partial_ptr):
+        N.check(N.lib().jh_tp_ffn_rows(self.h, layer, C.c_void_p(reduced_ptr), C.c_void_p(partial_ptr)))
+
+    def tp_finish_layer_rows(self, reduced_ptr):
+        N.check(N.lib().jh_tp_finish_layer_rows(self.h, C.c_void_p(reduced_ptr)))
+
+    def tp_finish_rows(self, rows_out_ptr=None):
+        N.check(N.lib().jh_tp_finish_rows(self.h, C.c_void_p(rows_out_ptr) if rows_out_ptr else None))
+
     def current_row(self):
         out = np.empty(self.model.cfg["embedding_length"], dtype=np.float32)
         N.check(N.lib().jh_session_get_row(self.h, N.ptr(out), 0))

@@ -1181,12 +1181,55 @@ def test_tensor_parallel_group_fused_reduce_loopback(gpu, oracle, monkeypatch, s
                 s.tp_finish_layer(red2.data_ptr()); s.synchronize()
         return hand[0].current_row()
 
-    rows = [hand_row(t, i) for i, t in enumerate(prompt)]
+    def hand_rows(tokens, pos):
+        """the chunk form of hand_row: [rows, E] partials, summed in shard order, once per half-layer"""
+        n = len(tokens)
+        parts = [torch.empty((n, E), dtype=torch.float32, device=dev) for _ in range(size)]
+        for s in hand:
+            s.tp_set_rows(tokens, pos)
+        for li in range(L):
+            for s, p in zip(hand, parts):
+                s.tp_attn_rows(li, p.data_ptr()); s.synchronize()
+            red = parts[0].clone()
+            for p in parts[1:]:
+                red = red + p
+            torch.cuda.synchronize()
+            for s, p in zip(hand, parts):
+                s.tp_ffn_rows(li, red.data_ptr(), p.data_ptr()); s.synchronize()
+            red2 = parts[0].clone()
+            for p in parts[1:]:
+                red2 = red2 + p
+            torch.cuda.synchronize()
+            for s in hand:
+                s.tp_finish_layer_rows(red2.data_ptr()); s.synchronize()
+        for s in hand:
+            s.tp_finish_rows(); s.synchronize()
+        return hand[0].current_row()
+
+    # the prompt: one chunk of rows where the shards' shapes have the batched path (one meeting per half-layer for all 13 rows),
+    # row by row otherwise -- the group and the hand loop take the same path and must agree bit for bit
+    batched = all(s.tp_rows_max() >= prompt.size for s in hand)
+    if batched:
+        last_row = hand_rows(prompt, 0)
+        if strict:                       # reference order: the chunk form IS the row form, bit for bit (KV pages included, see decode below)
+            chk = [m.session(64) for m in models]
+            hand, keep = chk, hand
+            for hs in hand:
+                hs.set_strict(True)
+            by_row = [hand_row(t, i) for i, t in enumerate(prompt)][-1]
+            np.testing.assert_array_equal(last_row, by_row)
+            hand = keep
+    else:
+        last_row = [hand_row(t, i) for i, t in enumerate(prompt)][-1]
+    # SMALL in halves has the batched path in both modes; in quarters its projections are too narrow for the reference-order GEMM
+    assert batched == (size == 2 or not strict)
     grp.forward(prompt, 0)
     for s in grp.sessions:
-        np.testing.assert_array_equal(s.current_row(), rows[-1])          # every shard: the same residual stream, same bits
+        np.testing.assert_array_equal(s.current_row(), last_row)          # every shard: the same residual stream, same bits
     want_tp = oracle.forward_tp(osess, prompt, 0)
-    assert _rel(rows[-1], want_tp[-1]) <= TRUNK_TOL
+    assert _rel(last_row, want_tp[-1]) <= TRUNK_TOL
+    if strict:
+        np.testing.assert_array_equal(last_row, want_tp[-1])              # reference order: the lock-step oracle's bits (jo_forward_tp)
     first = grp.sample()
     assert first == hand[0].sample()
     # Shards that meet in kernels need a hardware queue each and CUs the other shards' waiting kernels cannot occupy: on ONE device

@@ -101,10 +101,32 @@ def _tp_worker(rank, world, port, cfg, prompt, n_gen, q):
         def sample(self):
             return self.full.sample(self.x[0])[0]
 
+        # prompt chunks: [rows, E] partials, one all-reduce per half-layer and chunk (distributed.tp_forward_prompt)
+        def rows_max(self):
+            return 4 if rank == 0 else 5          # (the host takes the minimum over the ranks: chunks of 4 rows, then single rows)
+
+        def set_rows(self, tokens, pos):
+            self.x, self.pos = self.m.embed_rows(list(tokens)), pos
+            self.chunks = getattr(self, "chunks", 0) + 1
+
+        def attn_rows(self, layer, partial):
+            partial.copy_(torch.from_numpy(self.s.tp_attn(layer, self.x, self.pos)))
+
+        def ffn_rows(self, layer, reduced, partial):
+            self.x1 = self.x + reduced.numpy()
+            partial.copy_(torch.from_numpy(self.s.tp_ffn(layer, self.x1)))
+
+        def finish_layer_rows(self, reduced):
+            self.x = self.x1 + reduced.numpy()
+
+        def finish_rows(self):
+            self.x = self.x[-1:]
+
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    toks = D.tp_generate(dist, OracleTPEngine(), rank, prompt, n_gen, cfg, "cpu", torch.float32)
+    eng = OracleTPEngine()
+    toks = D.tp_generate(dist, eng, rank, prompt, n_gen, cfg, "cpu", torch.float32)
     if rank == 0:
-        q.put(toks.tolist())
+        q.put((toks.tolist(), getattr(eng, "chunks", 0)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -120,10 +142,11 @@ def test_two_process_tp_equals_lockstep_oracle(oracle):
     ps = [ctx.Process(target=_tp_worker, args=(r, 2, port, cfg, prompt, n_gen, q)) for r in range(2)]
     for p in ps:
         p.start()
-    got = q.get(timeout=240)
+    got, chunks = q.get(timeout=240)
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert chunks == 1          # 7 prompt rows = one chunk of 4 (the ranks' minimum) + 3 single rows: both host paths ran
     # lock-step reference: both shards in this process, partials summed r=0 then r=1
     w = S.make_weights(cfg, seed=12)
     full = oracle.OracleModel(cfg, w)
@@ -153,7 +176,7 @@ def test_four_process_tp_matches_lockstep_oracle_within_noise(oracle):
     ps = [ctx.Process(target=_tp_worker, args=(r, 4, port, cfg, prompt, n_gen, q)) for r in range(4)]
     for p_ in ps:
         p_.start()
-    got = q.get(timeout=300)
+    got, _ = q.get(timeout=300)
     for p_ in ps:
         p_.join(timeout=60)
         assert p_.exitcode == 0
