@@ -25,8 +25,8 @@ def rows(path):
     return out
 
 
-def is_gateup(name):   # gemv_i8q4_kernel<PRO_RMS_Q8=1, EPI_SILU_MUL=2, ...> or the persistent layer kernel
-    return re.match(r"gemv_i8q4_kernel<1, 2,", name) is not None
+def is_gateup(name):   # gemv_t16_kernel<PRO_RMS_Q8=1, EPI_SILU_MUL=2, ...> (both decode loops since round 4), gemv_i8q4_kernel<1, 2, ...> where T16 does not fit
+    return re.match(r"gemv_t16_kernel<1, 2,", name) is not None or re.match(r"gemv_i8q4_kernel<1, 2,", name) is not None
 
 
 trace = [r for r in rows(prefix + "_kernel_trace_stats.md") if is_gateup(r[0])]

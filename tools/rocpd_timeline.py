@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Timeline of consecutive decode tokens out of a rocprofv3 (rocpd sqlite) kernel trace: where the time of one token goes --
 inside kernels (begin..end of each dispatch) or between them (end of one dispatch .. begin of the next on the same stream).
-A token = the dispatches between two finish_token_kernel dispatches; only tokens of the graph-replayed fast decode loop
-(as many gate+up GEMVs as the model has layers, no strict-order kernels) are used.
-Usage: tools/rocpd_timeline.py <results.db> [n_tokens=4]"""
+A token = the dispatches between two finish_token_kernel dispatches; only tokens of a graph-replayed decode loop are used
+(as many gate+up GEMVs as the model has layers: 6 dispatches per layer in reference order, 5 in the order-free loop).
+Usage: tools/rocpd_timeline.py <results.db> [n_tokens=4] [reference-order|order-free]"""
 import re
 import sqlite3
 import sys
@@ -22,18 +22,22 @@ def short(name):
 
 
 rows = [(short(n), s, e) for n, s, e in rows]
-# token boundaries
+# token boundaries.  Two replayed loops can be in a trace: the reference-order one (jh_p16.h / jh_t16.h kernels: 6 dispatches per layer --
+# q|k|v, scores, softmax + values, o, gate|up, down) and the order-free one (5 per layer); `want` picks which (argv[3], default: the
+# reference-order loop if the trace has one)
 cuts = [i for i, r in enumerate(rows) if r[0].startswith("finish_token_kernel")]
-tokens = []
+by_kind = {"reference-order": [], "order-free": []}
 for a, b in zip(cuts, cuts[1:]):
     seg = rows[a + 1:b + 1]          # dispatches after the previous finish, up to and including this token's finish
     names = [r[0] for r in seg]
-    if any("p16" in n or "strict" in n for n in names):
+    gu = sum(1 for n in names if re.match(r"gemv_t16_kernel<1, 2,", n) or re.match(r"gemv_i8q4_kernel<1, 2,", n))
+    strict = any("p16" in n for n in names)
+    if gu == 0 or len(seg) != (6 if strict else 5) * gu + 2:   # + LM head + finish: the replayed decode graph only
         continue
-    gu = sum(1 for n in names if re.match(r"gemv_i8q4_kernel<1, 2,", n))
-    if gu == 0 or len(seg) != 5 * gu + 2:   # 5 dispatches per layer + LM head + finish: the replayed decode graph only
-        continue
-    tokens.append((a, seg))
+    by_kind["reference-order" if strict else "order-free"].append((a, seg))
+want = sys.argv[3] if len(sys.argv) > 3 else ("reference-order" if by_kind["reference-order"] else "order-free")
+tokens = by_kind[want]
+print(f"{want} decode loop ({len(by_kind['reference-order'])} reference-order and {len(by_kind['order-free'])} order-free replayed tokens in the trace)\n")
 # the longest run of consecutive tokens, taken from its middle
 runs, cur_run = [], []
 for t in tokens:
