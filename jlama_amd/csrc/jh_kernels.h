@@ -1122,6 +1122,16 @@ __global__ void splitk_reduce_kernel(const float* ws, int nsplit, int m, int n, 
     const size_t idx = (size_t)ldc * row + (n0 + col) - roffset;
     c[idx] = resid ? v + resid[idx] : v;
 }
+// the same sums, four columns per thread (n, ldc, n0 - roffset multiples of 4; 16-byte aligned buffers): grid (n/4 / 256, m)
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const f32x4* ws, int nsplit, int m, int n4, f32x4* c, int ldc4, int coff4, const f32x4* resid) {
+    const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (col >= n4) return;
+    const size_t i = (size_t)row * n4 + col, stride = (size_t)m * n4;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < nsplit; s++) v = v + ws[s * stride + i];
+    const size_t idx = (size_t)ldc4 * row + coff4 + col;
+    c[idx] = resid ? v + resid[idx] : v;
+}
 
 // ---- K3t: BF16 GEMM on MFMA-ordered operands (the prefill path of a BF16 model).
 // Both operands are tiled so that one wave-load is one MFMA operand, 1 KB contiguous:

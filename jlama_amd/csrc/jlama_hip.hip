@@ -298,6 +298,21 @@ int launch_gemm_q8q4_tile(const MfmaQ4Params& g, int mtiles, hipStream_t st) {
 
 // gemm_q8q4_lds_kernel: one row tile x CW*CT column tiles per workgroup, A staged through LDS; K split over grid.y when the
 // output alone does not fill the chip (partials in ws, summed in ascending K order by splitk_reduce_kernel)
+// second pass of a split-K GEMM (partials summed in ascending K order): four columns per thread where the shapes allow (the
+// one-float-per-thread form spent 19 us on the 2 x 14.8 MB of the BF16 gate|up GEMM at 129 rows: 64-bit divisions per element)
+int launch_splitk_reduce(const float* ws, int S, int m, int n, int n0, float* c, int ldc, int roffset, const float* resid, hipStream_t st) {
+    const int coff = n0 - roffset;
+    if (n % 4 == 0 && ldc % 4 == 0 && coff % 4 == 0 && ((uintptr_t)ws | (uintptr_t)c | (uintptr_t)resid) % 16 == 0) {
+        hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)((n / 4 + 255) / 256), (unsigned)m), dim3(256), 0, st, (const f32x4*)ws, S, m, n / 4,
+                           (f32x4*)c, ldc / 4, coff / 4, (const f32x4*)resid);
+    } else {
+        const size_t tot = (size_t)m * n;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ws, S, m, n, n0, c, ldc, roffset, resid);
+    }
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+
 template <int CW, int CT, int S, bool PK = false>
 int launch_gemm_q8q4_lds(const MfmaQ4Params& g, int mtiles, float* ws, size_t ws_bytes, hipStream_t st) {
     const int nblk = g.k / QB;
@@ -314,12 +329,7 @@ int launch_gemm_q8q4_lds(const MfmaQ4Params& g, int mtiles, float* ws, size_t ws
     JHCHK(allow_lds((gemm_q8q4_lds_kernel<CW, CT, S, PK>), lds));
     hipLaunchKernelGGL((gemm_q8q4_lds_kernel<CW, CT, S, PK>), dim3(8 * mtiles * gg, Z), dim3(CW * S * 64), lds, st, g, mtiles, nbz, Z > 1 ? ws : nullptr);
     HIPCHK(hipGetLastError());
-    if (Z > 1) {
-        const size_t tot = (size_t)g.m * g.n;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)ws, Z, g.m, g.n, g.n0, g.c, g.ldc,
-                           g.roffset, g.resid);
-        HIPCHK(hipGetLastError());
-    }
+    if (Z > 1) JHCHK(launch_splitk_reduce((const float*)ws, Z, g.m, g.n, g.n0, g.c, g.ldc, g.roffset, g.resid, st));
     return JH_OK;
 }
 
@@ -399,12 +409,7 @@ int launch_gemm_bf16_mfma_mt(const MfmaGemmParams& g0, hipStream_t st) {
     else if (waves == 2) { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 2>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 2>), dim3(grid, S), dim3(128), lds, st, g); }
     else { JHCHK(allow_lds(gemm_bf16_mfma_kernel<MT, 1>, lds)); hipLaunchKernelGGL((gemm_bf16_mfma_kernel<MT, 1>), dim3(grid, S), dim3(64), lds, st, g); }
     HIPCHK(hipGetLastError());
-    if (S > 1) {
-        const size_t tot = (size_t)g.m * g.n;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)g.ws, S, g.m, g.n, g.n0, g.c, g.ldc,
-                           g.roffset, g.resid);
-        HIPCHK(hipGetLastError());
-    }
+    if (S > 1) JHCHK(launch_splitk_reduce((const float*)g.ws, S, g.m, g.n, g.n0, g.c, g.ldc, g.roffset, g.resid, st));
     return JH_OK;
 }
 constexpr size_t BF16_SPLITK_WS_BYTES = (size_t)8 * 256 * 16384 * 4;   // S x 256 rows x N floats with S*N <= 8*16384 (enforced by the launcher)
@@ -434,12 +439,7 @@ int launch_gemm_bf16_tile_mc(MfmaBf16TileParams g, int S, hipStream_t st) {
         hipLaunchKernelGGL((gemm_bf16_tile_kernel<MT, CWB>), dim3(grid, S), dim3(CWB * 64), 0, st, g);
     }
     HIPCHK(hipGetLastError());
-    if (S > 1) {
-        const size_t tot = (size_t)g.m * g.n;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)g.ws, S, g.m, g.n, 0, g.c, g.ldc, 0,
-                           g.resid);
-        HIPCHK(hipGetLastError());
-    }
+    if (S > 1) JHCHK(launch_splitk_reduce((const float*)g.ws, S, g.m, g.n, 0, g.c, g.ldc, 0, g.resid, st));
     return JH_OK;
 }
 // both operands in MFMA order (gemm_bf16_tile_kernel); n % 32 == 0, k % 16 == 0
