@@ -2,6 +2,7 @@
 import ctypes as C
 import hashlib
 import os
+import sys
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -230,10 +231,13 @@ def options_from_env(prefix="JH_"):
     for k, v in os.environ.items():
         if k.startswith(prefix):
             try:
-                set_option(k, int(v))
+                val = int(v)
             except ValueError:
-                if k == "JH_TILED_COPY":
-                    set_option(k, {"resident": 1, "transient": 2}.get(v, 0))
+                if k != "JH_TILED_COPY":
+                    continue
+                val = {"resident": 1, "transient": 2}.get(v, 0)
+            if lib().jh_set_option(k.encode(), val) != 0:
+                print(f"[jlama_amd] {k}: the library has no such option (ignored)", file=sys.stderr)
 
 
 def init(device=0):

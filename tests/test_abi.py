@@ -118,3 +118,26 @@ def test_ctypes_prototypes_have_the_headers_arity():
     assert set(arity) == set(N.EXPORTS)
     bad = {name: (len(proto[1]), arity[name]) for name, proto in N._PROTOS.items() if len(proto[1]) != arity[name]}
     assert not bad, bad
+
+
+def test_process_options_are_explicit_and_named():
+    """jh_set_option / jh_clear_options work without a GPU; a name the library never asks for is an error (a misspelt switch must
+    not be a silent no-op), the table of known names equals the names at the opt_int() call sites, and nothing but the
+    environment snapshot of jh_init calls getenv."""
+    from jlama_amd import _native as N
+    N.clear_options()
+    N.set_option("JH_ATTN_SPLITS", 3)
+    N.set_option("JH_TILED_COPY", "transient")
+    with pytest.raises(Exception) as e:
+        N.set_option("JH_ATTN_SPLITZ", 3)
+    assert "no option named" in str(e.value)
+    N.clear_options()
+    src = open(os.path.join(ROOT, "jlama_amd", "csrc", "jlama_hip.hip")).read()
+    asked = set(re.findall(r'opt_int\("([A-Z0-9_]+)"', src))
+    table = src[src.index("JH_KNOWN_OPTIONS[] = {"):]
+    table = set(re.findall(r'"(JH_[A-Z0-9_]+)"', table[:table.index("};")]))
+    assert asked == table, (sorted(asked - table), sorted(table - asked))
+    listed = set(re.findall(r'"(JH_[A-Z0-9_]+)"', src[src.index("JH_ENV_OPTIONS[] = {"):].split("};")[0]))
+    assert listed <= table and len(listed) <= 6
+    code = "\n".join(open(os.path.join(ROOT, "jlama_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "jlama_amd", "csrc")))
+    assert len(re.findall(r"\bgetenv\s*\(", code)) == 1
