@@ -32,7 +32,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6290.0  # what a float4 copy reaches on this part (MI355X_MICROARCH.md: 79 % of peak): roofline.frac_of_achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense BF16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline includes 2:1 sparsity)
 MFMA_I8_PEAK_TOPS = 5000.0       # dense I8 MFMA ~ 2x the BF16 rate (MI355X_MICROARCH.md: >= 3944 TOPS measured)
-DOMINANT_KERNEL = "gemv_i8q4_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV, fused RMSNorm+Q8 prologue, SiLU*up epilogue)"
+DOMINANT_KERNEL = ("gate+up GEMV of the order-free loop, fused RMSNorm+Q8 prologue, SiLU*up epilogue: gemv_t16_kernel<PRO_RMS_Q8,EPI_SILU_MUL> since round 4 "
+                   "(the reference-order kernel is the faster one; jh_t16.h), gemv_i8q4_kernel<PRO_RMS_Q8,EPI_SILU_MUL> where its T16 copy is not resident")
 DOMINANT_KERNEL_REF_ORDER = ("gemv_t16_kernel<PRO_RMS_Q8,EPI_SILU_MUL> (gate+up GEMV in the reference's summation order: block pair sums on "
                              "v_mfma_i32_16x16x32_i8 with a one-hot activation operand, cvt + fma chains on the VALU; jh_t16.h)")
 
