@@ -191,3 +191,58 @@ def test_four_process_tp_matches_lockstep_oracle_within_noise(oracle):
         assert g == t or top2[1] - top2[0] <= 4e-2, (g, t)
         x = oracle.forward_tp(sess, [g], pos)
         pos += 1
+
+
+def test_prompt_host_picks_chunks_or_rows_consistently():
+    """distributed.tp_forward_prompt: the chunk size is the minimum of rows_max() over the ranks; pieces shorter than TP_ROWS_MIN and
+    engines without a batched path go row by row; every position is fed exactly once, in order."""
+    import torch
+
+    class FakeDist:
+        class ReduceOp:
+            MIN, SUM = "min", "sum"
+
+        def __init__(self, other_cap):
+            self.other_cap = other_cap
+
+        def all_reduce(self, t, op=None):
+            if op == "min":
+                t.clamp_(max=self.other_cap)
+
+    class Rec(D.TPEngine):
+        def __init__(self, cap):
+            self.cap, self.log = cap, []
+
+        def rows_max(self):
+            return self.cap
+
+        def set_row(self, token, pos):
+            self.log.append(("row", pos, 1))
+
+        def attn(self, layer, partial): pass
+        def ffn(self, layer, reduced, partial): pass
+        def finish_layer(self, reduced): pass
+
+        def set_rows(self, tokens, pos):
+            self.log.append(("rows", pos, len(tokens)))
+
+        def attn_rows(self, layer, partial):
+            assert partial.shape[0] == self.log[-1][2]
+
+        def ffn_rows(self, layer, reduced, partial): pass
+        def finish_layer_rows(self, reduced): pass
+        def finish_rows(self): pass
+
+    cfg = dict(S.TINY)
+    buf = torch.empty(cfg["embedding_length"])
+    for mine, other, n, want in [
+        (256, 256, 129, [("rows", 0, 129)]),
+        (256, 6, 15, [("rows", 0, 6), ("rows", 6, 6), ("row", 12, 1), ("row", 13, 1), ("row", 14, 1)]),   # 3 left: below TP_ROWS_MIN
+        (0, 256, 5, [("row", i, 1) for i in range(5)]),                                                 # one rank has no batched path
+        (256, 256, 3, [("row", i, 1) for i in range(3)]),
+        (8, 8, 20, [("rows", 0, 8), ("rows", 8, 8), ("rows", 16, 4)]),
+    ]:
+        eng = Rec(mine)
+        info = D.tp_forward_prompt(FakeDist(other), eng, list(range(n)), 0, (0, 2), cfg, "cpu", torch.float32, buf)
+        assert eng.log == want, (mine, other, n, eng.log)
+        assert sum(c for _, _, c in eng.log) == n and info["rows_batched"] == sum(c for k, _, c in eng.log if k == "rows")
