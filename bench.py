@@ -174,9 +174,7 @@ def full_size_parity(cfg, model, host_w, n_prompt=8, n_free=256, n_tf=TF_STEPS):
     last_logits_o = lg
     out["oracle_panama_order_s"] = round(time.perf_counter() - t0, 1)
     ids_o = np.array(ids_o, dtype=np.int32)
-    if cfg["weight_dtype"] != O.DT_Q4:
-        return _full_size_parity_dense(cfg, model, prompt, out, ids_o, logits_o, n_free, n_tf), ids_o
-    # ---- B: GPU strict order, free-running
+    # ---- B: GPU in reference order (JQ4: jh_t16.h / jh_p16.h; BF16: jh_bf16r.h), free-running
     ss = model.session(prompt.size + n_free + 8)
     ss.set_strict(True)
     ss.batch_forward(prompt, 0)
@@ -195,6 +193,8 @@ def full_size_parity(cfg, model, host_w, n_prompt=8, n_free=256, n_tf=TF_STEPS):
     out["strict_order"] = {"ids_equal": int((ids_s == ids_o).cumprod().sum()), "n_ids": int(ids_o.size),
                            "logits_vs_panama_oracle": _dist(logits_s, logits_o[:len(logits_s)]),
                            "last_step_logits_max_abs_diff": float(np.abs(last_logits_s - last_logits_o).max())}
+    if cfg["weight_dtype"] != O.DT_Q4:
+        return _full_size_parity_dense(cfg, model, prompt, out, ids_o, logits_o, n_free, n_tf), ids_o
     # ---- C: teacher-forced on A's ids: GPU fast kernels, and the oracle on the reference's compiled C GEMM
     fs = model.session(prompt.size + n_tf + 8)
     fs.batch_forward(prompt, 0)
@@ -331,7 +331,7 @@ def run_single(args, cfg):
     # ---- the same K steps in REFERENCE ORDER (jh_p16.h: every float accumulation in the Panama provider's order; ids and logits
     # bit-identical to the oracle, see parity_full_size): timed exactly like `value`, in this same process
     strict = None
-    if cfg["weight_dtype"] == N.DT_Q4 and not args.no_strict:
+    if not args.no_strict:
         ss = model.session(max_ctx)
         ss.set_strict(True)                    # the whole leg in reference order: prompt (M-row p16 GEMMs), sampling, decode
         ss.batch_forward(prompt, 0)
@@ -352,13 +352,13 @@ def run_single(args, cfg):
         assert stoks.size == args.steps
         sev_ms, skernels = ss.decode_stats()
         sprobe = {}
-        for i, nm in ((0, "qkv"), (1, "attention"), (2, "o_proj"), (3, "gate_up"), (4, "down"), (9, "lm_head")):
+        for i, nm in ((0, "qkv"), (1, "attention"), (2, "o_proj"), (3, "gate_up"), (4, "down"), (9, "lm_head")) if is_q4 else ():
             ms, b = ss.kernel_bench(i, args.probe_iters)
             sprobe[nm] = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
         ss.close()
         strict = {"tokens_per_s": round(args.steps / sdt, 2), "ms_per_step": round(sdt / args.steps * 1e3, 4), "prefill_ms": round(sprompt_ms, 2),
                   "event_ms_per_token": round(sev_ms, 4), "kernels_per_token": skernels, "kernels": sprobe,
-                  "note": "reference-order kernels (jh_t16.h, jh_p16.h): bit-identical ids and logits vs the Panama-order oracle "
+                  "note": "reference-order kernels (" + ("jh_t16.h, jh_p16.h" if is_q4 else "jh_bf16r.h, jh_p16.h") + "): bit-identical ids and logits vs the Panama-order oracle "
                           "(parity_full_size.strict_order), same K steps, same bracket as `value`"}
     wbytes = S.weight_bytes(cfg)
     kvb = S.kv_bytes_per_position(cfg)
@@ -407,12 +407,18 @@ def run_single(args, cfg):
         # the dominant kernel of that path (gemv_i8q4_p16_kernel, gate|up) against the same roofline, counter traffic hash-gated as above
         ro = (prof or {}).get("reference_order") or {}
         fresh = bool(prof and prof.get("matches_this_build"))
-        gu = strict["kernels"]["gate_up"]
-        strict["roofline"] = {"bound": "hbm", "kernel": DOMINANT_KERNEL_REF_ORDER,
-                              "achieved": gu["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gu["GBps"] / HBM_PEAK_GBS, 4),
-                              "frac_of_achievable": round(gu["GBps"] / HBM_ACHIEVABLE_GBS, 4),
-                              "traffic": ro.get("traffic_bytes_per_launch") if fresh else None, "bytes_per_launch": gu["bytes"], "us_per_launch": gu["us"],
-                              "us_per_launch_rocprof": ro.get("us_per_launch_rocprof") if fresh else None}
+        if is_q4:
+            gu = strict["kernels"]["gate_up"]
+            strict["roofline"] = {"bound": "hbm", "kernel": DOMINANT_KERNEL_REF_ORDER,
+                                  "achieved": gu["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gu["GBps"] / HBM_PEAK_GBS, 4),
+                                  "frac_of_achievable": round(gu["GBps"] / HBM_ACHIEVABLE_GBS, 4),
+                                  "traffic": ro.get("traffic_bytes_per_launch") if fresh else None, "bytes_per_launch": gu["bytes"], "us_per_launch": gu["us"],
+                                  "us_per_launch_rocprof": ro.get("us_per_launch_rocprof") if fresh else None}
+        else:   # BF16: no per-kernel probe -- the whole reference-order decode step against the token's bytes
+            sg = bytes_per_token * strict["tokens_per_s"] / 1e9
+            strict["roofline"] = {"bound": "hbm", "kernel": "whole decode step, reference order (gemv_bf16r_kernel x 4 + attention per layer)",
+                                  "achieved": round(sg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sg / HBM_PEAK_GBS, 4),
+                                  "frac_of_achievable": round(sg / HBM_ACHIEVABLE_GBS, 4), "traffic": None}
         out["strict_tokens_per_s"] = strict["tokens_per_s"]
         out["strict_order"] = strict
         if not args.fast_order:   # the path with bit-exact ids is the headline of this line
@@ -432,8 +438,10 @@ def run_single(args, cfg):
             so_tflops = prefill_flops / (strict["prefill_ms"] * 1e-3) / 1e12
             pm.update({"achieved_TFLOPs": round(so_tflops, 1), "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "frac": round(so_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
                        "hbm_bound_frac": round(min(1.0, 2.0 * prompt.size * HBM_PEAK_GBS * 1e9 / (bytes_per_weight * MFMA_BF16_PEAK_TFLOPS * 1e12)), 3),
-                       "note": "reference-order prompt: projection GEMMs (2*rows*weights flops) over the whole prefill time against the dense F16 MFMA "
-                               "peak; every (row, weight row, block) still pays 16 ordered fmas on the VALU (jh_t16.h), which bounds it far below"})
+                       "note": ("reference-order prompt: projection GEMMs (2*rows*weights flops) over the whole prefill time against the dense F16 MFMA "
+                                "peak; every (row, weight row, block) still pays 16 ordered fmas on the VALU (jh_t16.h), which bounds it far below") if is_q4 else
+                               ("reference-order prompt of a BF16 model: GemmerBF16's chains are one VALU fma per (prompt row, weight) -- no matrix-core "
+                                "formulation keeps the rounding order (jh_bf16r.h); the MFMA figure of this config is prefill_mfma_fast_kernels")})
             out["config"]["workload"] += " -- REFERENCE ORDER (every float accumulation in the Panama provider's order; ids and logits bit-identical)"
             tr = out["token_roofline"]
             tr["achieved_GBps"] = round(tr["bytes_per_token"] * out["value"] / 1e9, 1)
@@ -449,14 +457,15 @@ def run_single(args, cfg):
     if not args.no_parity and not is_q4:
         host_w = host_w or ST.to_host(w)
         # the BF16 oracle streams 14 GB per row on the host cores: a bounded sample (8-row prompt, 16 teacher-forced + 16 free steps)
-        par, _ = full_size_parity(cfg, model, host_w, 8, min(args.parity_steps, 16), 16)
+        par, _ = full_size_parity(cfg, model, host_w, 8, args.parity_steps, 16)
         out["parity_full_size"] = par
     if not args.no_parity and is_q4:
         host_w = host_w or ST.to_host(w)
-        par, ids_o = full_size_parity(cfg, model, host_w, 8, args.parity_steps, TF_STEPS)
+        # on the metric's own prompt: the same prompt.size rows the timed run prefills (batched reference-order prefill)
+        par, ids_o = full_size_parity(cfg, model, host_w, int(prompt.size), args.parity_steps, TF_STEPS)
         # free-running ids of the FAST kernels vs the oracle's (diverge at the first near-tie, as any two float summation
         # orders do on random weights; the strict-order run above does not)
-        pp = S.prompt_tokens(cfg, n=7, seed=1234)
+        pp = S.prompt_tokens(cfg, n=int(prompt.size) - 1, seed=1234)
         ps = model.session(pp.size + args.parity_steps + 8)
         ps.batch_forward(pp, 0)
         gfirst = ps.sample()

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libjlamahip.so")
 SRC = os.path.join(HERE, "csrc", "jlama_hip.hip")
 HDRS = [os.path.join(HERE, "csrc", "jh_kernels.h"), os.path.join(HERE, "csrc", "jh_p16.h"),
         os.path.join(HERE, "csrc", "jh_t16.h"), os.path.join(HERE, "csrc", "jh_seqsum.h"),
+        os.path.join(HERE, "csrc", "jh_bf16r.h"),
         os.path.join(ROOT, "include", "jlama_hip.h")]
 
 JH_OK, JH_ERR_NO_DEVICE, JH_ERR_OOM, JH_ERR_UNSUPPORTED, JH_ERR_INVALID, JH_ERR_HIP = 0, -1, -2, -3, -4, -5

@@ -1,0 +1,440 @@
+// jh_bf16r.h -- dense BF16 weights (Mistral-7B, BASELINE configs[3]) with every float accumulation in the order of the
+// reference's Panama AVX-512 provider ("reference order"), so that a BF16 session can be bit-identical to the restated
+// provider like the JQ4 sessions of jh_p16.h / jh_t16.h.
+//
+// What has to be reproduced (FloatVector.SPECIES_512 = 16 float lanes, ShortVector.SPECIES_512 = 32 shorts per step):
+//   BF16 x BF16 (GemmerBF16 1x1, PTO:1279-1311):  per 32-element step l:  acc_t = fma(a[l+t], b[l+t], acc_t);
+//            acc_t = fma(a[l+16+t], b[l+16+t], acc_t)   (convertShape part 0 / part 1, both operands widened by << 16),
+//            then reduceLanes(ADD) = the halving tree (row16_tree_sum).  The activation row was rounded to BF16 before
+//            (RNE, PTO:1624-1628 -> FloatConversions.float32ToBFloat16).
+//   F32 x BF16 (GemmerF32BF16 1x1, PTO:1511-1538): the same chains with the UN-rounded F32 row (LM head,
+//            AbstractModel.java:443-449).
+//   The batch form (GemmerBF16 with M rows, AbstractModel.batchForward) keeps one 16-lane accumulator per (prompt row,
+//   weight row): every pair is the GEMV's chain, batching only shares the weight side.
+//
+// MI355X mapping (same "p16" idea as jh_p16.h: a 16-lane DPP row plays the 16 Panama lanes, a wave64 serves 4 weight rows):
+//   * lane (r, t) owns chain t of weight row 4q + r.  In the checkpoint's row-major layout a 16-byte load is 8 consecutive
+//     elements = 8 DIFFERENT chains, so the kernels read a resident copy in "BF16T" order made once per weight
+//     (bf16t_pack_kernel): inside every group of 128 elements (256 bytes of a row) the 16-byte chunk t holds
+//     dword i = (e[32i + t], e[32i + 16 + t]) for the group's four 32-element steps i = 0..3 -- one load per lane IS the
+//     next 8 links of its chain, in order; a wave instruction still moves 4 x 256 contiguous bytes;
+//   * widening is one shift / one mask per element, the chain one v_fmac_f32 per element, pinned in program order;
+//   * the activation row lives in LDS as F32 (already BF16-rounded and widened for BF16 x BF16) in the same pair order:
+//     float4 entry (p, t) = (y[64p + t], y[64p + 16 + t], y[64p + 32 + t], y[64p + 48 + t]) -- two conflict-free
+//     ds_read_b128 per group, broadcast to the wave's four 16-lane rows;
+//   * decode is HBM-bound (2 bytes per weight): the VALU work (2 ops per weight) is ~1/5 of the stream time, so the
+//     reference order costs nothing against the order-free kernel (gemv_bf16_kernel);
+//   * the M-row form (gemm_bf16r_kernel) keeps 4 row quads x 8 prompt rows of accumulators per lane, the activations of
+//     an 8-row tile staged through LDS in K chunks; row tiles of one weight slice are neighbours on one XCD (L2 reuse).
+// Compiled with -ffp-contract=off like the rest: every FMA is explicit.
+#pragma once
+#include "jh_p16.h"
+
+namespace jh {
+
+constexpr int BF16R_GROUP = 128;   // elements of a row per 16-lane x 16-byte load
+static inline size_t bf16t_row_bytes(int K) { return (size_t)((K + BF16R_GROUP - 1) / BF16R_GROUP) * 256; }
+
+// BF16T copy of a row-major BF16 weight [nrows, ldw elements]: one thread per output 16-byte chunk; steps past K hold zeros
+// (never multiplied: the kernels stop at the row's last step).
+__global__ __launch_bounds__(256) void bf16t_pack_kernel(const uint16_t* __restrict__ w, int nrows, int K, int ldw, uint8_t* __restrict__ out) {
+    const int G = (K + BF16R_GROUP - 1) / BF16R_GROUP;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)nrows * G * 16) return;
+    const int t = (int)(idx & 15);
+    const long long rg = idx >> 4;
+    const int g = (int)(rg % G);
+    const long long row = rg / G;
+    const uint16_t* src = w + (size_t)row * ldw + (size_t)g * BF16R_GROUP;
+    i32x4 v = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int e = g * BF16R_GROUP + 32 * i;
+        if (e < K) v[i] = (int)((unsigned)src[32 * i + t] | ((unsigned)src[32 * i + 16 + t] << 16));
+    }
+    ((i32x4*)out)[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ activation row in LDS
+struct ActBFR {
+    f32x4* a4;     // [2 * G][16]: entry (p, t) = y[64p + t], y[64p + 16 + t], y[64p + 32 + t], y[64p + 48 + t]
+    double* red;   // [32]
+    float* bestv;  // [16]
+    int* besti;    // [16]
+};
+__device__ __forceinline__ ActBFR carve_bfr(char* smem, int K) {
+    const int G = (K + BF16R_GROUP - 1) / BF16R_GROUP;
+    ActBFR a;
+    a.a4 = (f32x4*)smem;
+    a.red = (double*)(a.a4 + (size_t)G * 32);
+    a.bestv = (float*)(a.red + 32);
+    a.besti = (int*)(a.bestv + 16);
+    return a;
+}
+static inline size_t lds_bytes_bfr(int K) { return (size_t)((K + BF16R_GROUP - 1) / BF16R_GROUP) * 512 + 32 * 8 + 16 * 4 + 16 * 4; }
+// float index of element e inside the pair-ordered row
+__device__ __forceinline__ int bfr_slot(int e) {
+    const int b = e >> 5, half = (e >> 4) & 1, t = e & 15;
+    return (((b >> 1) * 16 + t) << 2) + ((b & 1) << 1) + half;
+}
+
+// the 8 links one 16-byte chunk adds to a chain (NS = valid 32-element steps of the group, 4 except in a short last group)
+template <int NS>
+__device__ __forceinline__ void bfr_group(const i32x4& x, const f32x4* af, float& acc) {
+    const f32x4 a0 = af[0];
+    if (NS >= 1) { fmac_pinned(acc, a0.x, __int_as_float(x.x << 16)); fmac_pinned(acc, a0.y, __int_as_float(x.x & (int)0xffff0000)); }
+    if (NS >= 2) { fmac_pinned(acc, a0.z, __int_as_float(x.y << 16)); fmac_pinned(acc, a0.w, __int_as_float(x.y & (int)0xffff0000)); }
+    if (NS >= 3) {
+        const f32x4 a1 = af[16];
+        fmac_pinned(acc, a1.x, __int_as_float(x.z << 16)); fmac_pinned(acc, a1.y, __int_as_float(x.z & (int)0xffff0000));
+        if (NS >= 4) { fmac_pinned(acc, a1.z, __int_as_float(x.w << 16)); fmac_pinned(acc, a1.w, __int_as_float(x.w & (int)0xffff0000)); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMV (decode), reference order
+// PRO: PROB_RMS_BF16 (RMSNorm, round to BF16), PROB_QUANT_BF16 (round to BF16), PROB_RMS_F32 (RMSNorm, keep F32: LM head), PROB_F32.
+// Work split as gemv_i8q4_p16_kernel: waves [0, tw) own `per` row quads each, NP passes per quad (gate then up for EPI_SILU_MUL),
+// G groups per pass streamed through a ring of D prefetched chunks (the host picks D | G).
+template <int PRO, int EPI, bool ARGMAX, int D, int UM>
+__global__ __launch_bounds__(P16_THREADS) void gemv_bf16r_kernel(GemvParams p, int per, int tw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool RMS = (PRO == PROB_RMS_BF16 || PRO == PROB_RMS_F32), ROUND = (PRO == PROB_RMS_BF16 || PRO == PROB_QUANT_BF16);
+    const int K = p.K, G = (K + BF16R_GROUP - 1) / BF16R_GROUP;   // host: G % D == 0, K % 32 == 0, K <= UM * 4096
+    const ActBFR a = carve_bfr(smem, K);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int r = lane >> 4, t = lane & 15;
+    constexpr int NP = (EPI == EPI_SILU_MUL) ? 2 : 1;
+    const int nq = (p.nrows + 3) >> 2;
+    int q0 = wave < tw ? (blockIdx.x * tw + wave) * per : nq;
+    if (q0 > nq) q0 = nq;
+    int q1 = q0 + per;
+    if (q1 > nq) q1 = nq;
+    const int items = (q1 - q0) * NP * G;
+
+    float xv[UM][8], wv[UM][8];
+    auto stage_issue = [&]() __attribute__((always_inline)) {   // activation row (+ norm weights): one round trip, branch-free
+        const int units = K / 8;
+#pragma unroll
+        for (int u = 0; u < UM; u++) {
+            int unit = threadIdx.x + u * P16_THREADS;
+            unit = unit < units ? unit : units - 1;
+            const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
+            xv[u][0] = xa.x; xv[u][1] = xa.y; xv[u][2] = xa.z; xv[u][3] = xa.w;
+            xv[u][4] = xb.x; xv[u][5] = xb.y; xv[u][6] = xb.z; xv[u][7] = xb.w;
+            if (RMS) load8_norm(p.nw, unit * 8, wv[u]);
+        }
+    };
+    auto stage_finish = [&]() __attribute__((always_inline)) {
+        const int units = K / 8;
+        float fs = 1.0f;
+        if (RMS) {   // RMSNorm.java:41-49: float squares, double sum, /E, +eps, 1/sqrt in double
+            double ss = 0.0;
+#pragma unroll
+            for (int u = 0; u < UM; u++)
+                if ((int)threadIdx.x + u * P16_THREADS < units)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) ss += (double)(xv[u][i] * xv[u][i]);
+            ss = block_sum_d(ss, a.red);
+            ss /= (double)K;
+            ss += (double)p.eps;
+            ss = 1.0 / sqrt(ss);
+            fs = (float)ss;
+        }
+        float* af = (float*)a.a4;
+#pragma unroll
+        for (int u = 0; u < UM; u++) {
+            const int unit = threadIdx.x + u * P16_THREADS;
+            if (unit < units) {
+                const int s0 = bfr_slot(unit * 8);          // 8 consecutive elements: t = t0 .. t0 + 7 of one half-step, 16 bytes apart
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float y = RMS ? wv[u][i] * (fs * xv[u][i]) : xv[u][i];
+                    if (ROUND) y = bf16_to_f32(f32_to_bf16(y));   // quantizeBF16 (RNE), widened again
+                    af[s0 + 4 * i] = y;
+                }
+            }
+        }
+        lds_barrier();
+    };
+
+    i32x4 wq[D];
+    int lq = q0, lpass = 0, lg = 0;
+    const uint8_t* wrow;
+    auto set_row = [&]() __attribute__((always_inline)) {
+        int row = 4 * lq + r;
+        row = row < p.nrows ? row : p.nrows - 1;
+        wrow = ((NP == 2 && lpass) ? p.w2 : p.w) + (size_t)row * p.ldb;
+    };
+    set_row();
+    auto issue = [&](i32x4& w) __attribute__((always_inline)) {
+        w = __builtin_nontemporal_load((const i32x4*)wrow + 16 * lg + t);   // BF16T copy: chunk t of group lg
+        if (++lg == G) {
+            lg = 0;
+            if (++lpass == NP) { lpass = 0; ++lq; }
+            set_row();
+        }
+    };
+    float bestv = -INFINITY;
+    int besti = 0x7fffffff;
+    if (items == 0) {
+        // helper wave: its own copy of the prologue; must not join the streaming path before the argmax merge (see gemv_i8q4_p16_kernel)
+        stage_issue();
+        stage_finish();
+    } else {
+        stage_issue();                                          // activation loads first: vmcnt retires oldest-first
+        auto resid_of_batch = [&](int qb) __attribute__((always_inline)) {
+            int row = 4 * (qb + t) + r;
+            row = row < p.nrows ? row : p.nrows - 1;
+            return p.resid[row];
+        };
+        float rv = 0.0f;
+        if (EPI == EPI_RESID) rv = resid_of_batch(q0);
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            issue(wq[d]);
+            __builtin_amdgcn_sched_barrier(0);                  // request order = consumption order
+        }
+        stage_finish();
+
+        float acc = 0.0f, gres = 0.0f, gsel = 0.0f, usel = 0.0f;
+        int cq = q0, cpass = 0, cg = 0;
+        const int last_ns = (K - (G - 1) * BF16R_GROUP) / 32;   // steps of the row's last group (1..4)
+        auto compute = [&](const i32x4& x, int g, bool can_be_short) __attribute__((always_inline)) {
+            const f32x4* af = a.a4 + (size_t)(2 * g) * 16 + t;
+            if (can_be_short && g == G - 1 && last_ns < 4) {
+                if (last_ns == 1) bfr_group<1>(x, af, acc);
+                else if (last_ns == 2) bfr_group<2>(x, af, acc);
+                else bfr_group<3>(x, af, acc);
+            } else {
+                bfr_group<4>(x, af, acc);
+            }
+        };
+        auto pass_end = [&]() __attribute__((always_inline)) {
+            const float res = row16_tree_sum(acc);
+            acc = 0.0f;
+            if (EPI == EPI_SILU_MUL && cpass == 0) {
+                gres = res;
+                cpass = 1;
+                return;
+            }
+            cpass = 0;
+            const int row0 = 4 * cq + r;
+            if (ARGMAX && row0 < p.nrows && res > bestv) { bestv = res; besti = row0; }   // rows ascend within a lane: strict > keeps the first
+            const int n = (cq - q0) & 15;
+            if (t == n) { gsel = gres; usel = res; }
+            if (n == 15 || cq + 1 == q1) {                      // results parked in lane t == n, stored once per 16 tasks
+                const int row = 4 * (cq - n + t) + r;
+                if (t <= n && row < p.nrows) {
+                    float v = usel;
+                    if (EPI == EPI_SILU_MUL) v = silu_ref(gsel) * usel;   // MLPBlock.java:132-142
+                    if (EPI == EPI_RESID) v = v + rv;                      // TransformerBlock.java:185,203
+                    p.out[row] = v;
+                }
+                if (EPI == EPI_RESID && cq + 1 < q1) rv = resid_of_batch(cq + 1);
+            }
+            ++cq;
+        };
+        for (int it = 0; it + D < items; it += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const i32x4 x = wq[d];
+                __builtin_amdgcn_sched_barrier(0);
+                issue(wq[d]);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(x, cg + d, d == D - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cg += D;
+            if (cg == G) { cg = 0; pass_end(); }
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            compute(wq[d], cg + d, d == D - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pass_end();
+    }
+    if (ARGMAX && p.amax_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bestv, o);
+            const int oi = __shfl_xor(besti, o);
+            if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+        }
+        if (lane == 0) { a.bestv[wave] = bestv; a.besti[wave] = besti; }
+        lds_barrier();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < nwaves; w++)
+                if (a.bestv[w] > bestv || (a.bestv[w] == bestv && a.besti[w] < besti)) { bestv = a.bestv[w]; besti = a.besti[w]; }
+            p.amax_part[blockIdx.x] = bestv;
+            p.amax_idx[blockIdx.x] = besti;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ prompt rows (M > 1), reference order
+// GemmerBF16 with M rows (AbstractModel.batchForward, AbstractModel.java:295-312): every (prompt row, weight row) pair is the
+// GEMV's 16-lane chain; only the weight side is shared.  The activations of a chunk are written ONCE per projection input as the
+// LDS image the GEMM reads (rows_act_bf16r_kernel), 8-row tiles:
+//   image[tile][p][j][rq][t][rr] (floats)   p = 64-element pair of steps, j = 0..3: element 64p + 16j + t,
+//                                           rq = row quad of the tile (0, 1), t = chain, rr = row inside the quad
+// so that one ds_read_b128 hands lane t the values of 4 prompt rows for one link of its chain (16 lanes = 256 contiguous bytes,
+// conflict-free; the wave's four 16-lane rows read the same addresses: broadcast), and a K chunk of a tile is contiguous.
+constexpr int BFR_MR = 8;            // prompt rows per tile
+constexpr int BFR_QW = 4;            // row quads (4 weight rows each) per wave
+constexpr int BFR_WAVES = 4;         // waves per workgroup: 64 weight rows
+constexpr int BFR_CG = 8;            // groups of 128 elements per LDS chunk (1024 elements x 8 rows x 4 B = 32 KiB)
+static inline size_t bfr_image_floats(int rows_cap, int K) { return (size_t)((rows_cap + BFR_MR - 1) / BFR_MR) * ((K + BF16R_GROUP - 1) / BF16R_GROUP) * 2 * 512; }
+static inline size_t lds_bytes_gemm_bf16r() { return (size_t)2 * BFR_CG * 2 * 512 * 4; }
+
+enum { PROB_SILU_BF16 = 4 };         // y = silu(gate) * up (MLPBlock.java:132-142), rounded to BF16: the down projection's input
+struct RowsBfrParams {
+    const float* x; int ldx;         // input rows (F32)
+    const float* x2; int ldx2;       // PROB_SILU_BF16: the `up` rows
+    const float* nw; float eps;      // PROB_RMS_BF16: norm weights (F32)
+    int K;                           // multiple of 128
+    float* image;                    // bfr image of the chunk's rows
+};
+// one workgroup per prompt row
+template <int PRO>
+__global__ __launch_bounds__(256) void rows_act_bf16r_kernel(RowsBfrParams p) {
+    __shared__ double red[32];
+    const int row = blockIdx.x;
+    const float* x = p.x + (size_t)row * p.ldx;
+    float fs = 1.0f;
+    if (PRO == PROB_RMS_BF16) fs = rms_factor(x, p.K, p.eps, red);
+    const int NP = p.K / 64;
+    float* img = p.image + (size_t)(row / BFR_MR) * NP * 512 + ((row % BFR_MR) >> 2) * 64 + (row & 3);
+    for (int unit = threadIdx.x; unit < p.K / 8; unit += blockDim.x) {
+        const int e0 = unit * 8;
+        const float4 xa = *(const float4*)(x + e0), xb = *(const float4*)(x + e0 + 4);
+        float y[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        if (PRO == PROB_RMS_BF16) {
+            float w[8];
+            load8_norm(p.nw, e0, w);
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = w[i] * (fs * y[i]);
+        }
+        if (PRO == PROB_SILU_BF16) {
+            const float* u = p.x2 + (size_t)row * p.ldx2 + e0;
+            const float4 ua = *(const float4*)u, ub = *(const float4*)(u + 4);
+            const float uu[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = silu_ref(y[i]) * uu[i];
+        }
+        const int pp = e0 >> 6, j = (e0 >> 4) & 3, t0 = e0 & 15;
+        float* dst = img + ((size_t)pp * 4 + j) * 128 + t0 * 4;
+#pragma unroll
+        for (int i = 0; i < 8; i++) dst[4 * i] = bf16_to_f32(f32_to_bf16(y[i]));   // quantizeBF16 (RNE), widened again
+    }
+}
+
+struct GemmBfrParams {
+    const uint8_t* w;                // BF16T copy, row stride ldb bytes
+    int ldb, nrows, K, rows;         // weight rows, K (multiple of 128), prompt rows
+    const float* image;              // activations (rows_act_bf16r_kernel)
+    float* out; int ldc;             // out[row * ldc + weight row]
+    const float* resid; int ldr;     // EPI_RESID
+    int nslices, nrt;                // 64-row weight slices, 8-row tiles
+};
+// grid: ((nslices + 7) / 8) * 8 * nrt workgroups; the row tiles of one weight slice are consecutive in launch order on ONE XCD
+// (blockIdx & 7), so all but the first find the slice in that XCD's L2.
+template <int EPI>
+__global__ __launch_bounds__(BFR_WAVES * 64) void gemm_bf16r_kernel(GemmBfrParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* lds = (f32x4*)smem;                                  // [2][BFR_CG * 2 * 128] f32x4
+    constexpr int NT = BFR_WAVES * 64, CHUNK4 = BFR_CG * 2 * 128, LU = CHUNK4 / NT;   // 16-byte units per chunk / per thread
+    const int id = blockIdx.x, xcd = id & 7, k = id >> 3, rt = k % p.nrt, slice = (k / p.nrt) * 8 + xcd;
+    if (slice >= p.nslices) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane >> 4, t = lane & 15;
+    const int G = p.K / BF16R_GROUP, nchunks = (G + BFR_CG - 1) / BFR_CG;
+    const f32x4* img = (const f32x4*)p.image + (size_t)rt * G * 256;   // 2 * 512 floats = 256 f32x4 per group
+    const i32x4* wrow[BFR_QW];
+#pragma unroll
+    for (int q = 0; q < BFR_QW; q++) {
+        int row = slice * 64 + wave * 16 + q * 4 + r;
+        row = row < p.nrows ? row : p.nrows - 1;
+        wrow[q] = (const i32x4*)(p.w + (size_t)row * p.ldb) + t;
+    }
+    float acc[BFR_QW][BFR_MR];
+#pragma unroll
+    for (int q = 0; q < BFR_QW; q++)
+#pragma unroll
+        for (int m = 0; m < BFR_MR; m++) acc[q][m] = 0.0f;
+    f32x4 sreg[LU];
+    auto stage_load = [&](int c) __attribute__((always_inline)) {
+        const int n4 = (G - c * BFR_CG < BFR_CG ? G - c * BFR_CG : BFR_CG) * 256;
+#pragma unroll
+        for (int u = 0; u < LU; u++) {
+            int idx = tid + u * NT;
+            idx = idx < n4 ? idx : n4 - 1;
+            sreg[u] = img[(size_t)c * CHUNK4 + idx];
+        }
+    };
+    auto stage_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < LU; u++) lds[buf * CHUNK4 + tid + u * NT] = sreg[u];
+    };
+    i32x4 wa[BFR_QW], wb[BFR_QW];
+    auto wload = [&](i32x4 (&w)[BFR_QW], int g) __attribute__((always_inline)) {
+        const int gg = g < G ? g : G - 1;
+#pragma unroll
+        for (int q = 0; q < BFR_QW; q++) w[q] = wrow[q][16 * gg];
+    };
+    auto compute = [&](const i32x4 (&w)[BFR_QW], const f32x4* a) __attribute__((always_inline)) {
+        // a: the group's image in LDS: [p = 0, 1][j][rq][t] f32x4
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const f32x4 a0 = a[(i * 2 + 0) * 16 + t], a1 = a[(i * 2 + 1) * 16 + t];
+            float wv[BFR_QW];
+#pragma unroll
+            for (int q = 0; q < BFR_QW; q++) {
+                const int d = w[q][i >> 1];
+                wv[q] = __int_as_float((i & 1) ? (d & (int)0xffff0000) : (d << 16));
+            }
+#pragma unroll
+            for (int q = 0; q < BFR_QW; q++) {
+                acc[q][0] = fmaf(a0.x, wv[q], acc[q][0]); acc[q][1] = fmaf(a0.y, wv[q], acc[q][1]);
+                acc[q][2] = fmaf(a0.z, wv[q], acc[q][2]); acc[q][3] = fmaf(a0.w, wv[q], acc[q][3]);
+                acc[q][4] = fmaf(a1.x, wv[q], acc[q][4]); acc[q][5] = fmaf(a1.y, wv[q], acc[q][5]);
+                acc[q][6] = fmaf(a1.z, wv[q], acc[q][6]); acc[q][7] = fmaf(a1.w, wv[q], acc[q][7]);
+            }
+        }
+    };
+    stage_load(0);
+    wload(wa, 0);
+    stage_store(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage_load(c + 1);
+        const f32x4* a = lds + buf * CHUNK4;
+        const int g0 = c * BFR_CG, ng = G - g0 < BFR_CG ? G - g0 : BFR_CG;   // ng even whenever G is (the host requires G % 2 == 0)
+        for (int gi = 0; gi < ng; gi += 2) {
+            wload(wb, g0 + gi + 1);
+            compute(wa, a + (size_t)gi * 256);
+            wload(wa, g0 + gi + 2);
+            compute(wb, a + (size_t)(gi + 1) * 256);
+        }
+        if (c + 1 < nchunks) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue: the 16 lanes of a row all hold the finished sums; lane t stores (prompt row t & 7, quads t >> 3 and 2 + (t >> 3))
+#pragma unroll
+    for (int q = 0; q < BFR_QW; q++)
+#pragma unroll
+        for (int m = 0; m < BFR_MR; m++) {
+            const float res = row16_tree_sum(acc[q][m]);
+            if (t == (q & 1) * 8 + m) {
+                const int wr = slice * 64 + wave * 16 + q * 4 + r, prow = rt * BFR_MR + m;
+                if (wr < p.nrows && prow < p.rows) {
+                    float v = res;
+                    if (EPI == EPI_RESID) v = v + p.resid[(size_t)prow * p.ldr + wr];
+                    p.out[(size_t)prow * p.ldc + wr] = v;
+                }
+            }
+        }
+}
+
+}  // namespace jh

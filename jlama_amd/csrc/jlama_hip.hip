@@ -17,6 +17,7 @@
 
 #include "jh_kernels.h"
 #include "jh_t16.h"
+#include "jh_bf16r.h"
 
 using namespace jh;
 
@@ -105,6 +106,7 @@ const void* reg_ptr(int64_t id) {
 // a constant chosen by the launch planners.
 std::mutex g_opt_mu;
 std::map<std::string, int> g_opts;
+std::map<std::string, int> g_env_opts;   // what jh_init copied from the environment: jh_clear_options() falls back to these
 int opt_int(const char* name, int dflt) {
     std::lock_guard<std::mutex> lk(g_opt_mu);
     auto it = g_opts.find(name);
@@ -114,7 +116,7 @@ int opt_int(const char* name, int dflt) {
 // misspelt option is an error, not a silent no-op
 const char* const JH_KNOWN_OPTIONS[] = {
     "JH_ATTN_LONG_MIN", "JH_ATTN_LONG_SPLITS", "JH_ATTN_MID_MAX", "JH_ATTN_MID_SPLITS", "JH_ATTN_SPLITS", "JH_BF16_CWB",
-    "JH_BF16_LDS", "JH_BF16_S", "JH_DOWN_GRIDX", "JH_DOWN_PIPE", "JH_DOWN_R", "JH_DOWN_WAVES", "JH_FAST_GATEUP_T16",
+    "JH_BF16_LDS", "JH_BF16R_PREFILL", "JH_BF16_S", "JH_DOWN_GRIDX", "JH_DOWN_PIPE", "JH_DOWN_R", "JH_DOWN_WAVES", "JH_FAST_GATEUP_T16",
     "JH_GATEUP_GRIDX", "JH_GATEUP_PIPE", "JH_GATEUP_R", "JH_GATEUP_WAVES", "JH_GEMM_CW", "JH_GEMM_LDS", "JH_GEMM_LDS_CT",
     "JH_GEMM_LDS_CW", "JH_GEMM_LDS_PK", "JH_GEMM_LDS_S", "JH_GEMM_S", "JH_GEMM_Z", "JH_GEMV_PIPE", "JH_GEMV_R", "JH_GEMV_WAVES",
     "JH_LM_GRIDX", "JH_LM_R", "JH_LM_WAVES", "JH_NO_GRAPH", "JH_O_GRIDX", "JH_O_PIPE", "JH_O_R", "JH_O_WAVES",
@@ -125,7 +127,7 @@ const char* const JH_KNOWN_OPTIONS[] = {
 };
 // JH_TRACE=1          synchronize + report after every launch (debugging)
 // JH_NO_GRAPH=1       decode without hipGraph replay (debugging)
-// JH_STRICT_ORDER=0   new sessions start with the order-free kernels instead of the reference-order ones (jh_session_set_strict)
+// JH_STRICT_ORDER=1   new sessions start in reference order (default 0: order-free kernels; jh_session_set_strict switches a session)
 // JH_TILED_COPY=auto|resident|transient   where the order-free prefill GEMM's MFMA-ordered weight operand lives
 // JH_TP_LOUD=1        a tensor-parallel meeting that times out is an error instead of a (reported) fall-back to the event loop
 const char* const JH_ENV_OPTIONS[] = {"JH_TRACE", "JH_NO_GRAPH", "JH_STRICT_ORDER", "JH_TILED_COPY", "JH_TP_LOUD"};
@@ -140,6 +142,7 @@ void options_from_environment_once() {
         int val = atoi(v);
         if (!strcmp(name, "JH_TILED_COPY")) val = !strcmp(v, "resident") ? 1 : !strcmp(v, "transient") ? 2 : 0;
         g_opts[name] = val;
+        g_env_opts[name] = val;
     }
 }
 
@@ -150,10 +153,8 @@ int allow_lds(K kernel, size_t bytes) {
 }
 
 std::mutex g_capture_mu;   // one hipGraph capture at a time per process (captures are rare; concurrent ones from different host threads are fragile)
-int g_trace = -1;
 int trace_sync(const char* what, hipStream_t st) {
-    if (g_trace < 0) g_trace = opt_int("JH_TRACE", 0);
-    if (!g_trace) return JH_OK;
+    if (!opt_int("JH_TRACE", 0)) return JH_OK;   // read when asked (no latch: jh_set_option / jh_clear_options take effect at once)
     fprintf(stderr, "[jh] %s ...", what);
     fflush(stderr);
     hipError_t e = hipStreamSynchronize(st);
@@ -376,7 +377,7 @@ int launch_gemm_q8q4_mfma(const MfmaQ4Params& g, hipStream_t st, bool tiled = fa
         const long long tiles = (long long)mt * (g.n / 32);
         int S = 1;
         while (S < 8 && tiles * S < (long long)g_cu_count * 8 && nblk % (16 * S) == 0) S *= 2;   // nblk/S stays a multiple of 8
-        static const int cw_env = opt_int("JH_GEMM_CW", 0), s_env = opt_int("JH_GEMM_S", 0);
+        const int cw_env = opt_int("JH_GEMM_CW", 0), s_env = opt_int("JH_GEMM_S", 0);
         if (s_env > 0 && nblk % (8 * s_env) == 0) S = s_env;
         int CW = 1;
         if (tiled) {
@@ -460,7 +461,7 @@ int launch_gemm_bf16_tile(const MfmaBf16TileParams& g, hipStream_t st) {
     const int mt = (g.m + 31) / 32, tiles = g.n / 32, nks = g.k / 16;
     // waves per workgroup (column tiles sharing the A fragments through L1) vs workgroups: want >= ~2 workgroups per CU
     // before splitting K, because the split's reduce pass moves S*M*N*8 bytes
-    static const int cwb_env = opt_int("JH_BF16_CWB", 0), s_env = opt_int("JH_BF16_S", 0);
+    const int cwb_env = opt_int("JH_BF16_CWB", 0), s_env = opt_int("JH_BF16_S", 0);
     int cwb = 8;
     while (cwb > 1 && ((tiles % cwb) != 0 || tiles / cwb < g_cu_count * 2)) cwb >>= 1;
     if (cwb < 4 && tiles % 4 == 0 && nks >= 512) cwb = 4;      // long K, few tiles: measured best (tools/gemm_bench.py)
@@ -576,7 +577,7 @@ int jh_set_option(const char* name, int32_t value) {
 }
 int jh_clear_options(void) {
     std::lock_guard<std::mutex> lk(g_opt_mu);
-    g_opts.clear();
+    g_opts = g_env_opts;   // explicit options go; the process-wide environment snapshot of jh_init stays in force
     return JH_OK;
 }
 const char* jh_name(void) { return "HIP CDNA4 (gfx950) Operations"; }
@@ -1121,7 +1122,7 @@ struct JWeight {
     float* tiled_scales = nullptr;
     uint8_t* t16 = nullptr;          // Q4 only: resident copy in T16 order (jh_t16.h) for the reference-order MFMA GEMV
     float* t16_scales = nullptr;
-    uint8_t* p16t = nullptr;         // Q4 only: resident copy in P16T order (jh_p16.h), what every other reference-order GEMV / GEMM reads
+    uint8_t* p16t = nullptr;         // resident copy for the reference-order GEMVs: Q4 in P16T order (jh_p16.h), BF16 in BF16T order (jh_bf16r.h)
 };
 struct jh_model {
     jh_config c;
@@ -1136,6 +1137,7 @@ struct jh_model {
     int kv_head_offset = 0;   // tensor-parallel shard (jh_model_set_kv_head_offset)
     int weights_version = 0;  // bumped by jh_model_set_weight: sessions drop graphs that captured the old device pointers
     int tiled_mode = 0;       // TILED_*: where the prefill GEMM's MFMA-ordered weight operand lives (decided at the first prefill)
+    std::mutex op_mu;         // the operand copies (T16 / P16T / BF16T) are per model and shared by its sessions: made under this lock, published packed
 };
 // The prefill GEMM reads its weight operand in MFMA order.  RESIDENT keeps a second, re-tiled copy of every projection weight in
 // HBM (2x the checkpoint; the default while the device has room: this part has 288 GB).  TRANSIENT keeps only the row-major
@@ -1196,6 +1198,7 @@ struct jh_session {
     float* p16_scores_b = nullptr;                     // reference-order prefill: score rows of a whole chunk [rows][n_heads][p16_sc_stride]
     uint8_t* pb_sel = nullptr;                         // reference-order prefill on the MFMA (gemm_t16_kernel): one-hot selector operands of a chunk's rows
     float* pb_sad = nullptr;                           // ... and their block scales [nblk][PB_MAX_ROWS]
+    float* pb_bfr = nullptr;                           // reference-order prefill of a BF16 model: the activation image of a chunk (jh_bf16r.h)
     uint8_t* tile_w = nullptr;                         // TILED_TRANSIENT: scratch for ONE weight in MFMA order (+ its scales)
     float* tile_s = nullptr;
     size_t tile_w_bytes = 0, tile_s_bytes = 0;
@@ -1363,11 +1366,12 @@ int launch_gemv_t16(const GemvParams& p, hipStream_t st) {
     return JH_OK;
 }
 int tiled_mode_for(jh_model* m);
+thread_local int g_operand_packs = 0;   // operand copies this thread has queued a pack kernel for (ensure_strict_operands waits for them)
 // the order-free sessions use the MFMA gate|up GEMV as well (option JH_FAST_GATEUP_T16=0: their own VALU kernel, for comparisons)
 bool fast_gateup_t16(jh_model* m) { return opt_int("JH_FAST_GATEUP_T16", 1) != 0 && tiled_mode_for(m) == TILED_RESIDENT; }   // (a second copy: not under JH_TILED_COPY=transient)
 // gate|up of layer li in T16 order (tile u = gate rows 8u..8u+7, up rows 8u..8u+7): made once, before any graph capture
 bool t16_gateup_ok(const jh_model* m, int li) {
-    static const int enabled = opt_int("JH_T16", 1);
+    const int enabled = opt_int("JH_T16", 1);
     const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     const JWeight &G = W[JH_W_GATE], &U = W[JH_W_UP];
     return enabled && G.data && U.data && G.dtype == JH_DT_Q4 && U.dtype == JH_DT_Q4 && G.rows == U.rows && G.cols == U.cols &&
@@ -1382,7 +1386,12 @@ int ensure_gateup_t16(jh_model* m, int li, hipStream_t st) {
     F.dtype = G.dtype; F.rows = rows; F.cols = K;
     hipError_t e = hipMalloc((void**)&F.t16, t16_w_bytes(rows, K));
     if (e == hipSuccess) e = hipMalloc((void**)&F.t16_scales, t16_s_bytes(rows, K));
-    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc T16 gate|up copy");
+    if (e != hipSuccess) {   // never leave half a copy behind: later calls would take it for a finished one
+        if (F.t16) hipFree(F.t16);
+        F.t16 = nullptr; F.t16_scales = nullptr;
+        return set_err(JH_ERR_OOM, "hipMalloc T16 gate|up copy");
+    }
+    g_operand_packs++;
     const long long threads = (long long)ntiles * (nblk / 4) * 16;
     hipLaunchKernelGGL(t16_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const i32x4*)G.data, (const float*)G.scales,
                        (const i32x4*)U.data, (const float*)U.scales, nblk, ntiles, 1, (i32x4*)F.t16, (f32x4t*)F.t16_scales);
@@ -1396,7 +1405,12 @@ int ensure_t16(JWeight& W, hipStream_t st) {
     const int nblk = W.cols / QB, ntiles = W.rows / 16;
     hipError_t e = hipMalloc((void**)&W.t16, t16_w_bytes(W.rows, W.cols));
     if (e == hipSuccess) e = hipMalloc((void**)&W.t16_scales, t16_s_bytes(W.rows, W.cols));
-    if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc T16 weight copy");
+    if (e != hipSuccess) {
+        if (W.t16) hipFree(W.t16);
+        W.t16 = nullptr; W.t16_scales = nullptr;
+        return set_err(JH_ERR_OOM, "hipMalloc T16 weight copy");
+    }
+    g_operand_packs++;
     const long long threads = (long long)ntiles * (nblk / 4) * 16;
     hipLaunchKernelGGL(t16_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const i32x4*)W.data, (const float*)W.scales,
                        (const i32x4*)nullptr, (const float*)nullptr, nblk, ntiles, 0, (i32x4*)W.t16, (f32x4t*)W.t16_scales);
@@ -1405,10 +1419,21 @@ int ensure_t16(JWeight& W, hipStream_t st) {
 }
 // P16T copy of a Q4 weight (jh_p16.h: byte t of the 16 blocks of a group in one 16-byte chunk), made once
 int ensure_p16t(JWeight& W, hipStream_t st) {
-    if (W.p16t || !W.data || W.dtype != JH_DT_Q4) return JH_OK;
+    if (W.p16t || !W.data) return JH_OK;
+    if (W.dtype == JH_DT_BF16) {   // BF16T order (jh_bf16r.h): the 16-byte chunk t of a 128-element group = the next 8 links of chain t
+        const size_t rb = bf16t_row_bytes(W.cols);
+        if (hipMalloc((void**)&W.p16t, (size_t)W.rows * rb + 64) != hipSuccess) { W.p16t = nullptr; return set_err(JH_ERR_OOM, "hipMalloc BF16T weight copy"); }
+        g_operand_packs++;
+        const long long threads = (long long)W.rows * (long long)(rb / 16);
+        hipLaunchKernelGGL(bf16t_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const uint16_t*)W.data, W.rows, W.cols, W.cols, W.p16t);
+        HIPCHK(hipGetLastError());
+        return JH_OK;
+    }
+    if (W.dtype != JH_DT_Q4) return JH_OK;
     const int nblk = W.cols / QB;
     const size_t rb = p16t_row_bytes(W.cols);
-    if (hipMalloc((void**)&W.p16t, (size_t)W.rows * rb + 64) != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc P16T weight copy");
+    if (hipMalloc((void**)&W.p16t, (size_t)W.rows * rb + 64) != hipSuccess) { W.p16t = nullptr; return set_err(JH_ERR_OOM, "hipMalloc P16T weight copy"); }
+    g_operand_packs++;
     const long long threads = (long long)W.rows * (long long)(rb / 16);
     hipLaunchKernelGGL(p16t_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const uint8_t*)W.data, W.rows, nblk, W.cols / 2, W.p16t);
     HIPCHK(hipGetLastError());
@@ -1416,14 +1441,64 @@ int ensure_p16t(JWeight& W, hipStream_t st) {
 }
 // the reference-order kernels' view of a weight: P16T nibbles + the checkpoint's scales
 int use_p16t(GemvParams& p, const JWeight& W) {
-    if (!W.p16t) return set_err(JH_ERR_INVALID, "reference-order GEMV: the weight has no P16T copy (ensure_strict_operands)");
-    p.w = W.p16t; p.ldb = (int)p16t_row_bytes(W.cols);
+    if (!W.p16t) return set_err(JH_ERR_INVALID, "reference-order GEMV: the weight has no P16T / BF16T copy (ensure_strict_operands)");
+    p.w = W.p16t; p.ldb = (int)(W.dtype == JH_DT_BF16 ? bf16t_row_bytes(W.cols) : p16t_row_bytes(W.cols));
+    return JH_OK;
+}
+// ---- reference-order GEMV of a dense BF16 weight (jh_bf16r.h): same work split as the p16 kernels
+template <int PRO, int EPI, bool ARGMAX>
+int launch_gemv_bf16r(const GemvParams& p, int* grid_out, hipStream_t st) {
+    if (p.K % 32 || p.K > 32768) return set_err(JH_ERR_UNSUPPORTED, "reference-order BF16 GEMV: K must be a multiple of 32, at most 32768");
+    const P16Plan pl = p16_plan(p.nrows, ARGMAX ? 2 : 1);   // LM head: two workgroups per CU (argmax partial buffers hold 4096 entries)
+    if (grid_out) *grid_out = pl.grid;
+    const int G = (p.K + BF16R_GROUP - 1) / BF16R_GROUP;
+    const size_t lds = lds_bytes_bfr(p.K);
+#define JH_BFR(DV, UMV)                                                                                                          \
+    do {                                                                                                                         \
+        JHCHK(allow_lds((gemv_bf16r_kernel<PRO, EPI, ARGMAX, DV, UMV>), lds));                                                   \
+        hipLaunchKernelGGL((gemv_bf16r_kernel<PRO, EPI, ARGMAX, DV, UMV>), dim3(pl.grid), dim3(P16_THREADS), lds, st, p, pl.per, pl.tw); \
+    } while (0)
+#define JH_BFR_D(UMV)                                                                                                            \
+    do {                                                                                                                         \
+        if (G % 8 == 0) JH_BFR(8, UMV); else if (G % 4 == 0) JH_BFR(4, UMV); else if (G % 2 == 0) JH_BFR(2, UMV); else JH_BFR(1, UMV); \
+    } while (0)
+    if (p.K <= 8192) JH_BFR_D(2); else if (p.K <= 16384) JH_BFR_D(4); else JH_BFR_D(8);
+#undef JH_BFR_D
+#undef JH_BFR
+    HIPCHK(hipGetLastError());
+    g_last_gemv_grid = pl.grid;
     return JH_OK;
 }
 bool prefill_t16_ok(jh_session* s);
+bool prefill_bf16r_ok(jh_session* s);
 // every operand copy a reference-order session of this shard will touch (allocation must not happen inside a graph capture)
+int ensure_strict_operands_locked(jh_session* s, hipStream_t st);
+// The copies belong to the MODEL: every session of it (other streams, other host threads) reads them.  They are created under the
+// model's lock, and the lock is released only once the pack kernels this call queued have FINISHED -- a second session then either
+// waits here or finds complete copies; nobody launches a reference-order GEMV against a half-packed operand.
 int ensure_strict_operands(jh_session* s, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(s->m->op_mu);
+    const int before = g_operand_packs;
+    const int rc = ensure_strict_operands_locked(s, st);
+    if (g_operand_packs != before) HIPCHK(hipStreamSynchronize(st));
+    return rc;
+}
+int ensure_strict_operands_locked(jh_session* s, hipStream_t st) {
     jh_model* m = s->m;
+    if (m->c.weight_dtype == JH_DT_BF16) {
+        if (!s->strict) return JH_OK;
+        for (int li = m->c.layer_start; li < m->c.layer_end; li++) {   // BF16T copies of every projection (jh_bf16r.h)
+            JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+            JHCHK(ensure_p16t(m->qkv[(size_t)li], st));
+            JHCHK(ensure_p16t(W[JH_W_O], st));
+            JHCHK(ensure_p16t(W[JH_W_GATE], st));
+            JHCHK(ensure_p16t(W[JH_W_UP], st));
+            JHCHK(ensure_p16t(W[JH_W_DOWN], st));
+        }
+        JWeight* lmw = m->global_w[JH_W_LMHEAD].data ? &m->global_w[JH_W_LMHEAD] : &m->global_w[JH_W_EMBED];
+        if (lmw->data && m->global_w[JH_W_FINALNORM].data) JHCHK(ensure_p16t(*lmw, st));
+        return JH_OK;
+    }
     if (m->c.weight_dtype != JH_DT_Q4) return JH_OK;
     if (!s->strict) {
         // the order-free sessions take the gate|up GEMV from jh_t16.h too (it is the faster kernel -- and bit-exact): its T16 copy only
@@ -1579,7 +1654,8 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
         p.x = s->x; p.nw = (const float*)W[JH_W_NORM1].data; p.eps = c.rms_eps;
-        if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st))); }
+        if (c.weight_dtype == JH_DT_BF16 && s->strict) { JHCHK(use_p16t(p, F)); JHCHK((launch_gemv_bf16r<PROB_RMS_BF16, EPI_STORE, false>(p, nullptr, st))); }
+        else if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st))); }
         else if (s->strict) { JHCHK(use_p16t(p, F)); JHCHK((launch_gemv_i8q4_p16<PRO_RMS_Q8, EPI_STORE>(p, s->p16_depth, st))); }
         else JHCHK((launch_gemv_i8q4<PRO_RMS_Q8, EPI_STORE>(p, s->cfg_qkv, st)));
         JHCHK(trace_sync("qkv", st));
@@ -1604,7 +1680,11 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         p.w = (const uint8_t*)W[JH_W_O].data; p.ws = W[JH_W_O].scales; p.nrows = E; p.out = out;
         p.K = A; p.ldb = A / 2; p.ldbf = A / QB;
         p.x = s->attf; p.resid = resid;   // maybeQuantize(valueBatch) (:364) happens in the prologue
-        if (c.weight_dtype == JH_DT_BF16) {
+        if (c.weight_dtype == JH_DT_BF16 && s->strict) {
+            JHCHK(use_p16t(p, W[JH_W_O]));
+            if (resid) JHCHK((launch_gemv_bf16r<PROB_QUANT_BF16, EPI_RESID, false>(p, nullptr, st)));
+            else JHCHK((launch_gemv_bf16r<PROB_QUANT_BF16, EPI_STORE, false>(p, nullptr, st)));
+        } else if (c.weight_dtype == JH_DT_BF16) {
             p.ldb = A * 2;
             if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
             else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
@@ -1644,7 +1724,13 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
         p.x = s->x1; p.nw = (const float*)W[JH_W_NORM2].data; p.eps = c.rms_eps;
         p.out = s->hf;   // silu(gate)*up, F32; the down projection's prologue quantizes it (MLPBlock.java:144)
-        if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, g_cu_count * 4, nullptr, st))); }
+        if (c.weight_dtype == JH_DT_BF16 && s->strict) {
+            JHCHK(use_p16t(p, W[JH_W_GATE]));
+            if (!W[JH_W_UP].p16t) return set_err(JH_ERR_INVALID, "reference-order GEMV: up projection has no BF16T copy");
+            p.w2 = W[JH_W_UP].p16t;
+            JHCHK((launch_gemv_bf16r<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, nullptr, st)));
+        }
+        else if (c.weight_dtype == JH_DT_BF16) { p.ldb = E * 2; JHCHK((launch_gemv_bf16<PROB_RMS_BF16, EPI_SILU_MUL, false>(p, g_cu_count * 4, nullptr, st))); }
         else if (t16_gateup_ok(m, li) && (s->strict || fast_gateup_t16(m))) {
             JHCHK(ensure_gateup_t16(m, li, st));   // (already there unless a weight was just replaced; never inside a capture: ensure_strict_operands)
             p.w = m->gateup[(size_t)li].t16; p.ws = m->gateup[(size_t)li].t16_scales; p.w2 = nullptr; p.ws2 = nullptr;
@@ -1666,7 +1752,11 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
         p.w = (const uint8_t*)W[JH_W_DOWN].data; p.ws = W[JH_W_DOWN].scales; p.nrows = E; p.out = out;
         p.K = H; p.ldb = H / 2; p.ldbf = H / QB;
         p.x = s->hf; p.resid = resid;
-        if (c.weight_dtype == JH_DT_BF16) {
+        if (c.weight_dtype == JH_DT_BF16 && s->strict) {
+            JHCHK(use_p16t(p, W[JH_W_DOWN]));
+            if (resid) JHCHK((launch_gemv_bf16r<PROB_QUANT_BF16, EPI_RESID, false>(p, nullptr, st)));
+            else JHCHK((launch_gemv_bf16r<PROB_QUANT_BF16, EPI_STORE, false>(p, nullptr, st)));
+        } else if (c.weight_dtype == JH_DT_BF16) {
             p.ldb = H * 2;
             if (resid) JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_RESID, false>(p, g_cu_count * 4, nullptr, st)));
             else JHCHK((launch_gemv_bf16<PROB_QUANT_BF16, EPI_STORE, false>(p, g_cu_count * 4, nullptr, st)));
@@ -1706,7 +1796,7 @@ constexpr int PF_MAX_SPLIT = 8;    // key-range splits of the MFMA prefill atten
 
 // reference-order sessions: prompt rows through the M-row p16 GEMM (jh_p16.h) -- whole groups of 16 Q blocks in every K
 bool prefill_p16_ok(jh_session* s) {
-    static const int enabled = opt_int("JH_P16_PREFILL", 1);
+    const int enabled = opt_int("JH_P16_PREFILL", 1);
     const jh_config& c = s->m->c;
     if (!enabled || !s->strict || c.weight_dtype != JH_DT_Q4) return false;
     const int hs = c.head_size, A = c.n_heads * hs, group = c.n_heads / c.n_kv_heads;
@@ -1715,15 +1805,24 @@ bool prefill_p16_ok(jh_session* s) {
 }
 // ... and through the F16-MFMA form of that GEMM (jh_t16.h: gemm_t16_kernel) when every projection has whole T16 tiles
 bool prefill_t16_ok(jh_session* s) {
-    static const int enabled = opt_int("JH_T16_PREFILL", 1);
+    const int enabled = opt_int("JH_T16_PREFILL", 1);
     const jh_config& c = s->m->c;
     if (!enabled || !prefill_p16_ok(s)) return false;                 // E, H, A are multiples of 512 (whole chunks of 16 blocks)
     const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs;
     return (A + 2 * KV) % 16 == 0 && c.embedding_length % 16 == 0 && c.hidden_length % 8 == 0 && t16_shape_ok(c.embedding_length);
 }
+// reference-order BF16 sessions: prompt rows through gemm_bf16r_kernel (jh_bf16r.h) -- whole pairs of 128-element groups in every K
+bool prefill_bf16r_ok(jh_session* s) {
+    const jh_config& c = s->m->c;
+    if (!opt_int("JH_BF16R_PREFILL", 1) || !s->strict || c.weight_dtype != JH_DT_BF16) return false;
+    const int hs = c.head_size, A = c.n_heads * hs, group = c.n_heads / c.n_kv_heads;
+    if (c.embedding_length % 256 || c.hidden_length % 256 || A % 256) return false;
+    return (hs == 128 || hs == 64) && (group == 1 || group == 2 || group == 4 || group == 8);
+}
 bool prefill_batch_ok(jh_session* s) {
     const jh_config& c = s->m->c;
     if (s->prefill_batch_min <= 0 || s->tap_layer >= 0) return false;
+    if (s->strict && c.weight_dtype == JH_DT_BF16) return prefill_bf16r_ok(s);
     if (s->strict) return prefill_t16_ok(s);
     if (c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16) return false;
     const int hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, group = c.n_heads / c.n_kv_heads;
@@ -1768,7 +1867,7 @@ int prefill_alloc(jh_session* s) {
 }
 // The prefill GEMM wants both operands in MFMA order (gemm_q8q4_tile_kernel, TILED): possible when K % 128 == 0
 bool prefill_tiled(jh_session* s, int K) {
-    static const int enabled = opt_int("JH_PREFILL_TILED", 1);
+    const int enabled = opt_int("JH_PREFILL_TILED", 1);
     const int nblk = K / QB;
     if (s->m->c.weight_dtype == JH_DT_BF16) return enabled && (K % 32) == 0;
     return enabled && s->m->c.weight_dtype == JH_DT_Q4 && nblk % 8 == 0 && (size_t)nblk * 128 <= 150 * 1024;
@@ -2125,6 +2224,23 @@ int prefill_attn_p16_launch(jh_session* s, int rel, int rows, int start_pos, hip
 // the two halves of a layer in reference order: pair sums on the F16 MFMA (gemm_t16_kernel), same chains and bits as the GEMVs
 int prefill_p16_operands(jh_session* s) {
     const jh_config& c = s->m->c;
+    if (c.weight_dtype == JH_DT_BF16) {
+        if (!prefill_bf16r_ok(s))
+            return set_err(JH_ERR_UNSUPPORTED, "reference-order prompt chunk: the model's shapes do not fit the BF16 M-row GEMM (rows go one at a time)");
+        if (!s->pb_bfr) {
+            const int E = c.embedding_length, H = c.hidden_length, A = c.n_heads * c.head_size;
+            int kmax = E > H ? E : H;
+            if (A > kmax) kmax = A;
+            const size_t bytes = bfr_image_floats(PB_MAX_ROWS, kmax) * 4;
+            if (hipMalloc((void**)&s->pb_bfr, bytes) != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc prompt activation image");
+            HIPCHK(hipMemsetAsync(s->pb_bfr, 0, bytes, s->stream));   // rows past a ragged last tile are read (never stored): keep them finite
+        }
+        if (!s->p16_scores_b) {
+            const hipError_t e = hipMalloc(&s->p16_scores_b, (size_t)PB_MAX_ROWS * c.n_heads * ((size_t)s->p16_sc_stride + 2) * 4);
+            if (e != hipSuccess) return set_err(JH_ERR_OOM, "hipMalloc score rows of a prompt chunk");
+        }
+        return JH_OK;
+    }
     if (!prefill_t16_ok(s))
         return set_err(JH_ERR_UNSUPPORTED, "reference-order prompt chunk: the model's shapes do not fit the T16 GEMM (rows go one at a time)");
     if (!s->pb_sel) {
@@ -2167,9 +2283,62 @@ int prefill_ffn_half_p16(jh_session* s, int li, int rows, const float* x1, float
     if (resid) return gemm_t16_launch<EPI_RESID>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rows, out, E, resid, E, st);
     return gemm_t16_launch<EPI_STORE>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rows, out, E, nullptr, 0, st);
 }
+// ---- the same two halves for a dense BF16 model in reference order (jh_bf16r.h): activation image per projection input, M-row chains
+template <int PRO>
+int rows_act_bf16r_launch(jh_session* s, const float* x, int ldx, const float* x2, int ldx2, const float* nw, float eps, int K, int rows, hipStream_t st) {
+    RowsBfrParams rp{x, ldx, x2, ldx2, nw, eps, K, s->pb_bfr};
+    hipLaunchKernelGGL((rows_act_bf16r_kernel<PRO>), dim3(rows), dim3(256), 0, st, rp);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+template <int EPI>
+int gemm_bf16r_launch(jh_session* s, const JWeight& W, int N, int K, int rows, float* out, int ldc, const float* resid, int ldr, hipStream_t st) {
+    if (!W.p16t) return set_err(JH_ERR_INVALID, "reference-order GEMM: the weight has no BF16T copy (ensure_strict_operands)");
+    const int nslices = (N + 63) / 64, nrt = (rows + BFR_MR - 1) / BFR_MR;
+    GemmBfrParams g{W.p16t, (int)bf16t_row_bytes(K), N, K, rows, s->pb_bfr, out, ldc, resid, ldr, nslices, nrt};
+    const size_t lds = lds_bytes_gemm_bf16r();
+    JHCHK(allow_lds((gemm_bf16r_kernel<EPI>), lds));
+    const int grid = ((nslices + 7) / 8) * 8 * nrt;
+    hipLaunchKernelGGL((gemm_bf16r_kernel<EPI>), dim3(grid), dim3(BFR_WAVES * 64), lds, st, g);
+    HIPCHK(hipGetLastError());
+    return JH_OK;
+}
+int prefill_attn_half_bf16r(jh_session* s, int li, int rows, int start_pos, float* out, const float* resid, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int E = c.embedding_length, hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    JHCHK(prefill_weights_set(s, li));
+    JHCHK((rows_act_bf16r_launch<PROB_RMS_BF16>(s, s->pb_x, E, nullptr, 0, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
+    JHCHK((gemm_bf16r_launch<EPI_STORE>(s, m->qkv[(size_t)li], A + 2 * KV, E, rows, s->pb_qkv, A + 2 * KV, nullptr, 0, st)));
+    JHCHK(prefill_attn_p16_launch(s, li - c.layer_start, rows, start_pos, st));
+    JHCHK((rows_act_bf16r_launch<PROB_QUANT_BF16>(s, s->pb_att, A, nullptr, 0, nullptr, 0.f, A, rows, st)));
+    if (resid) return gemm_bf16r_launch<EPI_RESID>(s, W[JH_W_O], E, A, rows, out, E, resid, E, st);
+    return gemm_bf16r_launch<EPI_STORE>(s, W[JH_W_O], E, A, rows, out, E, nullptr, 0, st);
+}
+int prefill_ffn_half_bf16r(jh_session* s, int li, int rows, const float* x1, float* out, const float* resid, hipStream_t st) {
+    jh_model* m = s->m;
+    const jh_config& c = m->c;
+    const int E = c.embedding_length, H = c.hidden_length;
+    JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+    JHCHK((rows_act_bf16r_launch<PROB_RMS_BF16>(s, x1, E, nullptr, 0, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
+    JHCHK((gemm_bf16r_launch<EPI_STORE>(s, W[JH_W_GATE], H, E, rows, s->pb_g, H, nullptr, 0, st)));
+    JHCHK((gemm_bf16r_launch<EPI_STORE>(s, W[JH_W_UP], H, E, rows, s->pb_u, H, nullptr, 0, st)));
+    JHCHK((rows_act_bf16r_launch<PROB_SILU_BF16>(s, s->pb_g, H, s->pb_u, H, nullptr, 0.f, H, rows, st)));   // silu(gate) * up, rounded to BF16
+    if (resid) return gemm_bf16r_launch<EPI_RESID>(s, W[JH_W_DOWN], E, H, rows, out, E, resid, E, st);
+    return gemm_bf16r_launch<EPI_STORE>(s, W[JH_W_DOWN], E, H, rows, out, E, nullptr, 0, st);
+}
 int prefill_layers_p16(jh_session* s, int rows, int start_pos, hipStream_t st) {
     const jh_config& c = s->m->c;
     JHCHK(prefill_p16_operands(s));
+    if (c.weight_dtype == JH_DT_BF16) {
+        for (int li = c.layer_start; li < c.layer_end; li++) {
+            JHCHK(prefill_attn_half_bf16r(s, li, rows, start_pos, s->pb_x1, s->pb_x, st));
+            JHCHK(prefill_ffn_half_bf16r(s, li, rows, s->pb_x1, s->pb_x, s->pb_x1, st));
+            JHCHK(trace_sync("prefill layer (reference order, BF16)", st));
+        }
+        return JH_OK;
+    }
     for (int li = c.layer_start; li < c.layer_end; li++) {
         JHCHK(prefill_attn_half_p16(s, li, rows, start_pos, s->pb_x1, s->pb_x, st));
         JHCHK(prefill_ffn_half_p16(s, li, rows, s->pb_x1, s->pb_x, s->pb_x1, st));
@@ -2204,7 +2373,7 @@ int prefill_chunk(jh_session* s, const int32_t* tokens, const float* x_in, bool 
     while (bound < start_pos + rows) bound *= 2;
     const bool attn_mfma = prefill_attn_mfma(s, start_pos, rows);
     if (!attn_mfma && !prefill_chunk_fits(s, 0, bound)) bound = start_pos + rows;
-    static const int use_graph = opt_int("JH_PREFILL_GRAPH", 1);
+    const int use_graph = opt_int("JH_PREFILL_GRAPH", 1);
     if (p16) {
         JHCHK(prefill_layers_p16(s, rows, start_pos, st));   // positions are launch arguments here: launched directly, no graph
     } else if (use_graph && !opt_int("JH_TRACE", 0)) {
@@ -2254,7 +2423,10 @@ int lmhead_launch(jh_session* s, hipStream_t st) {
     p.eps = c.rms_eps;
     p.amax_part = s->amax_v; p.amax_idx = s->amax_i;
     int grid = 0;
-    if (w->dtype == JH_DT_BF16) {
+    if (w->dtype == JH_DT_BF16 && s->strict) {
+        JHCHK(use_p16t(p, *w));
+        JHCHK((launch_gemv_bf16r<PROB_RMS_F32, EPI_STORE, true>(p, &grid, st)));       // F32 x BF16 in GemmerF32BF16's order (PTO:1511-1538)
+    } else if (w->dtype == JH_DT_BF16) {
         p.ldb = p.K * 2;
         JHCHK((launch_gemv_bf16<PROB_RMS_F32, EPI_STORE, true>(p, 4096, &grid, st)));   // F32 x BF16 (GemmerF32BF16)
     } else if (s->strict) {
@@ -2466,7 +2638,7 @@ int64_t jh_model_tiled_bytes(jh_model* m) {
     auto add = [&](const JWeight& w) {
         if (w.tiled) b += (int64_t)(tiled_w_bytes(w) + (w.tiled_scales ? tiled_s_bytes(w) : 0));
         if (w.t16) b += (int64_t)(t16_w_bytes(w.rows, w.cols) + t16_s_bytes(w.rows, w.cols));
-        if (w.p16t) b += (int64_t)((size_t)w.rows * p16t_row_bytes(w.cols));
+        if (w.p16t) b += (int64_t)((size_t)w.rows * (w.dtype == JH_DT_BF16 ? bf16t_row_bytes(w.cols) : p16t_row_bytes(w.cols)));
     };
     for (const JWeight& w : m->layer_w) add(w);
     for (const JWeight& w : m->qkv) add(w);
@@ -2591,7 +2763,7 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     JHCHK(ensure_out_tokens(s, max_ctx));
     s->p16_sc_stride = (max_ctx + 63) & ~63;
     HIPCHK(hipMalloc(&s->p16_scores, (size_t)c.n_heads * s->p16_sc_stride * 4));
-    if (s->strict && c.weight_dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "JH_STRICT_ORDER: strict-order kernels exist for JQ4 models only");
+    if (s->strict && c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16) return set_err(JH_ERR_UNSUPPORTED, "JH_STRICT_ORDER: reference-order kernels exist for JQ4 and BF16 models");
     if (!s->strict && prefill_batch_ok(s)) {
         // the MFMA-ordered weight copies of the prefill GEMM are made here, once per model, not inside the first prompt
         JHCHK(ensure_all_tiled(s, s->stream));
@@ -2601,7 +2773,7 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
 }
 int jh_session_set_strict(jh_session* s, int on) {
     if (!s) return set_err(JH_ERR_INVALID, "set_strict: null");
-    if (on && s->m->c.weight_dtype != JH_DT_Q4) return set_err(JH_ERR_UNSUPPORTED, "set_strict: strict-order kernels exist for JQ4 models only");
+    if (on && s->m->c.weight_dtype != JH_DT_Q4 && s->m->c.weight_dtype != JH_DT_BF16) return set_err(JH_ERR_UNSUPPORTED, "set_strict: reference-order kernels exist for JQ4 and BF16 models");
     HIPCHK(hipSetDevice(s->m->device));
     if ((on ? 1 : 0) != s->strict) {
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -2649,7 +2821,7 @@ int jh_session_destroy(jh_session* s) {
                     s->amax_v, s->amax_i, s->part_o, s->part_ml, s->counters, s->st, s->out_tokens};
     for (void* b : bufs) if (b) hipFree(b);
     for (float* t : s->taps) if (t) hipFree(t);
-    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start, (void*)s->pb_att_o, (void*)s->pb_att_ml, (void*)s->tile_w, (void*)s->tile_s, (void*)s->p16_scores_b, (void*)s->pb_sel, (void*)s->pb_sad}) if (b) hipFree(b);
+    for (void* b : {(void*)s->pb_x, (void*)s->pb_x1, (void*)s->pb_qkv, (void*)s->pb_att, (void*)s->pb_g, (void*)s->pb_ad, (void*)s->pb_aq, (void*)s->pb_tok, (void*)s->pb_ws, (void*)s->pb_start, (void*)s->pb_att_o, (void*)s->pb_att_ml, (void*)s->tile_w, (void*)s->tile_s, (void*)s->p16_scores_b, (void*)s->pb_sel, (void*)s->pb_sad, (void*)s->pb_bfr}) if (b) hipFree(b);
     for (auto& kv : s->pb_graphs) hipGraphExecDestroy(kv.second);
     for (hipGraph_t g : s->pb_graph_src) hipGraphDestroy(g);
     if (s->ev0) hipEventDestroy(s->ev0);
@@ -3065,6 +3237,7 @@ int jh_tp_attn_rows(jh_session* s, int layer, float* partial_out_dev) {
         return set_err(JH_ERR_INVALID, "tp_attn_rows: bad argument (jh_tp_set_rows first)");
     HIPCHK(hipSetDevice(s->m->device));
     const int rows = s->tp_rows, pos0 = s->tp_pos0;
+    if (s->strict && s->m->c.weight_dtype == JH_DT_BF16) return prefill_attn_half_bf16r(s, layer, rows, pos0, partial_out_dev, nullptr, s->stream);
     if (s->strict) return prefill_attn_half_p16(s, layer, rows, pos0, partial_out_dev, nullptr, s->stream);
     int bound = 1024;
     while (bound < pos0 + rows) bound *= 2;
@@ -3080,6 +3253,7 @@ int jh_tp_ffn_rows(jh_session* s, int layer, const float* reduced_attn_dev, floa
     // residual (TransformerBlock.java:185) after the reduction: x1 = x + sum_shards(o-proj partial), every row of the chunk
     hipLaunchKernelGGL(add_rows_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s->stream, (const float*)s->pb_x, reduced_attn_dev, s->pb_x1, cnt);
     HIPCHK(hipGetLastError());
+    if (s->strict && s->m->c.weight_dtype == JH_DT_BF16) return prefill_ffn_half_bf16r(s, layer, s->tp_rows, s->pb_x1, partial_out_dev, nullptr, s->stream);
     if (s->strict) return prefill_ffn_half_p16(s, layer, s->tp_rows, s->pb_x1, partial_out_dev, nullptr, s->stream);
     return prefill_ffn_half(s, layer, s->tp_rows, s->pb_x1, partial_out_dev, nullptr, s->stream);
 }
@@ -3750,7 +3924,7 @@ int jh_tp_group_decode_n(jh_tp_group* g, int32_t first_token, int start_pos, int
     HIPCHK(hipSetDevice(s0->m->device));
     JHCHK(ensure_out_tokens(s0, n));
     const int E = s0->m->c.embedding_length;
-    static const int tp_graph = opt_int("JH_TP_GRAPH", 1);
+    const int tp_graph = opt_int("JH_TP_GRAPH", 1);
     if (tp_graph && g->graph_ok) {
         // ---- one graph replay per shard and token, the shards meet in kernels (tp_build_graph)
         for (int v = 0; v < N_ATTN_VARIANTS; v++)
@@ -4036,6 +4210,12 @@ int jh_tp_rank_signature(jh_tp_group* g, int64_t* out) {
     mix((uint64_t)g_cu_count); mix((uint64_t)s->strict); mix((uint64_t)opt_int("JH_TP_FUSE", 1)); mix((uint64_t)c.weight_dtype);
     mix((uint64_t)c.embedding_length); mix((uint64_t)c.n_layers); mix((uint64_t)(c.n_heads * c.head_size)); mix((uint64_t)c.hidden_length);
     mix((uint64_t)g->sh.size());
+    // what shapes the o-proj / down launches, i.e. the number of flag words a producer raises and a consumer polls: the launch
+    // planners' inputs (explicit options land in these), the kernel family switches, and -- once the token graphs exist -- the
+    // planned flag counts themselves
+    for (const LaunchCfg* lc : {&s->cfg_o, &s->cfg_down}) { mix((uint64_t)lc->R); mix((uint64_t)lc->waves); mix((uint64_t)lc->grid_cap); mix((uint64_t)lc->pipe); }
+    mix((uint64_t)s->p16_depth); mix((uint64_t)opt_int("JH_T16", 1));
+    mix((uint64_t)(g->plan_flags[0] + 1)); mix((uint64_t)(g->plan_flags[1] + 1));
     *out = (int64_t)(h & 0x7fffffffffffffffull);
     return JH_OK;
 }

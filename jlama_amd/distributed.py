@@ -19,6 +19,8 @@ import time
 
 import numpy as np
 
+from ._native import UnsupportedOperation
+
 
 def layer_range(rank, world, n_layers):
     """DistributedContext layer split: contiguous, equal ranges (requires n_layers % world == 0)."""
@@ -421,7 +423,17 @@ def tp_forward_prompt(dist, engine, prompt, start_pos, layers, cfg, device, dtyp
             rows = min(cap, n - done)
             part = rows_buf[:rows]
             with engine.stream_context():
-                engine.set_rows(np.asarray(prompt[done:done + rows], dtype=np.int32), start_pos + done)
+                # a shard can refuse a chunk it has no batched path for at THIS position (jh_tp_set_rows: JH_ERR_UNSUPPORTED, e.g. the
+                # per-row attention kernel's score rows outgrow LDS); every rank must then take the row loop, so the verdict is MIN-reduced
+                try:
+                    engine.set_rows(np.asarray(prompt[done:done + rows], dtype=np.int32), start_pos + done)
+                    fits = 1
+                except UnsupportedOperation:
+                    fits = 0
+                ok = torch.tensor([fits], dtype=torch.int32, device=device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    break
                 for li in range(*layers):
                     engine.attn_rows(li, part)
                     dist.all_reduce(part, op=dist.ReduceOp.SUM)

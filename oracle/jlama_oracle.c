@@ -370,44 +370,161 @@ void jo_gemm_f32(const float* a, int lda, const float* b, int ldb, float* r, int
 
 /* BF16 x BF16 -> F32, GemmerBF16 1x1 PTO:1279-1311: per 32-element step lanes t<16 take
  * elements t then t+16 (convertShape part 0 / part 1), both operands widened by <<16. */
-void jo_gemm_bf16(const uint16_t* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
-                  int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+static inline float jo_dot_bf16_scalar(const uint16_t* ap, const uint16_t* bp, int K) {
+    float acc[16];
+    for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+    for (int l = 0; l < K; l += 32) {
+        for (int t = 0; t < 16; t++)
+            acc[t] = fmaf(jo_bf16_to_f32(ap[l + t]), jo_bf16_to_f32(bp[l + t]), acc[t]);
+        for (int t = 0; t < 16; t++)
+            acc[t] = fmaf(jo_bf16_to_f32(ap[l + 16 + t]), jo_bf16_to_f32(bp[l + 16 + t]), acc[t]);
+    }
+    return jo_reduce16(acc);
+}
+/* F32 x BF16 -> F32, GemmerF32BF16 1x1 PTO:1511-1538. */
+static inline float jo_dot_f32bf16_scalar(const float* ap, const uint16_t* bp, int K) {
+    float acc[16];
+    for (int t = 0; t < 16; t++) acc[t] = 0.0f;
+    for (int l = 0; l < K; l += 32) {
+        for (int t = 0; t < 16; t++) acc[t] = fmaf(ap[l + t], jo_bf16_to_f32(bp[l + t]), acc[t]);
+        for (int t = 0; t < 16; t++) acc[t] = fmaf(ap[l + 16 + t], jo_bf16_to_f32(bp[l + 16 + t]), acc[t]);
+    }
+    return jo_reduce16(acc);
+}
+#if JO_SIMD
+/* same lanes, same order: lanes 0..7 in acc0, 8..15 in acc1; widening = zero-extend to 32 bits, shift left 16 */
+static inline __m256 jo_widen8_bf16(const uint16_t* p) {
+    return _mm256_castsi256_ps(_mm256_slli_epi32(_mm256_cvtepu16_epi32(_mm_loadu_si128((const __m128i*)p)), 16));
+}
+static inline float jo_dot_bf16_simd(const uint16_t* ap, const uint16_t* bp, int K) {
+    __m256 acc0 = _mm256_setzero_ps(), acc1 = _mm256_setzero_ps();
+    for (int l = 0; l < K; l += 32) {
+        acc0 = _mm256_fmadd_ps(jo_widen8_bf16(ap + l), jo_widen8_bf16(bp + l), acc0);
+        acc1 = _mm256_fmadd_ps(jo_widen8_bf16(ap + l + 8), jo_widen8_bf16(bp + l + 8), acc1);
+        acc0 = _mm256_fmadd_ps(jo_widen8_bf16(ap + l + 16), jo_widen8_bf16(bp + l + 16), acc0);
+        acc1 = _mm256_fmadd_ps(jo_widen8_bf16(ap + l + 24), jo_widen8_bf16(bp + l + 24), acc1);
+    }
+    float acc[16];
+    _mm256_storeu_ps(acc, acc0);
+    _mm256_storeu_ps(acc + 8, acc1);
+    return jo_reduce16(acc);
+}
+static inline float jo_dot_f32bf16_simd(const float* ap, const uint16_t* bp, int K) {
+    __m256 acc0 = _mm256_setzero_ps(), acc1 = _mm256_setzero_ps();
+    for (int l = 0; l < K; l += 32) {
+        acc0 = _mm256_fmadd_ps(_mm256_loadu_ps(ap + l), jo_widen8_bf16(bp + l), acc0);
+        acc1 = _mm256_fmadd_ps(_mm256_loadu_ps(ap + l + 8), jo_widen8_bf16(bp + l + 8), acc1);
+        acc0 = _mm256_fmadd_ps(_mm256_loadu_ps(ap + l + 16), jo_widen8_bf16(bp + l + 16), acc0);
+        acc1 = _mm256_fmadd_ps(_mm256_loadu_ps(ap + l + 24), jo_widen8_bf16(bp + l + 24), acc1);
+    }
+    float acc[16];
+    _mm256_storeu_ps(acc, acc0);
+    _mm256_storeu_ps(acc + 8, acc1);
+    return jo_reduce16(acc);
+}
+#endif
+#if JO_SIMD
+/* four weight rows at a time: the activation widening is shared and eight independent fma chains keep the FMA ports busy;
+ * every row still is exactly jo_dot_*_simd (same lanes, same order) */
+#define JO_DOT4_BODY(LOADA)                                                                                   \
+    __m256 c0[4], c1[4];                                                                                      \
+    for (int q = 0; q < 4; q++) { c0[q] = _mm256_setzero_ps(); c1[q] = _mm256_setzero_ps(); }                 \
+    for (int l = 0; l < K; l += 32) {                                                                         \
+        const __m256 a0 = LOADA(ap + l), a1 = LOADA(ap + l + 8), a2 = LOADA(ap + l + 16), a3 = LOADA(ap + l + 24); \
+        for (int q = 0; q < 4; q++) {                                                                         \
+            const uint16_t* bp = b4[q] + l;                                                                   \
+            c0[q] = _mm256_fmadd_ps(a0, jo_widen8_bf16(bp), c0[q]);                                           \
+            c1[q] = _mm256_fmadd_ps(a1, jo_widen8_bf16(bp + 8), c1[q]);                                       \
+            c0[q] = _mm256_fmadd_ps(a2, jo_widen8_bf16(bp + 16), c0[q]);                                      \
+            c1[q] = _mm256_fmadd_ps(a3, jo_widen8_bf16(bp + 24), c1[q]);                                      \
+        }                                                                                                     \
+    }                                                                                                         \
+    for (int q = 0; q < 4; q++) {                                                                             \
+        float acc[16];                                                                                        \
+        _mm256_storeu_ps(acc, c0[q]);                                                                         \
+        _mm256_storeu_ps(acc + 8, c1[q]);                                                                     \
+        out[q] = jo_reduce16(acc);                                                                            \
+    }
+static inline void jo_dot4_bf16_simd(const uint16_t* ap, const uint16_t* const* b4, int K, float* out) { JO_DOT4_BODY(jo_widen8_bf16) }
+static inline void jo_dot4_f32bf16_simd(const float* ap, const uint16_t* const* b4, int K, float* out) { JO_DOT4_BODY(_mm256_loadu_ps) }
+#endif
+static void jo_gemm_bf16_impl(int simd, const uint16_t* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
+                              int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+    (void)simd;
+#if JO_SIMD
+    if (simd && N >= 4) {
+        const int N4 = N & ~3;
+#pragma omp parallel for schedule(static) if (N >= 512)
+        for (int j = bRowOff; j < bRowOff + N4; j += 4) {
+            const uint16_t* b4[4];
+            for (int q = 0; q < 4; q++) b4[q] = b + (int64_t)(j + q) * ldb + bColOff;
+            for (int i = 0; i < M; i++) {
+                float o4[4];
+                jo_dot4_bf16_simd(a + (int64_t)i * lda + aColOff, b4, K, o4);
+                for (int q = 0; q < 4; q++) r[(int64_t)i * ldc + j + q + rRowOff] = o4[q];
+            }
+        }
+        bRowOff += N4; N -= N4;
+    }
+#endif
 #pragma omp parallel for schedule(static) if (N >= 512)
     for (int j = bRowOff; j < bRowOff + N; j++) {
         for (int i = 0; i < M; i++) {
-            float acc[16];
-            for (int t = 0; t < 16; t++) acc[t] = 0.0f;
             const uint16_t* ap = a + (int64_t)i * lda + aColOff;
             const uint16_t* bp = b + (int64_t)j * ldb + bColOff;
-            for (int l = 0; l < K; l += 32) {
-                for (int t = 0; t < 16; t++)
-                    acc[t] = fmaf(jo_bf16_to_f32(ap[l + t]), jo_bf16_to_f32(bp[l + t]), acc[t]);
-                for (int t = 0; t < 16; t++)
-                    acc[t] = fmaf(jo_bf16_to_f32(ap[l + 16 + t]), jo_bf16_to_f32(bp[l + 16 + t]), acc[t]);
-            }
-            r[(int64_t)i * ldc + j + rRowOff] = jo_reduce16(acc);
+#if JO_SIMD
+            if (simd) { r[(int64_t)i * ldc + j + rRowOff] = jo_dot_bf16_simd(ap, bp, K); continue; }
+#endif
+            r[(int64_t)i * ldc + j + rRowOff] = jo_dot_bf16_scalar(ap, bp, K);
         }
     }
 }
-
-/* F32 x BF16 -> F32, GemmerF32BF16 1x1 PTO:1511-1538. */
-void jo_gemm_f32bf16(const float* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
-                     int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+void jo_gemm_bf16(const uint16_t* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
+                  int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+    jo_gemm_bf16_impl(1, a, lda, b, ldb, r, ldc, M, aColOff, bColOff, K, rRowOff, bRowOff, N);
+}
+void jo_gemm_bf16_scalar(const uint16_t* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
+                         int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+    jo_gemm_bf16_impl(0, a, lda, b, ldb, r, ldc, M, aColOff, bColOff, K, rRowOff, bRowOff, N);
+}
+static void jo_gemm_f32bf16_impl(int simd, const float* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
+                                 int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+    (void)simd;
+#if JO_SIMD
+    if (simd && N >= 4) {
+        const int N4 = N & ~3;
+#pragma omp parallel for schedule(static) if (N >= 512)
+        for (int j = bRowOff; j < bRowOff + N4; j += 4) {
+            const uint16_t* b4[4];
+            for (int q = 0; q < 4; q++) b4[q] = b + (int64_t)(j + q) * ldb + bColOff;
+            for (int i = 0; i < M; i++) {
+                float o4[4];
+                jo_dot4_f32bf16_simd(a + (int64_t)i * lda + aColOff, b4, K, o4);
+                for (int q = 0; q < 4; q++) r[(int64_t)i * ldc + j + q + rRowOff] = o4[q];
+            }
+        }
+        bRowOff += N4; N -= N4;
+    }
+#endif
 #pragma omp parallel for schedule(static) if (N >= 512)
     for (int j = bRowOff; j < bRowOff + N; j++) {
         for (int i = 0; i < M; i++) {
-            float acc[16];
-            for (int t = 0; t < 16; t++) acc[t] = 0.0f;
             const float* ap = a + (int64_t)i * lda + aColOff;
             const uint16_t* bp = b + (int64_t)j * ldb + bColOff;
-            for (int l = 0; l < K; l += 32) {
-                for (int t = 0; t < 16; t++) acc[t] = fmaf(ap[l + t], jo_bf16_to_f32(bp[l + t]), acc[t]);
-                for (int t = 0; t < 16; t++)
-                    acc[t] = fmaf(ap[l + 16 + t], jo_bf16_to_f32(bp[l + 16 + t]), acc[t]);
-            }
-            r[(int64_t)i * ldc + j + rRowOff] = jo_reduce16(acc);
+#if JO_SIMD
+            if (simd) { r[(int64_t)i * ldc + j + rRowOff] = jo_dot_f32bf16_simd(ap, bp, K); continue; }
+#endif
+            r[(int64_t)i * ldc + j + rRowOff] = jo_dot_f32bf16_scalar(ap, bp, K);
         }
     }
+}
+void jo_gemm_f32bf16(const float* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
+                     int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+    jo_gemm_f32bf16_impl(1, a, lda, b, ldb, r, ldc, M, aColOff, bColOff, K, rRowOff, bRowOff, N);
+}
+void jo_gemm_f32bf16_scalar(const float* a, int lda, const uint16_t* b, int ldb, float* r, int ldc, int M,
+                            int aColOff, int bColOff, int K, int rRowOff, int bRowOff, int N) {
+    jo_gemm_f32bf16_impl(0, a, lda, b, ldb, r, ldc, M, aColOff, bColOff, K, rRowOff, bRowOff, N);
 }
 
 /* The control implementation, NaiveTensorOperations.java:61-100: float s += a.get()*b.get()

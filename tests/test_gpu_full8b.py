@@ -2,7 +2,8 @@
 synthetic weights generated on the GPU and copied to the host bit for bit).
 
 What is asserted (bench.py prints the same block as `parity_full_size` on the metric's 256-step run):
-  * STRICT ORDER: prompt + 96 free-running greedy steps -- ids identical to the Panama-order oracle's, logits equal;
+  * STRICT ORDER: the metric's 129-row prompt (one batched reference-order prefill, AbstractModel.java:549-555) + 96 free-running
+    greedy steps -- ids identical to the Panama-order oracle's, logits equal;
   * the fast kernels' teacher-forced logits sit inside (a small multiple of) the envelope spanned by the reference's OWN
     two CPU providers: the Panama-order restatement vs the reference's compiled C SIMD GEMM (oracle/_ref);
   * every one of the 32 layers in isolation (oracle layer l fed the GPU's input rows of layer l): strict order
@@ -13,7 +14,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N_PROMPT, N_FREE, N_TF = 8, 96, 16
+N_PROMPT, N_FREE, N_TF = 129, 96, 16   # the metric's own prompt: 128 ids + BOS through the batched reference-order prefill
 
 
 @pytest.fixture(scope="module")

@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N_PROMPT, N_FREE, N_TF = 8, 16, 16
+N_PROMPT, N_FREE, N_TF = 8, 64, 16
 
 
 @pytest.fixture(scope="module")
@@ -36,7 +36,17 @@ def test_full_size_bf16_logits_and_ids(mistral, oracle):
     cfg, model, host_w = mistral
     par, ids_o = bench.full_size_parity(cfg, model, host_w, N_PROMPT, N_FREE, N_TF)
     print("parity_full_size (Mistral-7B BF16):", par)
+    # REFERENCE ORDER (jh_bf16r.h: GemmerBF16's 16 chains per weight row, halving tree): no tolerance -- every free-running greedy
+    # id equals the oracle's, the logits of every compared step and of the last step are bit-identical
+    st = par["strict_order"]
+    assert st["n_ids"] == N_FREE + 1
+    assert st["ids_equal"] == st["n_ids"], st
+    assert st["logits_vs_panama_oracle"]["max"] == 0.0, st
+    assert st["last_step_logits_max_abs_diff"] == 0.0, st
+    # ORDER-FREE kernels (what the timed decode of the BF16 bench line runs), stated in ABSOLUTE terms: logit scale ~5.3, measured
+    # max |dlogit| 0.036 after 32 layers.
     tf = par["teacher_forced_logits_vs_oracle"]
+    assert tf["max"] <= 0.06, par
     # Measured: 7e-3 of the logit scale after 32 layers.  It is not F32 summation order alone (1e-6): the BF16 rounding of the
     # activations (FloatConversions.float32ToBFloat16, 4 times per layer) is a step function like the Q8 quantizer's, with a
     # step of 2^-8 relative -- an element whose F32 value sits within summation-order distance of a rounding boundary flips
@@ -45,7 +55,9 @@ def test_full_size_bf16_logits_and_ids(mistral, oracle):
     # the others; the end-to-end bar is therefore the Q8 path's 1e-2 (BASELINE north_star), with ids equal.
     assert tf["max_rel_to_logit_scale"] <= 1e-2, par
     assert par["teacher_forced_argmax_equal"] == par["teacher_forced_steps_compared"], par
-    assert par["free_running_ids_equal_prefix"] == par["free_running_ids_compared"] == N_FREE + 1, par
+    # free-running ids of the order-free kernels: equal until the first near-tie (a flipped BF16 rounding of one activation
+    # element moves a logit by ~1e-2); the reference-order ids above carry the "bit-exact ids" claim
+    assert par["free_running_ids_equal_prefix"] >= 17, par
 
 
 def test_full_size_bf16_every_layer_in_isolation(mistral, oracle):

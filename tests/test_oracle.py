@@ -294,3 +294,15 @@ def test_simd_bodies_equal_the_scalar_text(oracle):
         L.jo_gemm_i8q4(p(aq), p(ad), K, K // 32, p(bn), p(bs), K // 2, K // 32, p(a), N, M, 512, 512, 256, 0, 8, 16)
         L.jo_gemm_i8q4_scalar(p(aq), p(ad), K, K // 32, p(bn), p(bs), K // 2, K // 32, p(b), N, M, 512, 512, 256, 0, 8, 16)
         np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        # dense BF16 (GemmerBF16 / GemmerF32BF16 restated): what makes a full-size Mistral-7B oracle run affordable
+        from jlama_amd import jq4
+        xb, wb = jq4.f32_to_bf16(x), jq4.f32_to_bf16(w)
+        for fast, slow, act in ((L.jo_gemm_bf16, L.jo_gemm_bf16_scalar, xb), (L.jo_gemm_f32bf16, L.jo_gemm_f32bf16_scalar, x)):
+            a[:] = 0; b[:] = 0
+            fast(p(act), K, p(wb), K, p(a), N, M, 0, 0, K, 0, 0, N)
+            slow(p(act), K, p(wb), K, p(b), N, M, 0, 0, K, 0, 0, N)
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+            a[:] = 0; b[:] = 0
+            fast(p(act), K, p(wb), K, p(a), N, M, 512, 512, 256, 0, 8, 16)
+            slow(p(act), K, p(wb), K, p(b), N, M, 512, 512, 256, 0, 8, 16)
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
