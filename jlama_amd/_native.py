@@ -8,11 +8,15 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "lib", "libjlamahip.so")
-SRC = os.path.join(HERE, "csrc", "jlama_hip.hip")
-HDRS = [os.path.join(HERE, "csrc", "jh_kernels.h"), os.path.join(HERE, "csrc", "jh_p16.h"),
-        os.path.join(HERE, "csrc", "jh_t16.h"), os.path.join(HERE, "csrc", "jh_seqsum.h"),
-        os.path.join(HERE, "csrc", "jh_bf16r.h"),
-        os.path.join(ROOT, "include", "jlama_hip.h")]
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
+CSRC = os.path.join(HERE, "csrc")
+# translation units of libjlamahip.so (compiled in parallel, one object each)
+UNITS = ["core", "tier1", "model", "layers", "prefill", "decode", "tp", "pipeline", "probe", "gemm_launch",
+         "gemv_q4_a", "gemv_q4_b", "gemv_q4_c", "gemv_ref", "gemv_bf16"]
+SRCS = [os.path.join(CSRC, u + ".hip") for u in UNITS]
+HDRS = [os.path.join(CSRC, h) for h in ("jh_kernels.h", "jh_p16.h", "jh_t16.h", "jh_seqsum.h", "jh_bf16r.h", "jh_host.h", "jh_launch.h")] + \
+       [os.path.join(ROOT, "include", "jlama_hip.h")]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value"]
 
 JH_OK, JH_ERR_NO_DEVICE, JH_ERR_OOM, JH_ERR_UNSUPPORTED, JH_ERR_INVALID, JH_ERR_HIP = 0, -1, -2, -3, -4, -5
 DT_F32, DT_BF16, DT_I8, DT_Q4 = 0, 1, 2, 3
@@ -42,7 +46,7 @@ class Config(C.Structure):
 def source_hash():
     """sha256 over the library's sources; compiled into the .so (jh_source_hash) so a stale binary is detectable."""
     h = hashlib.sha256()
-    for p in [SRC] + HDRS:
+    for p in SRCS + HDRS:
         with open(p, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:32]
@@ -60,18 +64,51 @@ def built_hash():
     return blob[i + 10:i + 42].decode(errors="replace") if i >= 0 else None
 
 
-def build(force=False, verbose=False):
-    """Compile libjlamahip.so for gfx950 (hipcc cross-compiles without a GPU).  Without `force` the compile is skipped
-    only when the existing binary carries the hash of the current sources (never by timestamps)."""
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+def _unit_key(unit, hdr_digest):
+    h = hashlib.sha256(hdr_digest)
+    with open(os.path.join(CSRC, unit + ".hip"), "rb") as f:
+        h.update(f.read())
+    h.update(" ".join(CFLAGS).encode())
+    return h.hexdigest()[:32]
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile libjlamahip.so for gfx950 (hipcc cross-compiles without a GPU): one object per translation unit, in parallel,
+    then one link.  Without `force` the whole step is skipped only when the existing binary carries the hash of the current
+    sources, and an object is reused only when ITS source, every header and the flags hash to the key stored beside it
+    (never by timestamps).  `force` recompiles every unit."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
     want = source_hash()
     if not force and built_hash() == want:
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wno-unused-value", f'-DJH_SRC_HASH="{want}"', SRC, "-o", LIB_PATH]
+    hd = hashlib.sha256()
+    for p in HDRS:
+        with open(p, "rb") as f:
+            hd.update(f.read())
+    hdr_digest = hd.digest()
+
+    def compile_unit(unit):
+        obj, keyf = os.path.join(OBJ_DIR, unit + ".o"), os.path.join(OBJ_DIR, unit + ".key")
+        key = _unit_key(unit, hdr_digest) + (want if unit == "core" else "")   # core.hip carries the source hash of the whole library
+        if not force and os.path.exists(obj) and os.path.exists(keyf) and open(keyf).read() == key:
+            return unit, False
+        cmd = ["hipcc"] + CFLAGS + ["-c", os.path.join(CSRC, unit + ".hip"), "-o", obj]
+        if unit == "core":
+            cmd.insert(-3, f'-DJH_SRC_HASH="{want}"')
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(keyf, "w") as f:
+            f.write(key)
+        return unit, True
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 4)) as ex:
+        done = list(ex.map(compile_unit, UNITS))
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print("compiled:", [u for u, c in done if c], "reused:", [u for u, c in done if not c], flush=True)
+    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [os.path.join(OBJ_DIR, u + ".o") for u in UNITS]
+    subprocess.check_call(link)
     return LIB_PATH
 
 

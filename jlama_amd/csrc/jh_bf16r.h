@@ -37,7 +37,7 @@ static inline size_t bf16t_row_bytes(int K) { return (size_t)((K + BF16R_GROUP -
 
 // BF16T copy of a row-major BF16 weight [nrows, ldw elements]: one thread per output 16-byte chunk; steps past K hold zeros
 // (never multiplied: the kernels stop at the row's last step).
-__global__ __launch_bounds__(256) void bf16t_pack_kernel(const uint16_t* __restrict__ w, int nrows, int K, int ldw, uint8_t* __restrict__ out) {
+static __global__ __launch_bounds__(256) void bf16t_pack_kernel(const uint16_t* __restrict__ w, int nrows, int K, int ldw, uint8_t* __restrict__ out) {
     const int G = (K + BF16R_GROUP - 1) / BF16R_GROUP;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)nrows * G * 16) return;

@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_mfma_kernel(MfmaGemmPara
         }
 }
 // second pass of a split-K GEMM: C[i][j] = sum_s ws[s][i][j] (ascending K ranges => deterministic) (+ resid)
-__global__ void splitk_reduce_kernel(const float* ws, int nsplit, int m, int n, int n0, float* c, int ldc, int roffset, const float* resid) {
+static __global__ void splitk_reduce_kernel(const float* ws, int nsplit, int m, int n, int n0, float* c, int ldc, int roffset, const float* resid) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)m * n) return;
     const int row = (int)(i / n), col = (int)(i % n);
@@ -1123,7 +1123,7 @@ __global__ void splitk_reduce_kernel(const float* ws, int nsplit, int m, int n, 
     c[idx] = resid ? v + resid[idx] : v;
 }
 // the same sums, four columns per thread (n, ldc, n0 - roffset multiples of 4; 16-byte aligned buffers): grid (n/4 / 256, m)
-__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const f32x4* ws, int nsplit, int m, int n4, f32x4* c, int ldc4, int coff4, const f32x4* resid) {
+static __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const f32x4* ws, int nsplit, int m, int n4, f32x4* c, int ldc4, int coff4, const f32x4* resid) {
     const int col = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
     if (col >= n4) return;
     const size_t i = (size_t)row * n4 + col, stride = (size_t)m * n4;
@@ -1744,14 +1744,14 @@ __global__ __launch_bounds__(CW * S * 64) void gemm_q8q4_lds_kernel(MfmaQ4Params
     }
 }
 
-__global__ void add_rows_kernel(const float* a, const float* b, float* out, int n) {   // out = a + b (residual add)
+static __global__ void add_rows_kernel(const float* a, const float* b, float* out, int n) {   // out = a + b (residual add)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
 }
-__global__ void set_int_kernel(int* p, int v) { *p = v; }
+static __global__ void set_int_kernel(int* p, int v) { *p = v; }
 // tensor-parallel one-shot reduction: a shard's partial [E] goes straight into its slot of EVERY shard's
 // slot buffer (peer stores over xGMI when the destination lives on another device) ...
-__global__ void tp_scatter_kernel(const float* part, float* const* dst, int n_dst, int E) {
+static __global__ void tp_scatter_kernel(const float* part, float* const* dst, int n_dst, int E) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E) return;
     const float v = part[i];
@@ -1759,7 +1759,7 @@ __global__ void tp_scatter_kernel(const float* part, float* const* dst, int n_ds
 }
 // ... and every shard sums the N slots locally, in shard order 0..N-1 (the lock-step order: results never depend on which
 // peer arrived first)
-__global__ void tp_sum_kernel(const float* slots, int n, int E, float* out, size_t stride) {   // stride: floats between two shards' slots
+static __global__ void tp_sum_kernel(const float* slots, int n, int E, float* out, size_t stride) {   // stride: floats between two shards' slots
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E) return;
     float v = slots[i];
@@ -1794,7 +1794,7 @@ __device__ __forceinline__ bool tp_wait_ge(const unsigned* f, unsigned want, uns
     }
     return true;
 }
-__global__ __launch_bounds__(256) void tp_scatter_flag_kernel(const float* part, float* const* dst, unsigned* const* fdst, int n_dst, int E,
+static __global__ __launch_bounds__(256) void tp_scatter_flag_kernel(const float* part, float* const* dst, unsigned* const* fdst, int n_dst, int E,
                                                               const unsigned* seqp, int li, int L) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < E) {
@@ -1808,7 +1808,7 @@ __global__ __launch_bounds__(256) void tp_scatter_flag_kernel(const float* part,
         for (int j = 0; j < n_dst; j++) __hip_atomic_store(fdst[j] + blockIdx.x, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-__global__ __launch_bounds__(256) void tp_sum_wait_kernel(const float* slots, const unsigned* flags, int n, int E, int nwg, unsigned* seqp,
+static __global__ __launch_bounds__(256) void tp_sum_wait_kernel(const float* slots, const unsigned* flags, int n, int E, int nwg, unsigned* seqp,
                                                           int li, int L, const float* resid, float* out) {
     const unsigned seq = *seqp * (unsigned)L + (unsigned)li + 1u;
     if ((int)threadIdx.x < n) tp_wait_ge(flags + (size_t)threadIdx.x * nwg + blockIdx.x, seq, seqp + 1);
@@ -1822,7 +1822,7 @@ __global__ __launch_bounds__(256) void tp_sum_wait_kernel(const float* slots, co
 // the same meeting when the producers were the o-proj / down GEMVs themselves (GemvParams::tp_*): their workgroups own row ranges
 // that depend on the launch plan, so every consumer workgroup waits for ALL nflags workgroup flags of the N producers (a few
 // hundred words polled by 16 workgroups -- not the 256 x 256 of a grid barrier)
-__global__ __launch_bounds__(256) void tp_sum_wait_all_kernel(const float* slots, const unsigned* flags, int n, int E, int nflags, int stride,
+static __global__ __launch_bounds__(256) void tp_sum_wait_all_kernel(const float* slots, const unsigned* flags, int n, int E, int nflags, int stride,
                                                               unsigned* seqp, int li, int L, const float* resid, float* out) {
     const unsigned seq = *seqp * (unsigned)L + (unsigned)li + 1u;
     {   // a thread's flags are polled TOGETHER (independent loads, one memory round trip per sweep), bounded like tp_wait_ge
@@ -1846,7 +1846,7 @@ __global__ __launch_bounds__(256) void tp_sum_wait_all_kernel(const float* slots
     out[i] = resid[i] + v;                                                      // TransformerBlock.java:185 / :203
 }
 // shard 0, after finish_token_kernel: the next row (token, position) to every other shard's mailbox
-__global__ void tp_publish_token_kernel(const DecodeState* st, TPMail* const* mails, int n, const unsigned* seqp) {
+static __global__ void tp_publish_token_kernel(const DecodeState* st, TPMail* const* mails, int n, const unsigned* seqp) {
     if (threadIdx.x >= (unsigned)n) return;
     TPMail* m = mails[threadIdx.x];
     __hip_atomic_store(&m->token, st->token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1855,20 +1855,20 @@ __global__ void tp_publish_token_kernel(const DecodeState* st, TPMail* const* ma
     __hip_atomic_store(&m->seq, *seqp + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the other shards, first node of their token graph: wait for the row of this replay, take it over
-__global__ void tp_wait_token_kernel(const TPMail* mail, unsigned* seqp, DecodeState* st) {
+static __global__ void tp_wait_token_kernel(const TPMail* mail, unsigned* seqp, DecodeState* st) {
     tp_wait_ge(&mail->seq, *seqp, seqp + 1);
     st->token = __hip_atomic_load(&mail->token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     st->pos = __hip_atomic_load(&mail->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void tp_bump_seq_kernel(unsigned* seqp) { *seqp = *seqp + 1u; }
-__global__ void set_pos_kernel(DecodeState* st, int pos) { st->pos = pos; }   // pipeline stages: the token / step words stay
+static __global__ void tp_bump_seq_kernel(unsigned* seqp) { *seqp = *seqp + 1u; }
+static __global__ void set_pos_kernel(DecodeState* st, int pos) { st->pos = pos; }   // pipeline stages: the token / step words stay
 // one pipeline stage per process: the token id arrives in device memory (shipped by the last stage), never through the host
-__global__ void set_state_dev_kernel(DecodeState* st, int pos, const int* token_dev) {
+static __global__ void set_state_dev_kernel(DecodeState* st, int pos, const int* token_dev) {
     st->pos = pos; st->step = 0; st->done = 0;
     if (token_dev) st->token = *token_dev;
 }
-__global__ void store_token_kernel(const DecodeState* st, int* out) { *out = st->token; }
-__global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
+static __global__ void store_token_kernel(const DecodeState* st, int* out) { *out = st->token; }
+static __global__ void set_state_kernel(DecodeState* st, int pos, int token, int step) {
     st->pos = pos; st->token = token; st->step = step; st->done = 0;
 }
 
@@ -1894,7 +1894,7 @@ __device__ __forceinline__ void embed_row(const void* table, const float* scales
     }
 }
 
-__global__ void embed_kernel(const void* table, const float* scales, int dtype, const DecodeState* st, int E,
+static __global__ void embed_kernel(const void* table, const float* scales, int dtype, const DecodeState* st, int E,
                              float* x) {
     embed_row(table, scales, dtype, st->token, E, x);
 }
@@ -1908,7 +1908,7 @@ __global__ void embed_kernel(const void* table, const float* scales, int dtype, 
 //   acc >= u -> token i (V-1 if never).  The exponentials are independent (sample_exp_kernel, whole chip); the two float
 //   accumulations are defined by their index order -- sample_pick_kernel below reproduces them bit for bit -- and a T > 0
 //   generation stays at one graph replay per token, no host round trip.
-__global__ __launch_bounds__(256) void sample_exp_kernel(const float* logits, int V, const float* partv, int nparts, float temperature, float* prob) {
+static __global__ __launch_bounds__(256) void sample_exp_kernel(const float* logits, int V, const float* partv, int nparts, float temperature, float* prob) {
     __shared__ float red[4];
     float m = -INFINITY;
     for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, partv[i]);   // the LM head's per-workgroup maxima
@@ -2083,7 +2083,7 @@ __global__ __launch_bounds__(SAMPLE_T) void sample_sum_kernel(const float* prob,
     seq_pass<SAMPLE_T, SAMPLE_E>(prob, V, INFINITY, sh, (float*)smem, sum, pick);   // AbstractModel.java:475-480
     if (threadIdx.x == 0) *sum_out = sum;
 }
-__global__ __launch_bounds__(256) void sample_norm_kernel(float* prob, int V, const DecodeState* st, const float* sum) {
+static __global__ __launch_bounds__(256) void sample_norm_kernel(float* prob, int V, const DecodeState* st, const float* sum) {
     if (st->done) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < V) prob[i] = prob[i] / *sum;                              // :481-483
@@ -2099,7 +2099,7 @@ __global__ __launch_bounds__(SAMPLE_T) void sample_pick_kernel(const float* prob
     if (threadIdx.x == 0) *tok_out = pick >= 0 ? pick : V - 1;
 }
 
-__global__ void finish_token_kernel(const float* partv, const int* parti, int nparts, DecodeState* st,
+static __global__ void finish_token_kernel(const float* partv, const int* parti, int nparts, DecodeState* st,
                                     int* out_tokens, const void* table, const float* scales, int dtype, int E,
                                     float* x, int do_embed, const int* eos,   // eos: [count, id0, id1, ...] (jh_session_set_eos)
                                     const int* forced) {                      // non-null: the sampled id (sample_pick_kernel) replaces the argmax
@@ -2662,7 +2662,7 @@ __global__ __launch_bounds__(256) void rows_bf16_kernel(RowsParams p) {
 // destination is [N/32][nch][32 rows][16 B] (+ Q4 scales [N/32][nch][32]).  One workgroup moves a 32-row x 64-chunk tile
 // through LDS: reads are 1 KiB contiguous per wave (a row's 64 chunks), writes 1 KiB contiguous per wave (2 chunks x 32 rows).
 // LDS rows are padded by one chunk so that the transposed ds_read_b128 (32 lanes = 32 rows of one chunk) is conflict-free.
-__global__ __launch_bounds__(256) void retile16_kernel(const i32x4* __restrict__ w, const float* __restrict__ ws, int N, int nch,
+static __global__ __launch_bounds__(256) void retile16_kernel(const i32x4* __restrict__ w, const float* __restrict__ ws, int N, int nch,
                                                        i32x4* __restrict__ wt, float* __restrict__ st) {
     __shared__ i32x4 tile[32 * 65];
     __shared__ float stile[32 * 65];
@@ -2691,7 +2691,7 @@ __global__ __launch_bounds__(256) void retile16_kernel(const i32x4* __restrict__
     }
 }
 
-__global__ void embed_rows_kernel(const void* table, const float* scales, int dtype, const int* tokens, int E, float* x) {
+static __global__ void embed_rows_kernel(const void* table, const float* scales, int dtype, const int* tokens, int E, float* x) {
     embed_row(table, scales, dtype, tokens[blockIdx.x], E, x + (size_t)blockIdx.x * E);
 }
 
@@ -2709,7 +2709,7 @@ struct PrefillAttnParams {
 
 // RoPE of q (in place) and k, and the KV page writes, for every row of the chunk (CausalSelfAttention.java:199-286;
 // the table offset is position*half + kvHead*headSize for q and k alike -- SURVEY.md 8a "RoPE quirk").
-__global__ __launch_bounds__(256) void rows_rope_kv_kernel(PrefillAttnParams p) {
+static __global__ __launch_bounds__(256) void rows_rope_kv_kernel(PrefillAttnParams p) {
     const int row = blockIdx.x, pos = p.start_pos[0] + row;
     const int HS = p.head_size, half = HS / 2, A = p.n_heads * HS, KV = p.n_kv_heads * HS, group = p.n_heads / p.n_kv_heads;
     float* r = p.qkv + (size_t)row * p.ldqkv;
@@ -2988,7 +2988,7 @@ __global__ __launch_bounds__(GROUP * 64) void attn_prefill_mfma_kernel(PrefillAt
 static inline size_t prefill_mfma_lds(int hs, int group) { return ((size_t)32 * (hs + 4) + 32 * hs + (size_t)group * 32 * 33 + group * 32) * 4; }
 
 // merge the key-range splits of attn_prefill_mfma_kernel: w_s = exp(m_s - M), out = sum_s w_s O_s / sum_s w_s l_s (split order)
-__global__ __launch_bounds__(128) void attn_prefill_combine_kernel(PrefillAttnParams p, PrefillMfmaExtra e) {
+static __global__ __launch_bounds__(128) void attn_prefill_combine_kernel(PrefillAttnParams p, PrefillMfmaExtra e) {
     const int row = blockIdx.x, head = blockIdx.y, HS = p.head_size;
     const float* ml = e.ws_ml + ((size_t)row * p.n_heads + head) * e.nsplit * 2;
     float M = -INFINITY;
@@ -3081,7 +3081,7 @@ __global__ void ew_kernel(float* a, const float* b, float f, int n) {
     else if (OP == EW_SAXPY) a[i] = fmaf(b[i], f, a[i]);
     else a[i] = silu_ref(a[i]) * b[i];
 }
-__global__ void acc_q4_kernel(float* a, const uint8_t* nib, const float* sc, int offset, int n) {
+static __global__ void acc_q4_kernel(float* a, const uint8_t* nib, const float* sc, int offset, int n) {
     const int i = offset + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= offset + n) return;
     const int blk = i / 32, in = i % 32;
@@ -3090,7 +3090,7 @@ __global__ void acc_q4_kernel(float* a, const uint8_t* nib, const float* sc, int
     a[i] = a[i] + (float)x * sc[blk];
 }
 // batched saxpy: thread per element, fma chain over rows in ascending order (PTO:2648-2698)
-__global__ void saxpy_batch_kernel(const float* alpha, const float* x, int ldx, float* y, int limit, int rows) {
+static __global__ void saxpy_batch_kernel(const float* alpha, const float* x, int ldx, float* y, int limit, int rows) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= limit) return;
     float acc = y[t];
@@ -3098,7 +3098,7 @@ __global__ void saxpy_batch_kernel(const float* alpha, const float* x, int ldx, 
     y[t] = acc;
 }
 // quantize F32 -> I8 (PTO:1684-1723): one 32-lane half-wave per block
-__global__ void quantize_q8_kernel(const float* x, int rows, int ldx, int offset, int length, int8_t* q, int ldq,
+static __global__ void quantize_q8_kernel(const float* x, int rows, int ldx, int offset, int length, int8_t* q, int ldq,
                                    float* d, int ldd) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int hw = gid >> 5, l = gid & 31;
@@ -3117,21 +3117,21 @@ __global__ void quantize_q8_kernel(const float* x, int rows, int ldx, int offset
     q[(size_t)r * ldq + e] = (int8_t)f2b(v);
     if (l == 0) d[(size_t)r * ldd + e / QB] = dd;
 }
-__global__ void widen_bf16_kernel(const uint16_t* in, long long n, float* out) {
+static __global__ void widen_bf16_kernel(const uint16_t* in, long long n, float* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = bf16_to_f32(in[i]);
 }
-__global__ void quantize_bf16_kernel(const float* x, long long n, uint16_t* out) {
+static __global__ void quantize_bf16_kernel(const float* x, long long n, uint16_t* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = f32_to_bf16(x[i]);
 }
 // BF16 result tensor of a Tier-1 GEMM: out[i*ld + j] = bf16(in[i*ld + j]) for j < n, one grid row per matrix row
-__global__ void store_bf16_2d_kernel(const float* in, uint16_t* out, int n, int ld) {
+static __global__ void store_bf16_2d_kernel(const float* in, uint16_t* out, int n, int ld) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) out[(size_t)blockIdx.y * ld + j] = f32_to_bf16(in[(size_t)blockIdx.y * ld + j]);
 }
 // RMSNorm.forward (core/model/RMSNorm.java:33-56), single workgroup per row
-__global__ __launch_bounds__(1024) void rmsnorm_kernel(const float* x, const float* w, float adj, int n, float eps,
+static __global__ __launch_bounds__(1024) void rmsnorm_kernel(const float* x, const float* w, float adj, int n, float eps,
                                                        float* out) {
     __shared__ double red[32];
     double ss = 0.0;
@@ -3147,7 +3147,7 @@ __global__ __launch_bounds__(1024) void rmsnorm_kernel(const float* x, const flo
 // LayerNorm.forward (core/model/LayerNorm.java:41-67), GPT-2's norm: FLOAT sums accumulated in index order (one lane
 // walks the row so the running sums round exactly as the Java loop's), var = sumSq/E - mean^2,
 // 1/(float)sqrt(var+eps), then ((x-mean)*inv)*w + b with no fused multiply-add.  One wave per row.
-__global__ __launch_bounds__(64) void layernorm_kernel(const float* x, const float* w, const float* b, int ld, int offset, int length,
+static __global__ __launch_bounds__(64) void layernorm_kernel(const float* x, const float* w, const float* b, int ld, int offset, int length,
                                                        int divisor, float eps, float* out) {
     const float* row = x + (size_t)blockIdx.x * ld;
     float* orow = out + (size_t)blockIdx.x * ld;
@@ -3169,13 +3169,13 @@ __global__ __launch_bounds__(64) void layernorm_kernel(const float* x, const flo
     for (int i = offset + threadIdx.x; i < offset + length; i += blockDim.x) orow[i] = (row[i] - mean) * inv * w[i] + b[i];
 }
 // ActivationFunction.eval GELU (core/math/ActivationFunction.java:32-34): tanh approximation evaluated in double
-__global__ void gelu_kernel(float* x, int n) {
+static __global__ void gelu_kernel(float* x, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double v = (double)x[i];
     x[i] = (float)(0.5 * v * (1.0 + tanh(sqrt(2.0 / 3.14159265358979323846) * (v + 0.044715 * pow(v, 3.0)))));
 }
-__global__ __launch_bounds__(1024) void softmax_kernel(float* x, int offset, int length) {
+static __global__ __launch_bounds__(1024) void softmax_kernel(float* x, int offset, int length) {
     __shared__ float redf[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     float m = -INFINITY;
@@ -3200,7 +3200,7 @@ __global__ __launch_bounds__(1024) void softmax_kernel(float* x, int offset, int
     for (int i = threadIdx.x; i < offset + length; i += blockDim.x) x[i] = x[i] / s;  // reference divides from index 0
 }
 // RoPE rotation, GQA branch (core/model/CausalSelfAttention.java:247-286)
-__global__ void rope_kernel(float* q, float* k, const float* rope, int position, int n_heads, int n_kv_heads, int hs) {
+static __global__ void rope_kernel(float* q, float* k, const float* rope, int position, int n_heads, int n_kv_heads, int hs) {
     const int half = hs / 2, group = n_heads / n_kv_heads;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int poffset = position * half;

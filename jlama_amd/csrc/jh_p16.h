@@ -51,7 +51,7 @@ __device__ __forceinline__ int perm_b(int hi_src, int lo_src, int sel) {   // se
 // P16T copy of a Q4 weight: row stride G * 256 bytes (G = groups of 16 blocks, the last one zero-padded); inside a group the 16-byte
 // chunk t holds nibble pair t (elements t and t+16) of the group's 16 blocks, four blocks per dword in the nibble order below.
 // One thread per output 16-byte chunk.
-__global__ __launch_bounds__(256) void p16t_pack_kernel(const uint8_t* __restrict__ w, int nrows, int nblk, int ldb, uint8_t* __restrict__ out) {
+static __global__ __launch_bounds__(256) void p16t_pack_kernel(const uint8_t* __restrict__ w, int nrows, int nblk, int ldb, uint8_t* __restrict__ out) {
     const int G = (nblk + 15) >> 4;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)nrows * G * 16) return;

@@ -35,7 +35,7 @@ constexpr int T16_SEL_STRIDE = 136;   // bytes per block in the selector table: 
 // ------------------------------------------------------------------------------------------------ packer
 // mode 0: tile u = rows 16u..16u+15 of w;  mode 1 (gate|up): tile u = rows 8u..8u+7 of w (gate) then 8u..8u+7 of w2 (up).
 // One thread per (tile, q, j): 64 contiguous bytes (4 blocks) of its row in, 4 x 16 bytes out (one per lane group).
-__global__ __launch_bounds__(256) void t16_pack_kernel(const i32x4* __restrict__ w, const float* __restrict__ ws, const i32x4* __restrict__ w2,
+static __global__ __launch_bounds__(256) void t16_pack_kernel(const i32x4* __restrict__ w, const float* __restrict__ ws, const i32x4* __restrict__ w2,
                                                        const float* __restrict__ ws2, int nblk, int ntiles, int mode, i32x4* __restrict__ tw,
                                                        f32x4t* __restrict__ ts) {
     const int nq = nblk >> 2;

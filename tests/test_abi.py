@@ -132,7 +132,8 @@ def test_process_options_are_explicit_and_named():
         N.set_option("JH_ATTN_SPLITZ", 3)
     assert "no option named" in str(e.value)
     N.clear_options()
-    src = open(os.path.join(ROOT, "jlama_amd", "csrc", "jlama_hip.hip")).read()
+    csrc = os.path.join(ROOT, "jlama_amd", "csrc")
+    src = "\n".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h")))
     asked = set(re.findall(r'opt_int\("([A-Z0-9_]+)"', src))
     table = src[src.index("JH_KNOWN_OPTIONS[] = {"):]
     table = set(re.findall(r'"(JH_[A-Z0-9_]+)"', table[:table.index("};")]))

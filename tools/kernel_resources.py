@@ -2,8 +2,10 @@
 """Summarise hipcc -Rpass-analysis=kernel-resource-usage for libjlamahip (VGPR/SGPR/scratch/occupancy per kernel)."""
 import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "jlama_amd", "csrc", "jlama_hip.hip")
-out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-c",
+# usage: kernel_resources.py [kernel name filter] [translation unit = gemv_ref]   (units: jlama_amd/_native.py UNITS)
+unit = sys.argv[2] if len(sys.argv) > 2 else "gemv_ref"
+src = os.path.join(ROOT, "jlama_amd", "csrc", unit + ".hip")
+out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-c",
                       "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage", src, "-o", "/tmp/_jh_res.o"],
                      capture_output=True, text=True).stderr
 rows, cur = [], None
