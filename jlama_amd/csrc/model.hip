@@ -429,6 +429,7 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     s->p16_sc_stride = (max_ctx + 63) & ~63;
     HIPCHK(hipMalloc(&s->p16_scores, (size_t)c.n_heads * s->p16_sc_stride * 4));
     if (s->strict && c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16) return set_err(JH_ERR_UNSUPPORTED, "JH_STRICT_ORDER: reference-order kernels exist for JQ4 and BF16 models");
+    if (s->strict) JHCHK(ensure_strict_operands(s, s->stream));   // a session that STARTS in reference order (JH_STRICT_ORDER=1): same copies as jh_session_set_strict makes
     if (!s->strict && prefill_batch_ok(s)) {
         // the MFMA-ordered weight copies of the prefill GEMM are made here, once per model, not inside the first prompt
         JHCHK(ensure_all_tiled(s, s->stream));

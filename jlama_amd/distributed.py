@@ -46,13 +46,16 @@ class ShardEngine:
 class HipShardEngine(ShardEngine):
     """A layer shard resident on one MI355X (Tier-2 C ABI); activations never leave HBM between RCCL and the kernels."""
 
-    def __init__(self, cfg, weights, rank, world, device_index, n_sessions, max_ctx):
+    def __init__(self, cfg, weights, rank, world, device_index, n_sessions, max_ctx, strict=False):
         import torch
         from .model import HipLlamaModel
         self.torch = torch
         ls, le = layer_range(rank, world, cfg["n_layers"])
         self.model = HipLlamaModel(cfg, weights, layer_range=(ls, le), device=device_index)
         self.sessions = [self.model.session(max_ctx) for _ in range(n_sessions)]
+        if strict:   # reference order (the path whose ids are bit-exact: what `value` is at N = 1)
+            for s in self.sessions:
+                s.set_strict(True)
 
     def _sync_torch(self):
         self.torch.cuda.current_stream().synchronize()
@@ -504,6 +507,90 @@ def tp_generate_ipc(dist, engine, rank, size, prompt, n_gen, cfg, device, dtype)
     return np.concatenate([[first], ids]).astype(np.int32) if rank == 0 else None
 
 
+def tp_rank_bench(dist, engine, rank, size, prompt, steps, cfg, device, dtype, use_ipc=True):
+    """Single-stream decode rate of the head-split group with one shard per rank (DistributedContext.java:79-98): the prompt in
+    chunks (tp_forward_prompt: one all-reduce per half-layer and chunk), then `steps` greedy tokens -- on the IPC-mapped token
+    graphs (jh_tp_rank_*: partials pushed into every rank's slot over xGMI, nothing on the host inside a token) when `use_ipc`,
+    else row by row with two all-reduces per layer (tp_forward_row; also what runs when the IPC mapping is refused).  Timed like
+    every leg of the bench: barrier + synchronize on both sides, MAX over the ranks.  Returns a dict on every rank."""
+    import torch
+    buf = torch.empty(cfg["embedding_length"], dtype=dtype, device=device)
+    layers = (0, cfg["n_layers"])
+    on_gpu = device != "cpu" and getattr(device, "type", "cpu") != "cpu"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    xdev = device if dist.get_backend() == "nccl" else torch.device("cpu")    # (gloo gathers host tensors only)
+    t0 = time.perf_counter()
+    info = tp_forward_prompt(dist, engine, prompt, 0, layers, cfg, device, dtype, buf)
+    tok = torch.zeros(1, dtype=torch.int32, device=device)
+    with engine.stream_context():
+        if rank == 0:
+            tok[0] = engine.sample()
+        dist.broadcast(tok, src=0)
+        first = int(tok.item())
+    prefill_ms = (time.perf_counter() - t0) * 1e3
+    mode, err, tpr = "all-reduce rows (2 per layer and token)", None, None
+    if use_ipc:
+        try:
+            from .model import HipTPRank
+            tpr = HipTPRank(engine.s, rank, size)
+            mine = torch.frombuffer(bytearray(tpr.handles()), dtype=torch.uint8).to(xdev)
+            gathered = [torch.empty_like(mine) for _ in range(size)]
+            dist.all_gather(gathered, mine)
+            tpr.connect(b"".join(bytes(g.cpu().numpy().tobytes()) for g in gathered))
+            sig = torch.tensor([tpr.signature()], dtype=torch.int64, device=xdev)
+            sigs = [torch.empty_like(sig) for _ in range(size)]
+            dist.all_gather(sigs, sig)
+            if len({int(x.item()) for x in sigs}) != 1:
+                raise RuntimeError("ranks disagree on the launch plan")
+            ok = 1
+        except Exception as e:   # noqa: BLE001 -- the leg falls back, the line says why
+            err, ok = repr(e)[:300], 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=xdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            mode = "token graphs on IPC-mapped peer memory (in-kernel meetings over xGMI)"
+        else:
+            if tpr is not None and ok:
+                tpr.close()
+            tpr = None
+
+    def run(n):
+        if tpr is not None:
+            ids = tpr.decode_n(first, len(prompt), n)
+            return ids
+        out, nxt, pos = [], first, len(prompt)
+        for _ in range(n):
+            tp_forward_row(dist, engine, nxt, pos, layers, buf)
+            with engine.stream_context():
+                if rank == 0:
+                    tok[0] = engine.sample()
+                dist.broadcast(tok, src=0)
+                nxt = int(tok.item())
+            out.append(nxt)
+            pos += 1
+        return np.asarray(out, dtype=np.int32)
+
+    run(min(4, steps))                       # graph capture / warm-up, untimed (rewrites the same KV rows)
+    dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    ids = run(steps)
+    sync()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=xdev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    st = tpr.status() if tpr is not None else {}
+    if tpr is not None:
+        dist.barrier()                       # nobody unmaps while a peer's last graph may still be storing
+        tpr.close()
+    return {"shards": size, "single_stream_tokens_per_s": round(steps / dt, 2), "ms_per_token": round(dt / steps * 1e3, 4), "steps": int(steps),
+            "seconds": dt, "decode": mode, "ipc_error": err, "prompt_rows": int(len(prompt)), "prompt_rows_batched": info["rows_batched"],
+            "prompt_rows_per_chunk": info["rows_per_chunk"], "prefill_ms": round(prefill_ms, 2),
+            "first_ids": [int(first)] + [int(t) for t in (ids[:7] if ids is not None else [])],
+            "meeting_timeouts": st.get("timeouts"), "gemv_push": st.get("gemv_push"), "flags_per_launch": st.get("flags_per_launch")}
+
+
 def _tp_ipc_selftest(rank, world, port, n_gen, strict):
     """One rank of tests/test_gpu_model.py::test_rank_per_process_tensor_parallel_over_ipc: both ranks on HIP device 0, gloo for
     the handle exchange and the prompt's all-reduces; rank 0 prints the generated ids as JSON."""
@@ -523,13 +610,19 @@ def _tp_ipc_selftest(rank, world, port, n_gen, strict):
     engine = HipTPEngine(cfg, w, rank, world, 0, 96)
     if strict:
         engine.s.set_strict(True)
+    if os.environ.get("JH_TP_SELFTEST_BENCH"):   # the bench's rank-per-GPU tensor-parallel leg over the same two processes
+        leg = tp_rank_bench(dist, engine, rank, world, prompt, n_gen - 1, cfg, device, torch.float32, use_ipc=True)
+        if rank == 0:
+            print(json.dumps({"leg": leg}), flush=True)
+        dist.destroy_process_group()
+        return
     ids = tp_generate_ipc(dist, engine, rank, world, prompt, n_gen, cfg, device, torch.float32)
     if rank == 0:
         print(json.dumps({"ids": [int(t) for t in ids]}), flush=True)
     dist.destroy_process_group()
 
 
-def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=None, probe_iters=3):
+def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=None, probe_iters=3, strict=False):
     """The one-process N-device host (jh_pipeline_*, BASELINE north_star): stage k on HIP device k, hops are stream-ordered
     peer copies.  Measures the single-stream (batch-1) decode rate and the aggregate rate of N sessions in flight over the
     same stage models -- EXACTLY `steps` tokens in each timed leg, bracketed by a synchronize of every stage stream.
@@ -550,6 +643,8 @@ def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=
         torch.cuda.synchronize()
         return w
 
+    N.init(devices[0])
+    N.set_option("JH_STRICT_ORDER", 1 if strict else 0)   # every session created below starts in that mode (reference order = the N = 1 line's `value`)
     models = build_stage_models(cfg, weights_for_stage, devices)
     pipes = [HipPipeline(models, max_ctx) for _ in range(n)]
     tp0 = time.perf_counter()
@@ -595,6 +690,7 @@ def one_process_pipeline_bench(config, n_gpus, steps, warmup, prompt_n, devices=
         except Exception as e:   # noqa: BLE001 -- an optional leg must never cost the line
             tp = {"error": repr(e)[:400]}
     return {"mode": "one process, %d devices, hipMemcpyPeerAsync hops ordered by events" % n, "devices": devices, "tensor_parallel": tp,
+            "order": "reference order (bit-exact ids)" if strict else "order-free kernels",
             "single_stream_tokens_per_s": round(steps / dt_single, 2), "single_stream_ms_per_token": round(dt_single / steps * 1e3, 4),
             "aggregate_tokens_per_s": round(per_session * n / dt_agg, 2), "aggregate_s": dt_agg, "sessions": n,
             "steps_per_session": per_session, "sessions_agree": bool(same), "peer_access": peer_access,
@@ -625,7 +721,7 @@ def one_process_tp_leg(cfg, devices, prompt, steps):
         del sw
     del w
     torch.cuda.empty_cache()
-    n_prompt = min(int(prompt.size), 16)                     # the group feeds prompt rows one at a time (event-ordered loop)
+    n_prompt = int(prompt.size)                              # the whole prompt, in chunks (jh_tp_group_forward)
     grp = HipTPGroup(models, n_prompt + steps + 16)
     grp.forward(prompt[:n_prompt], 0)
     first = grp.sample()
@@ -667,13 +763,17 @@ def multi_gpu_extras(args, cfg, gate_up_probe, device_index=0):
     return roof, cpu
 
 
-def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
+def bench_pipeline(args, cfg, backend="nccl", engine_factory=None, tp_engine_factory=None):
     """bench.py's N>1 leg (one rank per GPU under torch.distributed.run).  Returns the JSON dict on rank 0.
     Three measurements: N sessions in flight through the rank-per-GPU RCCL pipeline (the timed K tokens of the contract),
     the same pipeline with ONE session (single-stream, batch-1: bounded by a single GPU's rate by construction), and --
     from rank 0 in a child process -- the one-process N-device host over the same GPUs.
-    ``backend="gloo"`` + ``engine_factory(rank, world, n_sessions, max_ctx) -> ShardEngine`` run the same control flow on CPU
-    (tests/test_distributed.py drives every branch of the N>1 line that way; the product path is nccl + HipShardEngine)."""
+    Then the head-split group with one shard per rank (tp_rank_bench).  `value` of the line is the best SINGLE-STREAM rate over
+    the two modes -- like for like with the N = 1 line, which is one batch-1 stream -- and `config.parallelism` names the mode;
+    the throughput of N sessions in flight is reported beside it as `aggregate_tokens_per_s`.
+    ``backend="gloo"`` + ``engine_factory(rank, world, n_sessions, max_ctx) -> ShardEngine`` (+ ``tp_engine_factory(rank, world,
+    max_ctx) -> TPEngine``) run the same control flow on CPU (tests/test_distributed.py drives every branch of the N>1 line that
+    way; the product path is nccl + HipShardEngine / HipTPEngine)."""
     import json
     import subprocess
     import sys
@@ -729,7 +829,8 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
     n_sess2 = 0 if os.environ.get("JH_BENCH_NO_EXTRA_LEG") else 2 * n_sess
     n_all = max(n_sess, n_sess2)
     steps_per_session = max(1, args.steps // n_sess)
-    single_steps = max(8, min(64, args.steps))
+    single_steps = args.steps                      # the leg `value` can come from: EXACTLY K steps of one stream
+    strict = not getattr(args, "fast_order", False)   # reference order, as the N = 1 line's `value`
     max_ctx = prompt.size + max(steps_per_session, args.warmup, single_steps) + 8
     if engine_factory is not None:
         engine = engine_factory(rank, world, n_all, max_ctx)
@@ -737,7 +838,8 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
         from . import synthetic_torch as ST
         w = ST.make_weights(cfg, seed=0, layers=(ls, le), device=device, need_embed=(rank == 0 or cfg.get("tied", False)),
                             need_head=(rank == world - 1))
-        engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=n_all, max_ctx=max_ctx)
+        engine = HipShardEngine(cfg, w, rank, world, local, n_sessions=n_all, max_ctx=max_ctx, strict=strict)
+        del w
     firsts_all = [pipeline_prefill(dist, engine, rank, world, j, prompt, E, device, torch.float32) for j in range(n_all)]
     firsts = firsts_all[:n_sess]
     if on_gpu:   # the RCCL banner (printed at communicator creation through buffered C stdio) leaves every rank's buffer NOW,
@@ -809,7 +911,8 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
             try:
                 env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
                 r = subprocess.run([sys.executable, "-m", "jlama_amd.distributed", "--one-process", "--config", args.config, "--gpus", str(world),
-                                    "--steps", str(args.steps), "--warmup", str(args.warmup), "--prompt", str(args.prompt)],
+                                    "--steps", str(args.steps), "--warmup", str(args.warmup), "--prompt", str(args.prompt),
+                                    "--strict", "1" if strict else "0"],
                                    capture_output=True, text=True, timeout=420, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
                 one_proc = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or "")[-400:]}
             except Exception as e:   # noqa: BLE001 -- the contract line must be printed whatever this optional leg does
@@ -821,6 +924,29 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
             except Exception:   # noqa: BLE001 -- fall through to the collective barrier below
                 pass
     dist.barrier()
+    # ---- the head-split (tensor-parallel) group, one shard per rank: the mode whose single-stream rate CAN grow with N
+    tp_leg = None
+    can_tp = world > 1 and cfg["n_kv_heads"] % world == 0 and cfg["n_heads"] % world == 0 and cfg["hidden_length"] % (32 * world) == 0
+    if world > 1 and not can_tp:
+        tp_leg = {"skipped": f"{cfg['n_kv_heads']} kv heads / H = {cfg['hidden_length']} do not split over {world} shards"}
+    elif world > 1 and not os.environ.get("JH_BENCH_NO_TP_LEG") and (tp_engine_factory is not None or (on_gpu and cfg["weight_dtype"] == 3)):
+        try:
+            tp_ctx = prompt.size + args.steps + 16
+            if tp_engine_factory is not None:
+                tp_engine = tp_engine_factory(rank, world, tp_ctx)
+            else:
+                from . import synthetic_torch as ST
+                engine.close() if hasattr(engine, "close") else None
+                wf = ST.make_weights(cfg, seed=0, device=device)      # the full model on every rank's own device; its windows stay
+                torch.cuda.synchronize()
+                tp_engine = HipTPEngine(cfg, wf, rank, world, local, tp_ctx)
+                del wf
+                torch.cuda.empty_cache()
+                if strict:
+                    tp_engine.s.set_strict(True)
+            tp_leg = tp_rank_bench(dist, tp_engine, rank, world, prompt, args.steps, cfg, device, torch.float32, use_ipc=on_gpu)
+        except Exception as e:   # noqa: BLE001 -- an optional leg never costs the line (a rank that fails alone would hang the others:
+            tp_leg = {"error": repr(e)[:400]}   # every collective of the leg sits inside tp_rank_bench, after construction)
     out = None
     if rank == 0:
         gate_up = None
@@ -836,31 +962,45 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None):
         tps = total / dt
         wbytes, kvb = S.weight_bytes(cfg), S.kv_bytes_per_position(cfg)
         bytes_per_token = wbytes + kvb * (prompt.size + (steps_per_session - 1) / 2.0 + 2)
+        # `value`: ONE batch-1 stream of K tokens, whichever mode serves it faster (the N = 1 line is one stream too)
+        pp_single = single_steps / dt1
+        tp_single = (tp_leg or {}).get("single_stream_tokens_per_s") or 0.0
+        best_tp = world > 1 and tp_single > pp_single
+        value, value_dt = (tp_single, tp_leg["seconds"]) if best_tp else (pp_single, dt1)
+        parallelism = (f"tensor parallel tp{world}: head-split shards, one per GPU, {tp_leg['decode']}" if best_tp else
+                       f"layer-sharded pp{world} ({L // world} layers/GPU), RCCL send/recv of [1,E] F32, one stream through all stages")
         out = {"metric": "decode tokens/sec Llama-3-8B JQ4, 128-tok prompt" if args.config == "LLAMA3_8B" else f"decode tokens/sec {args.config} JQ4",
-               "value": round(tps, 2), "unit": "tokens/s", "n_gpus": world, "steps": total, "warmup": args.warmup,
-               "ms_per_step": round(dt / total * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-               "scaling_detail": f"fixed total of {total} tokens; value = throughput of {n_sess} sessions in flight (one per GPU), the "
-                                 "batch-1 single-stream rate is single_stream_tokens_per_s",
-               "single_stream_tokens_per_s": round(single_steps / dt1, 2), "vs_baseline": None,
+               "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(value_dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+               "scaling_detail": f"one batch-1 stream of {args.steps} tokens whatever N (total work fixed): value = the best single-stream rate "
+                                 f"over the two modes (layer split {round(pp_single, 2)}, tensor parallel {round(tp_single, 2) if tp_single else None} tok/s); "
+                                 f"the throughput of {n_sess} independent sessions in flight is aggregate_tokens_per_s",
+               "aggregate_tokens_per_s": round(tps, 2), "aggregate_steps": total,
+               "single_stream_tokens_per_s": round(pp_single, 2), "tensor_parallel_tokens_per_s": round(tp_single, 2) if tp_single else None,
+               "order": "reference order (bit-exact ids)" if strict else "order-free kernels", "vs_baseline": None,
                "rccl_ranks_seen": ranks_seen, "rank_devices": rank_devices,
                "dtype": "i8xq4->f32", "data": "synthetic",
-               "config": {"workload": f"{args.config} JQ4, {prompt.size}-row prefill + {steps_per_session} greedy decode steps x {n_sess} "
-                                      f"sessions in flight", "parallelism": f"layer-sharded pp{world} ({L // world} layers/GPU), RCCL send/recv of [1,E] F32",
+               "config": {"workload": f"{args.config} JQ4, {prompt.size}-row prefill + {args.steps} greedy decode steps, batch 1 (one stream); "
+                                      f"aggregate leg: {steps_per_session} steps x {n_sess} sessions in flight", "parallelism": parallelism,
                           "sessions_in_flight": n_sess, "sessions_per_gpu": spg, "aggregate_tokens_per_s": round(tps, 2),
                           "per_session_tokens_per_s": round(tps / n_sess, 2), "two_sessions_per_gpu": double_up,
                           "single_stream_tokens_per_s": round(single_steps / dt1, 2), "single_stream_steps": single_steps,
                           "hops": "stream-ordered (RCCL send/recv on the session streams, token id fed back as a device word)" if streamed
                                   else "host-synchronised", "streamed_ids_equal_host_synchronised": streamed_ok,
                           "host_synchronised_aggregate_tokens_per_s": host_sync,
-                          "note": "value = aggregate of the sessions in flight; a single stream passes through all GPUs in sequence and "
-                                  "cannot exceed the 1-GPU rate (SURVEY.md 8d multi-GPU accounting)"},
+                          "note": "a layer-split stream passes through all GPUs in sequence and cannot exceed the 1-GPU rate (SURVEY.md 8d); "
+                                  "the head-split group can, which is why it is a candidate for value"},
                "roofline": roof_k if roof_k else {"bound": "hbm", "kernel": "whole pipeline (control-flow run: no GPU)", "achieved": None,
                                                    "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None},
                "pipeline_roofline": {"achieved_GBps_per_gpu": round(bytes_per_token * tps / 1e9 / world, 1),
                                      "frac_of_8TBps": round(bytes_per_token * tps / 1e9 / world / 8000.0, 4),
-                                     "note": "per-GPU average: algorithmic bytes of all sessions / time / GPUs"},
+                                     "note": "aggregate leg, per-GPU average: algorithmic bytes of all sessions / time / GPUs"},
+               "token_roofline": {"bytes_per_token": int(bytes_per_token), "achieved_GBps": round(bytes_per_token * value / 1e9, 1),
+                                  "frac_of_8TBps_x_N": round(bytes_per_token * value / 1e9 / (8000.0 * world), 4),
+                                  "note": "the single stream of `value` against N GPUs' HBM (a head-split token reads 1/N of the weights per GPU)"},
                "cpu_baseline": cpu_base, "one_process_pipeline": one_proc,
-               "tensor_parallel": (one_proc or {}).get("tensor_parallel") if isinstance(one_proc, dict) else None}
+               "tensor_parallel": {"rank_per_gpu": tp_leg,
+                                   "one_process": (one_proc or {}).get("tensor_parallel") if isinstance(one_proc, dict) else None}}
     dist.destroy_process_group()
     # RCCL prints its version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise land AFTER
     # the JSON line at exit: flush it now so that the contract line is the last thing on stdout
@@ -895,4 +1035,4 @@ if __name__ == "__main__":
         _tp_ipc_selftest(a.rank, a.world, a.port, a.n_gen, a.strict)
         raise SystemExit(0)
     devs = [int(d) for d in a.devices.split(",")] if a.devices else None
-    print(json.dumps(one_process_pipeline_bench(a.config, a.gpus, a.steps, a.warmup, a.prompt, devs)), flush=True)
+    print(json.dumps(one_process_pipeline_bench(a.config, a.gpus, a.steps, a.warmup, a.prompt, devs, strict=bool(a.strict))), flush=True)

@@ -158,8 +158,54 @@ def _bench_worker(rank, world, port, cfg, q):
             if token_out is not None:
                 token_out[0] = int(self.m.sample(x[-1])[0])
 
+    class OracleTPEngine(D.TPEngine):
+        """head-split shard on the oracle: the rank-per-GPU tensor-parallel leg of the line (tp_rank_bench) on CPU"""
+        def __init__(self, rank, world, max_ctx):
+            w = S.make_weights(cfg, seed=0)
+            lc, off = D.tp_shard_config(cfg, rank, world)
+            self.full = O.OracleModel(cfg, w) if rank == 0 else None
+            self.m = O.OracleModel(lc, D.tp_shard_weights(cfg, w, rank, world), kv_head_offset=off)
+            self.s = self.m.session()
+            self.x = self.x1 = None
+            self.pos = 0
+
+        def set_row(self, token, pos):
+            self.x, self.pos = self.m.embed_rows([token]), pos
+
+        def attn(self, layer, partial):
+            partial.copy_(torch.from_numpy(self.s.tp_attn(layer, self.x, self.pos)[0]))
+
+        def ffn(self, layer, reduced, partial):
+            self.x1 = self.x + reduced.numpy()[None, :]
+            partial.copy_(torch.from_numpy(self.s.tp_ffn(layer, self.x1)[0]))
+
+        def finish_layer(self, reduced):
+            self.x = self.x1 + reduced.numpy()[None, :]
+
+        def sample(self):
+            return self.full.sample(self.x[0])[0]
+
+        def rows_max(self):
+            return 4
+
+        def set_rows(self, tokens, pos):
+            self.x, self.pos = self.m.embed_rows(list(tokens)), pos
+
+        def attn_rows(self, layer, partial):
+            partial.copy_(torch.from_numpy(self.s.tp_attn(layer, self.x, self.pos)))
+
+        def ffn_rows(self, layer, reduced, partial):
+            self.x1 = self.x + reduced.numpy()
+            partial.copy_(torch.from_numpy(self.s.tp_ffn(layer, self.x1)))
+
+        def finish_layer_rows(self, reduced):
+            self.x = self.x1 + reduced.numpy()
+
+        def finish_rows(self):
+            self.x = self.x[-1:]
+
     args = argparse.Namespace(gpus=world, steps=8, warmup=2, prompt=5, config="TINY")
-    out = D.bench_pipeline(args, cfg, backend="gloo", engine_factory=OracleShardEngine)
+    out = D.bench_pipeline(args, cfg, backend="gloo", engine_factory=OracleShardEngine, tp_engine_factory=OracleTPEngine)
     if rank == 0:
         q.put(out)
 
@@ -183,7 +229,19 @@ def test_bench_pipeline_control_flow_on_cpu(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert out["n_gpus"] == world and out["steps"] == (8 // world) * world and out["value"] > 0
+    # the line is ONE batch-1 stream of exactly K steps (like the N = 1 line): value = the best single-stream rate over the two modes,
+    # named in config.parallelism; N sessions in flight are reported beside it
+    assert out["n_gpus"] == world and out["steps"] == 8 and out["value"] > 0 and out["scaling"] == "strong"
+    tpl = out["tensor_parallel"]["rank_per_gpu"]
+    if world == 2:     # TINY has 2 kv heads: two head-split shards exist, four do not
+        assert tpl["shards"] == 2 and tpl["steps"] == 8 and tpl["single_stream_tokens_per_s"] > 0 and tpl["prompt_rows_batched"] == 4
+        assert tpl["decode"].startswith("all-reduce rows")        # (the IPC token graphs need GPUs)
+        assert out["tensor_parallel_tokens_per_s"] == tpl["single_stream_tokens_per_s"]
+    else:
+        assert "skipped" in tpl and out["tensor_parallel_tokens_per_s"] is None
+    assert out["value"] == max(out["single_stream_tokens_per_s"], out["tensor_parallel_tokens_per_s"] or 0.0)
+    assert ("tensor parallel" in out["config"]["parallelism"]) == ((out["tensor_parallel_tokens_per_s"] or 0.0) > out["single_stream_tokens_per_s"])
+    assert out["aggregate_tokens_per_s"] > 0 and out["aggregate_steps"] == (8 // world) * world
     c = out["config"]
     assert c["sessions_in_flight"] == world and c["sessions_per_gpu"] == 1 and c["streamed_ids_equal_host_synchronised"] is True
     assert c["two_sessions_per_gpu"]["sessions_in_flight"] == 2 * world and c["two_sessions_per_gpu"]["aggregate_tokens_per_s"] > 0

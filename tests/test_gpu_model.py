@@ -1109,6 +1109,47 @@ def test_rank_per_process_tensor_parallel_over_ipc(gpu, oracle, strict):
     assert got == [int(t) for t in want]
 
 
+def test_bench_tensor_parallel_leg_rank_per_process(gpu):
+    """bench.py's N > 1 line under a launcher times the head-split group with ONE SHARD PER RANK (distributed.tp_rank_bench): the prompt
+    in chunks through all-reduces, then the token graphs on IPC-mapped peer memory.  Here two processes on device 0 (gloo for the
+    exchange): the leg must run on the graph path with no timed-out meeting, and its ids must be the one-process group's."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from jlama_amd import distributed as D, synthetic as S
+    from jlama_amd.model import HipLlamaModel, HipTPGroup
+    n_gen = 12
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY="0", JH_TP_SELFTEST_BENCH="1")
+    procs = [subprocess.Popen([sys.executable, "-m", "jlama_amd.distributed", "--tp-ipc-selftest", "--rank", str(r), "--world", "2", "--port", str(port),
+                               "--n-gen", str(n_gen), "--strict", "1"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    leg = json.loads(outs[0][0].strip().splitlines()[-1])["leg"]
+    assert leg["shards"] == 2 and leg["steps"] == n_gen - 1 and leg["single_stream_tokens_per_s"] > 0, leg
+    assert leg["decode"].startswith("token graphs") and leg["ipc_error"] is None and leg["meeting_timeouts"] == 0, leg
+    assert leg["prompt_rows"] == 13 and leg["prompt_rows_batched"] == 13, leg
+    cfg = dict(S.SMALL)
+    w = S.make_weights(cfg, seed=41)
+    prompt = S.prompt_tokens(cfg, n=12, seed=7)
+    models = []
+    for r in range(2):
+        lc, off = D.tp_shard_config(cfg, r, 2)
+        models.append(HipLlamaModel(lc, D.tp_shard_weights(cfg, w, r, 2), kv_head_offset=off))
+    grp = HipTPGroup(models, 96)
+    for gs in grp.sessions:
+        gs.set_strict(True)
+    grp.forward(prompt, 0)
+    first = grp.sample()
+    want = [first] + list(grp.decode_n(first, prompt.size, 7))
+    grp.close()
+    assert leg["first_ids"] == [int(t) for t in want], (leg["first_ids"], want)
+
+
 def test_one_process_bench_host_with_its_tensor_parallel_leg(gpu):
     """What a bare `python bench.py --gpus N` measures (distributed.one_process_pipeline_bench), here with two stages / two
     head-split shards on ONE device: the layer-split pipeline (single stream + N sessions in flight, all sessions agreeing)
@@ -1122,6 +1163,10 @@ def test_one_process_bench_host_with_its_tensor_parallel_leg(gpu):
     tp = r["tensor_parallel"]
     assert "error" not in tp, tp
     assert tp["shards"] == 2 and tp["steps"] == 16 and tp["single_stream_tokens_per_s"] > 0
+    assert r["order"] == "order-free kernels"
+    # ... and in reference order, what bench.py asks for by default (like for like with the N = 1 line's `value`)
+    r2 = D.one_process_pipeline_bench("TINY", 2, 16, 4, 8, devices=[0, 0], probe_iters=1, strict=True)
+    assert r2["order"].startswith("reference order") and r2["sessions_agree"] is True and "error" not in r2["tensor_parallel"], r2
 
 
 @pytest.mark.parametrize("size,mode", [(2, "fast"), (4, "fast"), (2, "fast-unfused"), (2, "strict"), (4, "strict"), (2, "strict-unfused")])

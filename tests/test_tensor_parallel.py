@@ -246,3 +246,15 @@ def test_prompt_host_picks_chunks_or_rows_consistently():
         info = D.tp_forward_prompt(FakeDist(other), eng, list(range(n)), 0, (0, 2), cfg, "cpu", torch.float32, buf)
         assert eng.log == want, (mine, other, n, eng.log)
         assert sum(c for _, _, c in eng.log) == n and info["rows_batched"] == sum(c for k, _, c in eng.log if k == "rows")
+    # a shard that refuses a chunk at some position (jh_tp_set_rows: JH_ERR_UNSUPPORTED) sends every rank to the row loop for the rest
+
+    class Refuses(Rec):
+        def set_rows(self, tokens, pos):
+            if pos >= 8:
+                raise D.UnsupportedOperation(-3, "no batched path at this position")
+            super().set_rows(tokens, pos)
+
+    eng = Refuses(4)
+    info = D.tp_forward_prompt(FakeDist(4), eng, list(range(14)), 0, (0, 2), cfg, "cpu", torch.float32, buf)
+    assert eng.log == [("rows", 0, 4), ("rows", 4, 4)] + [("row", i, 1) for i in range(8, 14)] and info["rows_batched"] == 8
+
