@@ -218,9 +218,9 @@ int build_graph(jh_session* s, int v, float temperature) {
     }
     s->graph[v] = g;
     HIPCHK(hipGraphInstantiate(&s->exec[v], g, nullptr, nullptr, 0));
-    const bool p16_two_launch_attn = s->strict != 0;
-    const int per_layer = 5 + (p16_two_launch_attn ? 1 : 0);
-    s->kernels_per_token = (c.layer_end - c.layer_start) * per_layer + (has_out ? 2 : 0);
+    size_t n_nodes = 0;                                   // what the graph actually holds (kernel nodes; no memcpy / memset nodes are captured)
+    HIPCHK(hipGraphGetNodes(g, nullptr, &n_nodes));
+    s->kernels_per_token = (int)n_nodes;
     return JH_OK;
 }
 

@@ -174,9 +174,51 @@ int launch_gemm_bf16_tile_mc(MfmaBf16TileParams g, int S, hipStream_t st) {
     if (S > 1) JHCHK(launch_splitk_reduce((const float*)g.ws, S, g.m, g.n, 0, g.c, g.ldc, 0, g.resid, st));
     return JH_OK;
 }
+// gemm_bf16_cw2_kernel: two column tiles per MFMA wave, A staged by a loader wave (jh_kernels.h).  128 columns per workgroup; K is
+// split (partials + reduce pass) only until the launch covers the chip.
+template <int MT>
+int launch_gemm_bf16_cw2(MfmaBf16TileParams g, int S, hipStream_t st) {
+    constexpr int PW = 4;                                    // 4 chunks x 4 slices x 2 KiB = 32 KiB of weights in flight per MFMA wave
+    g.nsplit = S;
+    const size_t lds = (size_t)2 * MT * 4 * 1024;
+    const int knock = opt_int("JH_BF16_CW2", 1);            // 11 / 12: knock-outs of the A / the weight stream (tools/gemm_bench.py; results wrong)
+    if (knock == 11 && MT == 5) {
+        JHCHK(allow_lds((gemm_bf16_cw2_kernel<5, PW, 1>), lds));
+        hipLaunchKernelGGL((gemm_bf16_cw2_kernel<5, PW, 1>), dim3(g.n / 128, S), dim3(BF16_CW2_WAVES * 64), lds, st, g);
+    } else if (knock == 12 && MT == 5) {
+        JHCHK(allow_lds((gemm_bf16_cw2_kernel<5, PW, 2>), lds));
+        hipLaunchKernelGGL((gemm_bf16_cw2_kernel<5, PW, 2>), dim3(g.n / 128, S), dim3(BF16_CW2_WAVES * 64), lds, st, g);
+    } else {
+        JHCHK(allow_lds((gemm_bf16_cw2_kernel<MT, PW>), lds));
+        hipLaunchKernelGGL((gemm_bf16_cw2_kernel<MT, PW>), dim3(g.n / 128, S), dim3(BF16_CW2_WAVES * 64), lds, st, g);
+    }
+    HIPCHK(hipGetLastError());
+    if (S > 1) JHCHK(launch_splitk_reduce((const float*)g.ws, S, g.m, g.n, 0, g.c, g.ldc, 0, g.resid, st));
+    return JH_OK;
+}
 // both operands in MFMA order (gemm_bf16_tile_kernel); n % 32 == 0, k % 16 == 0
 int launch_gemm_bf16_tile(const MfmaBf16TileParams& g, hipStream_t st) {
     const int mt = (g.m + 31) / 32, tiles = g.n / 32, nks = g.k / 16;
+    // prompt-sized M (2..6 row tiles), whole 128-column groups and enough of them to cover the chip WITHOUT splitting K (gate|up of an
+    // 8B-class model: 224 groups): the loader-wave kernel, no reduce pass.  Everywhere else it measured equal or slower than the
+    // LDS kernel below with its K split (profiles/r05c_*): JH_BF16_CW2=2 forces it (with a K split) for comparisons.
+    const int cw2 = opt_int("JH_BF16_CW2", 1);
+    if (cw2 && mt >= 2 && mt <= 6 && g.n % 128 == 0 && nks % 16 == 0 && (cw2 >= 2 || (g.n / 128) * 4 >= g_cu_count * 3)) {
+        int S = 1;
+        const int s_env2 = opt_int("JH_BF16_S", 0);
+        if (g.ws && cw2 >= 2) {
+            auto fits = [&](int s2) { return nks % (16 * s2) == 0 && (size_t)s2 * g.n <= (size_t)8 * 16384 && (g.n <= 8192 || s2 * g.m <= 512); };
+            while (S < 16 && fits(2 * S) && (g.n / 128) * 2 * S <= g_cu_count) S *= 2;   // one workgroup per CU at most (3 waves of ~400 registers)
+            if (s_env2 > 0 && fits(s_env2)) S = s_env2;
+        }
+        switch (mt) {
+            case 2: return launch_gemm_bf16_cw2<2>(g, S, st);
+            case 3: return launch_gemm_bf16_cw2<3>(g, S, st);
+            case 4: return launch_gemm_bf16_cw2<4>(g, S, st);
+            case 5: return launch_gemm_bf16_cw2<5>(g, S, st);
+            default: return launch_gemm_bf16_cw2<6>(g, S, st);
+        }
+    }
     // waves per workgroup (column tiles sharing the A fragments through L1) vs workgroups: want >= ~2 workgroups per CU
     // before splitting K, because the split's reduce pass moves S*M*N*8 bytes
     const int cwb_env = opt_int("JH_BF16_CWB", 0), s_env = opt_int("JH_BF16_S", 0);

@@ -1295,6 +1295,139 @@ __global__ __launch_bounds__(CWB * 64) void gemm_bf16_lds_kernel(MfmaBf16TilePar
             }
         }
 }
+// Round 5: the same GEMM with TWO column tiles per MFMA wave and a LOADER wave.
+// What bounded gemm_bf16_lds_kernel at M = 129 (tools/gemm_bf16_lab.hip, profiles/r04h_*): every MFMA read its A fragment from LDS
+// (1 KiB per 32-cycle instruction and SIMD = the LDS's 128 B/clk, so the matrix pipe idled at 58 cycles per MFMA even with no
+// global load at all), and the MFMA waves staged A themselves, so their waits for the young A loads (L2) were waits for every older
+// weight load (HBM) -- vector loads retire in order.  Here
+//   * an MFMA wave owns 2 adjacent column tiles: an A fragment read from LDS feeds 2 MFMAs (2 x MT accumulator tiles; 64 B/clk);
+//   * a third wave does nothing but stage A (global -> registers one chunk ahead -> LDS double buffer, one barrier per chunk), so the
+//     MFMA waves request WEIGHTS only, PW chunks of 4 k slices ahead (PW x 8 KiB per wave in flight);
+//   * 2 MFMA waves per workgroup = 128 columns: the un-split gate|up GEMM of an 8B-class model is 224 workgroups -- a workgroup per
+//     CU with NO split-K reduce pass; the smaller GEMMs split K until the chip is covered (partials + splitk_reduce4_kernel).
+// MFMA order inside an output element is the k-slice order, as before: results equal gemm_bf16_lds_kernel's bit for bit per split.
+constexpr int BF16_CW2_WAVES = 3;                            // 2 MFMA waves + the loader
+template <int MT, int PW, int KNOCK = 0>                     // KNOCK (measurement only, wrong results): 1 = the loader re-files chunk 0 (no A traffic), 2 = weights loaded once
+__global__ __launch_bounds__(BF16_CW2_WAVES * 64) void gemm_bf16_cw2_kernel(MfmaBf16TileParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLC = 4, PIECES = MT * SLC, NW = 2;
+    i32x4* ring = (i32x4*)smem;                              // [2][MT][SLC][64] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nks = p.k / 16, nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    const int per = nks / nsplit, s0 = blockIdx.y * per;     // host: per % (PW * SLC) == 0
+    const int nchunks = per / SLC;
+    if (wv == NW) {
+        // ---- loader: A chunk c+2 requested while chunk c+1 is filed and chunk c is multiplied
+        const i32x4* ap = (const i32x4*)p.a + (size_t)s0 * 64 + lane;
+        const size_t a_rt = (size_t)nks * 64;
+        i32x4 r0[PIECES], r1[PIECES];
+        auto request = [&](i32x4 (&r)[PIECES], int c) __attribute__((always_inline)) {
+            c = c < nchunks ? c : nchunks - 1;
+            if (KNOCK == 1 && c > 1) return;
+#pragma unroll
+            for (int pc = 0; pc < PIECES; pc++) {
+                const int t = pc / SLC, q = pc - t * SLC;
+                r[pc] = ap[(size_t)t * a_rt + (size_t)(c * SLC + q) * 64];
+            }
+        };
+        auto file = [&](const i32x4 (&r)[PIECES], int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pc = 0; pc < PIECES; pc++) ring[((size_t)buf * PIECES + pc) * 64 + lane] = r[pc];
+        };
+        request(r0, 0);
+        request(r1, 1);
+        file(r0, 0);
+        lds_barrier();
+        for (int c = 0; c < nchunks; c += 2) {
+            request(r0, c + 2);
+            file(r1, 1);
+            lds_barrier();
+            request(r1, c + 3);
+            file(r0, 0);
+            lds_barrier();
+        }
+        return;
+    }
+    const int nl = lane & 31, h = lane >> 5;
+    const int ct0 = (blockIdx.x * NW + wv) * 2;              // host: n % 128 == 0
+    const i32x4* wp0 = (const i32x4*)p.w + ((size_t)ct0 * nks + s0) * 64 + lane;
+    const i32x4* wp1 = wp0 + (size_t)nks * 64;
+    f32x16 acc0[MT], acc1[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[t][r] = 0.0f; acc1[t][r] = 0.0f; }
+    const int last = per - 1;
+    i32x4 wr0[PW][SLC], wr1[PW][SLC];
+    auto load_w = [&](i32x4 (&w0)[SLC], i32x4 (&w1)[SLC], int sl0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < SLC; q++) {
+            int sl = sl0 + q;
+            sl = sl < last ? sl : last;
+            if (KNOCK == 2 && sl0 >= PW * SLC) continue;
+            w0[q] = __builtin_nontemporal_load(wp0 + (size_t)sl * 64);
+            w1[q] = __builtin_nontemporal_load(wp1 + (size_t)sl * 64);
+        }
+    };
+    auto read_a = [&](i32x4 (&av)[MT], int buf, int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < MT; t++) av[t] = ring[((size_t)buf * PIECES + t * SLC + q) * 64 + lane];
+    };
+    auto mma_slice = [&](const i32x4 (&av)[MT], const i32x4& w0, const i32x4& w1) __attribute__((always_inline)) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, w0), b1 = __builtin_bit_cast(bf16x8, w1);
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, av[t]);
+            acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1[t], 0, 0, 0);
+        }
+    };
+    auto mma_chunk = [&](int buf, const i32x4 (&w0)[SLC], const i32x4 (&w1)[SLC]) __attribute__((always_inline)) {
+        i32x4 a0[MT], a1[MT];                                // A fragments are read a slice ahead of their MFMAs
+        read_a(a0, buf, 0);
+#pragma unroll
+        for (int q = 0; q < SLC; q += 2) {
+            read_a(a1, buf, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_slice(a0, w0[q], w1[q]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < SLC) read_a(a0, buf, q + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_slice(a1, w0[q + 1], w1[q + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PW; i++) load_w(wr0[i], wr1[i], i * SLC);
+    lds_barrier();
+    for (int c = 0; c < nchunks; c += PW) {
+#pragma unroll
+        for (int i = 0; i < PW; i++) {
+            mma_chunk(i & 1, wr0[i], wr1[i]);                // PW is even: chunk c + i sits in buffer i & 1
+            load_w(wr0[i], wr1[i], (c + i + PW) * SLC);
+            lds_barrier();
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+        const int ncol = (ct0 + cc) * 32 + nl;
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int mrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = cc ? acc1[t][r] : acc0[t][r];
+                if (mrow < p.m) {
+                    if (nsplit > 1) {
+                        p.ws[((size_t)blockIdx.y * p.m + mrow) * p.n + ncol] = v;
+                    } else {
+                        const size_t idx = (size_t)p.ldc * mrow + ncol;
+                        p.c[idx] = p.resid ? v + p.resid[idx] : v;
+                    }
+                }
+            }
+    }
+}
 // ------------------------------------------------------------------------------------------------ K2: batched I8 x Q4 GEMM on MFMA
 // batchDotProduct I8 x Q4 -> F32 for M > 1 (prefill of a JQ4 model; GemmerI8Q4_512 2x2 tile PTO:958-1043, C twin
 // nc/simd/vector_simd.c:261-437):  C[i,j] = sum_blk (da[i,blk]*sb[j,blk]) * sum_t a[i,blk,t]*(nib[j,blk,t]-8).

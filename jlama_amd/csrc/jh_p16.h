@@ -839,6 +839,252 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     }
     if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
 }
+// LDS reads whose latency the CALLER hides: 64 consecutive bytes as four ds_read_b128, issued and NOT waited for -- hipcc closes
+// every LDS read it issues itself with s_waitcnt lgkmcnt(0) in these loops, which also waits for the chunk requested a moment ago
+// (measured: 20 cycles per link of a sequential float chain instead of 5).  lds_tie<N> is the matching wait: at most N younger LDS
+// operations stay in flight, and the four registers become readable (they are operands of the wait, so no use can move above it).
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void lds_read64_nowait(f32x4& a, f32x4& b, f32x4& c, f32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_tie(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------ the two launches above in ONE
+// (round 5).  Contexts of up to ~1 k positions do not need the scores spread over the chip: the K rows of a kv head are 512 bytes
+// per position, and a workgroup that asks for them with 16-byte loads, two passes ahead, ingests a 400-position context in ~2 us --
+// while the second launch of the split form costs a kernel boundary + ramp + the score round trip through memory (~4 us of the
+// pair's 11.6).  Grid = n_kv_heads x group x HS/32 workgroups, id % n_kv_heads = kv head, so that the 16 workgroups that read one
+// kv head's K / V run on one XCD (id % 8) and all but the first find the rows in its L2.  A workgroup = one query head x 32 value
+// columns: it rotates q and the new k itself (bit-identical in every workgroup), takes ALL scores of its head (redundantly with the
+// other three column quarters: 0.1 us of fmas), runs the softmax, then the value chains of its 32 columns exactly as
+// attn_p16_av_kernel.  The workgroup (query head 0 of the group, columns 0..31) files the new K / V rows into the KV page.
+//   score of position tt: GemmerF32's 16 lanes = the 4 lanes of a quad x 4 chains each (lane qd owns chains t = 4 qd + j: elements
+//   16 c + 4 qd + j are ONE 16-byte piece of q and of the K row); the halving tree runs (t, t+8) -> quad_perm xor 2, (t, t+4) ->
+//   quad_perm xor 1, then (0,2)/(1,3) and the last add inside the lane: jo_reduce16's association.
+template <int HS, int RU>
+__global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 32 * RU, TPP = TP + 4, half = HS / 2, NC = HS / 16, PPB = NT / 4;   // PPB positions per pass
+    const int group = p.n_heads / p.n_kv_heads;
+    const int id = blockIdx.x, kvh = id % p.n_kv_heads, rest = id / p.n_kv_heads, gi = rest % group, colq = rest / group;
+    const int h = kvh * group + gi, d0 = colq * DW;
+    const int pos = p.st->pos, n = pos + 1;
+    const int KV = p.n_kv_heads * HS, A = p.n_heads * HS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, qd = tid & 3, prow = tid >> 2;
+    float* vt = (float*)smem;              // [DW][TPP] V tile, TRANSPOSED: a column's positions are contiguous (one ds_read_b128 = 4 links of
+                                           // its chain; rows 4 banks apart: conflict-free)
+    float* redf = vt + (size_t)DW * TPP;   // [16]
+    float* qs = redf + 16;                 // [HS] rotated q of this head
+    float* knew = qs + HS;                 // [HS] rotated k of the new row
+    float* w = knew + HS;                  // [n, padded to 64] scores -> softmax weights
+    const float* qkv_row = p.qkv;
+#define JH_FSTAMP(kk) do { if (p.dbg && tid == 0 && (id >> 3) < 16) p.dbg[(id >> 3) * 16 + (kk)] = wall_clock64(); } while (0)   // workgroups of kv head (id & 7)
+    JH_FSTAMP(0);
+    // ---- K rows of the first two passes: their addresses depend on the position only (one round trip together with q / rope)
+    f32x4 ka[NC], kb[NC], kc[NC], kd[NC];
+    auto load_k = [&](f32x4 (&k)[NC], int pass) __attribute__((always_inline)) {
+        int tt = pass * PPB + prow;
+        tt = tt < n ? tt : n - 1;
+        const float* krow = kv_row(p, 0, tt, KV) + (size_t)kvh * HS + 4 * qd;
+#pragma unroll
+        for (int c = 0; c < NC; c++) k[c] = *(const f32x4*)(krow + 16 * c);
+    };
+    const int npass = (n + PPB - 1) / PPB;
+    load_k(ka, 0);
+    if (npass > 1) load_k(kb, 1);
+    if (npass > 2) load_k(kc, 2);
+    if (npass > 3) load_k(kd, 3);
+    // ---- V tile 0 of this workgroup's 32 columns (position `pos` is being filed by another workgroup right now: it comes from the
+    // q|k|v row instead; rows past n are clamped copies of it)
+    const int vr = tid >> 3, vc = tid & 7;
+    auto load_v = [&](f32x4 (&vreg)[RU], int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            if (tile * TP + 32 * u >= n) continue;
+            int tt = tile * TP + vr + 32 * u;
+            tt = tt < n ? tt : n - 1;
+            const float* vrow = tt == pos ? qkv_row + A + KV + (size_t)kvh * HS + d0 : kv_row(p, 1, tt, KV) + (size_t)kvh * HS + d0;
+            vreg[u] = ((const f32x4*)vrow)[vc];
+        }
+    };
+    // ---- RoPE of this head's q and of the new k row (table row pos + 2*kvHead: CausalSelfAttention.java:247-286)
+    const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
+    const bool owner = gi == 0 && colq == 0;
+    for (int i = tid; i < 2 * half; i += NT) {
+        const int which = i / half, d = i - which * half;
+        const float c = rf[2 * d], sn = rf[2 * d + 1];
+        if (which == 0) {
+            const float* qh = qkv_row + (size_t)h * HS;
+            const float q0 = qh[d], q1 = qh[d + half];
+            const float r0 = q0 * c - q1 * sn, r1 = q0 * sn + q1 * c;   // contraction off: mul, mul, sub / add as in Java
+            qs[d] = r0; qs[d + half] = r1;
+            if (p.tap_q && colq == 0) { p.tap_q[(size_t)h * HS + d] = r0; p.tap_q[(size_t)h * HS + d + half] = r1; }
+        } else {
+            const float* kh = qkv_row + A + (size_t)kvh * HS;
+            const float k0 = kh[d], k1 = kh[d + half];
+            const float r0 = k0 * c - k1 * sn, r1 = k0 * sn + k1 * c;
+            knew[d] = r0; knew[d + half] = r1;
+            if (owner) {   // K is stored post-RoPE (:273-286 rotates the page row in place)
+                float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
+                kdst[d] = r0; kdst[d + half] = r1;
+            }
+        }
+    }
+    if (owner)
+        for (int d = tid; d < HS; d += NT) ((float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS)[d] = qkv_row[A + KV + (size_t)kvh * HS + d];
+    auto file_v = [&](const f32x4 (&vreg)[RU], int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < RU; u++)
+            if (tile * TP + 32 * u < n) {
+                float* dst = vt + (size_t)(4 * vc) * TPP + vr + 32 * u;
+                dst[0] = vreg[u].x; dst[TPP] = vreg[u].y; dst[2 * TPP] = vreg[u].z; dst[3 * TPP] = vreg[u].w;
+            }
+    };
+    f32x4 vreg[RU];
+    load_v(vreg, 0);                                        // in flight across the scores and the softmax
+    JH_FSTAMP(1);
+    __syncthreads();
+    JH_FSTAMP(2);
+    f32x4 q4[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) q4[c] = *(const f32x4*)(qs + 16 * c + 4 * qd);
+    // ---- scores: PPB positions per pass, two passes in flight
+    float m = -INFINITY;
+    auto score_pass = [&](f32x4 (&k)[NC], int pass) __attribute__((always_inline)) {
+        const int tt = pass * PPB + prow;
+        if (tt == pos) {                                    // the page row is being written just now: the rotated row from LDS
+#pragma unroll
+            for (int c = 0; c < NC; c++) k[c] = *(const f32x4*)(knew + 16 * c + 4 * qd);
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {                      // GemmerF32 (PTO:1086-1102): chain t = 4 qd + j, steps of 16
+            s0 = fmaf(q4[c].x, k[c].x, s0); s1 = fmaf(q4[c].y, k[c].y, s1); s2 = fmaf(q4[c].z, k[c].z, s2); s3 = fmaf(q4[c].w, k[c].w, s3);
+        }
+        s0 = s0 + dpp_f<0x4E>(s0); s1 = s1 + dpp_f<0x4E>(s1); s2 = s2 + dpp_f<0x4E>(s2); s3 = s3 + dpp_f<0x4E>(s3);   // v[i] + v[i + 8]
+        s0 = s0 + dpp_f<0xB1>(s0); s1 = s1 + dpp_f<0xB1>(s1); s2 = s2 + dpp_f<0xB1>(s2); s3 = s3 + dpp_f<0xB1>(s3);   // a[i] + a[i + 4]
+        const float sc = ((s0 + s2) + (s1 + s3)) * p.scale;                                                           // (b0+b2) + (b1+b3); ops.scale after the dot (:332)
+        if (tt < n) {
+            if (qd == 0) w[tt] = sc;
+            m = fmaxf(m, sc);
+        }
+    };
+    for (int pass = 0; pass < npass; pass += 4) {          // four passes (256 positions) in flight
+        score_pass(ka, pass);
+        if (pass + 4 < npass) load_k(ka, pass + 4);
+        if (pass + 1 < npass) { score_pass(kb, pass + 1); if (pass + 5 < npass) load_k(kb, pass + 5); }
+        if (pass + 2 < npass) { score_pass(kc, pass + 2); if (pass + 6 < npass) load_k(kc, pass + 6); }
+        if (pass + 3 < npass) { score_pass(kd, pass + 3); if (pass + 7 < npass) load_k(kd, pass + 7); }
+    }
+    // ---- softMax (VectorMath.java:69-90): max, (float)exp in double, FLOAT sum in index order by one lane, division
+    JH_FSTAMP(3);
+    m = wave_max(m);
+    if (lane == 0) redf[wave] = m;
+    __syncthreads();
+    m = redf[0];
+    for (int i = 1; i < NT / 64; i++) m = fmaxf(m, redf[i]);
+    for (int tt = tid; tt < n; tt += NT) w[tt] = (float)exp((double)(w[tt] - m));
+    JH_FSTAMP(4);
+    __syncthreads();                                        // exponentials visible
+    JH_FSTAMP(5);
+    if (wave != 0) file_v(vreg, 0);                         // waves 1..3 file tile 0 (wave 0's share follows its sum) WHILE lane 0 sums
+    if (tid == 0) {
+        // one float accumulator in index order (VectorMath.java:80-85); the next 16 values are in flight while the current 16 are added
+        float sum = 0.0f;
+        f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
+        auto add16 = [&](const f32x4& e0, const f32x4& e1, const f32x4& e2, const f32x4& e3, int t0) __attribute__((always_inline)) {
+            if (t0 + 16 <= n) {
+                sum += e0.x; sum += e0.y; sum += e0.z; sum += e0.w; sum += e1.x; sum += e1.y; sum += e1.z; sum += e1.w;
+                sum += e2.x; sum += e2.y; sum += e2.z; sum += e2.w; sum += e3.x; sum += e3.y; sum += e3.z; sum += e3.w;
+            } else {
+                const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (t0 + j < n) sum += e[j];
+            }
+        };
+        const unsigned wad = lds_addr(w);                   // w[] is padded: the reads past n stay inside the workgroup's LDS
+        lds_read64_nowait(a0, a1, a2, a3, wad);
+        for (int t0 = 0; t0 < n; t0 += 32) {
+            lds_read64_nowait(b0, b1, b2, b3, wad + (unsigned)(t0 + 16) * 4u);
+            lds_tie<4>(a0, a1, a2, a3);
+            add16(a0, a1, a2, a3, t0);
+            lds_read64_nowait(a0, a1, a2, a3, wad + (unsigned)(t0 + 32) * 4u);
+            lds_tie<4>(b0, b1, b2, b3);
+            if (t0 + 16 < n) add16(b0, b1, b2, b3, t0 + 16);
+        }
+        lds_tie<0>(a0, a1, a2, a3);
+        redf[8] = sum;
+        JH_FSTAMP(6);
+    }
+    if (wave == 0) file_v(vreg, 0);
+    __syncthreads();
+    const float sum = redf[8];
+    for (int tt = tid; tt < n; tt += NT) w[tt] = w[tt] / sum;
+    // ---- value[d] = fma chain over positions (saxpy per position, PTO:2648-2698): lanes 0..31 of wave 0 own one column each
+    float acc = 0.0f;
+    const int ntiles = (n + TP - 1) / TP;
+    for (int tile = 0; tile < ntiles; tile++) {
+        if (tile > 0) {
+            __syncthreads();
+            f32x4 vnext[RU];
+            load_v(vnext, tile);
+            file_v(vnext, tile);
+        }
+        __syncthreads();
+        if (tid < DW) {
+            const int tbase = tile * TP, cnt = n - tbase < TP ? n - tbase : TP;
+            f32x4 va0, va1, va2, va3, wa0, wa1, wa2, wa3, vb0, vb1, vb2, vb3, wb0, wb1, wb2, wb3;
+            const unsigned vad = lds_addr(vt + (size_t)tid * TPP), wad = lds_addr(w + tbase);
+            auto chain16 = [&](const f32x4& v0, const f32x4& v1, const f32x4& v2, const f32x4& v3, const f32x4& w0, const f32x4& w1, const f32x4& w2,
+                               const f32x4& w3, int i0) __attribute__((always_inline)) {
+                if (i0 + 16 <= cnt) {
+                    acc = fmaf(v0.x, w0.x, acc); acc = fmaf(v0.y, w0.y, acc); acc = fmaf(v0.z, w0.z, acc); acc = fmaf(v0.w, w0.w, acc);
+                    acc = fmaf(v1.x, w1.x, acc); acc = fmaf(v1.y, w1.y, acc); acc = fmaf(v1.z, w1.z, acc); acc = fmaf(v1.w, w1.w, acc);
+                    acc = fmaf(v2.x, w2.x, acc); acc = fmaf(v2.y, w2.y, acc); acc = fmaf(v2.z, w2.z, acc); acc = fmaf(v2.w, w2.w, acc);
+                    acc = fmaf(v3.x, w3.x, acc); acc = fmaf(v3.y, w3.y, acc); acc = fmaf(v3.z, w3.z, acc); acc = fmaf(v3.w, w3.w, acc);
+                } else {
+                    const float vv[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+                    const float ww[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        if (i0 + j < cnt) acc = fmaf(vv[j], ww[j], acc);
+                }
+            };
+            // 16 links per chunk (one 64-byte read of the column, one of the weights); the next chunk is in flight during the chain.
+            // Reads past cnt stay inside the tile / the padded weight row and are never used.
+            lds_read64_nowait(va0, va1, va2, va3, vad);
+            lds_read64_nowait(wa0, wa1, wa2, wa3, wad);
+            for (int i0 = 0; i0 < cnt; i0 += 32) {
+                const unsigned nb = (unsigned)(i0 + 16 < TP ? i0 + 16 : 0) * 4u, na = (unsigned)(i0 + 32 < TP ? i0 + 32 : 0) * 4u;
+                lds_read64_nowait(vb0, vb1, vb2, vb3, vad + nb);
+                lds_read64_nowait(wb0, wb1, wb2, wb3, wad + nb);
+                lds_tie<8>(va0, va1, va2, va3);
+                lds_tie<8>(wa0, wa1, wa2, wa3);
+                chain16(va0, va1, va2, va3, wa0, wa1, wa2, wa3, i0);
+                lds_read64_nowait(va0, va1, va2, va3, vad + na);
+                lds_read64_nowait(wa0, wa1, wa2, wa3, wad + na);
+                lds_tie<8>(vb0, vb1, vb2, vb3);
+                lds_tie<8>(wb0, wb1, wb2, wb3);
+                if (i0 + 16 < cnt) chain16(vb0, vb1, vb2, vb3, wb0, wb1, wb2, wb3, i0 + 16);
+            }
+            lds_tie<0>(va0, va1, va2, va3);
+            lds_tie<0>(wa0, wa1, wa2, wa3);
+        }
+    }
+    if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
+    JH_FSTAMP(7);
+#undef JH_FSTAMP
+}
+static inline size_t lds_bytes_attn_p16_fused(int max_ctx, int hs) {
+    const int want = ((max_ctx + 63) & ~63) / 32;
+    const int ru = want <= 2 ? 2 : want <= 4 ? 4 : want <= 8 ? 8 : 16;
+    return ((size_t)32 * (ru * 32 + 4) + 16 + 2 * (size_t)hs + (size_t)((max_ctx + 63) & ~63) + 2 * 128) * 4;
+}
 static inline int p16_av_rows(int max_ctx) {   // RU: the whole context in one tile when it fits
     const int want = ((max_ctx + 63) & ~63) / 32;
     return want <= 2 ? 2 : want <= 4 ? 4 : want <= 8 ? 8 : 16;

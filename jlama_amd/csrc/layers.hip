@@ -43,6 +43,23 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
         if (lds_av > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "reference-order attention: the score row of max_ctx positions must fit in LDS");
         const dim3 grid_s(s->p16_att_splits, c.n_kv_heads), grid_v(hs / 32, c.n_heads);
         const int ru = p16_av_rows(s->max_ctx);
+        // contexts of up to ~1 k positions: scores, softmax and value chains in ONE launch (attn_p16_fused_kernel); beyond that the K
+        // rows of a head are too many for one workgroup to ingest and the scores stay spread over the chip (two launches)
+        const int fused_max = opt_int("JH_P16_ATT_FUSED", 1024);
+        const size_t lds_f = lds_bytes_attn_p16_fused(s->max_ctx, hs);
+        if (s->max_ctx <= fused_max && lds_f <= 158 * 1024 && (hs == 128 || hs == 64) && c.n_heads % c.n_kv_heads == 0) {
+            const dim3 grid_f(c.n_heads * (hs / 32));
+#define JH_P16_FUSED(HSV, RV)                                                                                                   \
+    if (hs == HSV && ru == RV) {                                                                                               \
+        JHCHK(allow_lds((attn_p16_fused_kernel<HSV, RV>), lds_f));                                                             \
+        hipLaunchKernelGGL((attn_p16_fused_kernel<HSV, RV>), grid_f, dim3(P16_ATT_THREADS), lds_f, st, p);                     \
+        HIPCHK(hipGetLastError());                                                                                             \
+        return JH_OK;                                                                                                          \
+    }
+            JH_P16_FUSED(128, 2) JH_P16_FUSED(128, 4) JH_P16_FUSED(128, 8) JH_P16_FUSED(128, 16)
+            JH_P16_FUSED(64, 2) JH_P16_FUSED(64, 4) JH_P16_FUSED(64, 8) JH_P16_FUSED(64, 16)
+#undef JH_P16_FUSED
+        }
 #define JH_P16_AV(HSV, RV)                                                                                                      \
     if (hs == HSV && ru == RV) {                                                                                               \
         JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                               \

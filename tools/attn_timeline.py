@@ -7,10 +7,15 @@ N.init(0)
 N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 m = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
 names = ["entry", "loads issued", "rope done", "scores", "softmax", "PV", "reduced", "published", "ticket", "combined"]
+strict = os.environ.get("ATT_STRICT")            # reference order: the one-launch kernel (attn_p16_fused_kernel) stamps its own phases
+if strict:
+    names = ["entry", "loads issued", "rope barrier", "scores", "max+exp", "tile filed", "sum", "values stored", "-", "-"]
 for env in ({},):
     os.environ.update(env)
-    s = m.session(1024)
-    for pos in (384,):
+    s = m.session(int(os.environ.get("ATT_CTX", "1024")))
+    if strict:
+        s.set_strict(True)
+    for pos in tuple(int(x) for x in os.environ.get("ATT_POS", "384").split(",")):
         out = np.zeros(256, dtype=np.int64)
         N.check(N.lib().jh_debug_attn_timeline(s.h, pos, N.ptr(out), 256))
         t = out.reshape(16, 16)
