@@ -21,6 +21,7 @@ void drop_stale_graphs(jh_session* s) {
         if (s->exec_s[v]) { hipGraphExecDestroy(s->exec_s[v]); s->exec_s[v] = nullptr; }
         if (s->graph_s[v]) { hipGraphDestroy(s->graph_s[v]); s->graph_s[v] = nullptr; }
         if (s->exec[v]) { hipGraphExecDestroy(s->exec[v]); s->exec[v] = nullptr; }
+        if (s->exec_m[v]) { hipGraphExecDestroy(s->exec_m[v]); s->exec_m[v] = nullptr; hipGraphDestroy(s->graph_m[v]); s->graph_m[v] = nullptr; }
         if (s->graph[v]) { hipGraphDestroy(s->graph[v]); s->graph[v] = nullptr; }
         if (s->row_exec[v]) { hipGraphExecDestroy(s->row_exec[v]); s->row_exec[v] = nullptr; }
         if (s->row_graph[v]) { hipGraphDestroy(s->row_graph[v]); s->row_graph[v] = nullptr; }
@@ -221,6 +222,24 @@ int build_graph(jh_session* s, int v, float temperature) {
     size_t n_nodes = 0;                                   // what the graph actually holds (kernel nodes; no memcpy / memset nodes are captured)
     HIPCHK(hipGraphGetNodes(g, nullptr, &n_nodes));
     s->kernels_per_token = (int)n_nodes;
+    // the same token tokens_per_graph times in ONE graph (greedy loop only)
+    if (has_out && s->tokens_per_graph > 1 && !s->exec_m[v]) {
+        s->tap_layer = -1;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = JH_OK;
+        for (int t = 0; t < s->tokens_per_graph && rc == JH_OK; t++) {
+            rc = layers_launch(s, st, 0);
+            if (rc == JH_OK) rc = lmhead_launch(s, st);
+            if (rc == JH_OK) rc = finish_launch(s, st, 1, 0.0f);
+        }
+        hipGraph_t gm = nullptr;
+        e = hipStreamEndCapture(st, &gm);
+        s->tap_layer = saved_tap;
+        if (rc != JH_OK) { if (gm) hipGraphDestroy(gm); return rc; }
+        if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture (multi-token graph): ") + hipGetErrorString(e));
+        s->graph_m[v] = gm;
+        HIPCHK(hipGraphInstantiate(&s->exec_m[v], gm, nullptr, nullptr, 0));
+    }
     return JH_OK;
 }
 
@@ -275,11 +294,18 @@ int decode_n_async_impl(jh_session* s, int32_t first_token, int start_pos, int n
     // never idles and at most 2*EOS_CHUNK steps are replayed for nothing.
     constexpr int EOS_CHUNK = 16;
     int launched = 0, chunk = 0;
+    const int T = s->tokens_per_graph;                       // (a divisor of EOS_CHUNK: a multi-token launch never straddles a snapshot)
     for (int i = 0; i < n; i++) {
         const int v = attn_variant_for(s, start_pos + i);   // the host knows every token's position in advance
         if (use_graph) {
             JHCHK(build_graph(s, v, temperature));
-            HIPCHK(hipGraphLaunch(sampled ? s->exec_s[v] : s->exec[v], st));
+            if (!sampled && T > 1 && s->exec_m[v] && i + T <= n && launched % T == 0 && attn_variant_for(s, start_pos + i + T - 1) == v) {   // (each variant is one range of positions)
+                HIPCHK(hipGraphLaunch(s->exec_m[v], st));   // T tokens, one launch
+                i += T - 1;
+                launched += T - 1;
+            } else {
+                HIPCHK(hipGraphLaunch(sampled ? s->exec_s[v] : s->exec[v], st));
+            }
         } else {
             const int saved = s->tap_layer;
             s->tap_layer = -1;

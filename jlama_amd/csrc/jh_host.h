@@ -143,6 +143,11 @@ struct jh_session {
     int graphs_version = 0;   // jh_model::weights_version the cached graphs were captured against
     hipGraph_t graph[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
     hipGraphExec_t exec[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
+    // the greedy loop replays JH_TOKENS_PER_GRAPH tokens per launch where it can (~8 us pass between two graph launches, only a kernel
+    // boundary between two tokens inside one graph): same nodes, same order, the position is a device word
+    hipGraph_t graph_m[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t exec_m[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
+    int tokens_per_graph = 4;
     hipGraph_t row_graph[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};   // this shard's layers only: single-row forward (pipeline stages)
     hipGraphExec_t row_exec[N_ATTN_VARIANTS] = {nullptr, nullptr, nullptr};
     int pending_n = 0;

@@ -344,6 +344,7 @@ int ensure_out_tokens(jh_session* s, int n) {
     s->out_cap = n;
     for (int v = 0; v < N_ATTN_VARIANTS; v++) {   // out_tokens pointer is baked into the captured graphs
         if (s->exec[v]) { hipGraphExecDestroy(s->exec[v]); s->exec[v] = nullptr; hipGraphDestroy(s->graph[v]); s->graph[v] = nullptr; }
+        if (s->exec_m[v]) { hipGraphExecDestroy(s->exec_m[v]); s->exec_m[v] = nullptr; hipGraphDestroy(s->graph_m[v]); s->graph_m[v] = nullptr; }
         if (s->exec_s[v]) { hipGraphExecDestroy(s->exec_s[v]); s->exec_s[v] = nullptr; hipGraphDestroy(s->graph_s[v]); s->graph_s[v] = nullptr; }
     }
     return JH_OK;

@@ -386,7 +386,7 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     if (s->long_splits > s->part_stride) s->part_stride = s->long_splits;
     // "direct" attention: contexts of up to 4 slices x 128 rows are combined by the o-projection's prologue
     s->direct_chunk = 128;
-    s->direct_max = 0;   // ("direct" mode -- the o-projection's prologue combining the attention slices -- measured slower, DESIGN.md 3: removed)
+    s->direct_max = 0;   // ("direct" mode -- the o-projection's prologue combining the attention slices -- measured slower, profiles/NOTEBOOK_rounds_1-4.md 3: removed)
     HIPCHK(hipMalloc(&s->part_o, (size_t)c.n_heads * s->part_stride * c.head_size * 4));
     HIPCHK(hipMalloc(&s->part_ml, (size_t)c.n_heads * s->part_stride * 2 * 4));
     HIPCHK(hipMemset(s->part_o, 0, (size_t)c.n_heads * s->part_stride * c.head_size * 4));
@@ -417,6 +417,8 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     HIPCHK(hipEventCreateWithFlags(&s->ev_chunk[1], hipEventDisableTiming));
     s->strict = opt_int("JH_STRICT_ORDER", 0) ? 1 : 0;
     s->p16_depth = opt_int("JH_P16_D", 8);   // upper bound of the prefetch depth (p16_depth_for)
+    s->tokens_per_graph = opt_int("JH_TOKENS_PER_GRAPH", 4);   // 1, 2, 4, 8 or 16 (a divisor of the stop-token snapshot interval)
+    if (s->tokens_per_graph != 2 && s->tokens_per_graph != 4 && s->tokens_per_graph != 8 && s->tokens_per_graph != 16) s->tokens_per_graph = 1;
     // reference-order attention: one slice of the context per 16 positions of max_ctx, at least 16, at most 256 (the slices that
     // lie beyond the current position return at once)
     s->p16_att_splits = opt_int("JH_P16_ATT_SPLITS", 0);
@@ -478,6 +480,7 @@ int jh_session_destroy(jh_session* s) {
         if (s->exec_s[v]) hipGraphExecDestroy(s->exec_s[v]);
         if (s->graph_s[v]) hipGraphDestroy(s->graph_s[v]);
         if (s->exec[v]) hipGraphExecDestroy(s->exec[v]);
+        if (s->exec_m[v]) { hipGraphExecDestroy(s->exec_m[v]); hipGraphDestroy(s->graph_m[v]); }
         if (s->graph[v]) hipGraphDestroy(s->graph[v]);
         if (s->row_exec[v]) hipGraphExecDestroy(s->row_exec[v]);
         if (s->row_graph[v]) hipGraphDestroy(s->row_graph[v]);

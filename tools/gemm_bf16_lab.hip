@@ -3,7 +3,7 @@
 //   ring  gemm_bf16_ring_lab: a fifth LOADER wave stages A (global -> registers one iteration ahead -> LDS double buffer), the
 //         MFMA waves request weights only, PW chunks of 4 fragments in flight; A fragments are read a slice ahead of their MFMAs.
 // Vector-memory loads retire in order, so in `base` the wait for the young A loads (L2) is a wait for every older weight load
-// (HBM) too; `ring` separates the two streams.  Round 4 measured: K walk 770 -> 456 cycles per k slice, gate|up
+// (HBM) too; `ring` separates the two streams.  Round 4 measured (profiles/NOTEBOOK_rounds_1-4.md 8.3): K walk 770 -> 456 cycles per k slice, gate|up
 // un-split 90 -> 61 us, but with the best K split per shape only 6 % per layer -- and WITHOUT any global load the loop still takes
 // 45 us (knock-outs below), i.e. the kernel is within 1.4x of its matrix-pipe time at 160 padded rows.
 // Results of ring are compared bit for bit with base (same MFMA order).  knock: 1 no A loads, 2 no W loads, 4 no barriers, 8 A
