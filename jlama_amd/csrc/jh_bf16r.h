@@ -274,18 +274,26 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_bf16r_kernel(GemvParams p, i
 
 // ------------------------------------------------------------------------------------------------ prompt rows (M > 1), reference order
 // GemmerBF16 with M rows (AbstractModel.batchForward, AbstractModel.java:295-312): every (prompt row, weight row) pair is the
-// GEMV's 16-lane chain; only the weight side is shared.  The activations of a chunk are written ONCE per projection input as the
-// LDS image the GEMM reads (rows_act_bf16r_kernel), 8-row tiles:
+// GEMV's 16-lane chain; only the weight side is shared.  What sizes the tile (first version, 8 prompt rows x 4 row quads per wave,
+// ran at 1/6 of its fma issue rate: profiles/r05d_*): every fma needs an activation value and a weight value, and the two paths
+// they come by are narrow -- LDS delivers 128 B/clk per CU, i.e. 32 x QW fmas per clock when an activation word read from LDS is
+// reused for QW row quads held in registers; the CU's L1 fill path delivers ~10 B/clk (~25 GB/s, the rate every streaming kernel of
+// this library sees), i.e. ~5 x MR fmas per clock when a weight fetched into the CU is reused for MR prompt rows.  With
+// QW x MR accumulators per lane bounded by the register file, QW = 4 and MR = 24 balance the two (128 vs 125 fmas per clock, against
+// 228 the packed fma could issue); 129 rows = 6 tiles of 24 (144 padded rows).
+// The activations of a chunk are written ONCE per projection input as the LDS image the GEMM reads (rows_act_bf16r_kernel):
 //   image[tile][p][j][rq][t][rr] (floats)   p = 64-element pair of steps, j = 0..3: element 64p + 16j + t,
-//                                           rq = row quad of the tile (0, 1), t = chain, rr = row inside the quad
+//                                           rq = row quad of the tile (0 .. MR/4 - 1), t = chain, rr = row inside the quad
 // so that one ds_read_b128 hands lane t the values of 4 prompt rows for one link of its chain (16 lanes = 256 contiguous bytes,
 // conflict-free; the wave's four 16-lane rows read the same addresses: broadcast), and a K chunk of a tile is contiguous.
-constexpr int BFR_MR = 8;            // prompt rows per tile
-constexpr int BFR_QW = 4;            // row quads (4 weight rows each) per wave
+constexpr int BFR_MR = 24;           // prompt rows per tile
+constexpr int BFR_RQ = BFR_MR / 4;   // row quads per tile
+constexpr int BFR_QW = 4;            // weight row quads (4 weight rows each) per wave
 constexpr int BFR_WAVES = 4;         // waves per workgroup: 64 weight rows
-constexpr int BFR_CG = 8;            // groups of 128 elements per LDS chunk (1024 elements x 8 rows x 4 B = 32 KiB)
-static inline size_t bfr_image_floats(int rows_cap, int K) { return (size_t)((rows_cap + BFR_MR - 1) / BFR_MR) * ((K + BF16R_GROUP - 1) / BF16R_GROUP) * 2 * 512; }
-static inline size_t lds_bytes_gemm_bf16r() { return (size_t)2 * BFR_CG * 2 * 512 * 4; }
+constexpr int BFR_CG = 2;            // groups of 128 elements per LDS chunk (256 elements x 24 rows x 4 B = 24 KiB; two buffers)
+constexpr int BFR_GROUP_F4 = 8 * BFR_RQ * 16;   // f32x4 words of one group's image: [p(2)][j(4)][rq][t(16)]
+static inline size_t bfr_image_floats(int rows_cap, int K) { return (size_t)((rows_cap + BFR_MR - 1) / BFR_MR) * ((K + BF16R_GROUP - 1) / BF16R_GROUP) * BFR_GROUP_F4 * 4; }
+static inline size_t lds_bytes_gemm_bf16r() { return (size_t)2 * BFR_CG * BFR_GROUP_F4 * 16; }
 
 enum { PROB_SILU_BF16 = 4 };         // y = silu(gate) * up (MLPBlock.java:132-142), rounded to BF16: the down projection's input
 struct RowsBfrParams {
@@ -303,8 +311,8 @@ __global__ __launch_bounds__(256) void rows_act_bf16r_kernel(RowsBfrParams p) {
     const float* x = p.x + (size_t)row * p.ldx;
     float fs = 1.0f;
     if (PRO == PROB_RMS_BF16) fs = rms_factor(x, p.K, p.eps, red);
-    const int NP = p.K / 64;
-    float* img = p.image + (size_t)(row / BFR_MR) * NP * 512 + ((row % BFR_MR) >> 2) * 64 + (row & 3);
+    const int NP = p.K / 64, rin = row % BFR_MR;
+    float* img = p.image + (size_t)(row / BFR_MR) * NP * (BFR_GROUP_F4 * 2) + (rin >> 2) * 64 + (rin & 3);   // (BFR_GROUP_F4 * 4 floats per group = 2 p)
     for (int unit = threadIdx.x; unit < p.K / 8; unit += blockDim.x) {
         const int e0 = unit * 8;
         const float4 xa = *(const float4*)(x + e0), xb = *(const float4*)(x + e0 + 4);
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(256) void rows_act_bf16r_kernel(RowsBfrParams p) {
             for (int i = 0; i < 8; i++) y[i] = silu_ref(y[i]) * uu[i];
         }
         const int pp = e0 >> 6, j = (e0 >> 4) & 3, t0 = e0 & 15;
-        float* dst = img + ((size_t)pp * 4 + j) * 128 + t0 * 4;
+        float* dst = img + ((size_t)pp * 4 + j) * (BFR_RQ * 64) + t0 * 4;
 #pragma unroll
         for (int i = 0; i < 8; i++) dst[4 * i] = bf16_to_f32(f32_to_bf16(y[i]));   // quantizeBF16 (RNE), widened again
     }
@@ -331,75 +339,120 @@ __global__ __launch_bounds__(256) void rows_act_bf16r_kernel(RowsBfrParams p) {
 
 struct GemmBfrParams {
     const uint8_t* w;                // BF16T copy, row stride ldb bytes
-    int ldb, nrows, K, rows;         // weight rows, K (multiple of 128), prompt rows
+    int ldb, nrows, K, rows;         // weight rows, K (multiple of 256), prompt rows
     const float* image;              // activations (rows_act_bf16r_kernel)
     float* out; int ldc;             // out[row * ldc + weight row]
     const float* resid; int ldr;     // EPI_RESID
-    int nslices, nrt;                // 64-row weight slices, 8-row tiles
+    int nslices, nrt;                // 64-row weight slices, MR-row tiles
 };
 // grid: ((nslices + 7) / 8) * 8 * nrt workgroups; the row tiles of one weight slice are consecutive in launch order on ONE XCD
 // (blockIdx & 7), so all but the first find the slice in that XCD's L2.
 template <int EPI>
-__global__ __launch_bounds__(BFR_WAVES * 64) void gemm_bf16r_kernel(GemmBfrParams p) {
+__global__ __launch_bounds__(BFR_WAVES * 64, 2) void gemm_bf16r_kernel(GemmBfrParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* lds = (f32x4*)smem;                                  // [2][BFR_CG * 2 * 128] f32x4
-    constexpr int NT = BFR_WAVES * 64, CHUNK4 = BFR_CG * 2 * 128, LU = CHUNK4 / NT;   // 16-byte units per chunk / per thread
+    f32x4* lds = (f32x4*)smem;                                  // [2][BFR_CG * BFR_GROUP_F4] f32x4
+    constexpr int NT = BFR_WAVES * 64, CHUNK4 = BFR_CG * BFR_GROUP_F4, LU = (CHUNK4 + NT - 1) / NT;   // 16-byte units per chunk / per thread
     const int id = blockIdx.x, xcd = id & 7, k = id >> 3, rt = k % p.nrt, slice = (k / p.nrt) * 8 + xcd;
     if (slice >= p.nslices) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane >> 4, t = lane & 15;
-    const int G = p.K / BF16R_GROUP, nchunks = (G + BFR_CG - 1) / BFR_CG;
-    const f32x4* img = (const f32x4*)p.image + (size_t)rt * G * 256;   // 2 * 512 floats = 256 f32x4 per group
-    const i32x4* wrow[BFR_QW];
+    const int G = p.K / BF16R_GROUP, nchunks = G / BFR_CG;      // host: G % 2 == 0
+    // uniform base pointers + 32-bit lane offsets (a weight copy is < 4 GiB, an activation image < 64 MiB): per-lane 64-bit pointers
+    // of four row quads and of the staging loads cost the registers the accumulators need
+    const char* img = (const char*)p.image + (size_t)rt * G * BFR_GROUP_F4 * 16;
+    unsigned woff[BFR_QW];
 #pragma unroll
     for (int q = 0; q < BFR_QW; q++) {
         int row = slice * 64 + wave * 16 + q * 4 + r;
         row = row < p.nrows ? row : p.nrows - 1;
-        wrow[q] = (const i32x4*)(p.w + (size_t)row * p.ldb) + t;
+        woff[q] = (unsigned)row * (unsigned)p.ldb + (unsigned)t * 16u;
     }
-    float acc[BFR_QW][BFR_MR];
+    // accumulators as register PAIRS updated in place by v_pk_fma_f32 (two prompt rows per instruction; each half is the fused fma of
+    // the chain).  Written as asm: left to hipcc, the packed fmas get fresh destination registers, the loop carries copies of every
+    // accumulator, and under the 256-register budget of two workgroups per CU the prefetched loads are spilled as they arrive.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc[BFR_QW][BFR_MR / 2];
 #pragma unroll
     for (int q = 0; q < BFR_QW; q++)
 #pragma unroll
-        for (int m = 0; m < BFR_MR; m++) acc[q][m] = 0.0f;
+        for (int m = 0; m < BFR_MR / 2; m++) acc[q][m] = f32x2{0.0f, 0.0f};
     f32x4 sreg[LU];
     auto stage_load = [&](int c) __attribute__((always_inline)) {
-        const int n4 = (G - c * BFR_CG < BFR_CG ? G - c * BFR_CG : BFR_CG) * 256;
 #pragma unroll
         for (int u = 0; u < LU; u++) {
             int idx = tid + u * NT;
-            idx = idx < n4 ? idx : n4 - 1;
-            sreg[u] = img[(size_t)c * CHUNK4 + idx];
+            idx = idx < CHUNK4 ? idx : CHUNK4 - 1;
+            sreg[u] = *(const f32x4*)(img + (unsigned)(c * CHUNK4 + idx) * 16u);
         }
     };
     auto stage_store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < LU; u++) lds[buf * CHUNK4 + tid + u * NT] = sreg[u];
+        for (int u = 0; u < LU; u++)
+            if (tid + u * NT < CHUNK4) lds[buf * CHUNK4 + tid + u * NT] = sreg[u];
     };
     i32x4 wa[BFR_QW], wb[BFR_QW];
     auto wload = [&](i32x4 (&w)[BFR_QW], int g) __attribute__((always_inline)) {
-        const int gg = g < G ? g : G - 1;
+        const unsigned gg = (unsigned)(g < G ? g : G - 1) * 256u;
 #pragma unroll
-        for (int q = 0; q < BFR_QW; q++) w[q] = wrow[q][16 * gg];
+        for (int q = 0; q < BFR_QW; q++) w[q] = *(const i32x4*)(p.w + (woff[q] + gg));
     };
+    // The activation words of a link: BFR_RQ ds_read_b128, 256 bytes apart, written as asm and NOT waited for -- hipcc otherwise
+    // hoists every LDS read of a group to its top (the reads of 8 links live at once: hundreds of registers, spills) and closes each
+    // with lgkmcnt(0).  bfr_tie: at most N younger LDS reads stay in flight, the words become readable (jh_p16.h: lds_tie).
+    auto read_link = [&](f32x4 (&av)[BFR_RQ], unsigned abase, int i) __attribute__((always_inline)) {
+        const unsigned ad = abase + (unsigned)(i * BFR_RQ) * 256u;
+        static_assert(BFR_RQ == 4 || BFR_RQ == 5 || BFR_RQ == 6, "asm below");
+        if constexpr (BFR_RQ == 4)
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:256\n\tds_read_b128 %2, %4 offset:512\n\tds_read_b128 %3, %4 offset:768"
+                         : "=&v"(av[0]), "=&v"(av[1]), "=&v"(av[2]), "=&v"(av[3]) : "v"(ad) : "memory");
+        else if constexpr (BFR_RQ == 5)
+            asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:256\n\tds_read_b128 %2, %5 offset:512\n\tds_read_b128 %3, %5 offset:768\n\t"
+                         "ds_read_b128 %4, %5 offset:1024"
+                         : "=&v"(av[0]), "=&v"(av[1]), "=&v"(av[2]), "=&v"(av[3]), "=&v"(av[4]) : "v"(ad) : "memory");
+        else
+            asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:256\n\tds_read_b128 %2, %6 offset:512\n\tds_read_b128 %3, %6 offset:768\n\t"
+                         "ds_read_b128 %4, %6 offset:1024\n\tds_read_b128 %5, %6 offset:1280"
+                         : "=&v"(av[0]), "=&v"(av[1]), "=&v"(av[2]), "=&v"(av[3]), "=&v"(av[4]), "=&v"(av[5]) : "v"(ad) : "memory");
+    };
+    auto tie_link = [&](f32x4 (&av)[BFR_RQ]) __attribute__((always_inline)) {   // the OLDER link's words have landed (the younger link's BFR_RQ reads may still fly)
+        if constexpr (BFR_RQ == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3])::"memory");
+        else if constexpr (BFR_RQ == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5])::"memory");
+    };
+    auto tie_last = [&](f32x4 (&av)[BFR_RQ]) __attribute__((always_inline)) {
+        if constexpr (BFR_RQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3])::"memory");
+        else if constexpr (BFR_RQ == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5])::"memory");
+    };
+    auto fma_link = [&](const f32x4 (&av)[BFR_RQ], const i32x4 (&w)[BFR_QW], int i) __attribute__((always_inline)) {
+        f32x2 wv[BFR_QW];
+#pragma unroll
+        for (int q = 0; q < BFR_QW; q++) {
+            const int d = w[q][i >> 1];
+            const float f = __int_as_float((i & 1) ? (d & (int)0xffff0000) : (d << 16));
+            wv[q] = f32x2{f, f};
+        }
+#pragma unroll
+        for (int q = 0; q < BFR_QW; q++)
+#pragma unroll
+            for (int rq = 0; rq < BFR_RQ; rq++) {
+                const f32x2 alo = __builtin_shufflevector(av[rq], av[rq], 0, 1), ahi = __builtin_shufflevector(av[rq], av[rq], 2, 3);
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[q][2 * rq]) : "v"(alo), "v"(wv[q]));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[q][2 * rq + 1]) : "v"(ahi), "v"(wv[q]));
+            }
+    };
+    // one group = 8 links; the words of link i+1 are requested before the fmas of link i
     auto compute = [&](const i32x4 (&w)[BFR_QW], const f32x4* a) __attribute__((always_inline)) {
-        // a: the group's image in LDS: [p = 0, 1][j][rq][t] f32x4
+        const unsigned abase = lds_addr(a + t);
+        f32x4 av0[BFR_RQ], av1[BFR_RQ];
+        read_link(av0, abase, 0);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const f32x4 a0 = a[(i * 2 + 0) * 16 + t], a1 = a[(i * 2 + 1) * 16 + t];
-            float wv[BFR_QW];
-#pragma unroll
-            for (int q = 0; q < BFR_QW; q++) {
-                const int d = w[q][i >> 1];
-                wv[q] = __int_as_float((i & 1) ? (d & (int)0xffff0000) : (d << 16));
-            }
-#pragma unroll
-            for (int q = 0; q < BFR_QW; q++) {
-                acc[q][0] = fmaf(a0.x, wv[q], acc[q][0]); acc[q][1] = fmaf(a0.y, wv[q], acc[q][1]);
-                acc[q][2] = fmaf(a0.z, wv[q], acc[q][2]); acc[q][3] = fmaf(a0.w, wv[q], acc[q][3]);
-                acc[q][4] = fmaf(a1.x, wv[q], acc[q][4]); acc[q][5] = fmaf(a1.y, wv[q], acc[q][5]);
-                acc[q][6] = fmaf(a1.z, wv[q], acc[q][6]); acc[q][7] = fmaf(a1.w, wv[q], acc[q][7]);
-            }
+        for (int i = 0; i < 8; i += 2) {
+            read_link(av1, abase, i + 1);
+            tie_link(av0);
+            fma_link(av0, w, i);
+            if (i + 2 < 8) { read_link(av0, abase, i + 2); tie_link(av1); } else tie_last(av1);
+            fma_link(av1, w, i + 1);
         }
     };
     stage_load(0);
@@ -410,23 +463,24 @@ __global__ __launch_bounds__(BFR_WAVES * 64) void gemm_bf16r_kernel(GemmBfrParam
         const int buf = c & 1;
         if (c + 1 < nchunks) stage_load(c + 1);
         const f32x4* a = lds + buf * CHUNK4;
-        const int g0 = c * BFR_CG, ng = G - g0 < BFR_CG ? G - g0 : BFR_CG;   // ng even whenever G is (the host requires G % 2 == 0)
-        for (int gi = 0; gi < ng; gi += 2) {
+        const int g0 = c * BFR_CG;
+#pragma unroll
+        for (int gi = 0; gi < BFR_CG; gi += 2) {
             wload(wb, g0 + gi + 1);
-            compute(wa, a + (size_t)gi * 256);
+            compute(wa, a + (size_t)gi * BFR_GROUP_F4);
             wload(wa, g0 + gi + 2);
-            compute(wb, a + (size_t)(gi + 1) * 256);
+            compute(wb, a + (size_t)(gi + 1) * BFR_GROUP_F4);
         }
         if (c + 1 < nchunks) stage_store(buf ^ 1);
         __syncthreads();
     }
-    // ---- epilogue: the 16 lanes of a row all hold the finished sums; lane t stores (prompt row t & 7, quads t >> 3 and 2 + (t >> 3))
+    // ---- epilogue: the 16 lanes of a row all hold the finished sums; result (q, m) is stored by lane (q * MR + m) mod 16
 #pragma unroll
     for (int q = 0; q < BFR_QW; q++)
 #pragma unroll
         for (int m = 0; m < BFR_MR; m++) {
-            const float res = row16_tree_sum(acc[q][m]);
-            if (t == (q & 1) * 8 + m) {
+            const float res = row16_tree_sum((m & 1) ? acc[q][m >> 1].y : acc[q][m >> 1].x);
+            if (t == ((q * BFR_MR + m) & 15)) {
                 const int wr = slice * 64 + wave * 16 + q * 4 + r, prow = rt * BFR_MR + m;
                 if (wr < p.nrows && prow < p.rows) {
                     float v = res;
@@ -434,6 +488,7 @@ __global__ __launch_bounds__(BFR_WAVES * 64) void gemm_bf16r_kernel(GemmBfrParam
                     p.out[(size_t)prow * p.ldc + wr] = v;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);                  // one result at a time (96 of them: hipcc otherwise keeps them all live)
         }
 }
 
