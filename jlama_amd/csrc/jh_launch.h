@@ -258,7 +258,7 @@ int launch_gemv_t16(const GemvParams& p, hipStream_t st) {
         JHCHK(allow_lds((gemv_t16_kernel<PRO, EPI, DV, UMV, NT>), lds));                                           \
         hipLaunchKernelGGL((gemv_t16_kernel<PRO, EPI, DV, UMV, NT>), dim3(grid), dim3(NT), lds, st, p, tpw, aw);   \
     } while (0)
-    if (nq % 4 == 0) {
+    if (nq % 4 == 0) {   // 4 q steps (4 KiB + 1 KiB of scales) in flight per wave; 8 measured slower (gate|up 14.2 -> 15.4 us, 186 VGPRs: round 5)
         if (p.K <= 4096) JH_T16_LAUNCH(4, 1); else JH_T16_LAUNCH(4, 2);
     } else {
         if (p.K <= 4096) JH_T16_LAUNCH(2, 1); else JH_T16_LAUNCH(2, 2);
