@@ -543,6 +543,9 @@ def main():
         out = D.bench_pipeline(args, cfg)
         if out is not None:
             print(json.dumps(out), flush=True)
+        if D.hard_exit["now"]:     # a leg left a collective stuck on some rank: the line is out, nobody waits for a teardown that cannot finish
+            sys.stdout.flush()
+            os._exit(0)
         return
     if args.gpus > 1 or os.environ.get("JH_BENCH_FORCE_PIPELINE"):
         out, rc = run_one_process(args, cfg)   # bare invocation: the one-process host, never a rendezvous

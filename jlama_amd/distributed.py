@@ -763,6 +763,9 @@ def multi_gpu_extras(args, cfg, gate_up_probe, device_index=0):
     return roof, cpu
 
 
+hard_exit = {"now": False}   # set when a leg left a collective stuck: bench.py prints rank 0's line and every rank leaves through os._exit
+
+
 def bench_pipeline(args, cfg, backend="nccl", engine_factory=None, tp_engine_factory=None):
     """bench.py's N>1 leg (one rank per GPU under torch.distributed.run).  Returns the JSON dict on rank 0.
     Three measurements: N sessions in flight through the rank-per-GPU RCCL pipeline (the timed K tokens of the contract),
@@ -930,23 +933,54 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None, tp_engine_fac
     if world > 1 and not can_tp:
         tp_leg = {"skipped": f"{cfg['n_kv_heads']} kv heads / H = {cfg['hidden_length']} do not split over {world} shards"}
     elif world > 1 and not os.environ.get("JH_BENCH_NO_TP_LEG") and (tp_engine_factory is not None or (on_gpu and cfg["weight_dtype"] == 3)):
-        try:
-            tp_ctx = prompt.size + args.steps + 16
-            if tp_engine_factory is not None:
-                tp_engine = tp_engine_factory(rank, world, tp_ctx)
-            else:
-                from . import synthetic_torch as ST
-                engine.close() if hasattr(engine, "close") else None
-                wf = ST.make_weights(cfg, seed=0, device=device)      # the full model on every rank's own device; its windows stay
-                torch.cuda.synchronize()
-                tp_engine = HipTPEngine(cfg, wf, rank, world, local, tp_ctx)
-                del wf
-                torch.cuda.empty_cache()
-                if strict:
-                    tp_engine.s.set_strict(True)
-            tp_leg = tp_rank_bench(dist, tp_engine, rank, world, prompt, args.steps, cfg, device, torch.float32, use_ipc=on_gpu)
-        except Exception as e:   # noqa: BLE001 -- an optional leg never costs the line (a rank that fails alone would hang the others:
-            tp_leg = {"error": repr(e)[:400]}   # every collective of the leg sits inside tp_rank_bench, after construction)
+        # This leg has never run on more than one GPU (1-GPU boxes): it must not be able to cost the line.  It runs on a helper
+        # thread; a rank whose leg raises, or is still inside a collective when the budget is over, says so on the rendezvous STORE
+        # (TCP, not RCCL), every rank reads everybody's verdict there, and if one is not "ok" no further collective is issued: rank 0
+        # prints the line from what it has measured and all ranks leave through os._exit (bench.py: `hard_exit`).
+        import threading
+        from datetime import timedelta
+        from torch.distributed.distributed_c10d import _get_default_store
+        state = {"leg": None, "err": None}
+
+        def _tp_work():
+            try:
+                if on_gpu:
+                    torch.cuda.set_device(local)             # the device is a per-thread setting of the HIP runtime
+                tp_ctx = prompt.size + args.steps + 16
+                if tp_engine_factory is not None:
+                    tp_engine = tp_engine_factory(rank, world, tp_ctx)
+                else:
+                    from . import synthetic_torch as ST
+                    wf = ST.make_weights(cfg, seed=0, device=device)      # the full model on every rank's own device; its windows stay
+                    torch.cuda.synchronize()
+                    tp_engine = HipTPEngine(cfg, wf, rank, world, local, tp_ctx)
+                    del wf
+                    torch.cuda.empty_cache()
+                    if strict:
+                        tp_engine.s.set_strict(True)
+                state["leg"] = tp_rank_bench(dist, tp_engine, rank, world, prompt, args.steps, cfg, device, torch.float32, use_ipc=on_gpu)
+            except Exception as e:   # noqa: BLE001
+                state["err"] = repr(e)[:400]
+
+        budget = float(os.environ.get("JH_BENCH_TP_TIMEOUT", "420"))
+        th = threading.Thread(target=_tp_work, daemon=True)
+        th.start()
+        th.join(timeout=budget)
+        mine = "hung" if th.is_alive() else ("error" if state["err"] else "ok")
+        store = _get_default_store()
+        store.set(f"jh_tp_leg_{rank}", mine)
+        verdicts = []
+        for r in range(world):
+            try:
+                store.wait([f"jh_tp_leg_{r}"], timedelta(seconds=budget + 60))
+                verdicts.append(store.get(f"jh_tp_leg_{r}").decode())
+            except Exception:   # noqa: BLE001 -- that rank never reported
+                verdicts.append("silent")
+        if all(v == "ok" for v in verdicts):
+            tp_leg = state["leg"]
+        else:
+            tp_leg = {"error": state["err"] or f"tensor-parallel leg did not complete on every rank within {budget:.0f} s", "rank_verdicts": verdicts}
+            hard_exit["now"] = True                          # a collective may be stuck: no barrier, no destroy_process_group from here on
     out = None
     if rank == 0:
         gate_up = None
@@ -1001,7 +1035,8 @@ def bench_pipeline(args, cfg, backend="nccl", engine_factory=None, tp_engine_fac
                "cpu_baseline": cpu_base, "one_process_pipeline": one_proc,
                "tensor_parallel": {"rank_per_gpu": tp_leg,
                                    "one_process": (one_proc or {}).get("tensor_parallel") if isinstance(one_proc, dict) else None}}
-    dist.destroy_process_group()
+    if not hard_exit["now"]:
+        dist.destroy_process_group()
     # RCCL prints its version banner through C stdio, which is block-buffered when stdout is a pipe and would otherwise land AFTER
     # the JSON line at exit: flush it now so that the contract line is the last thing on stdout
     try:

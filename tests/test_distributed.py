@@ -116,7 +116,7 @@ def test_layer_range_matches_distributed_context():
         D.layer_range(0, 3, 32)
 
 
-def _bench_worker(rank, world, port, cfg, q):
+def _bench_worker(rank, world, port, cfg, q, fail_tp_on_rank=-1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       OMP_NUM_THREADS="2")
     import argparse
@@ -161,6 +161,8 @@ def _bench_worker(rank, world, port, cfg, q):
     class OracleTPEngine(D.TPEngine):
         """head-split shard on the oracle: the rank-per-GPU tensor-parallel leg of the line (tp_rank_bench) on CPU"""
         def __init__(self, rank, world, max_ctx):
+            if rank == fail_tp_on_rank:
+                raise RuntimeError("this rank cannot build its shard")      # (the other rank is then alone in the leg's first collective)
             w = S.make_weights(cfg, seed=0)
             lc, off = D.tp_shard_config(cfg, rank, world)
             self.full = O.OracleModel(cfg, w) if rank == 0 else None
@@ -208,6 +210,10 @@ def _bench_worker(rank, world, port, cfg, q):
     out = D.bench_pipeline(args, cfg, backend="gloo", engine_factory=OracleShardEngine, tp_engine_factory=OracleTPEngine)
     if rank == 0:
         q.put(out)
+    if D.hard_exit["now"]:        # what bench.py does: a collective is stuck on some rank, nobody waits for a teardown
+        import time
+        time.sleep(1.0)           # (let the queue's feeder thread flush)
+        os._exit(0)
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -249,6 +255,34 @@ def test_bench_pipeline_control_flow_on_cpu(world):
     assert out["one_process_pipeline"] == {"skipped": "no GPU (control-flow run)"}
     for key in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "roofline"):
         assert key in out
+
+
+def test_bench_line_survives_a_tensor_parallel_leg_that_wedges():
+    """The rank-per-GPU tensor-parallel leg has never run on more than one GPU.  If it raises on one rank (the others are then stuck in
+    a collective) the line must still come out: verdicts travel over the rendezvous store, no further collective is issued, `value`
+    falls back to the layer-split single stream, the leg's key carries the error, and every rank leaves without a teardown."""
+    import torch.multiprocessing as mp
+    from jlama_amd import synthetic as S
+    cfg = dict(S.TINY)
+    cfg["n_layers"] = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    os.environ["JH_BENCH_TP_TIMEOUT"] = "6"
+    try:
+        procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, cfg, q, 1)) for r in range(2)]
+        for p in procs:
+            p.start()
+        out = q.get(timeout=240)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        del os.environ["JH_BENCH_TP_TIMEOUT"]
+    tpl = out["tensor_parallel"]["rank_per_gpu"]
+    assert "error" in tpl and sorted(tpl["rank_verdicts"]) == ["error", "hung"], tpl
+    assert out["tensor_parallel_tokens_per_s"] is None and out["value"] == out["single_stream_tokens_per_s"] > 0
+    assert "layer-sharded" in out["config"]["parallelism"] and out["steps"] == 8
 
 
 def test_bare_multi_gpu_bench_invocation_always_prints_one_json_line():
