@@ -72,6 +72,8 @@ def _quiesce(torch, kick=None):
     device is idle (seen with K = 20: torch.cuda.synchronize() behind a 28 ms decode took 39 ms more; never with K = 256, where
     that time has long passed) -- a closing synchronize must measure the K steps, not that.  `kick` (a few untimed steps of the
     same loop) runs after the pauses, so that the timed region does not start on clocks that dropped while this waited."""
+    if kick:       # first: every graph the timed region replays gets its FIRST launch here (round 5: the 4-tokens-per-launch graphs were
+        kick()     # first launched by the kick below, and the runtime's ~40 ms of deferred work after a first launch fell into the timed region)
     for _ in range(50):
         time.sleep(0.02)
         t = time.perf_counter()
