@@ -52,7 +52,7 @@ static __global__ __launch_bounds__(256) void bf16t_pack_kernel(const uint16_t* 
         const int e = g * BF16R_GROUP + 32 * i;
         if (e < K) v[i] = (int)((unsigned)src[32 * i + t] | ((unsigned)src[32 * i + 16 + t] << 16));
     }
-    ((i32x4*)out)[idx] = v;
+    ((i32x4*)out)[((row >> 2) * G + g) * 64 + (row & 3) * 16 + t] = v;   // the rows of a quad interleaved per group, as in the P16T copies (jh_p16.h)
 }
 
 // ------------------------------------------------------------------------------------------------ activation row in LDS
@@ -163,11 +163,11 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_bf16r_kernel(GemvParams p, i
     auto set_row = [&]() __attribute__((always_inline)) {
         int row = 4 * lq + r;
         row = row < p.nrows ? row : p.nrows - 1;
-        wrow = ((NP == 2 && lpass) ? p.w2 : p.w) + (size_t)row * p.ldb;
+        wrow = p16t_row_ptr((NP == 2 && lpass) ? p.w2 : p.w, row, p.ldb);
     };
     set_row();
     auto issue = [&](i32x4& w) __attribute__((always_inline)) {
-        w = __builtin_nontemporal_load((const i32x4*)wrow + 16 * lg + t);   // BF16T copy: chunk t of group lg
+        w = __builtin_nontemporal_load((const i32x4*)wrow + 64 * lg + t);   // BF16T copy: chunk t of group lg (1 KiB contiguous per wave instruction)
         if (++lg == G) {
             lg = 0;
             if (++lpass == NP) { lpass = 0; ++lq; }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(BFR_WAVES * 64, 2) void gemm_bf16r_kernel(GemmBfrPa
     for (int q = 0; q < BFR_QW; q++) {
         int row = slice * 64 + wave * 16 + q * 4 + r;
         row = row < p.nrows ? row : p.nrows - 1;
-        woff[q] = (unsigned)row * (unsigned)p.ldb + (unsigned)t * 16u;
+        woff[q] = (unsigned)(row >> 2) * ((unsigned)p.ldb * 4u) + (unsigned)(row & 3) * 256u + (unsigned)t * 16u;
     }
     // accumulators as register PAIRS updated in place by v_pk_fma_f32 (two prompt rows per instruction; each half is the fused fma of
     // the chain).  Written as asm: left to hipcc, the packed fmas get fresh destination registers, the loop carries copies of every
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(BFR_WAVES * 64, 2) void gemm_bf16r_kernel(GemmBfrPa
     };
     i32x4 wa[BFR_QW], wb[BFR_QW];
     auto wload = [&](i32x4 (&w)[BFR_QW], int g) __attribute__((always_inline)) {
-        const unsigned gg = (unsigned)(g < G ? g : G - 1) * 256u;
+        const unsigned gg = (unsigned)(g < G ? g : G - 1) * 1024u;
 #pragma unroll
         for (int q = 0; q < BFR_QW; q++) w[q] = *(const i32x4*)(p.w + (woff[q] + gg));
     };

@@ -16,8 +16,8 @@
 //     chains.  Round 3 transposed the 16x16 byte matrix of a group of 16 blocks in registers (28 DPP / v_perm ops per group, a
 //     fifth of the kernel's VALU work).  Now the weights these kernels read are a resident copy in "P16T" order, made once per
 //     weight by p16t_pack_kernel: inside every group of 16 blocks (256 bytes of a row) byte 16t + c = byte t of block c, so the
-//     16-byte load of lane t IS byte t of the group's 16 blocks -- same 256 contiguous bytes per row and 1 KiB per wave
-//     instruction, no shuffles; rows are padded to whole groups (zeros);
+//     16-byte load of lane t IS byte t of the group's 16 blocks, no shuffles; the four rows of a quad are interleaved per group so
+//     that a wave instruction reads 1 KiB contiguous; rows are padded to whole groups (zeros);
 //   * nibbles become int8 16*(nib-8) = ((nib << 4) ^ 0x80) with two bit ops per dword (4 blocks), so the pair sum
 //     lo*a[t] + hi*a[t+16] is ONE v_dot4_i32_i8 against a (a[t], a[t+16], 0, 0) activation word (byte-selected by v_perm), exact;
 //     the 1/16 goes into the activation block scale (a power of two: every rounding is unchanged);
@@ -60,6 +60,10 @@ static __global__ __launch_bounds__(256) void p16t_pack_kernel(const uint8_t* __
     const int g = (int)(rg % G);
     const long long row = rg / G;
     const uint8_t* src = w + (size_t)row * ldb + (size_t)g * 256 + t;
+    // where the chunk goes: the four rows of a row quad are INTERLEAVED per group -- [quad][group][row in quad][chunk t] -- so that the
+    // wave instruction of a quad (lane = 16 r + t) reads 1 KiB contiguous, like the T16 copies (round 5: as four 256-byte pieces 2 KB
+    // apart the LM head streamed at 4.4 TB/s against gate|up's 5.3, profiles/r05e_*)
+    const long long oidx = ((row >> 2) * G + g) * 64 + (row & 3) * 16 + t;
     // dword d of the chunk = nibble pair t of blocks 4d..4d+3 (b0..b3), nibble positions (from bit 0):
     //   [lo_b1, lo_b0, hi_b1, hi_b0, lo_b3, lo_b2, hi_b3, hi_b2]
     // so that  x & 0xF0F0F0F0         = bytes [lo_b0, hi_b0, lo_b2, hi_b2] * 16  (one op)
@@ -74,9 +78,13 @@ static __global__ __launch_bounds__(256) void p16t_pack_kernel(const uint8_t* __
         const int plo = (b == 0) ? 4 : (b == 1) ? 0 : (b == 2) ? 20 : 16;   // bit position of the low nibble; the high one sits 8 bits above
         v[c >> 2] |= (int)((lo << plo) | (hi << (plo + 8)));
     }
-    ((i32x4*)out)[idx] = v;
+    ((i32x4*)out)[oidx] = v;
 }
-static inline size_t p16t_row_bytes(int K) { return (size_t)((K / QB + 15) / 16) * 256; }
+static inline size_t p16t_row_bytes(int K) { return (size_t)((K / QB + 15) / 16) * 256; }   // bytes per row; a quad's four rows share 4 of them, interleaved
+// this lane's window into a P16T / BF16T copy: row `row` of its quad, then chunk (64 * group + t) in 16-byte units
+__device__ __forceinline__ const uint8_t* p16t_row_ptr(const uint8_t* base, int row, int ldb) {
+    return base + (size_t)(row >> 2) * ((size_t)ldb * 4) + (size_t)(row & 3) * 256;
+}
 
 // acc = fma(p[lane N of the row], f, acc) / m = p[lane N of the row] * f: the DPP operand of a VOP2 instruction does the broadcast
 template <int N> __device__ __forceinline__ void fmac_bcast(float& acc, float p, float f);
@@ -312,13 +320,13 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
     auto set_row = [&]() __attribute__((always_inline)) {
         int row = 4 * lq + r;
         row = row < p.nrows ? row : p.nrows - 1;
-        wrow = ((NP == 2 && lpass) ? p.w2 : p.w) + (size_t)row * p.ldb;
+        wrow = p16t_row_ptr((NP == 2 && lpass) ? p.w2 : p.w, row, p.ldb);
         srow = ((NP == 2 && lpass) ? p.ws2 : p.ws) + (size_t)row * p.ldbf;
     };
     set_row();
     auto issue = [&](i32x4& w, float& s) __attribute__((always_inline)) {
         int b = 16 * lg + t;
-        w = __builtin_nontemporal_load((const i32x4*)wrow + b);   // P16T: chunk t of group lg = byte t of its 16 blocks (rows padded to whole groups)
+        w = __builtin_nontemporal_load((const i32x4*)wrow + (64 * lg + t));   // P16T: chunk t of group lg = byte t of its 16 blocks (rows padded to whole groups)
         b = b < nblk ? b : nblk - 1;                        // short last group: the surplus lanes reload its last scale (unused)
         s = __builtin_nontemporal_load(srow + b);
         if (++lg == G) {
@@ -522,13 +530,13 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_f32q4_p16_kernel(GemvParams 
     auto set_row = [&]() __attribute__((always_inline)) {
         int row = 4 * lq + r;
         row = row < p.nrows ? row : p.nrows - 1;
-        wrow = p.w + (size_t)row * p.ldb;
+        wrow = p16t_row_ptr(p.w, row, p.ldb);
         srow = p.ws + (size_t)row * p.ldbf;
     };
     set_row();
     auto issue = [&](i32x4& w, float& s) __attribute__((always_inline)) {
         int b = 16 * lg + t;
-        w = __builtin_nontemporal_load((const i32x4*)wrow + b);   // P16T copy
+        w = __builtin_nontemporal_load((const i32x4*)wrow + (64 * lg + t));   // P16T copy
         b = b < nblk ? b : nblk - 1;
         s = __builtin_nontemporal_load(srow + b);
         if (++lg == G) { lg = 0; ++lq; set_row(); }

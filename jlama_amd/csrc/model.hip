@@ -60,7 +60,7 @@ int ensure_p16t(JWeight& W, hipStream_t st) {
     if (W.p16t || !W.data) return JH_OK;
     if (W.dtype == JH_DT_BF16) {   // BF16T order (jh_bf16r.h): the 16-byte chunk t of a 128-element group = the next 8 links of chain t
         const size_t rb = bf16t_row_bytes(W.cols);
-        if (hipMalloc((void**)&W.p16t, (size_t)W.rows * rb + 64) != hipSuccess) { W.p16t = nullptr; return set_err(JH_ERR_OOM, "hipMalloc BF16T weight copy"); }
+        if (hipMalloc((void**)&W.p16t, (size_t)((W.rows + 3) & ~3) * rb + 64) != hipSuccess) { W.p16t = nullptr; return set_err(JH_ERR_OOM, "hipMalloc BF16T weight copy"); }
         g_operand_packs++;
         const long long threads = (long long)W.rows * (long long)(rb / 16);
         hipLaunchKernelGGL(bf16t_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const uint16_t*)W.data, W.rows, W.cols, W.cols, W.p16t);
@@ -70,7 +70,7 @@ int ensure_p16t(JWeight& W, hipStream_t st) {
     if (W.dtype != JH_DT_Q4) return JH_OK;
     const int nblk = W.cols / QB;
     const size_t rb = p16t_row_bytes(W.cols);
-    if (hipMalloc((void**)&W.p16t, (size_t)W.rows * rb + 64) != hipSuccess) { W.p16t = nullptr; return set_err(JH_ERR_OOM, "hipMalloc P16T weight copy"); }
+    if (hipMalloc((void**)&W.p16t, (size_t)((W.rows + 3) & ~3) * rb + 64) != hipSuccess) { W.p16t = nullptr; return set_err(JH_ERR_OOM, "hipMalloc P16T weight copy"); }
     g_operand_packs++;
     const long long threads = (long long)W.rows * (long long)(rb / 16);
     hipLaunchKernelGGL(p16t_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, (const uint8_t*)W.data, W.rows, nblk, W.cols / 2, W.p16t);
