@@ -2,7 +2,7 @@
 """Timeline of consecutive decode tokens out of a rocprofv3 (rocpd sqlite) kernel trace: where the time of one token goes --
 inside kernels (begin..end of each dispatch) or between them (end of one dispatch .. begin of the next on the same stream).
 A token = the dispatches between two finish_token_kernel dispatches; only tokens of a graph-replayed decode loop are used
-(as many gate+up GEMVs as the model has layers: 6 dispatches per layer in reference order, 5 in the order-free loop).
+(as many gate+up GEMVs as the model has layers: 5 dispatches per layer; 6 in reference order with the three-launch attention).
 Usage: tools/rocpd_timeline.py <results.db> [n_tokens=4] [reference-order|order-free]"""
 import re
 import sqlite3
@@ -32,7 +32,8 @@ for a, b in zip(cuts, cuts[1:]):
     names = [r[0] for r in seg]
     gu = sum(1 for n in names if re.match(r"gemv_t16_kernel<1, 2,", n) or re.match(r"gemv_i8q4_kernel<1, 2,", n))
     strict = any("p16" in n for n in names)
-    if gu == 0 or len(seg) != (6 if strict else 5) * gu + 2:   # + LM head + finish: the replayed decode graph only
+    per_layer = 6 if strict and not any(n.startswith("attn_p16_fused") for n in names) else 5   # one-launch reference-order attention: 5
+    if gu == 0 or len(seg) != per_layer * gu + 2:              # + LM head + finish: the replayed decode graph only
         continue
     by_kind["reference-order" if strict else "order-free"].append((a, seg))
 want = sys.argv[3] if len(sys.argv) > 3 else ("reference-order" if by_kind["reference-order"] else "order-free")
