@@ -211,6 +211,7 @@ _PROTOS = {
     "jh_session_synchronize": (_i, [_p]),
     "jh_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _p]),
     "jh_debug_attn_timeline": (_i, [_p, _i, _p, _i]),
+    "jh_debug_gemv_timeline": (_i, [_p, _i, _p, _i]),
     "jh_kernel_bench": (_i, [_p, _i, _i, _p, _p]),
 }
 EXPORTS = sorted(_PROTOS)

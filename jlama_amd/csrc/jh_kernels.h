@@ -210,6 +210,7 @@ struct GemvParams {
     unsigned* const* tp_flags;   // [tp_n] flag row of this shard on shard j, one word per workgroup of THIS launch
     const unsigned* tp_seq;      // tokens replayed so far (device word)
     int tp_n, tp_li, tp_L;
+    long long* dbg;              // optional phase timestamps (wall_clock64, 100 MHz) of the reference-order few-row GEMVs: [workgroup][wave][8]
 };
 // EPI_TP's store: the shard's slot on every shard
 __device__ __forceinline__ void tp_store(const GemvParams& p, int row, float v) {

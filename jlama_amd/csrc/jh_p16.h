@@ -29,6 +29,7 @@
 //     per workgroup into LDS (same fused RMSNorm + Q8 prologue, Panama rule) as pair words, 4 blocks per 8-byte read.
 // Compiled with -ffp-contract=off like the rest: every FMA is explicit.
 #pragma once
+#include <type_traits>
 #include "jh_kernels.h"
 
 namespace jh {
@@ -81,6 +82,8 @@ static __global__ __launch_bounds__(256) void p16t_pack_kernel(const uint8_t* __
     ((i32x4*)out)[oidx] = v;
 }
 static inline size_t p16t_row_bytes(int K) { return (size_t)((K / QB + 15) / 16) * 256; }   // bytes per row; a quad's four rows share 4 of them, interleaved
+// 32-bit LDS byte address of a shared-memory pointer (operand of the asm ds_read forms below)
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
 // this lane's window into a P16T / BF16T copy: row `row` of its quad, then chunk (64 * group + t) in 16-byte units
 __device__ __forceinline__ const uint8_t* p16t_row_ptr(const uint8_t* base, int row, int ldb) {
     return base + (size_t)(row >> 2) * ((size_t)ldb * 4) + (size_t)(row & 3) * 256;
@@ -281,6 +284,43 @@ __device__ __forceinline__ void p16_group_i8(const i32x4& x, const i32x4* pt, fl
     p16_quad_chain<3, FULL>(q3, pscale, nb, acc);
 }
 
+// The same group with its activation operands held in REGISTERS and refilled in place for the NEXT group: hipcc closes every LDS
+// read it emits with s_waitcnt lgkmcnt(0) a few instructions later, i.e. a working wave (alone on its SIMD in the few-row GEMVs)
+// sat out the LDS round trip four times per group (gemv_timeline: 550-720 cycles per group for ~95 instructions).  Here the reads
+// are asm (no automatic wait), issued one group ahead in consumption order -- d16, pair words of quads 0..3 -- and every use waits
+// with lgkmcnt(4): LDS operations retire in order, so at most the four younger requests are still in flight.
+struct PairRegsP16 { i32x4 w0, w1, w2, w3; float d; };
+__device__ __forceinline__ void p16_req_pairs(i32x4& w, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=&v"(w) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void p16_req_d(float& d, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=&v"(d) : "v"(addr) : "memory"); }
+__device__ __forceinline__ void p16_tie4(i32x4& w) { asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w)::"memory"); }
+__device__ __forceinline__ void p16_tie4(float& d) { asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d)::"memory"); }
+// LAST: the wave's final group requests nothing -- a request still in flight when its registers are dead would land in whatever
+// hipcc has put there since (it cannot see the asm reads) -- and therefore waits for everything at once.
+template <bool FULL, bool LAST>
+__device__ __forceinline__ void p16_group_i8_regs(const i32x4& x, PairRegsP16& r, unsigned pt_next, float pscale, int nb, float& acc) {
+    if constexpr (LAST) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.w0), "+v"(r.w1), "+v"(r.w2), "+v"(r.w3)::"memory");
+    else p16_tie4(r.w0);
+    const Quad4 q0 = p16_quad_sums(x.x, r.w0);
+    if constexpr (!LAST) p16_req_pairs(r.w0, pt_next);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) p16_tie4(r.w1);
+    const Quad4 q1 = p16_quad_sums(x.y, r.w1);
+    if constexpr (!LAST) p16_req_pairs(r.w1, pt_next + 256u);
+    p16_quad_chain<0, FULL>(q0, pscale, nb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) p16_tie4(r.w2);
+    const Quad4 q2 = p16_quad_sums(x.z, r.w2);
+    if constexpr (!LAST) p16_req_pairs(r.w2, pt_next + 512u);
+    p16_quad_chain<1, FULL>(q1, pscale, nb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) p16_tie4(r.w3);
+    const Quad4 q3 = p16_quad_sums(x.w, r.w3);
+    if constexpr (!LAST) p16_req_pairs(r.w3, pt_next + 768u);
+    p16_quad_chain<2, FULL>(q2, pscale, nb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    p16_quad_chain<3, FULL>(q3, pscale, nb, acc);
+}
+
 // (da/16) * sb of the block this lane loaded, later read through the DPP operand of v_fmac_f32.  Written by asm with two idle
 // states behind it: a DPP read of a VGPR needs 2 wait states after the VALU write, and hipcc's hazard recognizer does not see
 // inside the asm blocks that do the reading.
@@ -344,11 +384,14 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
         return p.resid[row];
     };
     ActRegsP16<UM> ar;
+#define JH_GSTAMP(kk) do { if (p.dbg && lane == 0) p.dbg[((size_t)blockIdx.x * (NT / 64) + wave) * 8 + (kk)] = wall_clock64(); } while (0)
+    JH_GSTAMP(0);
     if (items == 0) {
         // helper wave: its own copy of the prologue (same barriers).  The two paths must not join: hipcc computes ONE vmcnt per wait
         // and would size the working waves' waits for the path without ring loads, i.e. drain the ring inside the prologue.
         stage_issue_p16<PRO, UM, NT>(p, ar);
         stage_finish_p16<PRO, UM, NT>(p, a, ar);
+        JH_GSTAMP(2);
         if constexpr (EPI == EPI_TP) tp_signal(p);       // every wave of the workgroup passes one tp_signal (its barrier)
         return;
     }
@@ -360,21 +403,40 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
         issue(wq[d], sq[d]);
         __builtin_amdgcn_sched_barrier(0);                  // request order = consumption order (the loop's vmcnt waits count on it)
     }
+    JH_GSTAMP(1);                                           // activation row + ring requested
     stage_finish_p16<PRO, UM, NT>(p, a, ar);
+    JH_GSTAMP(2);                                           // activation operands in LDS (workgroup barrier passed)
 
     float acc = 0.0f, gres = 0.0f, gsel = 0.0f, usel = 0.0f;
     int cq = q0, cpass = 0, cg = 0;                         // compute cursor
     // one group in two halves with the slot's refill between them: prep() takes the scale product out of the loaded registers
-    auto prep = [&](i32x4& x, float s, int g) __attribute__((always_inline)) {
+    // activation operands of the group being consumed (registers), requested one group ahead: see p16_group_i8_regs
+    PairRegsP16 pr;
+    const unsigned pt_base = lds_addr(a.pt) + (unsigned)t * 16u, d_base = lds_addr(a.d16);
+    auto d_addr = [&](int g) __attribute__((always_inline)) {
         int bd = 16 * g + t;
         bd = bd < nblk ? bd : nblk - 1;
-        return p16_scale_product(a.d16[bd], s);             // lane t carries the scale product of block 16*g + t
+        return d_base + (unsigned)bd * 4u;
     };
-    auto compute = [&](const i32x4& x, float pscale, int g, bool can_be_short) __attribute__((always_inline)) {
-        const i32x4* pt = a.pt + (size_t)(4 * g) * 16 + t;
+    // (a pass -- one row quad -- ends with nothing in flight: pass_end() is compiler-scheduled code with branches, and registers
+    // with a pending LDS write must not be moved or spilled by something that does not know about it)
+    auto request_first = [&]() __attribute__((always_inline)) {
+        p16_req_d(pr.d, d_addr(0));
+        p16_req_pairs(pr.w0, pt_base); p16_req_pairs(pr.w1, pt_base + 256u); p16_req_pairs(pr.w2, pt_base + 512u); p16_req_pairs(pr.w3, pt_base + 768u);
+    };
+    request_first();
+    auto prep = [&](i32x4& x, float s, int g, auto last) __attribute__((always_inline)) {
+        p16_tie4(pr.d);
+        const float ps = p16_scale_product(pr.d, s);        // lane t carries the scale product of block 16*g + t
+        if constexpr (!decltype(last)::value) p16_req_d(pr.d, d_addr(g + 1 == G ? 0 : g + 1));
+        return ps;
+    };
+    auto compute = [&](const i32x4& x, float pscale, int g, bool can_be_short, auto last) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last)::value;
+        const unsigned pt_next = pt_base + (unsigned)(g + 1 == G ? 0 : g + 1) * 1024u;
         const int nb = nblk - 16 * g;
-        if (can_be_short && nb < 16) p16_group_i8<false>(x, pt, pscale, nb, acc);
-        else p16_group_i8<true>(x, pt, pscale, 16, acc);
+        if (can_be_short && nb < 16) p16_group_i8_regs<false, LAST>(x, pr, pt_next, pscale, nb, acc);
+        else p16_group_i8_regs<true, LAST>(x, pr, pt_next, pscale, 16, acc);
     };
     auto pass_end = [&]() __attribute__((always_inline)) {
         const float res = row16_tree_sum(acc);
@@ -403,25 +465,42 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
     for (int it = 0; it + D < items; it += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            i32x4 x = wq[d];
-            const float pscale = prep(x, sq[d], cg + d);
-            __builtin_amdgcn_sched_barrier(0);              // keep the slots in program order (hipcc otherwise hoists all D transposes
-            issue(wq[d], sq[d]);                            // to the top of the block, which then waits for every load in flight)
+            // The slot is refilled AFTER its group is consumed, into the same registers.  Requested before the compute (round 4), the
+            // new words needed fresh registers, and hipcc closed the loop with a copy of the whole ring behind s_waitcnt vmcnt(13..1):
+            // every block of D groups ended by waiting for the load requested one group earlier -- a full memory round trip per block
+            // (tools/gemv_timeline.py: the main loop of the down-projection was 6.8 of its 11.8 us, and ring depth made no difference).
+            if (d == D - 1 && cg + D == G) {                // last group of a row quad: nothing requested past it
+                const float pscale = prep(wq[d], sq[d], cg + d, std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                compute(wq[d], pscale, cg + d, true, std::true_type{});
+            } else {
+                const float pscale = prep(wq[d], sq[d], cg + d, std::false_type{});
+                __builtin_amdgcn_sched_barrier(0);          // keep the slots in program order (hipcc otherwise hoists all D transposes
+                compute(wq[d], pscale, cg + d, false, std::false_type{});   // to the top of the block, which then waits for every load in flight)
+            }
             __builtin_amdgcn_sched_barrier(0);
-            compute(x, pscale, cg + d, d == D - 1);
+            issue(wq[d], sq[d]);
             __builtin_amdgcn_sched_barrier(0);
         }
         cg += D;
-        if (cg == G) { cg = 0; pass_end(); }
+        if (cg == G) { cg = 0; pass_end(); request_first(); }
     }
+    JH_GSTAMP(3);                                           // every group but the last ring block consumed
 #pragma unroll
-    for (int d = 0; d < D; d++) {                           // last block: nothing left to request
-        i32x4 x = wq[d];
-        const float pscale = prep(x, sq[d], cg + d);
-        compute(x, pscale, cg + d, d == D - 1);
+    for (int d = 0; d < D - 1; d++) {                       // last block: nothing left to request
+        const float pscale = prep(wq[d], sq[d], cg + d, std::false_type{});
+        compute(wq[d], pscale, cg + d, false, std::false_type{});
         __builtin_amdgcn_sched_barrier(0);
     }
+    {
+        const float pscale = prep(wq[D - 1], sq[D - 1], cg + D - 1, std::true_type{});
+        compute(wq[D - 1], pscale, cg + D - 1, true, std::true_type{});
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    JH_GSTAMP(4);
     pass_end();
+    JH_GSTAMP(5);                                           // row sums stored
+#undef JH_GSTAMP
     if constexpr (EPI == EPI_TP) tp_signal(p);
 }
 
@@ -586,12 +665,11 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_f32q4_p16_kernel(GemvParams 
         for (int it = 0; it + D < items; it += D) {
 #pragma unroll
             for (int d = 0; d < D; d++) {
-                i32x4 x = wq[d];
-                const float s16 = prep(x, sq[d]);
+                const float s16 = prep(wq[d], sq[d]);       // refill after the group, in place: see gemv_i8q4_p16_kernel
+                __builtin_amdgcn_sched_barrier(0);
+                compute(wq[d], s16, cg + d, d == D - 1);
                 __builtin_amdgcn_sched_barrier(0);
                 issue(wq[d], sq[d]);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(x, s16, cg + d, d == D - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             cg += D;
@@ -851,7 +929,6 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
 // every LDS read it issues itself with s_waitcnt lgkmcnt(0) in these loops, which also waits for the chunk requested a moment ago
 // (measured: 20 cycles per link of a sequential float chain instead of 5).  lds_tie<N> is the matching wait: at most N younger LDS
 // operations stay in flight, and the four registers become readable (they are operands of the wait, so no use can move above it).
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
 __device__ __forceinline__ void lds_read64_nowait(f32x4& a, f32x4& b, f32x4& c, f32x4& d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr) : "memory");

@@ -23,6 +23,24 @@ int jh_debug_attn_timeline(jh_session* s, int pos, long long* out, int n) {
     HIPCHK(hipFree(d));
     return JH_OK;
 }
+static long long* g_gemv_dbg = nullptr;   // jh_debug_gemv_timeline: stamp buffer of the LAST launch of the next jh_kernel_bench
+// Phase stamps of one reference-order few-row GEMV launch (which: 0 q|k|v, 2 o, 4 down; the last layer's launch of a sweep over
+// all layers, so its weights come from HBM): out[workgroup][wave][8] wall_clock64 ticks (100 MHz), -1 = not written.
+int jh_debug_gemv_timeline(jh_session* s, int which, long long* out, int n) {
+    if (!s || !out || n < 8 || !s->strict) return set_err(JH_ERR_INVALID, "gemv_timeline: a reference-order session and >= 8 slots");
+    if (which != 0 && which != 2 && which != 4) return set_err(JH_ERR_INVALID, "gemv_timeline: which = 0 (q|k|v), 2 (o) or 4 (down)");
+    HIPCHK(hipSetDevice(s->m->device));
+    long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)n * 8));
+    HIPCHK(hipMemset(d, 0xff, (size_t)n * 8));
+    g_gemv_dbg = d;
+    double ms = 0; int64_t b = 0;
+    const int rc = jh_kernel_bench(s, which, 2, &ms, &b);
+    g_gemv_dbg = nullptr;
+    if (rc == JH_OK) HIPCHK(hipMemcpy(out, d, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d));
+    return rc;
+}
 // Device-resident timing of the batched (prefill) MFMA GEMMs: kind 0 = I8xQ4, 1 = BF16xBF16.  `copies` distinct weight
 // matrices are cycled so the stream comes from HBM, not the Infinity Cache.  out_ms = average per GEMM.
 int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* out_ms) {
@@ -95,6 +113,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
             const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
             GemvParams p;
             memset(&p, 0, sizeof(p));
+            if (it == iters - 1 && li == c.layer_end - 1) p.dbg = g_gemv_dbg;
             if (which == 9) {          // LM head (+ final norm, argmax partials): one weight, re-streamed per launch
                 JHCHK(lmhead_launch(s, st));
             } else if (which == 0) {
