@@ -237,11 +237,9 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_bf16r_kernel(GemvParams p, i
         for (int it = 0; it + D < items; it += D) {
 #pragma unroll
             for (int d = 0; d < D; d++) {
-                const i32x4 x = wq[d];
-                __builtin_amdgcn_sched_barrier(0);
+                compute(wq[d], cg + d, d == D - 1);              // refilled in place AFTER the group (see gemv_i8q4_p16_kernel: requested
+                __builtin_amdgcn_sched_barrier(0);              // before it, the ring is copied -- behind vmcnt waits -- at the loop end)
                 issue(wq[d]);
-                __builtin_amdgcn_sched_barrier(0);
-                compute(x, cg + d, d == D - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             cg += D;
