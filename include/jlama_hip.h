@@ -387,7 +387,7 @@ void* jh_session_stream(jh_session* s);
 int jh_gemm_bench(int kind, int m, int n, int k, int copies, int iters, double* out_ms);
 /* Debug aid: wall-clock (100 MHz) phase stamps of one decode-attention launch at `pos`; out[split*16 + phase]. */
 int jh_debug_attn_timeline(jh_session* s, int pos, long long* out, int n);
-/* Phase stamps of one reference-order few-row GEMV launch (which: 0 q|k|v, 2 o, 4 down): out[workgroup][wave][8], 100 MHz ticks, -1 = unused. */
+/* Phase stamps of one reference-order few-row GEMV launch (which: 0 q|k|v, 2 o, 3 gate|up, 4 down): out[workgroup][wave][8], 100 MHz ticks, -1 = unused. */
 int jh_debug_gemv_timeline(jh_session* s, int which, long long* out, int n);
 /* Wait for everything queued on the session's stream. */
 int jh_session_synchronize(jh_session* s);

@@ -185,11 +185,11 @@ struct ActRegsP16 {
     float wv[UM][8];
 };
 template <int PRO, int UM, int NT = P16_THREADS>
-__device__ __forceinline__ void stage_issue_p16(const GemvParams& p, ActRegsP16<UM>& r) {
+__device__ __forceinline__ void stage_issue_p16(const GemvParams& p, ActRegsP16<UM>& r, int tid = threadIdx.x) {
     const int units = p.K / 8;
 #pragma unroll
     for (int u = 0; u < UM; u++) {
-        int unit = threadIdx.x + u * NT;
+        int unit = tid + u * NT;
         unit = unit < units ? unit : units - 1;             // branch-free (clamped): a guarded load is waited for at the end of its block
         const float4 xa = *(const float4*)(p.x + unit * 8), xb = *(const float4*)(p.x + unit * 8 + 4);
         r.xv[u][0] = xa.x; r.xv[u][1] = xa.y; r.xv[u][2] = xa.z; r.xv[u][3] = xa.w;
@@ -214,14 +214,14 @@ __device__ __forceinline__ float rms_factor_p16(const GemvParams& p, const ActRe
     return (float)ss;
 }
 template <int PRO, int UM, int NT = P16_THREADS>
-__device__ __forceinline__ void stage_finish_p16(const GemvParams& p, const ActP16& a, ActRegsP16<UM>& r) {
+__device__ __forceinline__ void stage_finish_p16(const GemvParams& p, const ActP16& a, ActRegsP16<UM>& r, int tid = threadIdx.x) {
     static_assert(PRO == PRO_RMS_Q8 || PRO == PRO_QUANT_Q8, "p16 prologues: RMSNorm+Q8 or plain Q8");
     const int units = p.K / 8;
     float fs = 1.0f;
-    if (PRO == PRO_RMS_Q8) fs = rms_factor_p16<UM, NT>(p, r, a.red);
+    if (PRO == PRO_RMS_Q8) fs = rms_factor_p16<UM, NT>(p, r, a.red);   // (block reduction: every thread of the workgroup, tid = threadIdx.x)
 #pragma unroll
     for (int u = 0; u < UM; u++) {
-        const int unit = threadIdx.x + u * NT;
+        const int unit = tid + u * NT;
         if (unit < units) {
             float y[8];
 #pragma unroll
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
         return;
     }
     stage_issue_p16<PRO, UM, NT>(p, ar);                        // activation loads first: vmcnt retires oldest-first
+    JH_GSTAMP(6);                                           // activation row requested
     float rv = 0.0f;
     if (EPI == EPI_RESID) rv = resid_of_batch(q0);
 #pragma unroll

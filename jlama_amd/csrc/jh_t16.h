@@ -162,13 +162,17 @@ __global__ __launch_bounds__(NT) void gemv_t16_kernel(GemvParams p, int tiles_pe
     const int items = (tile1 - tile0) * nq;
 
     ActRegsP16<UM> ar;
+#define JH_TSTAMP(kk) do { if (p.dbg && lane == 0) p.dbg[((size_t)blockIdx.x * (NT / 64) + wave) * 8 + (kk)] = wall_clock64(); } while (0)
+    JH_TSTAMP(0);
     if (items == 0) {
         // helper wave: its own copy of the prologue (same barriers).  The two paths must not join (see gemv_i8q4_p16_kernel)
         stage_issue_p16<PRO, UM, NT>(p, ar);
         stage_finish_t16<PRO, UM, NT>(p, a, ar);
+        JH_TSTAMP(2);
         return;
     }
     stage_issue_p16<PRO, UM, NT>(p, ar);                       // activation loads first: vmcnt retires oldest-first
+    JH_TSTAMP(6);
     i32x4 wq[D];
     f32x4t sq[D];
     const i32x4* wp = (const i32x4*)p.w + (size_t)tile0 * nq * 64 + lane;
@@ -185,7 +189,9 @@ __global__ __launch_bounds__(NT) void gemv_t16_kernel(GemvParams p, int tiles_pe
         issue(wq[d], sq[d]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    JH_TSTAMP(1);
     stage_finish_t16<PRO, UM, NT>(p, a, ar);
+    JH_TSTAMP(2);
 
     // this lane's selector address: the 16 lanes (t = j, g == t/4) read their entry, the others the zero word
     const char* sel = a.sel + (((j >> 2) == g) ? j * 8 : 128);
@@ -281,8 +287,12 @@ __global__ __launch_bounds__(NT) void gemv_t16_kernel(GemvParams p, int tiles_pe
         cq += D;
         if (cq == nq) cq = 0;
     }
+    JH_TSTAMP(3);
+    JH_TSTAMP(4);
     chain(dd[1], sv[1]);
     tile_end();
+    JH_TSTAMP(5);
+#undef JH_TSTAMP
 }
 
 // ================================================================================================ prompt rows (M > 1)

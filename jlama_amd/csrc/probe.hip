@@ -28,7 +28,7 @@ static long long* g_gemv_dbg = nullptr;   // jh_debug_gemv_timeline: stamp buffe
 // all layers, so its weights come from HBM): out[workgroup][wave][8] wall_clock64 ticks (100 MHz), -1 = not written.
 int jh_debug_gemv_timeline(jh_session* s, int which, long long* out, int n) {
     if (!s || !out || n < 8 || !s->strict) return set_err(JH_ERR_INVALID, "gemv_timeline: a reference-order session and >= 8 slots");
-    if (which != 0 && which != 2 && which != 4) return set_err(JH_ERR_INVALID, "gemv_timeline: which = 0 (q|k|v), 2 (o) or 4 (down)");
+    if (which != 0 && which != 2 && which != 3 && which != 4) return set_err(JH_ERR_INVALID, "gemv_timeline: which = 0 (q|k|v), 2 (o), 3 (gate|up) or 4 (down)");
     HIPCHK(hipSetDevice(s->m->device));
     long long* d = nullptr;
     HIPCHK(hipMalloc(&d, (size_t)n * 8));

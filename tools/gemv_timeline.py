@@ -24,6 +24,9 @@ base = t[:, :, 0][used].min()
 us = (t - base) / 100.0
 work = t[:, :, 5] >= 0          # waves that own rows
 print(f"which={which}: {used.any(axis=1).sum()} workgroups, {used.sum()} waves, {work.sum()} with rows; kernel span {us[:, :, :6][t[:, :, :6] >= 0].max():.2f} us")
+v6 = us[:, :, 6][work & (t[:, :, 6] >= 0)]
+if v6.size:
+    print(f"  {'row requested':18s} min {v6.min():6.2f}  p10 {np.percentile(v6, 10):6.2f}  median {np.median(v6):6.2f}  p90 {np.percentile(v6, 90):6.2f}  max {v6.max():6.2f}")
 for k, nm in enumerate(names):
     sel = work if k != 2 else used
     v = us[:, :, k][sel & (t[:, :, k] >= 0)]
@@ -33,3 +36,13 @@ w = us[work]
 for k in range(1, 6):
     d = w[:, k] - w[:, k - 1]
     print(f"  phase {names[k - 1]} -> {names[k]}: median {np.median(d):.2f} us, max {d.max():.2f}")
+# who finishes late: by XCD (workgroup x runs on XCD x & 7), by wave slot, and the slowest / fastest workgroups
+fin = np.where(t[:, :, 3] >= 0, us[:, :, 3], np.nan)
+wgs = np.nonzero(used.any(axis=1))[0]
+print("  main loop done by XCD     :", " ".join(f"{np.nanmedian(fin[wgs[wgs % 8 == x]]):.2f}/{np.nanmax(fin[wgs[wgs % 8 == x]]):.2f}" for x in range(8)), "(median/max)")
+print("  main loop done by wave    :", " ".join(f"{np.nanmedian(fin[wgs, w]):.2f}" for w in range(8) if np.isfinite(fin[wgs, w]).any()))
+wgmax = np.nanmax(fin[wgs], axis=1)
+order = np.argsort(wgmax)
+print("  fastest workgroups        :", " ".join(f"{wgs[i]}:{wgmax[i]:.2f}" for i in order[:8]))
+print("  slowest workgroups        :", " ".join(f"{wgs[i]}:{wgmax[i]:.2f}" for i in order[-12:]))
+print("  workgroup finish quantiles:", " ".join(f"{np.percentile(wgmax, q):.2f}" for q in (0, 10, 25, 50, 75, 90, 100)))
