@@ -10,7 +10,7 @@ which = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 mode = sys.argv[3] if len(sys.argv) > 3 else "strict"
 cfg = dict(getattr(S, os.environ.get("CONFIG", "LLAMA3_8B")))
-torch.cuda.set_device(0); N.init(0)
+torch.cuda.set_device(0); N.init(0); N.options_from_env()
 model = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
 s = model.session(400)
 s.batch_forward(S.prompt_tokens(cfg, n=8, seed=1), 0)
