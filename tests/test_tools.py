@@ -39,3 +39,21 @@ def test_decode_timeline_tool_on_a_synthetic_trace(tmp_path):
     per_token = 2 * (5.8 + 7.9 + 4.5 + 15.0 + 9.8) + 65.0 + 3.0
     assert f"per token: {per_token:.1f} us inside kernels + {12 * 0.5:.1f} us between them" in out
     assert "| gemv_i8q4_kernel<1, 2, 2, 2, 1> | 2 | 15.00 | 0.50 |" in out
+
+
+def test_reference_order_streaming_loops_do_not_copy_their_prefetch_ring():
+    """tools/isa_ring_copies.py on the two units that hold the reference-order streaming GEMVs: no loop may end with a block of
+    register moves behind s_waitcnt vmcnt(...) -- the shape hipcc gives a prefetch ring whose refills land in fresh registers, which
+    makes every ring block wait out a full memory round trip (what bounded the few-row GEMVs until round 5)."""
+    import subprocess
+    import sys
+    import shutil
+    import pytest
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "isa_ring_copies.py")
+    for unit in ("gemv_ref", "gemv_bf16"):
+        r = subprocess.run([sys.executable, tool, unit], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr
+        assert f"{unit}: no loop ends by copying a prefetch ring" in r.stdout, r.stdout[:2000]
