@@ -980,6 +980,18 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
         for (int c = 0; c < NC; c++) k[c] = *(const f32x4*)(krow + 16 * c);
     };
     const int npass = (n + PPB - 1) / PPB;
+    // the RoPE operands (q / new k of the q|k|v row the previous launch just wrote: L2-warm; the table row) are requested BEFORE the
+    // K rows (written tokens ago: HBM): loads retire in order, so the rotation and its barrier run while the K rows are still coming
+    static_assert(2 * half <= NT, "one RoPE element pair per thread");
+    const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
+    const bool rope_lane = tid < 2 * half;
+    const int rwhich = tid / half, rd = tid - rwhich * half;
+    float rc = 0.f, rsn = 0.f, rx0 = 0.f, rx1 = 0.f;
+    if (rope_lane) {
+        const float* src = rwhich == 0 ? qkv_row + (size_t)h * HS : qkv_row + A + (size_t)kvh * HS;
+        rc = rf[2 * rd]; rsn = rf[2 * rd + 1];
+        rx0 = src[rd]; rx1 = src[rd + half];
+    }
     load_k(ka, 0);
     if (npass > 1) load_k(kb, 1);
     if (npass > 2) load_k(kc, 2);
@@ -998,21 +1010,14 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
         }
     };
     // ---- RoPE of this head's q and of the new k row (table row pos + 2*kvHead: CausalSelfAttention.java:247-286)
-    const float* rf = p.rope + ((size_t)pos * half + (size_t)(kvh + p.kv_head_offset) * HS) * 2;
     const bool owner = gi == 0 && colq == 0;
-    for (int i = tid; i < 2 * half; i += NT) {
-        const int which = i / half, d = i - which * half;
-        const float c = rf[2 * d], sn = rf[2 * d + 1];
-        if (which == 0) {
-            const float* qh = qkv_row + (size_t)h * HS;
-            const float q0 = qh[d], q1 = qh[d + half];
-            const float r0 = q0 * c - q1 * sn, r1 = q0 * sn + q1 * c;   // contraction off: mul, mul, sub / add as in Java
+    if (rope_lane) {
+        const int d = rd;
+        const float r0 = rx0 * rc - rx1 * rsn, r1 = rx0 * rsn + rx1 * rc;   // contraction off: mul, mul, sub / add as in Java
+        if (rwhich == 0) {
             qs[d] = r0; qs[d + half] = r1;
             if (p.tap_q && colq == 0) { p.tap_q[(size_t)h * HS + d] = r0; p.tap_q[(size_t)h * HS + d + half] = r1; }
         } else {
-            const float* kh = qkv_row + A + (size_t)kvh * HS;
-            const float k0 = kh[d], k1 = kh[d + half];
-            const float r0 = k0 * c - k1 * sn, r1 = k0 * sn + k1 * c;
             knew[d] = r0; knew[d + half] = r1;
             if (owner) {   // K is stored post-RoPE (:273-286 rotates the page row in place)
                 float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
