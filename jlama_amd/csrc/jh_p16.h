@@ -298,8 +298,7 @@ __device__ __forceinline__ void p16_tie4(float& d) { asm volatile("s_waitcnt lgk
 // hipcc has put there since (it cannot see the asm reads) -- and therefore waits for everything at once.
 template <bool FULL, bool LAST>
 __device__ __forceinline__ void p16_group_i8_regs(const i32x4& x, PairRegsP16& r, unsigned pt_next, float pscale, int nb, float& acc) {
-    if constexpr (LAST) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.w0), "+v"(r.w1), "+v"(r.w2), "+v"(r.w3)::"memory");
-    else p16_tie4(r.w0);
+    if constexpr (!LAST) p16_tie4(r.w0);                    // (LAST: the caller has waited for all four before it branched)
     const Quad4 q0 = p16_quad_sums(x.x, r.w0);
     if constexpr (!LAST) p16_req_pairs(r.w0, pt_next);
     __builtin_amdgcn_sched_barrier(0);
@@ -375,6 +374,16 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
             set_row();
         }
     };
+    // The same request where the load cursor cannot leave its row: slot d of a ring block asks for group (cg + d + D) mod G, and with
+    // D | G that is the row's last group only for d == D - 1.  Slots 0 .. D-2 therefore stay free of branches (see the note on
+    // pending LDS writes below).
+    auto issue_in_row = [&](i32x4& w, float& s) __attribute__((always_inline)) {
+        int b = 16 * lg + t;
+        w = __builtin_nontemporal_load((const i32x4*)wrow + (64 * lg + t));
+        b = b < nblk ? b : nblk - 1;
+        s = __builtin_nontemporal_load(srow + b);
+        ++lg;
+    };
     // Results are parked: the 16 lanes of a row all hold a finished row sum, lane t keeps the one of the wave's task n == t, and the
     // wave stores once per 16 tasks (normally once, after the loop): no store or residual load inside the streaming loop, whose
     // vmcnt waits then count ring loads only.
@@ -419,23 +428,28 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
         bd = bd < nblk ? bd : nblk - 1;
         return d_base + (unsigned)bd * 4u;
     };
-    // (a pass -- one row quad -- ends with nothing in flight: pass_end() is compiler-scheduled code with branches, and registers
-    // with a pending LDS write must not be moved or spilled by something that does not know about it)
-    auto request_first = [&]() __attribute__((always_inline)) {
-        p16_req_d(pr.d, d_addr(0));
-        p16_req_pairs(pr.w0, pt_base); p16_req_pairs(pr.w1, pt_base + 256u); p16_req_pairs(pr.w2, pt_base + 512u); p16_req_pairs(pr.w3, pt_base + 768u);
+    // A register with a pending LDS write must not cross a basic-block boundary: hipcc does not know about the write, and at a
+    // control-flow merge it is free to COPY the register (it did: `v_mov_b64 v[38:39], v[54:55]` in front of the wait, i.e. a copy of
+    // words that need not have landed -- correct only by timing).  So the pipeline lives inside ONE straight-line region, a ring block
+    // of D groups: the block's first group is requested at its top, slots 0 .. D-2 request the next group, the last slot requests
+    // nothing and waits for everything before its first use; `issue`'s row switch, a short last group, pass_end() and the loop's
+    // back-edge all sit behind that slot.  tools/isa_pending_lds.py checks the compiled ISA for exactly this (tests/test_tools.py).
+    auto request_first = [&](int g) __attribute__((always_inline)) {
+        const unsigned a0 = pt_base + (unsigned)g * 1024u;
+        p16_req_d(pr.d, d_addr(g));
+        p16_req_pairs(pr.w0, a0); p16_req_pairs(pr.w1, a0 + 256u); p16_req_pairs(pr.w2, a0 + 512u); p16_req_pairs(pr.w3, a0 + 768u);
     };
-    request_first();
     auto prep = [&](i32x4& x, float s, int g, auto last) __attribute__((always_inline)) {
         p16_tie4(pr.d);
         const float ps = p16_scale_product(pr.d, s);        // lane t carries the scale product of block 16*g + t
-        if constexpr (!decltype(last)::value) p16_req_d(pr.d, d_addr(g + 1 == G ? 0 : g + 1));
+        if constexpr (!decltype(last)::value) p16_req_d(pr.d, d_addr(g + 1));
         return ps;
     };
     auto compute = [&](const i32x4& x, float pscale, int g, bool can_be_short, auto last) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last)::value;
-        const unsigned pt_next = pt_base + (unsigned)(g + 1 == G ? 0 : g + 1) * 1024u;
+        const unsigned pt_next = pt_base + (unsigned)(g + 1) * 1024u;   // (used by the slots that are not a block's last: g + 1 < G)
         const int nb = nblk - 16 * g;
+        if constexpr (LAST) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr.w0), "+v"(pr.w1), "+v"(pr.w2), "+v"(pr.w3)::"memory");   // before the branch below
         if (can_be_short && nb < 16) p16_group_i8_regs<false, LAST>(x, pr, pt_next, pscale, nb, acc);
         else p16_group_i8_regs<true, LAST>(x, pr, pt_next, pscale, 16, acc);
     };
@@ -464,29 +478,33 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
         ++cq;
     };
     for (int it = 0; it + D < items; it += D) {
+        request_first(cg);
 #pragma unroll
-        for (int d = 0; d < D; d++) {
+        for (int d = 0; d < D - 1; d++) {
             // The slot is refilled AFTER its group is consumed, into the same registers.  Requested before the compute (round 4), the
             // new words needed fresh registers, and hipcc closed the loop with a copy of the whole ring behind s_waitcnt vmcnt(13..1):
             // every block of D groups ended by waiting for the load requested one group earlier -- a full memory round trip per block
             // (tools/gemv_timeline.py: the main loop of the down-projection was 6.8 of its 11.8 us, and ring depth made no difference).
-            if (d == D - 1 && cg + D == G) {                // last group of a row quad: nothing requested past it
-                const float pscale = prep(wq[d], sq[d], cg + d, std::true_type{});
-                __builtin_amdgcn_sched_barrier(0);
-                compute(wq[d], pscale, cg + d, true, std::true_type{});
-            } else {
-                const float pscale = prep(wq[d], sq[d], cg + d, std::false_type{});
-                __builtin_amdgcn_sched_barrier(0);          // keep the slots in program order (hipcc otherwise hoists all D transposes
-                compute(wq[d], pscale, cg + d, false, std::false_type{});   // to the top of the block, which then waits for every load in flight)
-            }
+            const float pscale = prep(wq[d], sq[d], cg + d, std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);              // keep the slots in program order (hipcc otherwise hoists all D transposes
+            compute(wq[d], pscale, cg + d, false, std::false_type{});   // to the top of the block, which then waits for every load in flight)
             __builtin_amdgcn_sched_barrier(0);
-            issue(wq[d], sq[d]);
+            issue_in_row(wq[d], sq[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const float pscale = prep(wq[D - 1], sq[D - 1], cg + D - 1, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            compute(wq[D - 1], pscale, cg + D - 1, true, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            issue(wq[D - 1], sq[D - 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
         cg += D;
-        if (cg == G) { cg = 0; pass_end(); request_first(); }
+        if (cg == G) { cg = 0; pass_end(); }
     }
     JH_GSTAMP(3);                                           // every group but the last ring block consumed
+    request_first(cg);
 #pragma unroll
     for (int d = 0; d < D - 1; d++) {                       // last block: nothing left to request
         const float pscale = prep(wq[d], sq[d], cg + d, std::false_type{});
@@ -1082,34 +1100,38 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
     JH_FSTAMP(4);
     __syncthreads();                                        // exponentials visible
     JH_FSTAMP(5);
-    if (wave != 0) file_v(vreg, 0);                         // waves 1..3 file tile 0 (wave 0's share follows its sum) WHILE lane 0 sums
-    if (tid == 0) {
-        // one float accumulator in index order (VectorMath.java:80-85); the next 16 values are in flight while the current 16 are added
+    if (wave != 0) file_v(vreg, 0);                         // waves 1..3 file tile 0 (wave 0's share follows its sum) WHILE wave 0 sums
+    if (wave == 0) {
+        // one float accumulator in index order (VectorMath.java:80-85).  Lane l of wave 0 holds w[64c + l]; the chain takes the
+        // values in order through v_readlane (an SGPR operand of the add): no LDS access inside the chain, and every value the
+        // compiler schedules around is one it knows about (the asm LDS pipeline this replaces kept reads pending across the
+        // loop's branches, where hipcc is free to copy registers: tools/isa_pending_lds.py).
         float sum = 0.0f;
-        f32x4 a0, a1, a2, a3, b0, b1, b2, b3;
-        auto add16 = [&](const f32x4& e0, const f32x4& e1, const f32x4& e2, const f32x4& e3, int t0) __attribute__((always_inline)) {
-            if (t0 + 16 <= n) {
-                sum += e0.x; sum += e0.y; sum += e0.z; sum += e0.w; sum += e1.x; sum += e1.y; sum += e1.z; sum += e1.w;
-                sum += e2.x; sum += e2.y; sum += e2.z; sum += e2.w; sum += e3.x; sum += e3.y; sum += e3.z; sum += e3.w;
-            } else {
-                const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+        const int nfull = n >> 6, rem = n & 63;
+        float x = w[lane];                                  // (w is padded by 64: in bounds; entries >= n are never added)
+        for (int c = 0; c < nfull; c++) {                   // whole chunks: 64 links, no branch
+            const float xn = w[(c + 1) * 64 + lane];        // the next chunk (or the tail's, or padding) is in flight during the chain
+            const int xi = __float_as_int(x);
 #pragma unroll
-                for (int j = 0; j < 16; j++)
-                    if (t0 + j < n) sum += e[j];
-            }
-        };
-        const unsigned wad = lds_addr(w);                   // w[] is padded: the reads past n stay inside the workgroup's LDS
-        lds_read64_nowait(a0, a1, a2, a3, wad);
-        for (int t0 = 0; t0 < n; t0 += 32) {
-            lds_read64_nowait(b0, b1, b2, b3, wad + (unsigned)(t0 + 16) * 4u);
-            lds_tie<4>(a0, a1, a2, a3);
-            add16(a0, a1, a2, a3, t0);
-            lds_read64_nowait(a0, a1, a2, a3, wad + (unsigned)(t0 + 32) * 4u);
-            lds_tie<4>(b0, b1, b2, b3);
-            if (t0 + 16 < n) add16(b0, b1, b2, b3, t0 + 16);
+            for (int l = 0; l < 64; l++) sum += __int_as_float(__builtin_amdgcn_readlane(xi, l));
+            __builtin_amdgcn_sched_barrier(0);
+            x = xn;
         }
-        lds_tie<0>(a0, a1, a2, a3);
-        redf[8] = sum;
+        if (rem) {                                          // the last n % 64 values, 16 at a time
+            const int xi = __float_as_int(x);
+#pragma unroll
+            for (int l0 = 0; l0 < 64; l0 += 16) {
+                if (l0 + 16 <= rem) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) sum += __int_as_float(__builtin_amdgcn_readlane(xi, l0 + j));
+                } else if (l0 < rem) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        if (l0 + j < rem) sum += __int_as_float(__builtin_amdgcn_readlane(xi, l0 + j));
+                }
+            }
+        }
+        if (lane == 0) redf[8] = sum;
         JH_FSTAMP(6);
     }
     if (wave == 0) file_v(vreg, 0);
@@ -1127,44 +1149,64 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
             file_v(vnext, tile);
         }
         __syncthreads();
-        if (tid < DW) {
+        if (wave == 0) {
+            // lanes 0..31 own one column each (lanes 32..63 run the same chain on column lane - 32 and store nothing).  The weights are
+            // uniform: lane l holds w[tbase + 64c + l] and the chain reads them through v_readlane; the column's values come 4 links
+            // per ds_read_b128 from the transposed tile, one 16-link piece ahead -- plain C, every wait is hipcc's own.
             const int tbase = tile * TP, cnt = n - tbase < TP ? n - tbase : TP;
-            f32x4 va0, va1, va2, va3, wa0, wa1, wa2, wa3, vb0, vb1, vb2, vb3, wb0, wb1, wb2, wb3;
-            const unsigned vad = lds_addr(vt + (size_t)tid * TPP), wad = lds_addr(w + tbase);
-            auto chain16 = [&](const f32x4& v0, const f32x4& v1, const f32x4& v2, const f32x4& v3, const f32x4& w0, const f32x4& w1, const f32x4& w2,
-                               const f32x4& w3, int i0) __attribute__((always_inline)) {
-                if (i0 + 16 <= cnt) {
-                    acc = fmaf(v0.x, w0.x, acc); acc = fmaf(v0.y, w0.y, acc); acc = fmaf(v0.z, w0.z, acc); acc = fmaf(v0.w, w0.w, acc);
-                    acc = fmaf(v1.x, w1.x, acc); acc = fmaf(v1.y, w1.y, acc); acc = fmaf(v1.z, w1.z, acc); acc = fmaf(v1.w, w1.w, acc);
-                    acc = fmaf(v2.x, w2.x, acc); acc = fmaf(v2.y, w2.y, acc); acc = fmaf(v2.z, w2.z, acc); acc = fmaf(v2.w, w2.w, acc);
-                    acc = fmaf(v3.x, w3.x, acc); acc = fmaf(v3.y, w3.y, acc); acc = fmaf(v3.z, w3.z, acc); acc = fmaf(v3.w, w3.w, acc);
-                } else {
-                    const float vv[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-                    const float ww[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
-#pragma unroll
-                    for (int j = 0; j < 16; j++)
-                        if (i0 + j < cnt) acc = fmaf(vv[j], ww[j], acc);
-                }
+            const float* vrow = vt + (size_t)(lane & (DW - 1)) * TPP;
+            const float* wt = w + tbase;
+            const int nfull = cnt >> 6, rem = cnt & 63;
+            f32x4 va[4], vb[4];
+            auto ldv = [&](f32x4 (&v)[4], int i0) __attribute__((always_inline)) {
+                const f32x4* q = (const f32x4*)(vrow + i0);
+                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
             };
-            // 16 links per chunk (one 64-byte read of the column, one of the weights); the next chunk is in flight during the chain.
-            // Reads past cnt stay inside the tile / the padded weight row and are never used.
-            lds_read64_nowait(va0, va1, va2, va3, vad);
-            lds_read64_nowait(wa0, wa1, wa2, wa3, wad);
-            for (int i0 = 0; i0 < cnt; i0 += 32) {
-                const unsigned nb = (unsigned)(i0 + 16 < TP ? i0 + 16 : 0) * 4u, na = (unsigned)(i0 + 32 < TP ? i0 + 32 : 0) * 4u;
-                lds_read64_nowait(vb0, vb1, vb2, vb3, vad + nb);
-                lds_read64_nowait(wb0, wb1, wb2, wb3, wad + nb);
-                lds_tie<8>(va0, va1, va2, va3);
-                lds_tie<8>(wa0, wa1, wa2, wa3);
-                chain16(va0, va1, va2, va3, wa0, wa1, wa2, wa3, i0);
-                lds_read64_nowait(va0, va1, va2, va3, vad + na);
-                lds_read64_nowait(wa0, wa1, wa2, wa3, wad + na);
-                lds_tie<8>(vb0, vb1, vb2, vb3);
-                lds_tie<8>(wb0, wb1, wb2, wb3);
-                if (i0 + 16 < cnt) chain16(vb0, vb1, vb2, vb3, wb0, wb1, wb2, wb3, i0 + 16);
+            auto links16 = [&](const f32x4 (&v)[4], int xi, auto kc) __attribute__((always_inline)) {
+                constexpr int L0 = 16 * decltype(kc)::value;
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc = fmaf(v[j >> 2][j & 3], __int_as_float(__builtin_amdgcn_readlane(xi, L0 + j)), acc);
+            };
+            float xw = wt[lane];
+            ldv(va, 0);
+            for (int c = 0; c < nfull; c++) {               // whole chunks: 64 links, no branch; reads past the tile's used part stay
+                const float xwn = wt[(c + 1) * 64 + lane];  // inside the padded weight row / the tile and are never used
+                const int xi = __float_as_int(xw);
+                const int nx = 64 * (c + 1) < TP ? 64 * (c + 1) : 0;
+                ldv(vb, 64 * c + 16);
+                __builtin_amdgcn_sched_barrier(0);
+                links16(va, xi, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                ldv(va, 64 * c + 32);
+                __builtin_amdgcn_sched_barrier(0);
+                links16(vb, xi, std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                ldv(vb, 64 * c + 48);
+                __builtin_amdgcn_sched_barrier(0);
+                links16(va, xi, std::integral_constant<int, 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                ldv(va, nx);
+                __builtin_amdgcn_sched_barrier(0);
+                links16(vb, xi, std::integral_constant<int, 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+                xw = xwn;
             }
-            lds_tie<0>(va0, va1, va2, va3);
-            lds_tie<0>(wa0, wa1, wa2, wa3);
+            if (rem) {                                      // the tile's last cnt % 64 positions, 16 at a time (va holds the first 16)
+                const int xi = __float_as_int(xw), b0 = 64 * nfull;
+                auto tail16 = [&](const f32x4 (&v)[4], auto kc) __attribute__((always_inline)) {
+                    constexpr int L0 = 16 * decltype(kc)::value;
+                    if (L0 + 16 <= rem) links16(v, xi, kc);
+                    else if (L0 < rem) {
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            if (L0 + j < rem) acc = fmaf(v[j >> 2][j & 3], __int_as_float(__builtin_amdgcn_readlane(xi, L0 + j)), acc);
+                    }
+                };
+                tail16(va, std::integral_constant<int, 0>{});
+                if (rem > 16) { ldv(vb, b0 + 16); tail16(vb, std::integral_constant<int, 1>{}); }
+                if (rem > 32) { ldv(va, b0 + 32); tail16(va, std::integral_constant<int, 2>{}); }
+                if (rem > 48) { ldv(vb, b0 + 48); tail16(vb, std::integral_constant<int, 3>{}); }
+            }
         }
     }
     if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
