@@ -1112,9 +1112,24 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
         for (int c = 0; c < nfull; c++) {                   // whole chunks: 64 links, no branch
             const float xn = w[(c + 1) * 64 + lane];        // the next chunk (or the tail's, or padding) is in flight during the chain
             const int xi = __float_as_int(x);
+            // The values are lifted into SGPRs 8 links ahead of their adds, one readlane between two adds: a v_readlane result needs
+            // two wait states before a VALU may read it (left alone hipcc alternates readlane / s_nop / add: 3 issue slots per link),
+            // and the independent readlane sits in the dependent add's latency.
+            float e[8], f[8];
 #pragma unroll
-            for (int l = 0; l < 64; l++) sum += __int_as_float(__builtin_amdgcn_readlane(xi, l));
+            for (int j = 0; j < 8; j++) e[j] = __int_as_float(__builtin_amdgcn_readlane(xi, j));
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int l0 = 0; l0 < 64; l0 += 8) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (l0 + 8 < 64) f[j] = __int_as_float(__builtin_amdgcn_readlane(xi, l0 + 8 + j));
+                    sum += e[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) e[j] = f[j];
+            }
             x = xn;
         }
         if (rem) {                                          // the last n % 64 values, 16 at a time
@@ -1164,8 +1179,21 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
             };
             auto links16 = [&](const f32x4 (&v)[4], int xi, auto kc) __attribute__((always_inline)) {
                 constexpr int L0 = 16 * decltype(kc)::value;
+                float e[8], f[8];                           // weights lifted into SGPRs 8 links ahead, one readlane between two fmas (see the sum)
 #pragma unroll
-                for (int j = 0; j < 16; j++) acc = fmaf(v[j >> 2][j & 3], __int_as_float(__builtin_amdgcn_readlane(xi, L0 + j)), acc);
+                for (int j = 0; j < 8; j++) e[j] = __int_as_float(__builtin_amdgcn_readlane(xi, L0 + j));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j0 = 0; j0 < 16; j0 += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if (j0 + 8 < 16) f[j] = __int_as_float(__builtin_amdgcn_readlane(xi, L0 + j0 + 8 + j));
+                        acc = fmaf(v[(j0 + j) >> 2][(j0 + j) & 3], e[j], acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) e[j] = f[j];
+                }
             };
             float xw = wt[lane];
             ldv(va, 0);
