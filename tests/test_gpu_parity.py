@@ -369,3 +369,31 @@ def test_missing_weights_are_an_error_code_not_a_gpu_fault(gpu):
         with pytest.raises(N.JhError) as e:
             s.forward([1], 0)                      # decode path
         assert e.value.code == N.JH_ERR_INVALID
+
+
+@pytest.mark.gpu
+def test_one_launch_reference_order_attention_equals_the_two_launch_form_past_one_value_tile(gpu, oracle):
+    """attn_p16_fused_kernel keeps a 512-position V tile in LDS; contexts between 513 and 1,024 positions take a second tile (and
+    whole 64-link chunks + a 16-link tail in both).  The two-launch form (attn_p16_scores_kernel + attn_p16_av_kernel, selected by
+    JH_P16_ATT_FUSED=0) is an independent implementation of the same sums: greedy ids and logits must agree bit for bit while the
+    context grows from 540 to 600 positions."""
+    from jlama_amd import synthetic as S
+    cfg = dict(S.SMALL)
+    cfg["context_length"] = 1024
+    hm, om, w = _pair(cfg, 5, oracle)
+    prompt = S.prompt_tokens(cfg, n=539, seed=23)
+    out = []
+    for fused in (1024, 0):
+        _N.set_option("JH_P16_ATT_FUSED", str(fused))
+        s = hm.session(1024)
+        s.set_strict(True)
+        s.forward(prompt, 0)
+        t, l0 = s.sample(0.0, 0.5, want_logits=True)
+        ids = list(s.decode_n(t, prompt.size, 60))
+        out.append((t, l0.copy(), ids, s.logits().copy()))
+        s.close()
+        _N.clear_options()
+    assert out[0][0] == out[1][0]
+    np.testing.assert_array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    assert out[0][2] == out[1][2]
+    np.testing.assert_array_equal(out[0][3].view(np.uint32), out[1][3].view(np.uint32))

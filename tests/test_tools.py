@@ -57,3 +57,32 @@ def test_reference_order_streaming_loops_do_not_copy_their_prefetch_ring():
         r = subprocess.run([sys.executable, tool, unit], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr
         assert f"{unit}: no loop ends by copying a prefetch ring" in r.stdout, r.stdout[:2000]
+    # the same ISA (isa_ring_copies.py leaves it in /tmp/_isa_<unit>.s): no register with a pending asm-issued LDS write is touched,
+    # and none is pending at a label or a branch (tools/isa_pending_lds.py; the few-row GEMVs hold their activation operands that way)
+    pend = os.path.join(root, "tools", "isa_pending_lds.py")
+    r = subprocess.run([sys.executable, pend, "--file", "/tmp/_isa_gemv_ref.s"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "no register touched while its LDS write is pending" in r.stdout, r.stdout[-3000:]
+    assert " 0 asm LDS reads" not in r.stdout, "the checker found no hand-pipelined read at all: " + r.stdout
+
+
+def test_pending_lds_checker_flags_a_copy_in_front_of_the_wait(tmp_path):
+    """The checker itself, on hand-made ISA: (1) the pattern hipcc produced at a control-flow merge -- a copy of the pending
+    registers in front of the wait; (2) a read still pending at a branch; (3) the legal form."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pend = os.path.join(root, "tools", "isa_pending_lds.py")
+
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text("_Z1kv:\n" + body + "\ts_endpgm\n")
+        return subprocess.run([sys.executable, pend, "--file", str(f)], capture_output=True, text=True)
+
+    req = "\t;;#ASMSTART\n\tds_read_b128 v[4:7], v1\n\t;;#ASMEND\n"
+    tie = "\t;;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n\t;;#ASMEND\n"
+    bad_copy = run(req + "\tv_mov_b64_e32 v[8:9], v[4:5]\n" + tie + "\tv_add_f32_e32 v2, v8, v2\n")
+    assert bad_copy.returncode == 1 and "v_mov_b64_e32" in bad_copy.stdout, bad_copy.stdout
+    bad_branch = run(req + "\ts_cbranch_scc1 .LBB0_2\n" + tie + ".LBB0_2:\n")
+    assert bad_branch.returncode == 1 and "s_cbranch_scc1" in bad_branch.stdout, bad_branch.stdout
+    good = run(req + "\tv_add_f32_e32 v2, v3, v2\n" + tie + "\tv_add_f32_e32 v2, v4, v2\n\ts_cbranch_scc1 .LBB0_2\n.LBB0_2:\n")
+    assert good.returncode == 0 and "1 asm LDS reads" in good.stdout, good.stdout
