@@ -49,6 +49,7 @@ def source_hash():
     for p in SRCS + HDRS:
         with open(p, "rb") as f:
             h.update(f.read())
+    h.update(" ".join(CFLAGS).encode())   # a flag change (-ffp-contract, visibility ...) makes the binary stale too
     return h.hexdigest()[:32]
 
 
@@ -77,11 +78,24 @@ def build(force=False, verbose=False, jobs=None):
     then one link.  Without `force` the whole step is skipped only when the existing binary carries the hash of the current
     sources, and an object is reused only when ITS source, every header and the flags hash to the key stored beside it
     (never by timestamps).  `force` recompiles every unit."""
-    from concurrent.futures import ThreadPoolExecutor
+    import fcntl
     os.makedirs(OBJ_DIR, exist_ok=True)
     want = source_hash()
     if not force and built_hash() == want:
         return LIB_PATH
+    # several ranks of one torchrun may get here at once: one builds, the others wait and find the fresh binary
+    with open(os.path.join(os.path.dirname(LIB_PATH), ".build.lock"), "w") as lockf:
+        fcntl.flock(lockf, fcntl.LOCK_EX)
+        try:
+            if not force and built_hash() == want:
+                return LIB_PATH
+            return _build_locked(want, force, verbose, jobs)
+        finally:
+            fcntl.flock(lockf, fcntl.LOCK_UN)
+
+
+def _build_locked(want, force, verbose, jobs):
+    from concurrent.futures import ThreadPoolExecutor
     hd = hashlib.sha256()
     for p in HDRS:
         with open(p, "rb") as f:
@@ -93,12 +107,16 @@ def build(force=False, verbose=False, jobs=None):
         key = _unit_key(unit, hdr_digest) + (want if unit == "core" else "")   # core.hip carries the source hash of the whole library
         if not force and os.path.exists(obj) and os.path.exists(keyf) and open(keyf).read() == key:
             return unit, False
-        cmd = ["hipcc"] + CFLAGS + ["-c", os.path.join(CSRC, unit + ".hip"), "-o", obj]
+        if os.path.exists(keyf):
+            os.remove(keyf)                       # a failed compile must not leave an old key beside a clobbered object
+        tmp = obj + ".tmp"
+        cmd = ["hipcc"] + CFLAGS + ["-c", os.path.join(CSRC, unit + ".hip"), "-o", tmp]
         if unit == "core":
             cmd.insert(-3, f'-DJH_SRC_HASH="{want}"')
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        os.replace(tmp, obj)
         with open(keyf, "w") as f:
             f.write(key)
         return unit, True
@@ -107,9 +125,40 @@ def build(force=False, verbose=False, jobs=None):
         done = list(ex.map(compile_unit, UNITS))
     if verbose:
         print("compiled:", [u for u, c in done if c], "reused:", [u for u, c in done if not c], flush=True)
-    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [os.path.join(OBJ_DIR, u + ".o") for u in UNITS]
+    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + [os.path.join(OBJ_DIR, u + ".o") for u in UNITS]
     subprocess.check_call(link)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    build_host(force=True, verbose=verbose)
     return LIB_PATH
+
+
+# libjlamahost.so: the reference's host restated in C++ ABOVE the C ABI (csrc/host_mirror.cpp) -- the caller, not the backend.
+# Plain g++ (no device code); it links only the exported C ABI of libjlamahip.so.
+HOST_LIB_PATH = os.path.join(HERE, "lib", "libjlamahost.so")
+HOST_SRC = os.path.join(CSRC, "host_mirror.cpp")
+
+
+def host_source_hash():
+    h = hashlib.sha256()
+    for p in (HOST_SRC, os.path.join(ROOT, "include", "jlama_hip.h")):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:32]
+
+
+def build_host(force=False, verbose=False):
+    keyf = HOST_LIB_PATH + ".key"
+    want = host_source_hash()
+    if not force and os.path.exists(HOST_LIB_PATH) and os.path.exists(keyf) and open(keyf).read() == want:
+        return HOST_LIB_PATH
+    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-fopenmp", "-fvisibility=hidden", HOST_SRC, "-o", HOST_LIB_PATH,
+           "-L" + os.path.dirname(LIB_PATH), "-ljlamahip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(keyf, "w") as f:
+        f.write(want)
+    return HOST_LIB_PATH
 
 
 _lib = None
@@ -237,6 +286,36 @@ def lib():
             raise RuntimeError(f"jh_config layout mismatch: library {list(lay[:cnt])}, binding {mine}")
         _lib = L
     return _lib
+
+
+_host_lib = None
+_HOST_PROTOS = {
+    "jhost_last_error": (C.c_char_p, []),
+    "jhost_create": (_i, [_p, _i, _i, _l, _p]),
+    "jhost_destroy": (None, [_p]),
+    "jhost_set_weight": (_i, [_p, _i, _i, _i, _p, _p, _i, _i]),
+    "jhost_forward": (_i, [_p, _p, _p, _i, _i]),
+    "jhost_sample": (_i, [_p, _p, _p, _p]),
+    "jhost_generate": (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    "jhost_page_info": (_i, [_p, _p]),
+}
+HOST_EXPORTS = sorted(_HOST_PROTOS)
+
+
+def host_lib():
+    """libjlamahost.so (csrc/host_mirror.cpp): the reference's host above the C ABI.  Loads libjlamahip.so first (its only dependency)."""
+    global _host_lib
+    if _host_lib is None:
+        lib()
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(HOST_LIB_PATH)
+        for name, (res, args) in _HOST_PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _host_lib = L
+    return _host_lib
 
 
 def check(rc):

@@ -1509,4 +1509,70 @@ __global__ __launch_bounds__(P16_ROWS_AV_THREADS) void rows_av_p16_kernel(AttnPa
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ Tier 1 in reference order
+// batchDotProduct of the provider API (jh_gemm_*) with every float accumulation in the Panama-512 order, for EVERY offset / stride /
+// window combination the reference's C entry points accept (nc/simd/vector_simd.h:22-38) and any M: one 16-lane DPP row per output
+// element C[i, j] (four outputs per wave), lane t walks chain t over K in ascending order, then the halving tree.  Operands are read
+// in the reference's own layouts (no operand copies): this is the Tier-1 path, whose cost is the PCIe round trip of the call.
+//   I8 x Q4   PTO:807-850     acc_t = fma(da*sb, (float)(short)(lo_t*a[t] + hi_t*a[t+16]), acc_t) per block
+//   F32 x Q4  PTO:336-374     acc_t = fma(a[t], (float)(lo_t-8)*s, acc_t); acc_t = fma(a[t+16], (float)(hi_t-8)*s, acc_t) per block
+//   F32 x F32 PTO:1086-1102   acc_t = fma(a[l+t], b[l+t], acc_t), l = 0, 16, ...
+//   BF16 x BF16 / F32 x BF16  PTO:1279-1311 / 1511-1538: per 32-element step elements t, then 16 + t = the same chain as l = 0, 16, ...
+template <int KIND>
+__global__ __launch_bounds__(256) void gemm_reford_kernel(GemmParams p) {
+    const int lane = threadIdx.x & 63, r = lane >> 4, t = lane & 15;
+    const long long total = (long long)p.m * p.n;
+    const long long o = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + r;
+    const bool live = o < total;
+    const long long oo = live ? o : total - 1;              // surplus rows recompute the last output (every lane takes part in the DPP tree)
+    const int i = (int)(oo / p.n), j = p.n0 + (int)(oo % p.n);
+    float acc = 0.0f;
+    if (KIND == G_Q8Q4) {
+        const int8_t* ar = (const int8_t*)p.a + (size_t)p.lda * i + p.aoffset;
+        const float* afr = p.af + (size_t)p.ldaf * i + p.aoffset / QB;
+        const uint8_t* br = (const uint8_t*)p.b + (size_t)p.ldb * j + p.boffset;
+        const float* bfr = p.bf + (size_t)p.ldbf * j + (p.boffset * 2) / QB;
+        const int nblk = p.k / QB;
+#pragma unroll 4
+        for (int blk = 0; blk < nblk; blk++) {
+            const int bb = br[blk * 16 + t];
+            const int lo = (bb & 0x0F) - 8, hi = ((bb >> 4) & 0x0F) - 8;
+            const int isum = lo * (int)ar[blk * 32 + t] + hi * (int)ar[blk * 32 + 16 + t];   // |.| <= 2032: the int16 of the reference, exact
+            const float scale = afr[blk] * bfr[blk];
+            acc = fmaf(scale, (float)isum, acc);
+        }
+    } else if (KIND == G_F32Q4) {
+        const float* ar = (const float*)p.a + (size_t)p.lda * i + p.aoffset;
+        const uint8_t* br = (const uint8_t*)p.b + (size_t)p.ldb * j + p.boffset;
+        const float* bfr = p.bf + (size_t)p.ldbf * j + (p.boffset * 2) / QB;
+        const int nblk = p.k / QB;
+#pragma unroll 4
+        for (int blk = 0; blk < nblk; blk++) {
+            const int bb = br[blk * 16 + t];
+            const float s = bfr[blk];
+            const float wl = (float)((bb & 0x0F) - 8) * s, wh = (float)(((bb >> 4) & 0x0F) - 8) * s;
+            acc = fmaf(ar[blk * 32 + t], wl, acc);
+            acc = fmaf(ar[blk * 32 + 16 + t], wh, acc);
+        }
+    } else if (KIND == G_F32) {
+        const float* ar = (const float*)p.a + (size_t)p.lda * i + p.aoffset;
+        const float* br = (const float*)p.b + (size_t)p.ldb * j + p.boffset;
+#pragma unroll 8
+        for (int l = 0; l < p.k; l += 16) acc = fmaf(ar[l + t], br[l + t], acc);
+    } else if (KIND == G_BF16) {
+        const uint16_t* ar = (const uint16_t*)p.a + (size_t)p.lda * i + p.aoffset;
+        const uint16_t* br = (const uint16_t*)p.b + (size_t)p.ldb * j + p.boffset;
+#pragma unroll 8
+        for (int l = 0; l < p.k; l += 16) acc = fmaf(bf16_to_f32(ar[l + t]), bf16_to_f32(br[l + t]), acc);
+    } else {
+        const float* ar = (const float*)p.a + (size_t)p.lda * i + p.aoffset;
+        const uint16_t* br = (const uint16_t*)p.b + (size_t)p.ldb * j + p.boffset;
+#pragma unroll 8
+        for (int l = 0; l < p.k; l += 16) acc = fmaf(ar[l + t], bf16_to_f32(br[l + t]), acc);
+    }
+    acc = row16_tree_sum(acc);
+    if (live && t == 0) p.r[(size_t)p.ldc * i + j - p.roffset] = acc;
+}
+
 }  // namespace jh

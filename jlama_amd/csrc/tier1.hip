@@ -62,9 +62,31 @@ int tier1_gemm(int kind, int64_t b_id, int64_t bf_id, const void* a, const float
     void* dR = nullptr;
     JHCHK(dev_buf(4, r_elems * 4, &dR));
 
-    bool fast = (m == 1) && q4 && (aoffset % QB == 0) && (boffset % 16 == 0) && (ldb % 16 == 0) &&
+    // JH_STRICT_ORDER=1: every float accumulation in the Panama-512 order (gemm_reford_kernel, jh_p16.h) -- any M, any window;
+    // results are bit-identical to the reference's compiled C GEMM where that keeps Panama's order (F32xQ4, F32xF32, BF16xBF16,
+    // F32xBF16) and to the restated Panama provider for I8xQ4 (the C twin groups its floats differently)
+    const bool strict = opt_int("JH_STRICT_ORDER", 0) != 0;
+    if (strict && !q4 && (k % 16))
+        return set_err(JH_ERR_UNSUPPORTED, "gemm (reference order): K must be a multiple of the 16-lane species (Panama reads whole vectors)");
+    if (strict && q4 && ((aoffset % QB) || (boffset % 16)))
+        return set_err(JH_ERR_UNSUPPORTED, "gemm (reference order): column offsets must be whole Q blocks");
+    bool fast = !strict && (m == 1) && q4 && (aoffset % QB == 0) && (boffset % 16 == 0) && (ldb % 16 == 0) &&
                 !opt_int("JH_TIER1_GENERIC", 0);
-    if (fast) {
+    if (strict) {
+        GemmParams g{dA, (const float*)dAf, dB, dBf, (float*)dR, aoffset, boffset, roffset, m, n0, n, k,
+                     lda, ldaf, ldb, ldbf, ldc};
+        const long long outs = (long long)m * n;
+        const unsigned grid = (unsigned)((outs + 15) / 16);   // 4 waves x 4 outputs per 256-thread workgroup
+        switch (kind) {
+            case G_Q8Q4: hipLaunchKernelGGL((gemm_reford_kernel<G_Q8Q4>), dim3(grid), dim3(256), 0, st, g); break;
+            case G_F32Q4: hipLaunchKernelGGL((gemm_reford_kernel<G_F32Q4>), dim3(grid), dim3(256), 0, st, g); break;
+            case G_F32: hipLaunchKernelGGL((gemm_reford_kernel<G_F32>), dim3(grid), dim3(256), 0, st, g); break;
+            case G_BF16: hipLaunchKernelGGL((gemm_reford_kernel<G_BF16>), dim3(grid), dim3(256), 0, st, g); break;
+            default: hipLaunchKernelGGL((gemm_reford_kernel<G_F32BF16>), dim3(grid), dim3(256), 0, st, g); break;
+        }
+        HIPCHK(hipGetLastError());
+        fast = true;
+    } else if (fast) {
         GemvParams p;
         memset(&p, 0, sizeof(p));
         p.nrows = n;

@@ -142,3 +142,34 @@ def test_process_options_are_explicit_and_named():
     assert listed <= table and len(listed) <= 6
     code = "\n".join(open(os.path.join(ROOT, "jlama_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "jlama_amd", "csrc")))
     assert len(re.findall(r"\bgetenv\s*\(", code)) == 1
+
+
+def test_host_mirror_library_is_a_caller_of_the_c_abi_only():
+    """libjlamahost.so (csrc/host_mirror.cpp: the reference's host restated above the boundary) loads without a GPU, exports its
+    jhost_* entry points, is built from the current source, depends on libjlamahip.so for every provider call (undefined jh_*
+    symbols = exactly entry points include/jlama_hip.h declares) and on no device runtime, torch or oracle itself."""
+    from jlama_amd import _native as N
+    assert os.path.exists(N.HOST_LIB_PATH), "run __graft_entry__.build() first"
+    assert open(N.HOST_LIB_PATH + ".key").read() == N.host_source_hash(), "libjlamahost.so is stale: run __graft_entry__.build()"
+    L = N.host_lib()
+    for s in N.HOST_EXPORTS:
+        assert hasattr(L, s), s
+    out = subprocess.run(["nm", "-D", N.HOST_LIB_PATH], capture_output=True, text=True).stdout
+    undefined = {l.split()[-1] for l in out.splitlines() if " U " in l}
+    used = {s for s in undefined if s.startswith("jh_")}
+    assert used and used <= set(_declared()), sorted(used - set(_declared()))
+    assert {"jh_gemm_q8_q4", "jh_gemm_f32_q4", "jh_gemm_f32", "jh_gemm_bf16", "jh_gemm_q8_q4_batch", "jh_quantize_q8", "jh_saxpy_batch_f32",
+            "jh_scale_f32", "jh_accumulate_f32", "jh_maccumulate_f32", "jh_register_tensor"} <= used
+    assert not [s for s in undefined if s.startswith(("hip", "jo_"))]
+    defined = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert {s for s in defined if s.startswith("jhost_")} == set(N.HOST_EXPORTS)
+    needed = subprocess.run(["readelf", "-d", N.HOST_LIB_PATH], capture_output=True, text=True).stdout
+    assert "libjlamahip.so" in needed and "amdhip" not in needed and "torch" not in needed and "oracle" not in needed
+    # without a GPU the host's constructor throws like the Java provider's would (TensorOperationsProvider then falls through)
+    try:
+        N.init(0)
+    except N.JhError:
+        from jlama_amd import synthetic as S
+        from jlama_amd.host_mirror import HostAsIsModel
+        with pytest.raises(N.JhError):
+            HostAsIsModel(dict(S.TINY), {})
