@@ -104,10 +104,13 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=256)   # ~12 s of CPU work at the reference path's ~21 tok/s
     ap.add_argument("--parity-steps", type=int, default=256)   # free-running strict-order ids compared with the oracle
     ap.add_argument("--probe-iters", type=int, default=3)
+    ap.add_argument("--no-tier1-host", action="store_true")   # skip the host-as-is leg (tier1_host_tokens_per_s)
+    ap.add_argument("--tier1-steps", type=int, default=8)     # decode steps of that leg (each ~0.1-0.3 s on the 8B model)
     return ap.parse_args()
 
 
 TF_STEPS = 32
+METRIC_STEPS = 256   # BASELINE.json: "128-tok prefill + 256-tok decode"
 
 
 def cpu_baseline(cfg, host_w, n_prompt, n_decode):
@@ -283,7 +286,7 @@ def run_single(args, cfg):
     gen_s = time.time() - t0
     model = HipLlamaModel(cfg, w)
     prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
-    max_ctx = prompt.size + max(args.steps, args.warmup) + 8
+    max_ctx = prompt.size + max(args.steps, args.warmup, METRIC_STEPS if not args.no_strict else 0) + 8
     # warm-up on a throw-away session (builds the hipGraph, faults the weights in)
     ws = model.session(max_ctx)
     ws.batch_forward(prompt[:8], 0)
@@ -353,12 +356,27 @@ def run_single(args, cfg):
         sdt = time.perf_counter() - t0
         assert stoks.size == args.steps
         sev_ms, skernels = ss.decode_stats()
+        # the metric's own shape (BASELINE: 256 decode steps behind the 129-row prompt) whatever K the caller asked for: the same
+        # session, the same bracket, positions prompt.size ... prompt.size + 255 -- the driver's K = 20 covers positions 129..148 only
+        metric_shape = None
+        if args.steps != METRIC_STEPS and max_ctx >= prompt.size + METRIC_STEPS + 8:
+            ss.decode_n(sfirst, prompt.size + METRIC_STEPS - 1, 1)     # graph variant of the last position, untimed
+            _quiesce(torch, lambda: ss.decode_n(sfirst, prompt.size, 4))
+            ss.synchronize()
+            t0 = time.perf_counter()
+            ss.decode_n_async(sfirst, prompt.size, METRIC_STEPS)
+            mtoks = ss.decode_wait(METRIC_STEPS)
+            torch.cuda.synchronize()
+            mdt = time.perf_counter() - t0
+            assert mtoks.size == METRIC_STEPS and np.array_equal(mtoks[:args.steps], stoks[:METRIC_STEPS])
+            metric_shape = {"tokens_per_s": round(METRIC_STEPS / mdt, 2), "ms_per_step": round(mdt / METRIC_STEPS * 1e3, 4), "steps": METRIC_STEPS}
         sprobe = {}
         for i, nm in ((0, "qkv"), (1, "attention"), (2, "o_proj"), (3, "gate_up"), (4, "down"), (9, "lm_head")) if is_q4 else ():
             ms, b = ss.kernel_bench(i, args.probe_iters)
             sprobe[nm] = {"us": round(ms * 1e3, 3), "bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1)}
         ss.close()
         strict = {"tokens_per_s": round(args.steps / sdt, 2), "ms_per_step": round(sdt / args.steps * 1e3, 4), "prefill_ms": round(sprompt_ms, 2),
+                  "metric_shape": metric_shape,
                   "event_ms_per_token": round(sev_ms, 4), "kernels_per_token": skernels, "kernels": sprobe,
                   "note": "reference-order kernels (" + ("jh_t16.h, jh_p16.h" if is_q4 else "jh_bf16r.h, jh_p16.h") + "): bit-identical ids and logits vs the Panama-order oracle "
                           "(parity_full_size.strict_order), same K steps, same bracket as `value`"}
@@ -423,6 +441,13 @@ def run_single(args, cfg):
                                   "frac_of_achievable": round(sg / HBM_ACHIEVABLE_GBS, 4), "traffic": None}
         out["strict_tokens_per_s"] = strict["tokens_per_s"]
         out["strict_order"] = strict
+        # reference-order rate over the metric's own 256 decode positions (timed in this run; = value when --steps 256)
+        ms_shape = strict.pop("metric_shape")
+        if ms_shape or args.steps == METRIC_STEPS:
+            out["value_at_metric_shape"] = dict(ms_shape or {"tokens_per_s": strict["tokens_per_s"], "ms_per_step": strict["ms_per_step"], "steps": METRIC_STEPS},
+                                                order="reference", prompt_rows=int(prompt.size))
+            bpt = wbytes + kvb * (prompt.size + (METRIC_STEPS - 1) / 2.0 + 1) + kvb
+            out["value_at_metric_shape"]["token_roofline_frac_of_8TBps"] = round(bpt * out["value_at_metric_shape"]["tokens_per_s"] / 1e9 / HBM_PEAK_GBS, 4)
         if not args.fast_order:   # the path with bit-exact ids is the headline of this line
             out["fast_tokens_per_s"] = out["value"]
             out["fast_roofline"] = out["roofline"]
@@ -458,8 +483,9 @@ def run_single(args, cfg):
         out["cpu_baseline"] = cpu_baseline(cfg, host_w, int(prompt.size), args.cpu_steps)
     if not args.no_parity and not is_q4:
         host_w = host_w or ST.to_host(w)
-        # the BF16 oracle streams 14 GB per row on the host cores: a bounded sample (8-row prompt, 16 teacher-forced + 16 free steps)
-        par, _ = full_size_parity(cfg, model, host_w, 8, args.parity_steps, 16)
+        # on the metric's own prompt (the rows the timed run prefills through the batched reference-order kernels); the oracle's
+        # BF16 GEMM takes the whole chunk per weight pass (AVX2 bodies, bit-equal to the scalar text), 16 teacher-forced steps
+        par, _ = full_size_parity(cfg, model, host_w, int(prompt.size), args.parity_steps, 16)
         out["parity_full_size"] = par
     if not args.no_parity and is_q4:
         host_w = host_w or ST.to_host(w)
@@ -474,7 +500,44 @@ def run_single(args, cfg):
         ids_fast = np.concatenate([[gfirst], ps.decode_n(gfirst, pp.size, args.parity_steps)])
         par["fast_free_running_ids_equal_prefix"] = int((ids_fast == ids_o).cumprod().sum())
         out["parity_full_size"] = par
+    if not args.no_tier1_host:
+        host_w = host_w or ST.to_host(w)
+        ids_ref = ids_o if (not args.no_parity and is_q4) else None
+        out["tier1_host"] = tier1_host_leg(cfg, host_w, prompt, args.tier1_steps, ids_ref)
+        out["tier1_host_tokens_per_s"] = out["tier1_host"]["tokens_per_s"]
     return out, toks
+
+
+def tier1_host_leg(cfg, host_w, prompt, n_steps, ids_ref):
+    """The cost of "the Java host stays as is" (BASELINE north_star), MEASURED: the reference's host restated above the C ABI
+    (libjlamahost.so, jlama_amd/csrc/host_mirror.cpp = AbstractModel / TransformerBlock / CausalSelfAttention / MLPBlock calling only
+    the provider entry points on host buffers) generates on the metric's own prompt, in reference order, with the provider's default
+    split (GEMMs on the device, element-wise methods on the host delegate: HipTensorOperations.java:45-57) and the reference's pfor
+    width T = max(2, available/2).  Every call is a PCIe round trip: this is Tier 1, never `value`."""
+    from jlama_amd import _native as N
+    from jlama_amd.host_mirror import HostAsIsModel
+    from oracle import oracle as O   # (available_cpus only: the JVM-like view of the container's CPU quota)
+    T = max(2, O.available_cpus() // 2)
+    N.set_option("JH_STRICT_ORDER", 1)
+    try:
+        hm = HostAsIsModel(cfg, host_w, elementwise_on_device=False, threads=T)
+        res = hm.generate(prompt, n_steps + 1)      # n_steps decode steps behind the first sampled token (AbstractModel.java:589)
+        hm.close()
+    finally:
+        N.clear_options()
+    out = {"tokens_per_s": round(n_steps / (res["decode_ms"] * 1e-3), 3), "ms_per_step": round(res["decode_ms"] / n_steps, 2),
+           "prompt_ms": round(res["prompt_ms"], 1), "prompt_rows": int(prompt.size), "steps": n_steps, "threads": T,
+           "provider_calls_per_token": None, "order": "reference (JH_STRICT_ORDER=1: gemm_reford_kernel)",
+           "elementwise": "host delegate (provider default)",
+           "note": "libjlamahost.so: the reference's host restated in C++ above the Tier-1 C ABI; every provider call ships host buffers over PCIe and "
+                   "synchronises (per layer and token: 8 weight GEMVs + heads x KV pages score GEMMs)"}
+    if ids_ref is not None:
+        k = min(len(ids_ref), res["tokens"].size)
+        out["ids_equal_to_oracle"] = int((res["tokens"][:k] == ids_ref[:k]).cumprod().sum())
+        out["ids_compared"] = int(k)
+    out["provider_calls_total"] = res["provider_calls"]
+    del out["provider_calls_per_token"]
+    return out
 
 
 def run_one_process(args, cfg):

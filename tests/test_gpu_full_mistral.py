@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N_PROMPT, N_FREE, N_TF = 8, 64, 16
+N_PROMPT, N_FREE, N_TF = 129, 64, 16   # the metric's own 129-row prompt (128 ids + BOS): batched reference-order prefill, 5 KV pages
 
 
 @pytest.fixture(scope="module")
