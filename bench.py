@@ -286,7 +286,9 @@ def run_single(args, cfg):
     gen_s = time.time() - t0
     model = HipLlamaModel(cfg, w)
     prompt = S.prompt_tokens(cfg, n=args.prompt, seed=1234)
-    max_ctx = prompt.size + max(args.steps, args.warmup, METRIC_STEPS if not args.no_strict else 0) + 8
+    want_metric_shape = (not args.no_strict and args.steps != METRIC_STEPS and
+                         prompt.size + METRIC_STEPS + 8 + 2 * cfg["n_kv_heads"] <= cfg["context_length"])
+    max_ctx = prompt.size + max(args.steps, args.warmup, METRIC_STEPS if want_metric_shape else 0) + 8
     # warm-up on a throw-away session (builds the hipGraph, faults the weights in)
     ws = model.session(max_ctx)
     ws.batch_forward(prompt[:8], 0)
@@ -359,7 +361,7 @@ def run_single(args, cfg):
         # the metric's own shape (BASELINE: 256 decode steps behind the 129-row prompt) whatever K the caller asked for: the same
         # session, the same bracket, positions prompt.size ... prompt.size + 255 -- the driver's K = 20 covers positions 129..148 only
         metric_shape = None
-        if args.steps != METRIC_STEPS and max_ctx >= prompt.size + METRIC_STEPS + 8:
+        if want_metric_shape:
             ss.decode_n(sfirst, prompt.size + METRIC_STEPS - 1, 1)     # graph variant of the last position, untimed
             _quiesce(torch, lambda: ss.decode_n(sfirst, prompt.size, 4))
             ss.synchronize()

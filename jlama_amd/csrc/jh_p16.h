@@ -284,6 +284,41 @@ __device__ __forceinline__ void p16_group_i8(const i32x4& x, const i32x4* pt, fl
     p16_quad_chain<3, FULL>(q3, pscale, nb, acc);
 }
 
+// The pair sums of the NEXT quad and the 4 chained fmas of THIS quad in ONE asm statement, interleaved: dot4 x 4, then fma / convert
+// alternating -- every convert sits >= 5 instructions behind its dot (a DOT result needs 3 wait states before a VALU read), every
+// dependent fma has an independent convert in its latency, and nothing pads the chain: as 4 separate statements hipcc put an
+// `s_nop 0` behind each fma (its fixed pad for an asm output), 12 of the ~96 instructions of a group in kernels whose working waves
+// sit alone on their SIMD and issue one instruction per ~4.5 cycles (round 6: the few-row GEMVs are ISSUE-bound, not HBM-bound).
+template <int K4> __device__ __forceinline__ void p16_sums_chain(const i32x4 pp, int e, int o, Quad4& nq, const Quad4& q, float pscale, float& acc);
+#define JH_P16_SUMS_CHAIN(K4, B0, B1, B2, B3)                                                                                                   \
+    template <> __device__ __forceinline__ void p16_sums_chain<K4>(const i32x4 pp, int e, int o, Quad4& nq, const Quad4& q, float pscale, float& acc) { \
+        int i0, i1, i2, i3;                                                                                                                     \
+        asm volatile("v_dot4_i32_i8 %5, %9, %13, 0\n\t"                                                                                          \
+                     "v_dot4_i32_i8 %6, %10, %14, 0\n\t"                                                                                         \
+                     "v_dot4_i32_i8 %7, %11, %13, 0\n\t"                                                                                         \
+                     "v_dot4_i32_i8 %8, %12, %14, 0\n\t"                                                                                         \
+                     "v_fmac_f32_dpp %4, %15, %16 row_newbcast:" #B0 " row_mask:0xf bank_mask:0xf\n\t"                                           \
+                     "v_cvt_f32_i32_e32 %0, %5\n\t"                                                                                              \
+                     "v_fmac_f32_dpp %4, %15, %17 row_newbcast:" #B1 " row_mask:0xf bank_mask:0xf\n\t"                                           \
+                     "v_cvt_f32_i32_e32 %1, %6\n\t"                                                                                              \
+                     "v_fmac_f32_dpp %4, %15, %18 row_newbcast:" #B2 " row_mask:0xf bank_mask:0xf\n\t"                                           \
+                     "v_cvt_f32_i32_e32 %2, %7\n\t"                                                                                              \
+                     "v_fmac_f32_dpp %4, %15, %19 row_newbcast:" #B3 " row_mask:0xf bank_mask:0xf\n\t"                                           \
+                     "v_cvt_f32_i32_e32 %3, %8"                                                                                                  \
+                     : "=&v"(nq.f0), "=&v"(nq.f1), "=&v"(nq.f2), "=&v"(nq.f3), "+v"(acc), "=&v"(i0), "=&v"(i1), "=&v"(i2), "=&v"(i3)              \
+                     : "v"(pp.x), "v"(pp.y), "v"(pp.z), "v"(pp.w), "v"(e), "v"(o), "v"(pscale), "v"(q.f0), "v"(q.f1), "v"(q.f2), "v"(q.f3));     \
+    }
+JH_P16_SUMS_CHAIN(0, 0, 1, 2, 3) JH_P16_SUMS_CHAIN(1, 4, 5, 6, 7) JH_P16_SUMS_CHAIN(2, 8, 9, 10, 11)
+#undef JH_P16_SUMS_CHAIN
+// the group's last quad: 4 chained fmas (blocks 12..15), one statement
+__device__ __forceinline__ void p16_chain_last(const Quad4& q, float pscale, float& acc) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %3 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %4 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %1, %5 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(pscale), "v"(q.f0), "v"(q.f1), "v"(q.f2), "v"(q.f3));
+}
+
 // The same group with its activation operands held in REGISTERS and refilled in place for the NEXT group: hipcc closes every LDS
 // read it emits with s_waitcnt lgkmcnt(0) a few instructions later, i.e. a working wave (alone on its SIMD in the few-row GEMVs)
 // sat out the LDS round trip four times per group (gemv_timeline: 550-720 cycles per group for ~95 instructions).  Here the reads
@@ -302,6 +337,23 @@ __device__ __forceinline__ void p16_group_i8_regs(const i32x4& x, PairRegsP16& r
     const Quad4 q0 = p16_quad_sums(x.x, r.w0);
     if constexpr (!LAST) p16_req_pairs(r.w0, pt_next);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FULL) {                                   // whole group (every real shape): sums of quad k+1 fused with the chain of quad k
+        Quad4 q1, q2, q3;
+        if constexpr (!LAST) p16_tie4(r.w1);
+        p16_sums_chain<0>(r.w1, nib_hi16(x.y), nib_lo16(x.y), q1, q0, pscale, acc);
+        if constexpr (!LAST) p16_req_pairs(r.w1, pt_next + 256u);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LAST) p16_tie4(r.w2);
+        p16_sums_chain<1>(r.w2, nib_hi16(x.z), nib_lo16(x.z), q2, q1, pscale, acc);
+        if constexpr (!LAST) p16_req_pairs(r.w2, pt_next + 512u);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LAST) p16_tie4(r.w3);
+        p16_sums_chain<2>(r.w3, nib_hi16(x.w), nib_lo16(x.w), q3, q2, pscale, acc);
+        if constexpr (!LAST) p16_req_pairs(r.w3, pt_next + 768u);
+        __builtin_amdgcn_sched_barrier(0);
+        p16_chain_last(q3, pscale, acc);
+        return;
+    }
     if constexpr (!LAST) p16_tie4(r.w1);
     const Quad4 q1 = p16_quad_sums(x.y, r.w1);
     if constexpr (!LAST) p16_req_pairs(r.w1, pt_next + 256u);
@@ -722,6 +774,126 @@ __global__ __launch_bounds__(P16_THREADS) void gemv_f32q4_p16_kernel(GemvParams 
     }
 }
 
+// 16 links of a sequential float chain in 16 instructions: the link's uniform operand is lane k of a register every 16-lane row
+// holds a copy of (lane t = element 16 j + t), taken through the DPP operand of the add / fma itself (row_newbcast:k) -- no
+// v_readlane, no SGPR, no wait state between the lift and the use.  Round 5 lifted the uniform operand into SGPRs (readlane + the two
+// wait states a VALU needs behind it: 2-3 issue slots per link, and a wave alone on its SIMD issues one instruction per ~4.5 cycles).
+__device__ __forceinline__ void add16_bcast(float& sum, float x) {      // sum = fl(sum + x[k]), k = 0..15 in order
+    asm volatile(
+        "s_nop 1\n\t"   // a DPP read needs 2 wait states behind a VALU write of its source (x may have just been moved); hipcc cannot see inside
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(sum) : "v"(x));
+}
+// acc = fma(w[k], v_k, acc), k = 0..15 in order: w = one register (lane t of every row holds weight 16 j + t), v = this lane's 16 values.
+// ONE asm statement: between separate statements hipcc pads the producer -> consumer edge of `acc` it cannot see into (round 6 timeline:
+// 23 cycles per link as 16 statements, against 7-8 for the 16 adds of add16_bcast in one).
+__device__ __forceinline__ void fma16_bcast(float& acc, float w, const f32x4 (&v)[4]) {
+    asm volatile(
+        "s_nop 1\n\t"   // (DPP source w: 2 wait states behind a VALU write)
+        "v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(w), "v"(v[0].x), "v"(v[0].y), "v"(v[0].z), "v"(v[0].w), "v"(v[1].x), "v"(v[1].y), "v"(v[1].z), "v"(v[1].w), "v"(v[2].x), "v"(v[2].y),
+          "v"(v[2].z), "v"(v[2].w), "v"(v[3].x), "v"(v[3].y), "v"(v[3].z), "v"(v[3].w));
+}
+// the same for a chain that ends inside the group: links k < cnt only (cnt wave-uniform)
+__device__ __forceinline__ void fma16_bcast_tail(float& acc, float w, const f32x4 (&v)[4], int cnt) {
+#define JH_FT(K, E) if (K < cnt) fmac_bcast<K>(acc, w, E);
+    JH_FT(0, v[0].x) JH_FT(1, v[0].y) JH_FT(2, v[0].z) JH_FT(3, v[0].w) JH_FT(4, v[1].x) JH_FT(5, v[1].y) JH_FT(6, v[1].z) JH_FT(7, v[1].w)
+    JH_FT(8, v[2].x) JH_FT(9, v[2].y) JH_FT(10, v[2].z) JH_FT(11, v[2].w) JH_FT(12, v[3].x) JH_FT(13, v[3].y) JH_FT(14, v[3].z) JH_FT(15, v[3].w)
+#undef JH_FT
+}
+
+// softMax's running sum (VectorMath.java:80-85) by ONE wave: w[0, n16) = the exponentials, zero-padded to a whole group of 16 (and
+// readable 64 floats further); register j holds w[16 j + t] in lane t of every 16-lane row, link k of a group is one v_add_f32
+// whose DPP operand broadcasts lane k.  Every lane returns the same sum.
+__device__ __forceinline__ float p16_seq_sum_wave(const float* w, int n16, int lane) {
+    float sum = 0.0f;
+    const int ng = n16 >> 4, t16 = lane & 15;
+    float x0 = w[t16], x1 = w[16 + t16], x2 = w[32 + t16], x3 = w[48 + t16];
+    int g = 0;
+    for (; g + 4 <= ng; g += 4) {                           // 64 links per trip, the next 64 values in flight
+        const float* nx = w + (g + 4) * 16 + t16;
+        const float y0 = nx[0], y1 = nx[16], y2 = nx[32], y3 = nx[48];
+        add16_bcast(sum, x0); add16_bcast(sum, x1); add16_bcast(sum, x2); add16_bcast(sum, x3);
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+    }
+    if (g < ng) add16_bcast(sum, x0);
+    if (g + 1 < ng) add16_bcast(sum, x1);
+    if (g + 2 < ng) add16_bcast(sum, x2);
+    return sum;
+}
+// value[d] += fma chain over the cnt positions of one V tile (saxpy per position, PTO:2648-2698), ONE wave: lanes 0..31 own one
+// column each (lanes 32..63 run the same chain on column lane - 32).  vrow = this lane's column in the TRANSPOSED tile (positions
+// contiguous: one ds_read_b128 = 4 links), wt = the tile's normalised weights (+ lane & 15): register j holds weight 16 j + t in lane
+// t of every row and reaches the chain through the DPP operand of the fma (fma16_bcast) -- one instruction per link, plain C
+// around it (every wait is hipcc's own), the column's values one 16-link piece ahead.  Reads past cnt stay inside the tile / the
+// padded weight row and are never used, except by guarded links.
+__device__ __forceinline__ void p16_value_chain_tile(float& acc, const float* vrow, const float* wt, int cnt, int TP) {
+    const int nfull = cnt >> 6, rem = cnt & 63;
+    f32x4 va[4], vb[4];
+    auto ldv = [&](f32x4 (&v)[4], int i0) __attribute__((always_inline)) {
+        const f32x4* q = (const f32x4*)(vrow + i0);
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+    };
+    float w0 = wt[0], w1 = wt[16], w2 = wt[32], w3 = wt[48];
+    ldv(va, 0);
+    for (int c = 0; c < nfull; c++) {
+        const float* wn = wt + (c + 1) * 64;
+        const float y0 = wn[0], y1 = wn[16], y2 = wn[32], y3 = wn[48];
+        const int nx = 64 * (c + 1) < TP ? 64 * (c + 1) : 0;
+        ldv(vb, 64 * c + 16);
+        __builtin_amdgcn_sched_barrier(0);
+        fma16_bcast(acc, w0, va);
+        __builtin_amdgcn_sched_barrier(0);
+        ldv(va, 64 * c + 32);
+        __builtin_amdgcn_sched_barrier(0);
+        fma16_bcast(acc, w1, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        ldv(vb, 64 * c + 48);
+        __builtin_amdgcn_sched_barrier(0);
+        fma16_bcast(acc, w2, va);
+        __builtin_amdgcn_sched_barrier(0);
+        ldv(va, nx);
+        __builtin_amdgcn_sched_barrier(0);
+        fma16_bcast(acc, w3, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        w0 = y0; w1 = y1; w2 = y2; w3 = y3;
+    }
+    if (rem) {                                              // the tile's last cnt % 64 positions, 16 at a time (va holds the first 16)
+        const int b0 = 64 * nfull;
+        auto tail16 = [&](const f32x4 (&v)[4], float wr, int l0) __attribute__((always_inline)) {
+            if (l0 + 16 <= rem) fma16_bcast(acc, wr, v);
+            else fma16_bcast_tail(acc, wr, v, rem - l0);    // the values past n in the tile may be anything (0 * NaN): guarded links
+        };
+        tail16(va, w0, 0);
+        if (rem > 16) { ldv(vb, b0 + 16); tail16(vb, w1, 16); }
+        if (rem > 32) { ldv(va, b0 + 32); tail16(va, w2, 32); }
+        if (rem > 48) { ldv(vb, b0 + 48); tail16(vb, w3, 48); }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ decode attention, reference order
 // CausalSelfAttention.java:199-357 in two launches, because the reference's order makes two parts of it sequential over the whole
 // context -- the float sum of the exponentials and the fma chain of every output element over the positions -- while its traffic
@@ -835,9 +1007,14 @@ __device__ __forceinline__ void p16_av_load_tile(const AttnParams& p, f32x4 (&vr
 }
 template <int RU>
 __device__ __forceinline__ void p16_av_store_tile(float* vt, const f32x4 (&vreg)[RU], int vr, int vc, int tile, int n) {
+    // TRANSPOSED tile [32 columns][TP + 4]: a column's positions are contiguous (one ds_read_b128 = 4 links of its chain)
+    constexpr int TPP = 32 * RU + 4;
 #pragma unroll
     for (int u = 0; u < RU; u++)
-        if (tile * (32 * RU) + 32 * u < n) ((f32x4*)(vt + (size_t)(vr + 32 * u) * 32))[vc] = vreg[u];
+        if (tile * (32 * RU) + 32 * u < n) {
+            float* dst = vt + (size_t)(4 * vc) * TPP + vr + 32 * u;
+            dst[0] = vreg[u].x; dst[TPP] = vreg[u].y; dst[2 * TPP] = vreg[u].z; dst[3 * TPP] = vreg[u].w;
+        }
 }
 // RU = V rows per thread and tile, i.e. TP = 32 * RU positions per V tile in LDS (host: 2, 4, 8 or 16 -- the smallest that holds
 // the session's max_ctx, at most 512 positions): a context of up to TP positions is ONE tile, requested at kernel start and
@@ -851,9 +1028,10 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     const int pos = p.st->pos, n = pos + 1;
     const int KV = p.n_kv_heads * HS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* vt = (float*)smem;              // [TP][DW] V tile
-    float* redf = vt + (size_t)TP * DW;    // [16]
-    float* w = redf + 16;                  // [n, padded to 64] scores -> softmax weights
+    constexpr int TPP = TP + 4;
+    float* vt = (float*)smem;              // [DW][TPP] V tile, transposed
+    float* redf = vt + (size_t)DW * TPP;   // [16]
+    float* w = redf + 16;                  // [n, padded to 64 (+ 64 readable)] scores -> softmax weights
     // V tile loads: thread (row = tid / 8, c4 = tid % 8) covers rows vr, vr + 32, ...
     const int vr = tid >> 3, vc = tid & 7;
     f32x4 vreg[RU];
@@ -872,22 +1050,14 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     __syncthreads();
     m = redf[0];
     for (int i = 1; i < NT / 64; i++) m = fmaxf(m, redf[i]);
-    for (int tt = tid; tt < n; tt += NT) w[tt] = (float)exp((double)(w[tt] - m));   // (float)FastMath.exp(x - max)
-    p16_av_store_tile<RU>(vt, vreg, vr, vc, 0, n);                  // tile 0 lands in LDS while lane 0 sums
+    const int n16 = (n + 15) & ~15;        // zero-padded to a whole group of 16: fl(s + 0) = s
+    for (int tt = tid; tt < n16; tt += NT) w[tt] = tt < n ? (float)exp((double)(w[tt] - m)) : 0.0f;   // (float)FastMath.exp(x - max)
     __syncthreads();
-    if (tid == 0) {
-        float sum = 0.0f;                   // VectorMath.java:80-85: one float accumulator, index order
-        int tt = 0;
-        for (; tt + 16 <= n; tt += 16) {
-            const float4 e0 = *(const float4*)(w + tt), e1 = *(const float4*)(w + tt + 4);
-            const float4 e2 = *(const float4*)(w + tt + 8), e3 = *(const float4*)(w + tt + 12);
-            sum += e0.x; sum += e0.y; sum += e0.z; sum += e0.w;
-            sum += e1.x; sum += e1.y; sum += e1.z; sum += e1.w;
-            sum += e2.x; sum += e2.y; sum += e2.z; sum += e2.w;
-            sum += e3.x; sum += e3.y; sum += e3.z; sum += e3.w;
-        }
-        for (; tt < n; tt++) sum += w[tt];
-        redf[8] = sum;
+    if (wave != 0) p16_av_store_tile<RU>(vt, vreg, vr, vc, 0, n);   // tile 0 lands in LDS while wave 0 sums
+    if (wave == 0) {
+        const float sum0 = p16_seq_sum_wave(w, n16, lane);          // VectorMath.java:80-85: one float accumulator, index order
+        if (lane == 0) redf[8] = sum0;
+        p16_av_store_tile<RU>(vt, vreg, vr, vc, 0, n);
     }
     __syncthreads();
     const float sum = redf[8];
@@ -903,60 +1073,13 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
             p16_av_store_tile<RU>(vt, vnext, vr, vc, tile, n);
         }
         __syncthreads();                    // tile (and, first time round, the normalised weights) visible
-        if (tid < DW) {
-            // 16 steps per chunk; the next chunk's LDS reads are issued before the current chunk's dependent fmas
+        if (wave == 0) {
             const int tbase = tile * TP, cnt = n - tbase < TP ? n - tbase : TP;
-            float va[16], vb[16];
-            float4 wa[4], wb[4];
-            auto ldchunk = [&](int i0, float (&v)[16], float4 (&ww)[4]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) v[j] = vt[(i0 + j) * DW + tid];          // i0 + j < TP: rows past cnt hold clamped copies
-#pragma unroll
-                for (int j = 0; j < 4; j++) ww[j] = *(const float4*)(w + tbase + i0 + 4 * j);   // 16-byte aligned; w[] is padded to 64
-            };
-            auto dochunk = [&](int i0, const float (&v)[16], const float4 (&ww)[4]) __attribute__((always_inline)) {
-                if (i0 + 16 <= cnt) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        acc = fmaf(v[4 * j + 0], ww[j].x, acc);
-                        acc = fmaf(v[4 * j + 1], ww[j].y, acc);
-                        acc = fmaf(v[4 * j + 2], ww[j].z, acc);
-                        acc = fmaf(v[4 * j + 3], ww[j].w, acc);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (i0 + 4 * j + 0 < cnt) acc = fmaf(v[4 * j + 0], ww[j].x, acc);
-                        if (i0 + 4 * j + 1 < cnt) acc = fmaf(v[4 * j + 1], ww[j].y, acc);
-                        if (i0 + 4 * j + 2 < cnt) acc = fmaf(v[4 * j + 2], ww[j].z, acc);
-                        if (i0 + 4 * j + 3 < cnt) acc = fmaf(v[4 * j + 3], ww[j].w, acc);
-                    }
-                }
-            };
-            ldchunk(0, va, wa);
-            for (int i0 = 0; i0 < cnt; i0 += 32) {
-                if (i0 + 16 < cnt) ldchunk(i0 + 16, vb, wb);
-                dochunk(i0, va, wa);
-                if (i0 + 32 < cnt) ldchunk(i0 + 32, va, wa);
-                if (i0 + 16 < cnt) dochunk(i0 + 16, vb, wb);
-            }
+            p16_value_chain_tile(acc, vt + (size_t)(lane & (DW - 1)) * TPP, w + tbase + (lane & 15), cnt, TP);
         }
     }
     if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
 }
-// LDS reads whose latency the CALLER hides: 64 consecutive bytes as four ds_read_b128, issued and NOT waited for -- hipcc closes
-// every LDS read it issues itself with s_waitcnt lgkmcnt(0) in these loops, which also waits for the chunk requested a moment ago
-// (measured: 20 cycles per link of a sequential float chain instead of 5).  lds_tie<N> is the matching wait: at most N younger LDS
-// operations stay in flight, and the four registers become readable (they are operands of the wait, so no use can move above it).
-__device__ __forceinline__ void lds_read64_nowait(f32x4& a, f32x4& b, f32x4& c, f32x4& d, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lds_tie(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
-
 // ------------------------------------------------------------------------------------------------ the two launches above in ONE
 // (round 5).  Contexts of up to ~1 k positions do not need the scores spread over the chip: the K rows of a kv head are 512 bytes
 // per position, and a workgroup that asks for them with 16-byte loads, two passes ahead, ingests a 400-position context in ~2 us --
@@ -1096,56 +1219,14 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
     __syncthreads();
     m = redf[0];
     for (int i = 1; i < NT / 64; i++) m = fmaxf(m, redf[i]);
-    for (int tt = tid; tt < n; tt += NT) w[tt] = (float)exp((double)(w[tt] - m));
+    const int n16 = (n + 15) & ~15;                         // the row is zero-padded to a whole group of 16: fl(s + 0) = s for the sum chain
+    for (int tt = tid; tt < n16; tt += NT) w[tt] = tt < n ? (float)exp((double)(w[tt] - m)) : 0.0f;
     JH_FSTAMP(4);
     __syncthreads();                                        // exponentials visible
     JH_FSTAMP(5);
     if (wave != 0) file_v(vreg, 0);                         // waves 1..3 file tile 0 (wave 0's share follows its sum) WHILE wave 0 sums
     if (wave == 0) {
-        // one float accumulator in index order (VectorMath.java:80-85).  Lane l of wave 0 holds w[64c + l]; the chain takes the
-        // values in order through v_readlane (an SGPR operand of the add): no LDS access inside the chain, and every value the
-        // compiler schedules around is one it knows about (the asm LDS pipeline this replaces kept reads pending across the
-        // loop's branches, where hipcc is free to copy registers: tools/isa_pending_lds.py).
-        float sum = 0.0f;
-        const int nfull = n >> 6, rem = n & 63;
-        float x = w[lane];                                  // (w is padded by 64: in bounds; entries >= n are never added)
-        for (int c = 0; c < nfull; c++) {                   // whole chunks: 64 links, no branch
-            const float xn = w[(c + 1) * 64 + lane];        // the next chunk (or the tail's, or padding) is in flight during the chain
-            const int xi = __float_as_int(x);
-            // The values are lifted into SGPRs 8 links ahead of their adds, one readlane between two adds: a v_readlane result needs
-            // two wait states before a VALU may read it (left alone hipcc alternates readlane / s_nop / add: 3 issue slots per link),
-            // and the independent readlane sits in the dependent add's latency.
-            float e[8], f[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) e[j] = __int_as_float(__builtin_amdgcn_readlane(xi, j));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int l0 = 0; l0 < 64; l0 += 8) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    if (l0 + 8 < 64) f[j] = __int_as_float(__builtin_amdgcn_readlane(xi, l0 + 8 + j));
-                    sum += e[j];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) e[j] = f[j];
-            }
-            x = xn;
-        }
-        if (rem) {                                          // the last n % 64 values, 16 at a time
-            const int xi = __float_as_int(x);
-#pragma unroll
-            for (int l0 = 0; l0 < 64; l0 += 16) {
-                if (l0 + 16 <= rem) {
-#pragma unroll
-                    for (int j = 0; j < 16; j++) sum += __int_as_float(__builtin_amdgcn_readlane(xi, l0 + j));
-                } else if (l0 < rem) {
-#pragma unroll
-                    for (int j = 0; j < 16; j++)
-                        if (l0 + j < rem) sum += __int_as_float(__builtin_amdgcn_readlane(xi, l0 + j));
-                }
-            }
-        }
+        const float sum = p16_seq_sum_wave(w, n16, lane);   // one float accumulator in index order (VectorMath.java:80-85)
         if (lane == 0) redf[8] = sum;
         JH_FSTAMP(6);
     }
@@ -1165,76 +1246,8 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
         }
         __syncthreads();
         if (wave == 0) {
-            // lanes 0..31 own one column each (lanes 32..63 run the same chain on column lane - 32 and store nothing).  The weights are
-            // uniform: lane l holds w[tbase + 64c + l] and the chain reads them through v_readlane; the column's values come 4 links
-            // per ds_read_b128 from the transposed tile, one 16-link piece ahead -- plain C, every wait is hipcc's own.
             const int tbase = tile * TP, cnt = n - tbase < TP ? n - tbase : TP;
-            const float* vrow = vt + (size_t)(lane & (DW - 1)) * TPP;
-            const float* wt = w + tbase;
-            const int nfull = cnt >> 6, rem = cnt & 63;
-            f32x4 va[4], vb[4];
-            auto ldv = [&](f32x4 (&v)[4], int i0) __attribute__((always_inline)) {
-                const f32x4* q = (const f32x4*)(vrow + i0);
-                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-            };
-            auto links16 = [&](const f32x4 (&v)[4], int xi, auto kc) __attribute__((always_inline)) {
-                constexpr int L0 = 16 * decltype(kc)::value;
-                float e[8], f[8];                           // weights lifted into SGPRs 8 links ahead, one readlane between two fmas (see the sum)
-#pragma unroll
-                for (int j = 0; j < 8; j++) e[j] = __int_as_float(__builtin_amdgcn_readlane(xi, L0 + j));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j0 = 0; j0 < 16; j0 += 8) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (j0 + 8 < 16) f[j] = __int_as_float(__builtin_amdgcn_readlane(xi, L0 + j0 + 8 + j));
-                        acc = fmaf(v[(j0 + j) >> 2][(j0 + j) & 3], e[j], acc);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) e[j] = f[j];
-                }
-            };
-            float xw = wt[lane];
-            ldv(va, 0);
-            for (int c = 0; c < nfull; c++) {               // whole chunks: 64 links, no branch; reads past the tile's used part stay
-                const float xwn = wt[(c + 1) * 64 + lane];  // inside the padded weight row / the tile and are never used
-                const int xi = __float_as_int(xw);
-                const int nx = 64 * (c + 1) < TP ? 64 * (c + 1) : 0;
-                ldv(vb, 64 * c + 16);
-                __builtin_amdgcn_sched_barrier(0);
-                links16(va, xi, std::integral_constant<int, 0>{});
-                __builtin_amdgcn_sched_barrier(0);
-                ldv(va, 64 * c + 32);
-                __builtin_amdgcn_sched_barrier(0);
-                links16(vb, xi, std::integral_constant<int, 1>{});
-                __builtin_amdgcn_sched_barrier(0);
-                ldv(vb, 64 * c + 48);
-                __builtin_amdgcn_sched_barrier(0);
-                links16(va, xi, std::integral_constant<int, 2>{});
-                __builtin_amdgcn_sched_barrier(0);
-                ldv(va, nx);
-                __builtin_amdgcn_sched_barrier(0);
-                links16(vb, xi, std::integral_constant<int, 3>{});
-                __builtin_amdgcn_sched_barrier(0);
-                xw = xwn;
-            }
-            if (rem) {                                      // the tile's last cnt % 64 positions, 16 at a time (va holds the first 16)
-                const int xi = __float_as_int(xw), b0 = 64 * nfull;
-                auto tail16 = [&](const f32x4 (&v)[4], auto kc) __attribute__((always_inline)) {
-                    constexpr int L0 = 16 * decltype(kc)::value;
-                    if (L0 + 16 <= rem) links16(v, xi, kc);
-                    else if (L0 < rem) {
-#pragma unroll
-                        for (int j = 0; j < 16; j++)
-                            if (L0 + j < rem) acc = fmaf(v[j >> 2][j & 3], __int_as_float(__builtin_amdgcn_readlane(xi, L0 + j)), acc);
-                    }
-                };
-                tail16(va, std::integral_constant<int, 0>{});
-                if (rem > 16) { ldv(vb, b0 + 16); tail16(vb, std::integral_constant<int, 1>{}); }
-                if (rem > 32) { ldv(va, b0 + 32); tail16(va, std::integral_constant<int, 2>{}); }
-                if (rem > 48) { ldv(vb, b0 + 48); tail16(vb, std::integral_constant<int, 3>{}); }
-            }
+            p16_value_chain_tile(acc, vt + (size_t)(lane & (DW - 1)) * TPP, w + tbase + (lane & 15), cnt, TP);
         }
     }
     if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
@@ -1250,7 +1263,7 @@ static inline int p16_av_rows(int max_ctx) {   // RU: the whole context in one t
     const int want = ((max_ctx + 63) & ~63) / 32;
     return want <= 2 ? 2 : want <= 4 ? 4 : want <= 8 ? 8 : 16;
 }
-static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)p16_av_rows(max_ctx) * 32 * 32 + 16 + (size_t)((max_ctx + 63) & ~63) + 2 * 128) * 4; }
+static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)32 * (p16_av_rows(max_ctx) * 32 + 4) + 16 + (size_t)((max_ctx + 63) & ~63) + 2 * 128) * 4; }
 
 // ------------------------------------------------------------------------------------------------ prompt rows in reference order
 // AbstractModel.batchForward (AbstractModel.java:295-312): the projections of a prompt chunk run on the F16 MFMA (jh_t16.h:

@@ -16,6 +16,8 @@ def main():
     import torch
     from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
     from jlama_amd.model import HipLlamaModel
+    if os.environ.get("JH_LIB"):           # tools only: A/B another build of the library on the SAME box (rates move ~5 % box to box)
+        N.LIB_PATH = os.path.abspath(os.environ["JH_LIB"])
     config = sys.argv[1] if len(sys.argv) > 1 else "LLAMA3_8B"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     cfg = dict(getattr(S, config))
