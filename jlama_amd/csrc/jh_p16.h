@@ -325,48 +325,59 @@ __device__ __forceinline__ void p16_chain_last(const Quad4& q, float pscale, flo
 // are asm (no automatic wait), issued one group ahead in consumption order -- d16, pair words of quads 0..3 -- and every use waits
 // with lgkmcnt(4): LDS operations retire in order, so at most the four younger requests are still in flight.
 struct PairRegsP16 { i32x4 w0, w1, w2, w3; float d; };
-__device__ __forceinline__ void p16_req_pairs(i32x4& w, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=&v"(w) : "v"(addr) : "memory"); }
-__device__ __forceinline__ void p16_req_d(float& d, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=&v"(d) : "v"(addr) : "memory"); }
+// (the group's distance from the ring block's first group is a compile-time constant: it travels in the instruction's 16-bit offset
+// field, so a block needs ONE address register per table instead of an add per request -- every instruction of these loops is an
+// issue slot of a wave that sits alone on its SIMD)
+template <int OFF = 0> __device__ __forceinline__ void p16_req_pairs(i32x4& w, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(w) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int OFF = 0> __device__ __forceinline__ void p16_req_d(float& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+template <class F, int... I> __device__ __forceinline__ void p16_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void p16_static_for(F&& f) { p16_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 __device__ __forceinline__ void p16_tie4(i32x4& w) { asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w)::"memory"); }
 __device__ __forceinline__ void p16_tie4(float& d) { asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d)::"memory"); }
 // LAST: the wave's final group requests nothing -- a request still in flight when its registers are dead would land in whatever
 // hipcc has put there since (it cannot see the asm reads) -- and therefore waits for everything at once.
-template <bool FULL, bool LAST>
-__device__ __forceinline__ void p16_group_i8_regs(const i32x4& x, PairRegsP16& r, unsigned pt_next, float pscale, int nb, float& acc) {
+template <bool FULL, bool LAST, int NOFF = 0>
+__device__ __forceinline__ void p16_group_i8_regs(const i32x4& x, PairRegsP16& r, unsigned pt_blk, float pscale, int nb, float& acc) {
     if constexpr (!LAST) p16_tie4(r.w0);                    // (LAST: the caller has waited for all four before it branched)
     const Quad4 q0 = p16_quad_sums(x.x, r.w0);
-    if constexpr (!LAST) p16_req_pairs(r.w0, pt_next);
+    if constexpr (!LAST) p16_req_pairs<NOFF>(r.w0, pt_blk);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FULL) {                                   // whole group (every real shape): sums of quad k+1 fused with the chain of quad k
         Quad4 q1, q2, q3;
         if constexpr (!LAST) p16_tie4(r.w1);
         p16_sums_chain<0>(r.w1, nib_hi16(x.y), nib_lo16(x.y), q1, q0, pscale, acc);
-        if constexpr (!LAST) p16_req_pairs(r.w1, pt_next + 256u);
+        if constexpr (!LAST) p16_req_pairs<NOFF + 256>(r.w1, pt_blk);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!LAST) p16_tie4(r.w2);
         p16_sums_chain<1>(r.w2, nib_hi16(x.z), nib_lo16(x.z), q2, q1, pscale, acc);
-        if constexpr (!LAST) p16_req_pairs(r.w2, pt_next + 512u);
+        if constexpr (!LAST) p16_req_pairs<NOFF + 512>(r.w2, pt_blk);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!LAST) p16_tie4(r.w3);
         p16_sums_chain<2>(r.w3, nib_hi16(x.w), nib_lo16(x.w), q3, q2, pscale, acc);
-        if constexpr (!LAST) p16_req_pairs(r.w3, pt_next + 768u);
+        if constexpr (!LAST) p16_req_pairs<NOFF + 768>(r.w3, pt_blk);
         __builtin_amdgcn_sched_barrier(0);
         p16_chain_last(q3, pscale, acc);
         return;
     }
     if constexpr (!LAST) p16_tie4(r.w1);
     const Quad4 q1 = p16_quad_sums(x.y, r.w1);
-    if constexpr (!LAST) p16_req_pairs(r.w1, pt_next + 256u);
+    if constexpr (!LAST) p16_req_pairs<NOFF + 256>(r.w1, pt_blk);
     p16_quad_chain<0, FULL>(q0, pscale, nb, acc);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!LAST) p16_tie4(r.w2);
     const Quad4 q2 = p16_quad_sums(x.z, r.w2);
-    if constexpr (!LAST) p16_req_pairs(r.w2, pt_next + 512u);
+    if constexpr (!LAST) p16_req_pairs<NOFF + 512>(r.w2, pt_blk);
     p16_quad_chain<1, FULL>(q1, pscale, nb, acc);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!LAST) p16_tie4(r.w3);
     const Quad4 q3 = p16_quad_sums(x.w, r.w3);
-    if constexpr (!LAST) p16_req_pairs(r.w3, pt_next + 768u);
+    if constexpr (!LAST) p16_req_pairs<NOFF + 768>(r.w3, pt_blk);
     p16_quad_chain<2, FULL>(q2, pscale, nb, acc);
     __builtin_amdgcn_sched_barrier(0);
     p16_quad_chain<3, FULL>(q3, pscale, nb, acc);
@@ -406,20 +417,28 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
     i32x4 wq[D];
     float sq[D];
     int lq = q0, lpass = 0, lg = 0;                         // load cursor (wave-uniform)
-    const uint8_t* wrow;                                    // this lane's weight / scale row of the pass being requested
-    const float* srow;
+    // The weight / scale stream is addressed as  table base + group distance (lg * 1024 / lg * 64: scalar)  +  this lane's row offset
+    // (ONE 32-bit VGPR per table, set per row): global_load ... saddr, two scalar 64-bit adds and two loads per group where per-lane
+    // 64-bit addressing took 11 instructions (two v_lshl_or, two sign extensions, two 64-bit adds, a clamp ...).  No clamp: the
+    // surplus lanes of a short last group read the next row's first scales (unused), behind the last row the 64 bytes of padding
+    // every scale allocation carries (jh_model_set_weight).  Round 6 same-box A/B (Llama-3-8B, K = 256): 655 -> 664 tok/s; the
+    // buffer-descriptor form of the same idea (4 instructions per group) cost the o-projection 0.2 us of latency: 661.
+    int wv, sv;                                             // this lane's byte offsets into the weight / scale table of the row being requested
     auto set_row = [&]() __attribute__((always_inline)) {
         int row = 4 * lq + r;
         row = row < p.nrows ? row : p.nrows - 1;
-        wrow = p16t_row_ptr((NP == 2 && lpass) ? p.w2 : p.w, row, p.ldb);
-        srow = ((NP == 2 && lpass) ? p.ws2 : p.ws) + (size_t)row * p.ldbf;
+        wv = (row >> 2) * (p.ldb * 4) + (row & 3) * 256 + t * 16;   // P16T: quad, row in quad, chunk t (p16t_row_ptr)
+        sv = (row * p.ldbf + t) * 4;
     };
     set_row();
+    auto load_group = [&](i32x4& w, float& s) __attribute__((always_inline)) {
+        const char* bw = (const char*)((NP == 2 && lpass) ? p.w2 : p.w) + ((size_t)lg << 10);
+        const char* bs = (const char*)((NP == 2 && lpass) ? p.ws2 : p.ws) + ((size_t)lg << 6);
+        w = __builtin_nontemporal_load((const i32x4*)(bw + (unsigned)wv));   // chunk t of group lg = byte t of its 16 blocks (rows padded to whole groups)
+        s = __builtin_nontemporal_load((const float*)(bs + (unsigned)sv));
+    };
     auto issue = [&](i32x4& w, float& s) __attribute__((always_inline)) {
-        int b = 16 * lg + t;
-        w = __builtin_nontemporal_load((const i32x4*)wrow + (64 * lg + t));   // P16T: chunk t of group lg = byte t of its 16 blocks (rows padded to whole groups)
-        b = b < nblk ? b : nblk - 1;                        // short last group: the surplus lanes reload its last scale (unused)
-        s = __builtin_nontemporal_load(srow + b);
+        load_group(w, s);
         if (++lg == G) {
             lg = 0;
             if (++lpass == NP) { lpass = 0; ++lq; }
@@ -430,10 +449,7 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
     // D | G that is the row's last group only for d == D - 1.  Slots 0 .. D-2 therefore stay free of branches (see the note on
     // pending LDS writes below).
     auto issue_in_row = [&](i32x4& w, float& s) __attribute__((always_inline)) {
-        int b = 16 * lg + t;
-        w = __builtin_nontemporal_load((const i32x4*)wrow + (64 * lg + t));
-        b = b < nblk ? b : nblk - 1;
-        s = __builtin_nontemporal_load(srow + b);
+        load_group(w, s);
         ++lg;
     };
     // Results are parked: the 16 lanes of a row all hold a finished row sum, lane t keeps the one of the wave's task n == t, and the
@@ -474,36 +490,54 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
     // one group in two halves with the slot's refill between them: prep() takes the scale product out of the loaded registers
     // activation operands of the group being consumed (registers), requested one group ahead: see p16_group_i8_regs
     PairRegsP16 pr;
-    const unsigned pt_base = lds_addr(a.pt) + (unsigned)t * 16u, d_base = lds_addr(a.d16);
-    auto d_addr = [&](int g) __attribute__((always_inline)) {
-        int bd = 16 * g + t;
-        bd = bd < nblk ? bd : nblk - 1;
-        return d_base + (unsigned)bd * 4u;
-    };
+    const unsigned pt_base = lds_addr(a.pt) + (unsigned)t * 16u, d_base = lds_addr(a.d16) + (unsigned)t * 4u;
+    // LDS addresses of this lane's pair words / block scale of the ring block's FIRST group (cg); the other groups of the block sit
+    // d * 1024 / d * 64 bytes further = the offset field of the request.  (A short last group reads up to 15 floats past the scale
+    // table: inside the reduction scratch behind it, never used -- the chain's guarded links stop at nb.)
+    unsigned blk_pt = pt_base, blk_d = d_base;
     // A register with a pending LDS write must not cross a basic-block boundary: hipcc does not know about the write, and at a
     // control-flow merge it is free to COPY the register (it did: `v_mov_b64 v[38:39], v[54:55]` in front of the wait, i.e. a copy of
     // words that need not have landed -- correct only by timing).  So the pipeline lives inside ONE straight-line region, a ring block
     // of D groups: the block's first group is requested at its top, slots 0 .. D-2 request the next group, the last slot requests
     // nothing and waits for everything before its first use; `issue`'s row switch, a short last group, pass_end() and the loop's
     // back-edge all sit behind that slot.  tools/isa_pending_lds.py checks the compiled ISA for exactly this (tests/test_tools.py).
-    auto request_first = [&](int g) __attribute__((always_inline)) {
-        const unsigned a0 = pt_base + (unsigned)g * 1024u;
-        p16_req_d(pr.d, d_addr(g));
-        p16_req_pairs(pr.w0, a0); p16_req_pairs(pr.w1, a0 + 256u); p16_req_pairs(pr.w2, a0 + 512u); p16_req_pairs(pr.w3, a0 + 768u);
+    auto request_first = [&]() __attribute__((always_inline)) {
+        p16_req_d<0>(pr.d, blk_d);
+        p16_req_pairs<0>(pr.w0, blk_pt); p16_req_pairs<256>(pr.w1, blk_pt); p16_req_pairs<512>(pr.w2, blk_pt); p16_req_pairs<768>(pr.w3, blk_pt);
     };
-    auto prep = [&](i32x4& x, float s, int g, auto last) __attribute__((always_inline)) {
+    // slot d < D-1 of a ring block: scale product out of the loaded registers, the group's chains with the NEXT group's operands
+    // requested as its registers free up; REFILL: the slot's registers ask for the group D ahead (main loop) or for nothing (last block)
+    auto slot = [&](auto dc, auto refill) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
         p16_tie4(pr.d);
-        const float ps = p16_scale_product(pr.d, s);        // lane t carries the scale product of block 16*g + t
-        if constexpr (!decltype(last)::value) p16_req_d(pr.d, d_addr(g + 1));
-        return ps;
+        const float ps = p16_scale_product(pr.d, sq[d]);    // lane t carries the scale product of block 16 * (cg + d) + t
+        p16_req_d<(d + 1) * 64>(pr.d, blk_d);
+        __builtin_amdgcn_sched_barrier(0);                  // keep the slots in program order (hipcc otherwise hoists all D unpacks
+        p16_group_i8_regs<true, false, (d + 1) * 1024>(wq[d], pr, blk_pt, ps, 16, acc);   // to the top of the block, which then waits for every load in flight)
+        __builtin_amdgcn_sched_barrier(0);
+        // The slot is refilled AFTER its group is consumed, into the same registers.  Requested before the compute (round 4), the
+        // new words needed fresh registers, and hipcc closed the loop with a copy of the whole ring behind s_waitcnt vmcnt(13..1):
+        // every block of D groups ended by waiting for the load requested one group earlier -- a full memory round trip per block
+        // (tools/gemv_timeline.py: the main loop of the down-projection was 6.8 of its 11.8 us, and ring depth made no difference).
+        if constexpr (decltype(refill)::value) {
+            issue_in_row(wq[d], sq[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
-    auto compute = [&](const i32x4& x, float pscale, int g, bool can_be_short, auto last) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(last)::value;
-        const unsigned pt_next = pt_base + (unsigned)(g + 1) * 1024u;   // (used by the slots that are not a block's last: g + 1 < G)
-        const int nb = nblk - 16 * g;
-        if constexpr (LAST) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr.w0), "+v"(pr.w1), "+v"(pr.w2), "+v"(pr.w3)::"memory");   // before the branch below
-        if (can_be_short && nb < 16) p16_group_i8_regs<false, LAST>(x, pr, pt_next, pscale, nb, acc);
-        else p16_group_i8_regs<true, LAST>(x, pr, pt_next, pscale, 16, acc);
+    // the block's last slot: nothing left to request from LDS; a short last group (K / 32 not a multiple of 16) takes the guarded chain
+    auto last_slot = [&](auto refill) __attribute__((always_inline)) {
+        p16_tie4(pr.d);
+        const float ps = p16_scale_product(pr.d, sq[D - 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nb = nblk - 16 * (cg + D - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr.w0), "+v"(pr.w1), "+v"(pr.w2), "+v"(pr.w3)::"memory");   // before the branch below
+        if (nb < 16) p16_group_i8_regs<false, true>(wq[D - 1], pr, blk_pt, ps, nb, acc);
+        else p16_group_i8_regs<true, true>(wq[D - 1], pr, blk_pt, ps, 16, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(refill)::value) {
+            issue(wq[D - 1], sq[D - 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     auto pass_end = [&]() __attribute__((always_inline)) {
         const float res = row16_tree_sum(acc);
@@ -530,44 +564,16 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
         ++cq;
     };
     for (int it = 0; it + D < items; it += D) {
-        request_first(cg);
-#pragma unroll
-        for (int d = 0; d < D - 1; d++) {
-            // The slot is refilled AFTER its group is consumed, into the same registers.  Requested before the compute (round 4), the
-            // new words needed fresh registers, and hipcc closed the loop with a copy of the whole ring behind s_waitcnt vmcnt(13..1):
-            // every block of D groups ended by waiting for the load requested one group earlier -- a full memory round trip per block
-            // (tools/gemv_timeline.py: the main loop of the down-projection was 6.8 of its 11.8 us, and ring depth made no difference).
-            const float pscale = prep(wq[d], sq[d], cg + d, std::false_type{});
-            __builtin_amdgcn_sched_barrier(0);              // keep the slots in program order (hipcc otherwise hoists all D transposes
-            compute(wq[d], pscale, cg + d, false, std::false_type{});   // to the top of the block, which then waits for every load in flight)
-            __builtin_amdgcn_sched_barrier(0);
-            issue_in_row(wq[d], sq[d]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        {
-            const float pscale = prep(wq[D - 1], sq[D - 1], cg + D - 1, std::true_type{});
-            __builtin_amdgcn_sched_barrier(0);
-            compute(wq[D - 1], pscale, cg + D - 1, true, std::true_type{});
-            __builtin_amdgcn_sched_barrier(0);
-            issue(wq[D - 1], sq[D - 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cg += D;
-        if (cg == G) { cg = 0; pass_end(); }
+        request_first();
+        p16_static_for<D - 1>([&](auto dc) __attribute__((always_inline)) { slot(dc, std::true_type{}); });
+        last_slot(std::true_type{});
+        cg += D; blk_pt += (unsigned)D * 1024u; blk_d += (unsigned)D * 64u;
+        if (cg == G) { cg = 0; blk_pt = pt_base; blk_d = d_base; pass_end(); }
     }
     JH_GSTAMP(3);                                           // every group but the last ring block consumed
-    request_first(cg);
-#pragma unroll
-    for (int d = 0; d < D - 1; d++) {                       // last block: nothing left to request
-        const float pscale = prep(wq[d], sq[d], cg + d, std::false_type{});
-        compute(wq[d], pscale, cg + d, false, std::false_type{});
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-        const float pscale = prep(wq[D - 1], sq[D - 1], cg + D - 1, std::true_type{});
-        compute(wq[D - 1], pscale, cg + D - 1, true, std::true_type{});
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    request_first();
+    p16_static_for<D - 1>([&](auto dc) __attribute__((always_inline)) { slot(dc, std::false_type{}); });   // last block: nothing left to request
+    last_slot(std::false_type{});
     JH_GSTAMP(4);
     pass_end();
     JH_GSTAMP(5);                                           // row sums stored

@@ -26,6 +26,10 @@ struct EngParams {
     unsigned long long* gran;       // [n1] {float bits, epoch}
     float* y2;                      // [n2]
     int K, epoch, slots, depth, mode;   // mode 1: no hand-off (phase 2 reuses the phase-1 activation) = the pure streaming time
+    // round 6 knobs (MI355X_MICROARCH.md price list): `thin` -- gather-pass: 0 the loader refills as slots free up (its burst queues in
+    // front of the gather's loads on this CU's memory path), 1 at most ONE fill outstanding while the workgroup gathers, 2 no new fill
+    // at all while it gathers; `one_gatherer` -- the sweep by ONE consumer wave (the others wait) instead of a chunk per consumer
+    int thin, one_gatherer;
     int* fail;                      // set when a bounded spin gave up
     long long* dbg;                 // optional [grid][8] wall-clock stamps (100 MHz)
 };
@@ -69,6 +73,7 @@ __global__ __launch_bounds__((NCONS + 1) * 64) void engine2_kernel(EngParams p) 
     volatile int* ready = (volatile int*)(smem + (size_t)p.slots * SLOT);
     volatile int* freed = ready + 16;
     volatile int* act2_ready = freed + 16;
+    volatile int* gathering = act2_ready + 1;               // 1 while this workgroup's consumers sweep the granules
     char* act1m = (char*)(act2_ready + 16);                 // ActI8 of the phase-1 input
     char* act2m = act1m + ACT_BYTES;               // ActI8 of the phase-2 input (= quantized phase-1 output)
     float* y1 = (float*)(act2m + ACT_BYTES);       // [4096] gathered phase-1 outputs
@@ -85,12 +90,22 @@ __global__ __launch_bounds__((NCONS + 1) * 64) void engine2_kernel(EngParams p) 
     __syncthreads();
     if (wave == 0) {
         // ---------------- loader: W1 slots then W2 slots, `depth` in flight, never stops at the phase boundary
+        int published = 0;
         for (int s = 0; s < nslots + p.depth; s++) {
             if (s < nslots) {
                 const int slot = s % p.slots;
                 if (s >= p.slots) {
                     int spin = 0;
                     while (flag_read(&freed[slot]) != s - p.slots + 1) { __builtin_amdgcn_s_sleep(1); if (++spin > SPIN_MAX) { *p.fail = 1; break; } }
+                }
+                if (p.thin && s >= S1) {                        // gather-pass knob: stay out of the gather's way
+                    int spin = 0;
+                    if (p.thin == 2 && flag_read(gathering) == 1) {
+                        wait_vm<0>();                           // everything issued so far has landed: publish it before going quiet
+                        for (; published < s; published++) if (lane == 0) flag_write(&ready[published % p.slots], published + 1);
+                        while (flag_read(gathering) == 1) { __builtin_amdgcn_s_sleep(2); if (++spin > SPIN_MAX) { *p.fail = 5; break; } }
+                    }
+                    else if (flag_read(gathering) == 1) wait_vm<0>();   // one outstanding fill: the previous one has landed before the next is issued
                 }
                 char* dst = ring + (size_t)slot * SLOT;
                 const bool ph1 = s < S1;
@@ -104,7 +119,8 @@ __global__ __launch_bounds__((NCONS + 1) * 64) void engine2_kernel(EngParams p) 
                 if (p.dbg && lane == 0 && (s == S1 - 1 || s == nslots - 1)) p.dbg[blockIdx.x * 8 + (s == S1 - 1 ? 6 : 7)] = wall_clock64();
             }
             const int done = s - p.depth;
-            if (done >= 0 && done < nslots) {
+            if (done >= published && done < nslots) {
+                published = done + 1;
                 const int newer = (s < nslots ? s : nslots - 1) - done;
                 wait_vm_rt(newer * LOADS);
                 if (lane == 0) flag_write(&ready[done % p.slots], done + 1);
@@ -134,7 +150,9 @@ __global__ __launch_bounds__((NCONS + 1) * 64) void engine2_kernel(EngParams p) 
                 //      trip when everything has landed), chunk j by consumer j % NCONS, each quantizing the units it gathered.
                 if (stamp) dbg[1] = wall_clock64();
                 if (p.mode == 0) {
-                    for (int j = c; j < p.n1 / 1024; j += NCONS) {
+                    if (lane == 0) flag_write(gathering, 1);
+                    const int jstep = p.one_gatherer ? 1 : NCONS;
+                    for (int j = p.one_gatherer ? (c == 0 ? 0 : p.n1 / 1024) : c; j < p.n1 / 1024; j += jstep) {
                         const u32x4* gp = (const u32x4*)(p.gran + j * 1024) + lane;
                         u32x4 g[8];
                         int spin = 0;
@@ -167,6 +185,7 @@ __global__ __launch_bounds__((NCONS + 1) * 64) void engine2_kernel(EngParams p) 
                     }
                     int spin = 0;
                     while (flag_read(act2_ready) != p.n1 / 1024) { __builtin_amdgcn_s_sleep(1); if (++spin > SPIN_MAX) { *p.fail = 3; break; } }
+                    if (lane == 0) flag_write(gathering, 2);
                 }
                 if (stamp) { dbg[3] = wall_clock64(); dbg[5] = polls; }
                 load_act(p.mode == 0 ? a2 : a1);
@@ -256,9 +275,13 @@ int main() {
     for (int mode : {0, 1})
     for (int ncons : {3, 7})
         for (int slots : {6})
-            for (int depth : {1, 2}) {
+            for (int depth : {1})
+            for (int thin : {0, 1, 2})
+            for (int oneg : {0, 1}) {
+                if (mode == 1 && (thin || oneg)) continue;
                 EngParams e; memset(&e, 0, sizeof(e));
                 e.n1 = N1; e.n2 = N2; e.x = dx; e.gran = gran; e.y2 = y2b; e.K = K; e.slots = slots; e.depth = depth; e.fail = fail; e.mode = mode;
+                e.thin = thin; e.one_gatherer = oneg;
                 const size_t lds = (size_t)slots * 20 * 1024 + 48 * 4 + 2 * lds_bytes_i8(K) + (size_t)N1 * 4;
                 auto launch = [&](int c) {
                     e.w1 = dw1 + c * w1s; e.ws1 = (const float*)((const char*)ds1 + c * s1s); e.w2 = dw2 + c * w2s; e.ws2 = (const float*)((const char*)ds2 + c * s2s);
@@ -269,6 +292,7 @@ int main() {
                 CK(hipFuncSetAttribute((const void*)engine2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 CK(hipFuncSetAttribute((const void*)engine2_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 CK(hipMemset(y2b, 0xff, N2 * 4));
+                CK(hipMemset(fail, 0, 4));
                 launch(0);
                 CK(hipStreamSynchronize(st)); CK(hipGetLastError());
                 CK(hipMemcpy(rb.data(), y2b, N2 * 4, hipMemcpyDeviceToHost));
@@ -281,15 +305,17 @@ int main() {
                 }
                 CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
                 float msB; CK(hipEventElapsedTime(&msB, e0, e1));
-                printf("(B) one persistent launch%s, %d consumers, ring %d slots, depth %d: %.2f us per pair  mismatches=%d fail=%d  (x%.2f of A)\n", mode ? " WITHOUT the hand-off (streaming floor; results differ by design)" : "", ncons, slots, depth,
+                printf("(B) one persistent launch%s, %d consumers, ring %d slots, depth %d, loader %s, %s: %.2f us per pair  mismatches=%d fail=%d  (x%.2f of A)\n", mode ? " WITHOUT the hand-off (streaming floor; results differ by design)" : "", ncons, slots, depth,
+                       thin == 0 ? "unthrottled" : thin == 1 ? "one fill outstanding during the gather" : "paused during the gather", oneg ? "ONE gatherer wave" : "a chunk per consumer",
                        msB * 1e3 / (4 * COPIES), bad, hf, msB / msA);
             }
     // ---------------- where the time goes: wall-clock stamps of consumer 0 / the loader of every workgroup, one launch each
     long long* dbg;
     CK(hipMalloc(&dbg, 256 * 8 * 8));
-    for (int mode : {0, 1}) {
+    for (int mode : {0, 2, 1}) {
         EngParams e; memset(&e, 0, sizeof(e));
-        e.n1 = N1; e.n2 = N2; e.x = dx; e.gran = gran; e.y2 = y2b; e.K = K; e.slots = 6; e.depth = 1; e.fail = fail; e.mode = mode; e.dbg = dbg;
+        e.n1 = N1; e.n2 = N2; e.x = dx; e.gran = gran; e.y2 = y2b; e.K = K; e.slots = 6; e.depth = 1; e.fail = fail; e.mode = mode == 1; e.dbg = dbg;
+        if (mode == 2) { e.thin = 2; e.one_gatherer = 1; printf("  (next three: loader paused during the gather, one gatherer wave)\n"); }
         const size_t lds = (size_t)6 * 20 * 1024 + 48 * 4 + 2 * lds_bytes_i8(K) + (size_t)N1 * 4;
         for (int rep = 0; rep < 3; rep++) {
             const int c = 3 + rep;
@@ -308,15 +334,15 @@ int main() {
                 printf("    %-44s min %6.2f  mean %6.2f  max %6.2f us\n", name, mn, sum / 256, mx);
             };
             double pl = 0; for (int b = 0; b < 256; b++) pl += h[b * 8 + 5];
-            printf("  mode %d launch %d (7 consumers, ring 6, depth 1), time since the first workgroup's start:\n", mode, rep);
+            printf("  mode %d launch %d (7 consumers, ring 6, depth 1), time since the first workgroup's start:\n", mode == 1, rep);
             stat(0, "consumers start (after the Q8 prologue)");
             stat(6, "loader issued the last W1 slot");
             stat(1, "consumer 0 reaches the hand-off");
-            if (mode == 0) stat(2, "first gather poll returned");
+            if (mode != 1) stat(2, "first gather poll returned");
             stat(3, "phase-2 activation ready");
             stat(7, "loader issued the last W2 slot");
             stat(4, "consumer 0 done");
-            if (mode == 0) printf("    mean polls of chunk(s) by consumer 0: %.2f\n", pl / 256);
+            if (mode != 1) printf("    mean polls of chunk(s) by consumer 0: %.2f\n", pl / 256);
         }
     }
     return 0;
