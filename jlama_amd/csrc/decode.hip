@@ -223,22 +223,34 @@ int build_graph(jh_session* s, int v, float temperature) {
     HIPCHK(hipGraphGetNodes(g, nullptr, &n_nodes));
     s->kernels_per_token = (int)n_nodes;
     // the same token tokens_per_graph times in ONE graph (greedy loop only)
+    // The multi-token graph is an optimisation on top of a working single-token graph: if its capture or instantiation fails the
+    // session keeps decoding one token per launch (tokens_per_graph = 1) instead of failing decode_n.
     if (has_out && s->tokens_per_graph > 1 && !s->exec_m[v]) {
+        struct TapGuard { jh_session* s; int v; ~TapGuard() { s->tap_layer = v; } } restore{s, saved_tap};   // every exit path
         s->tap_layer = -1;
-        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        rc = JH_OK;
-        for (int t = 0; t < s->tokens_per_graph && rc == JH_OK; t++) {
-            rc = layers_launch(s, st, 0);
-            if (rc == JH_OK) rc = lmhead_launch(s, st);
-            if (rc == JH_OK) rc = finish_launch(s, st, 1, 0.0f);
-        }
         hipGraph_t gm = nullptr;
-        e = hipStreamEndCapture(st, &gm);
-        s->tap_layer = saved_tap;
-        if (rc != JH_OK) { if (gm) hipGraphDestroy(gm); return rc; }
-        if (e != hipSuccess) return set_err(JH_ERR_HIP, std::string("hipStreamEndCapture (multi-token graph): ") + hipGetErrorString(e));
-        s->graph_m[v] = gm;
-        HIPCHK(hipGraphInstantiate(&s->exec_m[v], gm, nullptr, nullptr, 0));
+        hipGraphExec_t xm = nullptr;
+        bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            rc = JH_OK;
+            for (int t = 0; t < s->tokens_per_graph && rc == JH_OK; t++) {
+                rc = layers_launch(s, st, 0);
+                if (rc == JH_OK) rc = lmhead_launch(s, st);
+                if (rc == JH_OK) rc = finish_launch(s, st, 1, 0.0f);
+            }
+            ok = hipStreamEndCapture(st, &gm) == hipSuccess && rc == JH_OK && gm != nullptr;
+            if (ok) ok = hipGraphInstantiate(&xm, gm, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (ok) {
+            s->graph_m[v] = gm;
+            s->exec_m[v] = xm;
+        } else {
+            if (gm) hipGraphDestroy(gm);
+            (void)hipGetLastError();
+            s->tokens_per_graph = 1;
+            fprintf(stderr, "[jh] the %d-tokens-per-launch graph could not be built (%s): decoding one token per launch\n", s->tokens_per_graph,
+                    rc != JH_OK ? g_err.c_str() : "capture / instantiate failed");
+        }
     }
     return JH_OK;
 }

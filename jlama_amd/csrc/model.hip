@@ -240,6 +240,10 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
         bytes = n * 4;
     }
     const hipMemcpyKind kind = from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    // the operand copies (T16 / P16T / BF16T) this call frees are shared by the model's sessions: replaced under the same lock that
+    // ensure_strict_operands / the pack kernels hold.  Replacing a weight while ANOTHER session is decoding with it stays
+    // the caller's bug, as in the reference (weights are immutable after load).
+    std::lock_guard<std::mutex> op_lock(m->op_mu);
     if (layer >= 0 && (which == JH_W_Q || which == JH_W_K || which == JH_W_V)) {
         // q|k|v live stacked in one [A+2KV, E] allocation (CausalSelfAttention.java:161-171 issues three GEMVs over the
         // same activation; here they become one)

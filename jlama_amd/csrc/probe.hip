@@ -23,11 +23,14 @@ int jh_debug_attn_timeline(jh_session* s, int pos, long long* out, int n) {
     HIPCHK(hipFree(d));
     return JH_OK;
 }
-static long long* g_gemv_dbg = nullptr;   // jh_debug_gemv_timeline: stamp buffer of the LAST launch of the next jh_kernel_bench
+static thread_local long long* g_gemv_dbg = nullptr;   // jh_debug_gemv_timeline: stamp buffer of the LAST launch of THIS thread's next jh_kernel_bench
 // Phase stamps of one reference-order few-row GEMV launch (which: 0 q|k|v, 2 o, 4 down; the last layer's launch of a sweep over
 // all layers, so its weights come from HBM): out[workgroup][wave][8] wall_clock64 ticks (100 MHz), -1 = not written.
 int jh_debug_gemv_timeline(jh_session* s, int which, long long* out, int n) {
-    if (!s || !out || n < 8 || !s->strict) return set_err(JH_ERR_INVALID, "gemv_timeline: a reference-order session and >= 8 slots");
+    if (!s || !out || !s->strict) return set_err(JH_ERR_INVALID, "gemv_timeline: a reference-order session");
+    // the kernels stamp [workgroup][wave][8] without a bound: one 512-thread workgroup per CU at most (p16_plan / launch_gemv_t16)
+    const int need = g_cu_count * (P16_THREADS / 64) * 8;
+    if (n < need) return set_err(JH_ERR_INVALID, "gemv_timeline: needs " + std::to_string(need) + " slots (workgroups x 8 waves x 8 stamps)");
     if (which != 0 && which != 2 && which != 3 && which != 4) return set_err(JH_ERR_INVALID, "gemv_timeline: which = 0 (q|k|v), 2 (o), 3 (gate|up) or 4 (down)");
     HIPCHK(hipSetDevice(s->m->device));
     long long* d = nullptr;

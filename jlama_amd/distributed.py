@@ -530,29 +530,54 @@ def tp_rank_bench(dist, engine, rank, size, prompt, steps, cfg, device, dtype, u
     prefill_ms = (time.perf_counter() - t0) * 1e3
     mode, err, tpr = "all-reduce rows (2 per layer and token)", None, None
     if use_ipc:
-        try:
+        # Every rank walks the SAME collective sequence whatever happens locally (a rank that raised between two all_gathers
+        # left its peers inside one until the watchdog): each non-collective step (constructor, connect, signature) ends in a
+        # MIN-reduced verdict, and the ranks fall back together at the first step any of them failed.
+        def agree(ok_local):
+            flag = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=xdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        def step(fn):
+            nonlocal err
+            try:
+                return fn(), True
+            except Exception as e:   # noqa: BLE001 -- the leg falls back, the line says why
+                err = err or repr(e)[:300]
+                return None, False
+
+        def make():
             from .model import HipTPRank
-            tpr = HipTPRank(engine.s, rank, size)
-            mine = torch.frombuffer(bytearray(tpr.handles()), dtype=torch.uint8).to(xdev)
+            t = HipTPRank(engine.s, rank, size)
+            return t, torch.frombuffer(bytearray(t.handles()), dtype=torch.uint8).to(xdev)
+
+        made, ok = step(make)
+        ok = agree(ok)
+        if ok:
+            tpr, mine = made
             gathered = [torch.empty_like(mine) for _ in range(size)]
             dist.all_gather(gathered, mine)
-            tpr.connect(b"".join(bytes(g.cpu().numpy().tobytes()) for g in gathered))
-            sig = torch.tensor([tpr.signature()], dtype=torch.int64, device=xdev)
+            _, ok = step(lambda: tpr.connect(b"".join(bytes(g.cpu().numpy().tobytes()) for g in gathered)))
+            ok = agree(ok)
+        if ok:
+            sig_v, ok = step(lambda: int(tpr.signature()))
+            ok = agree(ok)
+        if ok:
+            sig = torch.tensor([sig_v], dtype=torch.int64, device=xdev)
             sigs = [torch.empty_like(sig) for _ in range(size)]
             dist.all_gather(sigs, sig)
-            if len({int(x.item()) for x in sigs}) != 1:
-                raise RuntimeError("ranks disagree on the launch plan")
-            ok = 1
-        except Exception as e:   # noqa: BLE001 -- the leg falls back, the line says why
-            err, ok = repr(e)[:300], 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=xdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+            if len({int(x.item()) for x in sigs}) != 1:     # every rank sees the same list: they fall back together
+                err, ok = err or "ranks disagree on the launch plan", False
+        if ok:
             mode = "token graphs on IPC-mapped peer memory (in-kernel meetings over xGMI)"
         else:
-            if tpr is not None and ok:
-                tpr.close()
+            if made is not None:
+                try:
+                    made[0].close()
+                except Exception:   # noqa: BLE001
+                    pass
             tpr = None
+            err = err or "a peer rank could not set up its IPC shard"
 
     def run(n):
         if tpr is not None:
