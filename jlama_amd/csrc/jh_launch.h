@@ -180,6 +180,7 @@ int launch_gemv_i8q4_p16_d(const GemvParams& p, const P16Plan& pl, bool wide, hi
     const size_t lds = lds_bytes_p16(p.K);
     constexpr int UM_LO = (PRO == PRO_RMS_Q8) ? 2 : 4;
     (void)wide;
+    if (p.nrows % 4) return set_err(JH_ERR_UNSUPPORTED, "reference-order GEMV: rows must be whole quads (a multiple of 4)");
     if (p.K <= UM_LO * 4096) {
         JHCHK(allow_lds((gemv_i8q4_p16_kernel<PRO, EPI, D, UM_LO>), lds));
         hipLaunchKernelGGL((gemv_i8q4_p16_kernel<PRO, EPI, D, UM_LO>), dim3(pl.grid), dim3(P16_THREADS), lds, st, p, pl.per, pl.tw);

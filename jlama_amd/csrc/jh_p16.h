@@ -423,27 +423,33 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
     // surplus lanes of a short last group read the next row's first scales (unused), behind the last row the 64 bytes of padding
     // every scale allocation carries (jh_model_set_weight).  Round 6 same-box A/B (Llama-3-8B, K = 256): 655 -> 664 tok/s; the
     // buffer-descriptor form of the same idea (4 instructions per group) cost the o-projection 0.2 us of latency: 661.
-    int wv, sv;                                             // this lane's byte offsets into the weight / scale table of the row being requested
+    // Row switch: a quad's four rows differ by lane-constant offsets (row r of the quad, chunk t), the quad itself by a UNIFORM one,
+    // so wv / sv are written once and the switch is scalar arithmetic.  (New VGPRs behind 2 * D loads in flight are a trap: in one
+    // build of round 6 hipcc gave a next-row offset the register of a pending ring load, the s_waitcnt vmcnt(0) in front of it
+    // drained the ring instead of overlapping it, and the o-projection ran 12 % slower with byte-identical streaming code --
+    // tools/isa_ring_drain.py.)  Whole quads only: the host refuses rows % 4 != 0 (every projection of the path is a multiple of 32).
+    const int wv = r * 256 + t * 16, sv = (r * p.ldbf + t) * 4;   // this lane's byte offsets inside its quad's weight / scale rows
+    size_t qw = 0, qs = 0;                                  // the quad's byte offsets (wave-uniform)
     auto set_row = [&]() __attribute__((always_inline)) {
-        int row = 4 * lq + r;
-        row = row < p.nrows ? row : p.nrows - 1;
-        wv = (row >> 2) * (p.ldb * 4) + (row & 3) * 256 + t * 16;   // P16T: quad, row in quad, chunk t (p16t_row_ptr)
-        sv = (row * p.ldbf + t) * 4;
+        const int lqc = lq < nq ? lq : nq - 1;              // (the cursor runs one quad past the wave's share: stay inside the table)
+        qw = (size_t)lqc * ((size_t)p.ldb * 4);
+        qs = (size_t)lqc * ((size_t)p.ldbf * 16);
     };
     set_row();
     auto load_group = [&](i32x4& w, float& s) __attribute__((always_inline)) {
-        const char* bw = (const char*)((NP == 2 && lpass) ? p.w2 : p.w) + ((size_t)lg << 10);
-        const char* bs = (const char*)((NP == 2 && lpass) ? p.ws2 : p.ws) + ((size_t)lg << 6);
+        const char* bw = (const char*)((NP == 2 && lpass) ? p.w2 : p.w) + qw + ((size_t)lg << 10);
+        const char* bs = (const char*)((NP == 2 && lpass) ? p.ws2 : p.ws) + qs + ((size_t)lg << 6);
         w = __builtin_nontemporal_load((const i32x4*)(bw + (unsigned)wv));   // chunk t of group lg = byte t of its 16 blocks (rows padded to whole groups)
         s = __builtin_nontemporal_load((const float*)(bs + (unsigned)sv));
     };
+    auto next_row = [&]() __attribute__((always_inline)) {
+        lg = 0;
+        if (++lpass == NP) { lpass = 0; ++lq; }
+        set_row();
+    };
     auto issue = [&](i32x4& w, float& s) __attribute__((always_inline)) {
         load_group(w, s);
-        if (++lg == G) {
-            lg = 0;
-            if (++lpass == NP) { lpass = 0; ++lq; }
-            set_row();
-        }
+        if (++lg == G) next_row();
     };
     // The same request where the load cursor cannot leave its row: slot d of a ring block asks for group (cg + d + D) mod G, and with
     // D | G that is the row's last group only for d == D - 1.  Slots 0 .. D-2 therefore stay free of branches (see the note on
@@ -857,46 +863,46 @@ __device__ __forceinline__ float p16_seq_sum_wave(const float* w, int n16, int l
 // around it (every wait is hipcc's own), the column's values one 16-link piece ahead.  Reads past cnt stay inside the tile / the
 // padded weight row and are never used, except by guarded links.
 __device__ __forceinline__ void p16_value_chain_tile(float& acc, const float* vrow, const float* wt, int cnt, int TP) {
-    const int nfull = cnt >> 6, rem = cnt & 63;
-    f32x4 va[4], vb[4];
-    auto ldv = [&](f32x4 (&v)[4], int i0) __attribute__((always_inline)) {
-        const f32x4* q = (const f32x4*)(vrow + i0);
+    // Pieces of 16 links through THREE register sets: piece k+2 is requested while piece k runs.  One piece ahead was not enough:
+    // 16 dependent fmas take ~77 cycles (tools/chain_lab.hip: 4.8 cycles per v_fmac_f32_dpp link for a wave alone on its SIMD), the
+    // four ds_read_b128 behind them ~130 -- the chain waited for LDS at every piece (round 6 timeline: 11 cycles per link).
+    (void)TP;
+    const int npf = cnt >> 4, rem = cnt & 15;               // full pieces, links of the partial one
+    f32x4 b0[4], b1[4], b2[4];
+    float w0, w1, w2;
+    auto ldp = [&](f32x4 (&v)[4], float& w, int piece) __attribute__((always_inline)) {   // (past the tile's used part: inside the padded
+        const f32x4* q = (const f32x4*)(vrow + 16 * piece);                               //  rows / weight row, never used unguarded)
         v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+        w = wt[16 * piece];
     };
-    float w0 = wt[0], w1 = wt[16], w2 = wt[32], w3 = wt[48];
-    ldv(va, 0);
-    for (int c = 0; c < nfull; c++) {
-        const float* wn = wt + (c + 1) * 64;
-        const float y0 = wn[0], y1 = wn[16], y2 = wn[32], y3 = wn[48];
-        const int nx = 64 * (c + 1) < TP ? 64 * (c + 1) : 0;
-        ldv(vb, 64 * c + 16);
+    ldp(b0, w0, 0);
+    ldp(b1, w1, 1);
+    int pc = 0;
+    for (; pc + 3 <= npf; pc += 3) {
+        ldp(b2, w2, pc + 2);
         __builtin_amdgcn_sched_barrier(0);
-        fma16_bcast(acc, w0, va);
+        fma16_bcast(acc, w0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        ldv(va, 64 * c + 32);
+        ldp(b0, w0, pc + 3);
         __builtin_amdgcn_sched_barrier(0);
-        fma16_bcast(acc, w1, vb);
+        fma16_bcast(acc, w1, b1);
         __builtin_amdgcn_sched_barrier(0);
-        ldv(vb, 64 * c + 48);
+        ldp(b1, w1, pc + 4);
         __builtin_amdgcn_sched_barrier(0);
-        fma16_bcast(acc, w2, va);
+        fma16_bcast(acc, w2, b2);
         __builtin_amdgcn_sched_barrier(0);
-        ldv(va, nx);
-        __builtin_amdgcn_sched_barrier(0);
-        fma16_bcast(acc, w3, vb);
-        __builtin_amdgcn_sched_barrier(0);
-        w0 = y0; w1 = y1; w2 = y2; w3 = y3;
     }
-    if (rem) {                                              // the tile's last cnt % 64 positions, 16 at a time (va holds the first 16)
-        const int b0 = 64 * nfull;
-        auto tail16 = [&](const f32x4 (&v)[4], float wr, int l0) __attribute__((always_inline)) {
-            if (l0 + 16 <= rem) fma16_bcast(acc, wr, v);
-            else fma16_bcast_tail(acc, wr, v, rem - l0);    // the values past n in the tile may be anything (0 * NaN): guarded links
-        };
-        tail16(va, w0, 0);
-        if (rem > 16) { ldv(vb, b0 + 16); tail16(vb, w1, 16); }
-        if (rem > 32) { ldv(va, b0 + 32); tail16(va, w2, 32); }
-        if (rem > 48) { ldv(vb, b0 + 48); tail16(vb, w3, 48); }
+    const int left = npf - pc;                              // 0, 1 or 2 full pieces, then the partial one (the values past n in the tile
+    if (left == 0) {                                        // may be anything, 0 * NaN: guarded links)
+        if (rem) fma16_bcast_tail(acc, w0, b0, rem);
+    } else if (left == 1) {
+        fma16_bcast(acc, w0, b0);
+        if (rem) fma16_bcast_tail(acc, w1, b1, rem);
+    } else {
+        ldp(b2, w2, pc + 2);
+        fma16_bcast(acc, w0, b0);
+        fma16_bcast(acc, w1, b1);
+        if (rem) fma16_bcast_tail(acc, w2, b2, rem);
     }
 }
 

@@ -63,6 +63,32 @@ def test_reference_order_streaming_loops_do_not_copy_their_prefetch_ring():
     r = subprocess.run([sys.executable, pend, "--file", "/tmp/_isa_gemv_ref.s"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "no register touched while its LDS write is pending" in r.stdout, r.stdout[-3000:]
     assert " 0 asm LDS reads" not in r.stdout, "the checker found no hand-pipelined read at all: " + r.stdout
+    # and no streaming kernel drains its prefetch ring in front of the prologue barrier (tools/isa_ring_drain.py: a wait for fewer
+    # loads than the ring holds between the fill and the barrier -- round 6: one register collision cost the o-projection 12 %)
+    drain = os.path.join(root, "tools", "isa_ring_drain.py")
+    for unit in ("gemv_ref", "gemv_bf16"):
+        r = subprocess.run([sys.executable, drain, "--file", f"/tmp/_isa_{unit}.s"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and ", 0 drain their ring" in r.stdout, r.stdout[-3000:]
+        assert " 0 streaming kernels checked" not in r.stdout
+
+
+def test_ring_drain_checker_on_hand_made_isa(tmp_path):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "isa_ring_drain.py")
+    ring = "\tglobal_load_dwordx4 v[4:7], v1, s[0:1] nt\n\tglobal_load_dword v8, v2, s[2:3] nt\n"
+
+    def run(wait):
+        f = tmp_path / "k.s"
+        f.write_text("_ZN2jh20gemv_i8q4_p16_kernelILi2ELi1ELi8ELi4ELi512EEEvNS_10GemvParamsEii:\n\tglobal_load_dwordx4 v[20:23], v[10:11], off\n" + ring +
+                     f"\ts_waitcnt vmcnt({wait})\n\tv_add_f32_e32 v3, v20, v3\n\ts_barrier\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n")
+        return subprocess.run([sys.executable, tool, "--file", str(f)], capture_output=True, text=True)
+
+    ok = run(2)            # waits for the activation load only: the two ring loads stay in flight
+    assert ok.returncode == 0 and "1 streaming kernels checked, 0 drain" in ok.stdout, ok.stdout
+    bad = run(0)
+    assert bad.returncode == 1 and "vmcnt(0)" in bad.stdout, bad.stdout
 
 
 def test_pending_lds_checker_flags_a_copy_in_front_of_the_wait(tmp_path):
