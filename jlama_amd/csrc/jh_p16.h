@@ -1232,20 +1232,26 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
     m = redf[0];
     for (int i = 1; i < NT / 64; i++) m = fmaxf(m, redf[i]);
     const int n16 = (n + 15) & ~15;                         // the row is zero-padded to a whole group of 16: fl(s + 0) = s for the sum chain
-    for (int tt = tid; tt < n16; tt += NT) w[tt] = tt < n ? (float)exp((double)(w[tt] - m)) : 0.0f;
+    // Wave 0 owns the two sequential chains, so everything else is kept off it: it files ITS share of V tile 0 while waves 1..3 take
+    // the exponentials (double exp: ~0.3 us per round), and they file theirs while it sums.  (Round 6 stamps: filed behind the sum,
+    // wave 0's 64 ds_write_b32 per lane sat on the critical path for 0.56 us.)
+    if (wave == 0) file_v(vreg, 0);
+    else for (int tt = tid - 64; tt < n16; tt += NT - 64) w[tt] = tt < n ? (float)exp((double)(w[tt] - m)) : 0.0f;
     JH_FSTAMP(4);
     __syncthreads();                                        // exponentials visible
     JH_FSTAMP(5);
-    if (wave != 0) file_v(vreg, 0);                         // waves 1..3 file tile 0 (wave 0's share follows its sum) WHILE wave 0 sums
+    if (wave != 0) file_v(vreg, 0);                         // waves 1..3 file their share of tile 0 WHILE wave 0 sums
     if (wave == 0) {
         const float sum = p16_seq_sum_wave(w, n16, lane);   // one float accumulator in index order (VectorMath.java:80-85)
         if (lane == 0) redf[8] = sum;
         JH_FSTAMP(6);
     }
-    if (wave == 0) file_v(vreg, 0);
+    JH_FSTAMP(8);
     __syncthreads();
+    JH_FSTAMP(9);
     const float sum = redf[8];
     for (int tt = tid; tt < n; tt += NT) w[tt] = w[tt] / sum;
+    JH_FSTAMP(10);
     // ---- value[d] = fma chain over positions (saxpy per position, PTO:2648-2698): lanes 0..31 of wave 0 own one column each
     float acc = 0.0f;
     const int ntiles = (n + TP - 1) / TP;
@@ -1257,11 +1263,13 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
             file_v(vnext, tile);
         }
         __syncthreads();
+        if (tile == 0) JH_FSTAMP(11);
         if (wave == 0) {
             const int tbase = tile * TP, cnt = n - tbase < TP ? n - tbase : TP;
             p16_value_chain_tile(acc, vt + (size_t)(lane & (DW - 1)) * TPP, w + tbase + (lane & 15), cnt, TP);
         }
     }
+    JH_FSTAMP(12);
     if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
     JH_FSTAMP(7);
 #undef JH_FSTAMP

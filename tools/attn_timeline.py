@@ -9,7 +9,7 @@ m = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
 names = ["entry", "loads issued", "rope done", "scores", "softmax", "PV", "reduced", "published", "ticket", "combined"]
 strict = os.environ.get("ATT_STRICT")            # reference order: the one-launch kernel (attn_p16_fused_kernel) stamps its own phases
 if strict:
-    names = ["entry", "loads issued", "rope barrier", "scores", "max+exp", "tile filed", "sum", "values stored", "-", "-"]
+    names = ["entry", "loads issued", "rope barrier", "scores", "max+exp", "tile filed", "sum", "values stored", "w0 filed", "sum barrier", "divided", "chain start", "chain done", "-", "-", "-"]
 for env in ({},):
     os.environ.update(env)
     s = m.session(int(os.environ.get("ATT_CTX", "1024")))
@@ -23,7 +23,7 @@ for env in ({},):
         print(env, "pos", pos)
         for sp in range(16):
             if t[sp, 0] <= 0: continue
-            row = [(names[k], round((t[sp, k] - base) / 100.0, 2)) for k in range(10) if t[sp, k] > 0]
+            row = [(names[k], round((t[sp, k] - base) / 100.0, 2)) for k in range(len(names)) if t[sp, k] > 0]
             print("  split", sp, " ".join(f"{n}={v}" for n, v in row))
     s.close()
     for k in env: del os.environ[k]

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#include "../jlama_amd/csrc/jh_p16.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 constexpr int LINKS = 4096;
@@ -57,6 +58,42 @@ __global__ __launch_bounds__(256) void chain_kernel(const float* in, float* out,
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// the attention kernel's own value chain (jh_p16.h: p16_value_chain_tile) on a synthetic transposed tile in LDS: what a link costs WITH its
+// operand traffic (4 ds_read_b128 + 1 ds_read_b32 per 16 links, three register sets), wave 0 of a 256-thread workgroup, the others idle
+template <int ACTIVE>
+__global__ __launch_bounds__(256) void tile_chain_kernel(const float* in, float* out, long long* cycles, int cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = 512, TPP = TP + 4, DW = 32;
+    float* vt = (float*)smem;
+    float* w = vt + DW * TPP;
+    for (int i = threadIdx.x; i < DW * TPP; i += 256) vt[i] = in[i & 255] * 1e-3f;
+    for (int i = threadIdx.x; i < TP + 128; i += 256) w[i] = in[(i * 7) & 255] * 1e-3f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    float acc = 0.0f;
+    long long t0 = 0, t1 = 0;
+    if (threadIdx.x < ACTIVE) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        jh::p16_value_chain_tile(acc, vt + (size_t)(lane & (DW - 1)) * TPP, w + (lane & 15), cnt, TP);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(acc) : "memory");
+        out[blockIdx.x * 64 + lane] = acc;
+        if (lane == 0) cycles[blockIdx.x] = t1 - t0;
+    }
+}
+__global__ __launch_bounds__(256) void sum_chain_kernel(const float* in, float* out, long long* cycles, int n16) {
+    __shared__ float w[1024 + 128];
+    for (int i = threadIdx.x; i < 1024 + 128; i += 256) w[i] = in[i & 255] * 1e-3f;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        long long t0, t1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        const float s = jh::p16_seq_sum_wave(w, n16, threadIdx.x);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(s) : "memory");
+        out[blockIdx.x * 64 + threadIdx.x] = s;
+        if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+    }
+}
+
 // every workgroup (one per CU) streams the SAME `bytes` buffer `reps` times with 16-byte loads, `waves` waves: L2-resident after the first pass
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512) void fill_kernel(const f32x4* buf, int n16, int reps, float* out) {
@@ -90,12 +127,34 @@ int main() {
         std::vector<long long> c(64);
         CK(hipMemcpy(c.data(), cyc, 64 * 8, hipMemcpyDeviceToHost));
         std::sort(c.begin(), c.end());
-        // s_memtime counts at 100 MHz on this part (wall clock): report ns per link and cycles at 2.4 GHz
-        printf("  %-34s %7.2f ns per link (median of 64 workgroups) = %5.1f cycles at 2.4 GHz\n", names[form], c[32] * 10.0 / LINKS, c[32] * 10.0 / LINKS * 2.4);
+        printf("  %-34s %6.2f cycles per link (s_memtime ticks = shader cycles; median of 64 workgroups)\n", names[form], (double)c[32] / LINKS);
     };
     printf("dependent float chain, %d links, one wave per SIMD (4 waves per workgroup, 64 workgroups):\n", LINKS);
     for (int f = 0; f < F_COUNT; f++) run(f);
 
+    {
+        const size_t lds = (size_t)(32 * 516 + 512 + 128) * 4;
+        CK(hipFuncSetAttribute((const void*)tile_chain_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute((const void*)tile_chain_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int cnt : {256, 384, 512}) {
+            std::vector<long long> c(64);
+            for (int act : {64, 32}) {
+                for (int it = 0; it < 3; it++) {
+                    if (act == 64) hipLaunchKernelGGL(tile_chain_kernel<64>, dim3(64), dim3(256), lds, 0, in, out, cyc, cnt);
+                    else hipLaunchKernelGGL(tile_chain_kernel<32>, dim3(64), dim3(256), lds, 0, in, out, cyc, cnt);
+                }
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(c.data(), cyc, 64 * 8, hipMemcpyDeviceToHost));
+                std::sort(c.begin(), c.end());
+                printf("  p16_value_chain_tile, %d links from an LDS tile, %d lanes active: %lld cycles = %.2f per link\n", cnt, act, c[32], (double)c[32] / cnt);
+            }
+            for (int it = 0; it < 3; it++) hipLaunchKernelGGL(sum_chain_kernel, dim3(64), dim3(256), 0, 0, in, out, cyc, cnt);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(c.data(), cyc, 64 * 8, hipMemcpyDeviceToHost));
+            std::sort(c.begin(), c.end());
+            printf("  p16_seq_sum_wave,     %d links from LDS:         %lld cycles = %.2f per link\n", cnt, c[32], (double)c[32] / cnt);
+        }
+    }
     const size_t bytes = 1331200;   // 129 rows x 4096 columns x 2.5 B ~ the activation image of a prompt chunk (BF16 selectors)
     f32x4* buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 1, bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
