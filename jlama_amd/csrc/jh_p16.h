@@ -1028,28 +1028,56 @@ __device__ __forceinline__ void p16_av_store_tile(float* vt, const f32x4 (&vreg)
             dst[0] = vreg[u].x; dst[TPP] = vreg[u].y; dst[2 * TPP] = vreg[u].z; dst[3 * TPP] = vreg[u].w;
         }
 }
-// RU = V rows per thread and tile, i.e. TP = 32 * RU positions per V tile in LDS (host: 2, 4, 8 or 16 -- the smallest that holds
-// the session's max_ctx, at most 512 positions): a context of up to TP positions is ONE tile, requested at kernel start and
-// landing while the softmax runs.
-constexpr int P16_AV_TPMAX = 512;
+// Second launch of the two-launch form (contexts beyond what one workgroup ingests: JH_P16_ATT_FUSED, 1 k positions): softMax of one
+// head's score row, then the value chains of 32 columns.  Two sequential chains of n links each bound it (tools/chain_lab.hip: 6.4 /
+// 9.3 cycles per link with their LDS operand traffic), so everything else is taken off wave 0 and, at length, off the sum itself:
+//   * the running sum of n >= 6144 exponentials is evaluated EXACTLY by all 256 threads (jh_seqsum.h / seq_pass: inside a binade
+//     fl(s + x) depends on s only through the parity of its significand; maps compose; one scan per binade crossing) instead of n
+//     dependent adds -- the sampler's method, bit-identical to the index-order loop by construction (tests/test_seqsum.py);
+//   * V tiles of TP = 32 * RU <= 256 positions are double-buffered: waves 1..3 request and file tile k+1 while wave 0 runs the
+//     chains of tile k (round 5: one tile buffer, every tile's memory round trip in front of its chain).
+constexpr int P16_AV_SEQ_MIN = 6144;     // positions from which the parallel exact sum beats the chain (round 6, 8B: 1 k 456 vs 518 tok/s, 2 k 383 vs 415,
+                                         // 4 k 301 vs 309, 8.1 k 212 vs 203: a scan + two barriers per binade crossing against 6.4 cycles per link)
+constexpr int P16_AV_SEQ_E = 16;         // values per thread and window of seq_pass<256, 16>
 template <int HS, int RU>
-__global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams p, const float* scores, int sc_stride) {
+__global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams p, const float* scores, int sc_stride, int w_cap, int seq_min) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 32 * RU;   // columns per workgroup, positions per tile
+    __shared__ SeqShared sh;
+    constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 32 * RU, TPP = TP + 4;   // columns per workgroup, positions per tile
+    constexpr int LT = NT - 64, RUV = (TP * 8 + LT - 1) / LT;                   // loader threads (waves 1..3), 16-byte pieces per loader thread and tile
     const int h = blockIdx.y, group = p.n_heads / p.n_kv_heads, kvh = h / group, d0 = blockIdx.x * DW;
     const int pos = p.st->pos, n = pos + 1;
     const int KV = p.n_kv_heads * HS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int TPP = TP + 4;
-    float* vt = (float*)smem;              // [DW][TPP] V tile, transposed
-    float* redf = vt + (size_t)DW * TPP;   // [16]
-    float* w = redf + 16;                  // [n, padded to 64 (+ 64 readable)] scores -> softmax weights
-    // V tile loads: thread (row = tid / 8, c4 = tid % 8) covers rows vr, vr + 32, ...
-    const int vr = tid >> 3, vc = tid & 7;
-    f32x4 vreg[RU];
+    float* vt0 = (float*)smem;                 // [2][DW][TPP] V tiles, transposed (a column's positions contiguous: one ds_read_b128 = 4 links)
+    float* redf = vt0 + (size_t)2 * DW * TPP;  // [16]
+    float* w = redf + 16;                      // [w_cap] scores -> exponentials -> softmax weights (zero-padded to a group of 16, readable 64 further)
+    float* xt = w + w_cap;                     // [256 * 16] seq_pass's window
+    const int lt = tid - 64, lvr = lt >> 3, lvc = lt & 7;   // loader thread: rows lvr, lvr + 24, ... of a tile, 16-byte piece lvc of the 32 columns
+    auto load_tile = [&](f32x4 (&v)[RUV], int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < RUV; u++) {
+            const int row = lvr + (LT / 8) * u;
+            if (row >= TP || tile * TP + (row & ~31) >= n) continue;   // 32-row groups wholly behind the context are neither requested nor filed
+            int tt = tile * TP + row;
+            tt = tt < n ? tt : n - 1;                                   // inside the last group rows past n are clamped copies
+            v[u] = ((const f32x4*)(kv_row(p, 1, tt, KV) + (size_t)kvh * HS + d0))[lvc];
+        }
+    };
+    auto file_tile = [&](const f32x4 (&v)[RUV], int tile) __attribute__((always_inline)) {
+        float* vt = vt0 + (size_t)(tile & 1) * DW * TPP;
+#pragma unroll
+        for (int u = 0; u < RUV; u++) {
+            const int row = lvr + (LT / 8) * u;
+            if (row >= TP || tile * TP + (row & ~31) >= n) continue;
+            float* dst = vt + (size_t)(4 * lvc) * TPP + row;
+            dst[0] = v[u].x; dst[TPP] = v[u].y; dst[2 * TPP] = v[u].z; dst[3 * TPP] = v[u].w;
+        }
+    };
+    f32x4 vreg[RUV];
+    if (wave != 0) load_tile(vreg, 0);         // in flight across the softmax
     float m = -INFINITY;
     {
-        p16_av_load_tile<HS, RU>(p, vreg, 0, n, KV, kvh, d0, vr, vc);   // in flight across the softmax
         const float* srow = scores + (size_t)h * sc_stride;
         for (int tt = tid; tt < n; tt += NT) {
             const float s = srow[tt];
@@ -1062,32 +1090,35 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
     __syncthreads();
     m = redf[0];
     for (int i = 1; i < NT / 64; i++) m = fmaxf(m, redf[i]);
-    const int n16 = (n + 15) & ~15;        // zero-padded to a whole group of 16: fl(s + 0) = s
+    const int n16 = (n + 15) & ~15;            // zero-padded to a whole group of 16: fl(s + 0) = s
     for (int tt = tid; tt < n16; tt += NT) w[tt] = tt < n ? (float)exp((double)(w[tt] - m)) : 0.0f;   // (float)FastMath.exp(x - max)
+    if (wave != 0) file_tile(vreg, 0);
     __syncthreads();
-    if (wave != 0) p16_av_store_tile<RU>(vt, vreg, vr, vc, 0, n);   // tile 0 lands in LDS while wave 0 sums
-    if (wave == 0) {
-        const float sum0 = p16_seq_sum_wave(w, n16, lane);          // VectorMath.java:80-85: one float accumulator, index order
-        if (lane == 0) redf[8] = sum0;
-        p16_av_store_tile<RU>(vt, vreg, vr, vc, 0, n);
+    float sum;
+    if (n16 >= seq_min) {                      // VectorMath.java:80-85, one float accumulator in index order -- evaluated exactly by every thread
+        int pick;
+        seq_pass<NT, P16_AV_SEQ_E>(w, n16, INFINITY, sh, xt, sum, pick);
+    } else {
+        if (wave == 0) {
+            const float s0 = p16_seq_sum_wave(w, n16, lane);
+            if (lane == 0) redf[8] = s0;
+        }
+        __syncthreads();
+        sum = redf[8];
     }
-    __syncthreads();
-    const float sum = redf[8];
     for (int tt = tid; tt < n; tt += NT) w[tt] = w[tt] / sum;
-    // ---- value[d] = fma chain over positions: lanes 0..31 of wave 0 own one column each, the V tiles stream through LDS
+    // ---- value[d] = fma chain over positions: lanes 0..31 of wave 0 own one column each; waves 1..3 stream the next tile meanwhile
     float acc = 0.0f;
     const int ntiles = (n + TP - 1) / TP;
     for (int tile = 0; tile < ntiles; tile++) {
-        if (tile > 0) {                     // contexts beyond one tile: plain copy per tile (the register array must not be
-            __syncthreads();                // loop-carried: hipcc then keeps it in scratch); the previous tile has been consumed
-            f32x4 vnext[RU];
-            p16_av_load_tile<HS, RU>(p, vnext, tile, n, KV, kvh, d0, vr, vc);
-            p16_av_store_tile<RU>(vt, vnext, vr, vc, tile, n);
-        }
-        __syncthreads();                    // tile (and, first time round, the normalised weights) visible
+        __syncthreads();                       // tile `tile` filed (and, first time round, the normalised weights visible); the other buffer is free
         if (wave == 0) {
             const int tbase = tile * TP, cnt = n - tbase < TP ? n - tbase : TP;
-            p16_value_chain_tile(acc, vt + (size_t)(lane & (DW - 1)) * TPP, w + tbase + (lane & 15), cnt, TP);
+            p16_value_chain_tile(acc, vt0 + (size_t)(tile & 1) * DW * TPP + (size_t)(lane & (DW - 1)) * TPP, w + tbase + (lane & 15), cnt, TP);
+        } else if (tile + 1 < ntiles) {
+            f32x4 vnext[RUV];
+            load_tile(vnext, tile + 1);
+            file_tile(vnext, tile + 1);
         }
     }
     if (tid < DW) p.outf[(size_t)h * HS + d0 + tid] = acc;
@@ -1283,7 +1314,15 @@ static inline int p16_av_rows(int max_ctx) {   // RU: the whole context in one t
     const int want = ((max_ctx + 63) & ~63) / 32;
     return want <= 2 ? 2 : want <= 4 ? 4 : want <= 8 ? 8 : 16;
 }
-static inline size_t lds_bytes_attn_p16(int max_ctx) { return ((size_t)32 * (p16_av_rows(max_ctx) * 32 + 4) + 16 + (size_t)((max_ctx + 63) & ~63) + 2 * 128) * 4; }
+// the two-launch form's second kernel: tiles of at most 256 positions, two of them; weight row + 256 readable floats; seq_pass's window
+static inline int p16_av2_rows(int max_ctx) {
+    const int want = ((max_ctx + 63) & ~63) / 32;
+    return want <= 2 ? 2 : want <= 4 ? 4 : 8;
+}
+static inline int p16_av2_wcap(int max_ctx) { return ((max_ctx + 63) & ~63) + 256; }
+static inline size_t lds_bytes_attn_p16(int max_ctx) {
+    return ((size_t)2 * 32 * (p16_av2_rows(max_ctx) * 32 + 4) + 16 + (size_t)p16_av2_wcap(max_ctx) + (size_t)P16_ATT_THREADS * P16_AV_SEQ_E) * 4;
+}
 
 // ------------------------------------------------------------------------------------------------ prompt rows in reference order
 // AbstractModel.batchForward (AbstractModel.java:295-312): the projections of a prompt chunk run on the F16 MFMA (jh_t16.h:

@@ -42,7 +42,7 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
         const size_t lds_av = lds_bytes_attn_p16(s->max_ctx);
         if (lds_av > 158 * 1024) return set_err(JH_ERR_UNSUPPORTED, "reference-order attention: the score row of max_ctx positions must fit in LDS");
         const dim3 grid_s(s->p16_att_splits, c.n_kv_heads), grid_v(hs / 32, c.n_heads);
-        const int ru = p16_av_rows(s->max_ctx);
+        const int ru = p16_av_rows(s->max_ctx), ru2 = p16_av2_rows(s->max_ctx);
         // contexts of up to ~1 k positions: scores, softmax and value chains in ONE launch (attn_p16_fused_kernel); beyond that the K
         // rows of a head are too many for one workgroup to ingest and the scores stay spread over the chip (two launches)
         const int fused_max = opt_int("JH_P16_ATT_FUSED", 1024);
@@ -61,15 +61,16 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
 #undef JH_P16_FUSED
         }
 #define JH_P16_AV(HSV, RV)                                                                                                      \
-    if (hs == HSV && ru == RV) {                                                                                               \
+    if (hs == HSV && ru2 == RV) {                                                                                               \
         JHCHK(allow_lds((attn_p16_av_kernel<HSV, RV>), lds_av));                                                               \
-        hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride); \
+        hipLaunchKernelGGL((attn_p16_av_kernel<HSV, RV>), grid_v, dim3(P16_ATT_THREADS), lds_av, st, p, (const float*)s->p16_scores, s->p16_sc_stride, \
+                           p16_av2_wcap(s->max_ctx), opt_int("JH_P16_AV_SEQ_MIN", P16_AV_SEQ_MIN));                            \
     }
 #define JH_P16_ATTN(HSV, GV)                                                                                                   \
     if (hs == HSV && group == GV) {                                                                                            \
         hipLaunchKernelGGL((attn_p16_scores_kernel<HSV, GV>), grid_s, dim3(P16_ATT_THREADS), 0, st, p, s->p16_scores, s->p16_sc_stride); \
         HIPCHK(hipGetLastError());                                                                                             \
-        JH_P16_AV(HSV, 2) JH_P16_AV(HSV, 4) JH_P16_AV(HSV, 8) JH_P16_AV(HSV, 16)                                                \
+        JH_P16_AV(HSV, 2) JH_P16_AV(HSV, 4) JH_P16_AV(HSV, 8)                                                                   \
         HIPCHK(hipGetLastError());                                                                                             \
         return JH_OK;                                                                                                          \
     }

@@ -383,8 +383,10 @@ def test_one_launch_reference_order_attention_equals_the_two_launch_form_past_on
     hm, om, w = _pair(cfg, 5, oracle)
     prompt = S.prompt_tokens(cfg, n=539, seed=23)
     out = []
-    for fused in (1024, 0):
+    for fused, seq_min in ((1024, 0), (0, 0), (0, 512)):      # one launch; two launches with the wave's sum chain; ... with the parallel exact sum
         _N.set_option("JH_P16_ATT_FUSED", str(fused))
+        if seq_min:
+            _N.set_option("JH_P16_AV_SEQ_MIN", str(seq_min))
         s = hm.session(1024)
         s.set_strict(True)
         s.forward(prompt, 0)
@@ -393,7 +395,8 @@ def test_one_launch_reference_order_attention_equals_the_two_launch_form_past_on
         out.append((t, l0.copy(), ids, s.logits().copy()))
         s.close()
         _N.clear_options()
-    assert out[0][0] == out[1][0]
-    np.testing.assert_array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
-    assert out[0][2] == out[1][2]
-    np.testing.assert_array_equal(out[0][3].view(np.uint32), out[1][3].view(np.uint32))
+    for other in out[1:]:
+        assert out[0][0] == other[0]
+        np.testing.assert_array_equal(out[0][1].view(np.uint32), other[1].view(np.uint32))
+        assert out[0][2] == other[2]
+        np.testing.assert_array_equal(out[0][3].view(np.uint32), other[3].view(np.uint32))

@@ -26,7 +26,7 @@ def main():
     N.options_from_env()   # tools only: JH_* environment variables become explicit library options
     w = ST.make_weights(cfg, seed=0, device="cuda")
     model = HipLlamaModel(cfg, w)
-    prompt = S.prompt_tokens(cfg, n=128, seed=1234)
+    prompt = S.prompt_tokens(cfg, n=int(os.environ.get("PROMPT", "128")), seed=1234)   # PROMPT=2048 / 8100: long-context decode
     out = {"config": config, "steps": steps}
     names = ["qkv", "attention", "o_proj", "gate_up", "down"]
     modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ("fast", "strict")
