@@ -71,7 +71,7 @@ int opt_int(const char* name, int dflt) {
 // misspelt option is an error, not a silent no-op
 const char* const JH_KNOWN_OPTIONS[] = {
     "JH_ATTN_LONG_MIN", "JH_ATTN_LONG_SPLITS", "JH_ATTN_MID_MAX", "JH_ATTN_MID_SPLITS", "JH_ATTN_SPLITS", "JH_BF16_CW2", "JH_BF16_CWB",
-    "JH_BF16_LDS", "JH_BF16R_DEEP", "JH_BF16R_PREFILL", "JH_BF16_S", "JH_DOWN_GRIDX", "JH_DOWN_PIPE", "JH_DOWN_R", "JH_DOWN_WAVES", "JH_FAST_GATEUP_T16",
+    "JH_BF16_LDS", "JH_BF16R_DEEP", "JH_BF16R_PREFILL", "JH_BF16_S", "JH_BF16_W8", "JH_DOWN_GRIDX", "JH_DOWN_PIPE", "JH_DOWN_R", "JH_DOWN_WAVES", "JH_FAST_GATEUP_T16",
     "JH_GATEUP_GRIDX", "JH_GATEUP_PIPE", "JH_GATEUP_R", "JH_GATEUP_WAVES", "JH_GEMM_CW", "JH_GEMM_LDS", "JH_GEMM_LDS_CT",
     "JH_GEMM_LDS_CW", "JH_GEMM_LDS_PK", "JH_GEMM_LDS_S", "JH_GEMM_S", "JH_GEMM_Z", "JH_GEMV_PIPE", "JH_GEMV_R", "JH_GEMV_WAVES",
     "JH_LM_GRIDX", "JH_LM_R", "JH_LM_WAVES", "JH_NO_GRAPH", "JH_O_GRIDX", "JH_O_PIPE", "JH_O_R", "JH_O_WAVES",

@@ -196,9 +196,39 @@ int launch_gemm_bf16_cw2(MfmaBf16TileParams g, int S, hipStream_t st) {
     if (S > 1) JHCHK(launch_splitk_reduce((const float*)g.ws, S, g.m, g.n, 0, g.c, g.ldc, 0, g.resid, st));
     return JH_OK;
 }
+// gemm_bf16_w8_kernel: 8 MFMA waves (4 column tiles x 2 K halves) + an LDS-DMA loader wave per workgroup; K additionally split over
+// grid.y (partials + reduce pass) until the launch covers the chip
+template <int MT>
+int launch_gemm_bf16_w8(MfmaBf16TileParams g, int S, hipStream_t st) {
+    g.nsplit = S;
+    const size_t lds = (size_t)BF16_W8_NBUF * MT * 8 * 1024;   // NBUF buffers x 2 halves x MT x 4 slices x 1 KiB (the reduce area reuses MT x 16 KiB of it)
+    JHCHK(allow_lds((gemm_bf16_w8_kernel<MT>), lds));
+    hipLaunchKernelGGL((gemm_bf16_w8_kernel<MT>), dim3(g.n / 128, S), dim3(BF16_W8_WAVES * 64), lds, st, g);
+    HIPCHK(hipGetLastError());
+    if (S > 1) JHCHK(launch_splitk_reduce((const float*)g.ws, S, g.m, g.n, 0, g.c, g.ldc, 0, g.resid, st));
+    return JH_OK;
+}
 // both operands in MFMA order (gemm_bf16_tile_kernel); n % 32 == 0, k % 16 == 0
 int launch_gemm_bf16_tile(const MfmaBf16TileParams& g, hipStream_t st) {
     const int mt = (g.m + 31) / 32, tiles = g.n / 32, nks = g.k / 16;
+    // prompt-sized M (2..6 row tiles) and whole 128-column groups: the 8-MFMA-wave kernel (round 6).  JH_BF16_W8=0 restores the
+    // round-5 dispatch below for comparisons.
+    if (opt_int("JH_BF16_W8", 1) && mt >= 2 && mt <= 6 && g.n % 128 == 0 && nks % 16 == 0) {
+        int S = 1;
+        auto fits = [&](int s2) { return nks % (16 * s2) == 0 && (s2 == 1 || (g.ws && (size_t)s2 * g.n <= (size_t)8 * 16384 && (g.n <= 8192 || s2 * g.m <= 512))); };
+        while (S < 16 && fits(2 * S) && (g.n / 128) * 2 * S <= g_cu_count) S *= 2;   // one 9-wave workgroup per CU
+        const int s_env3 = opt_int("JH_BF16_S", 0);
+        if (s_env3 > 0 && fits(s_env3)) S = s_env3;
+        if (fits(S)) {
+            switch (mt) {
+                case 2: return launch_gemm_bf16_w8<2>(g, S, st);
+                case 3: return launch_gemm_bf16_w8<3>(g, S, st);
+                case 4: return launch_gemm_bf16_w8<4>(g, S, st);
+                case 5: return launch_gemm_bf16_w8<5>(g, S, st);
+                default: return launch_gemm_bf16_w8<6>(g, S, st);
+            }
+        }
+    }
     // prompt-sized M (2..6 row tiles), whole 128-column groups and enough of them to cover the chip WITHOUT splitting K (gate|up of an
     // 8B-class model: 224 groups): the loader-wave kernel, no reduce pass.  Everywhere else it measured equal or slower than the
     // LDS kernel below with its K split (profiles/r05c_*): JH_BF16_CW2=2 forces it (with a K split) for comparisons.

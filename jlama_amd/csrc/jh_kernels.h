@@ -1429,6 +1429,147 @@ __global__ __launch_bounds__(BF16_CW2_WAVES * 64) void gemm_bf16_cw2_kernel(Mfma
             }
     }
 }
+// Round 6: the same GEMM with EIGHT MFMA waves per workgroup.  What bounded gemm_bf16_cw2_kernel at M = 129
+// was not the memory system (tools/chain_lab.hip: a CU fills 85-105 GB/s from an L2-resident buffer with 4-8 waves, not the ~30 GB/s
+// DESIGN assumed for the activation re-reads): its two MFMA waves sat on two of the CU's four SIMDs and issued a 32x32x16 every
+// 56-64 cycles each -- an issue-rate ceiling of ~4 TB/s of weights, reached at half that.  Here
+//   * 8 MFMA waves = 4 column tiles (128 columns) x 2 halves of the workgroup's K range: two waves per SIMD, every matrix pipe
+//     busy, 8 x PW x 4 KiB of weights in flight per CU; each wave keeps MT accumulator tiles (all prompt rows) of ITS half;
+//   * a ninth wave stages the A chunks of BOTH halves with LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write; 1 KiB per
+//     instruction straight into the double-buffered ring), one barrier per chunk -- the MFMA waves request weights only;
+//   * the halves meet in LDS at the end (the ring's space: 16 KiB per row tile), half 0 + half 1 in that order, then the store
+//     (or the split-K partial when the grid also splits K: few-column GEMMs need it to cover the chip).
+constexpr int BF16_W8_WAVES = 10;                            // 8 MFMA waves + one LDS-DMA loader per K half
+constexpr int BF16_W8_NBUF = 3;                              // A ring: chunk c is multiplied while c+1 has landed and c+2 is in flight
+template <int MT>
+__global__ __launch_bounds__(BF16_W8_WAVES * 64) void gemm_bf16_w8_kernel(MfmaBf16TileParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int SLC = 4, PIECES = MT * SLC, NC = 4, PW = 2, NBUF = BF16_W8_NBUF;
+    i32x4* ring = (i32x4*)smem;                              // [NBUF][2 halves][MT][SLC][64] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nks = p.k / 16, nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    const int per = nks / nsplit, s0 = blockIdx.y * per, half = per / 2;   // host: half % (SLC * PW) == 0
+    const int nchunks = half / SLC;
+    if (wv >= 2 * NC) {
+        // ---- loader of K half lh: a lone wave is latency-bound (~25 GB/s from L2 with one fill outstanding, tools/chain_lab.hip), so it
+        // keeps TWO fills in flight -- chunk c+2 is requested while chunk c+1 lands and chunk c is multiplied
+        const int lh = wv - 2 * NC;
+        const i32x4* ap = (const i32x4*)p.a + (size_t)(s0 + lh * half) * 64 + lane;
+        const size_t a_rt = (size_t)nks * 64;
+        auto fill = [&](int c) __attribute__((always_inline)) {
+            const int buf = c % NBUF;
+#pragma unroll
+            for (int pc = 0; pc < PIECES; pc++) {
+                const int t = pc / SLC, q = pc - t * SLC;
+                const i32x4* g = ap + (size_t)t * a_rt + (size_t)(c * SLC + q) * 64;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(ring + ((size_t)(buf * 2 + lh) * PIECES + pc) * 64), 16, 0, 0);
+            }
+        };
+        fill(0);
+        if (nchunks > 1) { fill(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // chunk 0 staged
+        for (int c = 0; c < nchunks; c++) {
+            if (c + 2 < nchunks) { fill(c + 2); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory"); }   // chunk c+1 has landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();                        // the halves' meeting
+        return;
+    }
+    const int ct = wv & (NC - 1), kh = wv >> 2;
+    const int nl = lane & 31, h = lane >> 5;
+    const int ctg = blockIdx.x * NC + ct;                    // host: n % 128 == 0
+    const i32x4* wp = (const i32x4*)p.w + ((size_t)ctg * nks + s0 + (size_t)kh * half) * 64 + lane;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    const int last = half - 1;
+    i32x4 wr[PW][SLC];
+    auto load_w = [&](i32x4 (&w)[SLC], int sl0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < SLC; q++) {
+            int sl = sl0 + q;
+            sl = sl < last ? sl : last;                      // (the prefetch past the end reloads the last slice)
+            w[q] = __builtin_nontemporal_load(wp + (size_t)sl * 64);
+        }
+    };
+    auto mma_chunk = [&](int buf, const i32x4 (&w)[SLC]) __attribute__((always_inline)) {
+        const i32x4* base = ring + ((size_t)(buf * 2 + kh) * PIECES) * 64 + lane;
+        i32x4 a0[MT], a1[MT];                                // A fragments are read a slice ahead of their MFMAs
+#pragma unroll
+        for (int t = 0; t < MT; t++) a0[t] = base[(size_t)(t * SLC) * 64];
+#pragma unroll
+        for (int q = 0; q < SLC; q += 2) {
+#pragma unroll
+            for (int t = 0; t < MT; t++) a1[t] = base[(size_t)(t * SLC + q + 1) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, w[q]);
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[t]), b, acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < SLC) {
+#pragma unroll
+                for (int t = 0; t < MT; t++) a0[t] = base[(size_t)(t * SLC + q + 2) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, w[q + 1]);
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1[t]), b, acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PW; i++) load_w(wr[i], i * SLC);
+    lds_barrier();                                           // chunk 0 staged
+    for (int c = 0; c < nchunks; c += PW) {
+#pragma unroll
+        for (int i = 0; i < PW; i++) {
+            mma_chunk((c + i) % NBUF, wr[i]);
+            load_w(wr[i], (c + i + PW) * SLC);
+            lds_barrier();
+        }
+    }
+    // ---- half 1 hands its accumulators to half 0 through LDS (the ring is free: the last barrier closed the last chunk)
+    f32x4* red = (f32x4*)smem;                               // [NC][MT][4][64] x 16 B = MT x 16 KiB
+    if (kh == 1) {
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++)
+                red[((size_t)(ct * MT + t) * 4 + r4) * 64 + lane] = f32x4{acc[t][4 * r4], acc[t][4 * r4 + 1], acc[t][4 * r4 + 2], acc[t][4 * r4 + 3]};
+    }
+    lds_barrier();
+    if (kh == 1) return;
+    const int ncol = ctg * 32 + nl;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const f32x4 o = red[((size_t)(ct * MT + t) * 4 + r4) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = 4 * r4 + i;
+                const int mrow = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = acc[t][r] + o[i];            // half 0 + half 1
+                if (mrow < p.m) {
+                    if (nsplit > 1) {
+                        p.ws[((size_t)blockIdx.y * p.m + mrow) * p.n + ncol] = v;
+                    } else {
+                        const size_t idx = (size_t)p.ldc * mrow + ncol;
+                        p.c[idx] = p.resid ? v + p.resid[idx] : v;
+                    }
+                }
+            }
+        }
+}
 // ------------------------------------------------------------------------------------------------ K2: batched I8 x Q4 GEMM on MFMA
 // batchDotProduct I8 x Q4 -> F32 for M > 1 (prefill of a JQ4 model; GemmerI8Q4_512 2x2 tile PTO:958-1043, C twin
 // nc/simd/vector_simd.c:261-437):  C[i,j] = sum_blk (da[i,blk]*sb[j,blk]) * sum_t a[i,blk,t]*(nib[j,blk,t]-8).
