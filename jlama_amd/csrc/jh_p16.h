@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
 //   score of position tt: GemmerF32's 16 lanes = the 4 lanes of a quad x 4 chains each (lane qd owns chains t = 4 qd + j: elements
 //   16 c + 4 qd + j are ONE 16-byte piece of q and of the K row); the halving tree runs (t, t+8) -> quad_perm xor 2, (t, t+4) ->
 //   quad_perm xor 1, then (0,2)/(1,3) and the last add inside the lane: jo_reduce16's association.
-template <int HS, int RU>
+template <int HS, int RU, bool POW2>   // POW2: ctxPerPage is a power of two (every geometry but the 70B ones): the page split is a shift and a mask, no branch
 __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 32 * RU, TPP = TP + 4, half = HS / 2, NC = HS / 16, PPB = NT / 4;   // PPB positions per pass
@@ -1156,12 +1156,42 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
     JH_FSTAMP(0);
     // ---- K rows of the first two passes: their addresses depend on the position only (one round trip together with q / rope)
     f32x4 ka[NC], kb[NC], kc[NC], kd[NC];
+    // Row addresses.  A thread's K rows (prow + 64 * pass) and V rows (vr + 32 * u) are arithmetic progressions, so the page split
+    // (position / ctxPerPage, position % ctxPerPage) is taken ONCE per progression and stepped -- a shift and a mask per step for
+    // power-of-two pages, a subtract loop otherwise -- and a row's place is a 32-bit BYTE offset behind kv_base (the host launches
+    // this kernel only while a layer page group stays below 4 GiB: contexts of <= ~1k positions are a few hundred MB), i.e. one
+    // scalar base + one VGPR per load.  Round 6: kv_row() per row (a 64-bit multiply-add chain, and the division path's code at
+    // every one of ~50 call sites) was most of the 2.4 us between kernel entry and the last request: ~2100 instructions in front of
+    // the first barrier for a wave that issues one per ~4.5 cycles.
+    const unsigned cpp = (unsigned)p.ctx_per_page, pe4 = (unsigned)p.page_elems * 4u, kvl4 = (unsigned)KV * 4u;
+    const unsigned lrow_k = (unsigned)(p.rel_layer_in_page * 2) * cpp, lrow_v = lrow_k + cpp;
+    struct RowWalk { unsigned cp, rc; };
+    auto walk_at = [&](int tt) __attribute__((always_inline)) {
+        RowWalk q;
+        if constexpr (POW2) { q.cp = (unsigned)tt >> p.cpp_shift; q.rc = (unsigned)tt & (cpp - 1u); }
+        else { q.cp = (unsigned)tt / cpp; q.rc = (unsigned)tt - q.cp * cpp; }
+        return q;
+    };
+    auto walk_step = [&](RowWalk& q, unsigned d) __attribute__((always_inline)) {
+        q.rc += d;
+        if constexpr (POW2) { q.cp += q.rc >> p.cpp_shift; q.rc &= cpp - 1u; }
+        else while (q.rc >= cpp) { q.rc -= cpp; ++q.cp; }
+    };
+    auto walk_off = [&](const RowWalk& q, unsigned lrow) __attribute__((always_inline)) { return q.cp * pe4 + (lrow + q.rc) * kvl4; };
+    const char* kvb = (const char*)p.kv_base;
+    const unsigned off_new_k = walk_off(walk_at(pos), lrow_k);      // the row being filed right now: what rows past n are clamped to
+    RowWalk kw = walk_at(prow);                                  // K row of the next pass to be requested (requests go in pass order)
+    int kw_t = prow;
+    const unsigned k_lane = (unsigned)(kvh * HS + 4 * qd) * 4u;
     auto load_k = [&](f32x4 (&k)[NC], int pass) __attribute__((always_inline)) {
-        int tt = pass * PPB + prow;
-        tt = tt < n ? tt : n - 1;
-        const float* krow = kv_row(p, 0, tt, KV) + (size_t)kvh * HS + 4 * qd;
+        (void)pass;
+        unsigned off = walk_off(kw, lrow_k);
+        off = kw_t < n ? off : off_new_k;
+        const char* krow = kvb + (off + k_lane);
 #pragma unroll
-        for (int c = 0; c < NC; c++) k[c] = *(const f32x4*)(krow + 16 * c);
+        for (int c = 0; c < NC; c++) k[c] = *(const f32x4*)(krow + 64 * c);
+        walk_step(kw, (unsigned)PPB);
+        kw_t += PPB;
     };
     const int npass = (n + PPB - 1) / PPB;
     // the RoPE operands (q / new k of the q|k|v row the previous launch just wrote: L2-warm; the table row) are requested BEFORE the
@@ -1178,19 +1208,23 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
     }
     load_k(ka, 0);
     if (npass > 1) load_k(kb, 1);
-    if (npass > 2) load_k(kc, 2);
-    if (npass > 3) load_k(kd, 3);
+    // (passes 2, 3 and the V tile are requested BEHIND the rotation's barrier: a wave alone on its SIMD issues one instruction per ~4.5
+    // cycles, and their ~400 instructions in front of the barrier delayed the first scores; K pass 0 is in flight either way)
     // ---- V tile 0 of this workgroup's 32 columns (position `pos` is being filed by another workgroup right now: it comes from the
     // q|k|v row instead; rows past n are clamped copies of it)
     const int vr = tid >> 3, vc = tid & 7;
+    const unsigned v_lane = (unsigned)(kvh * HS + d0 + 4 * vc) * 4u;
+    const f32x4* v_new = (const f32x4*)(qkv_row + A + KV + (size_t)kvh * HS + d0) + vc;   // the new row: not in the page yet
     auto load_v = [&](f32x4 (&vreg)[RU], int tile) __attribute__((always_inline)) {
+        RowWalk vw = walk_at(tile * TP + vr);
 #pragma unroll
         for (int u = 0; u < RU; u++) {
-            if (tile * TP + 32 * u >= n) continue;
-            int tt = tile * TP + vr + 32 * u;
-            tt = tt < n ? tt : n - 1;
-            const float* vrow = tt == pos ? qkv_row + A + KV + (size_t)kvh * HS + d0 : kv_row(p, 1, tt, KV) + (size_t)kvh * HS + d0;
-            vreg[u] = ((const f32x4*)vrow)[vc];
+            if (tile * TP + 32 * u < n) {                      // (wave-uniform)
+                const int tt = tile * TP + vr + 32 * u;
+                const f32x4* vrow = tt >= pos ? v_new : (const f32x4*)(kvb + (walk_off(vw, lrow_v) + v_lane));   // rows past n: clamped copies of the new one
+                vreg[u] = *vrow;
+            }
+            walk_step(vw, 32u);
         }
     };
     // ---- RoPE of this head's q and of the new k row (table row pos + 2*kvHead: CausalSelfAttention.java:247-286)
@@ -1204,13 +1238,13 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
         } else {
             knew[d] = r0; knew[d + half] = r1;
             if (owner) {   // K is stored post-RoPE (:273-286 rotates the page row in place)
-                float* kdst = (float*)kv_row(p, 0, pos, KV) + (size_t)kvh * HS;
+                float* kdst = (float*)(kvb + off_new_k) + (size_t)kvh * HS;
                 kdst[d] = r0; kdst[d + half] = r1;
             }
         }
     }
     if (owner)
-        for (int d = tid; d < HS; d += NT) ((float*)kv_row(p, 1, pos, KV) + (size_t)kvh * HS)[d] = qkv_row[A + KV + (size_t)kvh * HS + d];
+        for (int d = tid; d < HS; d += NT) ((float*)(kvb + walk_off(walk_at(pos), lrow_v)) + (size_t)kvh * HS)[d] = qkv_row[A + KV + (size_t)kvh * HS + d];
     auto file_v = [&](const f32x4 (&vreg)[RU], int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < RU; u++)
@@ -1220,13 +1254,15 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
             }
     };
     f32x4 vreg[RU];
-    load_v(vreg, 0);                                        // in flight across the scores and the softmax
     JH_FSTAMP(1);
     __syncthreads();
     JH_FSTAMP(2);
     f32x4 q4[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) q4[c] = *(const f32x4*)(qs + 16 * c + 4 * qd);
+    if (npass > 2) load_k(kc, 2);
+    if (npass > 3) load_k(kd, 3);
+    load_v(vreg, 0);                                        // in flight across the scores and the softmax
     // ---- scores: PPB positions per pass, two passes in flight
     float m = -INFINITY;
     auto score_pass = [&](f32x4 (&k)[NC], int pass) __attribute__((always_inline)) {

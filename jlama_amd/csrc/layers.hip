@@ -47,12 +47,18 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
         // rows of a head are too many for one workgroup to ingest and the scores stay spread over the chip (two launches)
         const int fused_max = opt_int("JH_P16_ATT_FUSED", 1024);
         const size_t lds_f = lds_bytes_attn_p16_fused(s->max_ctx, hs);
-        if (s->max_ctx <= fused_max && lds_f <= 158 * 1024 && (hs == 128 || hs == 64) && c.n_heads % c.n_kv_heads == 0) {
+        const bool kv_small = (size_t)s->n_ctx_alloc * s->page_elems * 4 < ((size_t)4 << 30);   // the one-launch kernel addresses rows with 32-bit byte offsets
+        if (s->max_ctx <= fused_max && lds_f <= 158 * 1024 && (hs == 128 || hs == 64) && c.n_heads % c.n_kv_heads == 0 && kv_small) {
             const dim3 grid_f(c.n_heads * (hs / 32));
 #define JH_P16_FUSED(HSV, RV)                                                                                                   \
     if (hs == HSV && ru == RV) {                                                                                               \
-        JHCHK(allow_lds((attn_p16_fused_kernel<HSV, RV>), lds_f));                                                             \
-        hipLaunchKernelGGL((attn_p16_fused_kernel<HSV, RV>), grid_f, dim3(P16_ATT_THREADS), lds_f, st, p);                     \
+        if (p.cpp_shift >= 0) {                                                                                                \
+            JHCHK(allow_lds((attn_p16_fused_kernel<HSV, RV, true>), lds_f));                                                   \
+            hipLaunchKernelGGL((attn_p16_fused_kernel<HSV, RV, true>), grid_f, dim3(P16_ATT_THREADS), lds_f, st, p);           \
+        } else {                                                                                                               \
+            JHCHK(allow_lds((attn_p16_fused_kernel<HSV, RV, false>), lds_f));                                                  \
+            hipLaunchKernelGGL((attn_p16_fused_kernel<HSV, RV, false>), grid_f, dim3(P16_ATT_THREADS), lds_f, st, p);          \
+        }                                                                                                                      \
         HIPCHK(hipGetLastError());                                                                                             \
         return JH_OK;                                                                                                          \
     }
