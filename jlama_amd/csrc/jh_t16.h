@@ -357,25 +357,39 @@ constexpr int GT16_SKEW = 2;               // the MFMAs run this many prompt row
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 static inline size_t lds_bytes_gemm_t16(int MT) { return (size_t)2 * MT * GT16_KC * GT16_ENTRY + (size_t)2 * MT * GT16_KC * 4; }
 
-// 8 nibbles of one dword -> the MFMA B operand of its lane: halves 0-3 = lo nibbles - 8 (elements 4g..4g+3), 4-7 = hi nibbles - 8
+// 8 nibbles of one dword -> the MFMA B operand of its lane: halves 0-3 = lo nibbles - 8 (elements 4g..4g+3), 4-7 = hi nibbles - 8.
+// 11 VALU per dword: two masks + one shift for the whole dword, then one v_perm per half pair that also drops in the 0x64 exponent
+// bytes (0x6400 | nib = 1024 + nib, ulp 1 there), and the packed f16 add of -1032 (1024 + nib - 1032 = nib - 8, exact).
 __device__ __forceinline__ f16x8 nib8_to_f16(int w) {
-    const unsigned u = (unsigned)w, u4 = u >> 4;
-    const unsigned m = 0x000F000Fu, k = 0x64006400u;           // 0x6400 = 1024.0: |nib has ulp 1 there
-    const unsigned l01 = (__builtin_amdgcn_perm(0u, u, 0x0C010C00u) & m) | k, l23 = (__builtin_amdgcn_perm(0u, u, 0x0C030C02u) & m) | k;
-    const unsigned h01 = (__builtin_amdgcn_perm(0u, u4, 0x0C010C00u) & m) | k, h23 = (__builtin_amdgcn_perm(0u, u4, 0x0C030C02u) & m) | k;
+    const unsigned u = (unsigned)w, lo = u & 0x0F0F0F0Fu, hi = (u >> 4) & 0x0F0F0F0Fu;
+    const unsigned k = 0x64646464u;                            // perm selector bytes 4-7 take from src0 = k
+    const unsigned l01 = __builtin_amdgcn_perm(k, lo, 0x04010400u), l23 = __builtin_amdgcn_perm(k, lo, 0x04030402u);
+    const unsigned h01 = __builtin_amdgcn_perm(k, hi, 0x04010400u), h23 = __builtin_amdgcn_perm(k, hi, 0x04030402u);
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 c = {(_Float16)-1032.0f, (_Float16)-1032.0f};     // 1024 + nib - 1032 = nib - 8, exact
+    const h2 c = {(_Float16)-1032.0f, (_Float16)-1032.0f};
     const h2 a0 = __builtin_bit_cast(h2, l01) + c, a1 = __builtin_bit_cast(h2, l23) + c, a2 = __builtin_bit_cast(h2, h01) + c, a3 = __builtin_bit_cast(h2, h23) + c;
     f16x8 r;
     r[0] = a0[0]; r[1] = a0[1]; r[2] = a1[0]; r[3] = a1[1]; r[4] = a2[0]; r[5] = a2[1]; r[6] = a3[0]; r[7] = a3[1];
     return r;
 }
 // acc = fma(s, d, acc) as a plain C fma (hipcc must see the MFMA -> VALU hazard on d), fenced so that the SLP vectoriser cannot
-// pack neighbouring chains into v_pk_fma_f32 (measured slower here: 577 vs 535 us on the 8B gate|up prompt GEMM)
+// re-pair neighbouring chains behind our back
 __device__ __forceinline__ void fma_c(float& acc, float s, float d) {
     acc = __builtin_fmaf(s, d, acc);
     asm volatile("" : "+v"(acc));
 }
+// two chains per instruction: v_pk_fma_f32 with the scale broadcast by op_sel (hipcc folds the splat), the two D registers and the
+// two accumulators as even-aligned pairs -- each half is the same IEEE fma as v_fmac_f32.  Measured and NOT used (GT16_PK = 0):
+// on this chip v_pk_fma_f32 costs 1.75x a v_fmac_f32 (tools/pkfma_lab.hip: 1.23 vs 1.40 ns per F32 FMA wave-op at 4 waves per SIMD),
+// beside MFMAs it is slower than the scalar pair (hipcc itself un-packs the ones it schedules behind an MFMA), gate|up 550 -> 609 us
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fma_pk(f32x2& acc, f32x2 s, f32x2 d) {
+    acc = __builtin_elementwise_fma(s, d, acc);
+    asm volatile("" : "+v"(acc));
+}
+#ifndef GT16_PK
+#define GT16_PK 0
+#endif
 
 template <int EPI, int MT, int CW>
 __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_t16_kernel(GemmT16Params p) {
@@ -417,13 +431,13 @@ __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const i32x4* wB = p.w + (size_t)tB * nq * 64 + lane;
     const f32x4t* sA = p.ws + (size_t)tA * nq * 16 + j;
     const f32x4t* sB = p.ws + (size_t)tB * nq * 16 + j;
-    float acc[MT][2][4];
+    f32x2 acc[MT][2][2];                                        // chains t = 4g + {0,1} and 4g + {2,3} of (prompt row, tile)
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[m][u][i] = 0.f;
+            for (int i = 0; i < 2; i++) acc[m][u][i] = f32x2{0.f, 0.f};
     stage(0, 0);
     i32x4 wa = wA[0], wb = wB[0];                               // (default cache policy: the sibling row tiles re-read these lines from L2)
     f32x4t sa = sA[0], sb = sB[0];
@@ -471,9 +485,19 @@ __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const int cur = m % (SK + 1);
                     if (m + SK < MT) pair(m + SK, dA[(m + SK) % (SK + 1)], dB[(m + SK) % (SK + 1)]);
                     const float da = dav[cb][m >> 2][m & 3];
-                    const float s0 = mul1(da, sa_c[d]), s1 = mul1(da, sb_c[d]);   // afr[blk] * bfr[blk] (PTO:819): the reference's own product
-                    fma_c(acc[m][0][0], s0, dA[cur][0]); fma_c(acc[m][0][1], s0, dA[cur][1]); fma_c(acc[m][0][2], s0, dA[cur][2]); fma_c(acc[m][0][3], s0, dA[cur][3]);
-                    fma_c(acc[m][1][0], s1, dB[cur][0]); fma_c(acc[m][1][1], s1, dB[cur][1]); fma_c(acc[m][1][2], s1, dB[cur][2]); fma_c(acc[m][1][3], s1, dB[cur][3]);
+                    if constexpr (GT16_PK) {
+                        const f32x2 s = f32x2{da, da} * f32x2{sa_c[d], sb_c[d]};   // afr[blk] * bfr[blk] (PTO:819), both tiles in one v_pk_mul_f32
+                        fma_pk(acc[m][0][0], s.xx, dA[cur].xy); fma_pk(acc[m][0][1], s.xx, dA[cur].zw);
+                        fma_pk(acc[m][1][0], s.yy, dB[cur].xy); fma_pk(acc[m][1][1], s.yy, dB[cur].zw);
+                    } else {
+                        const float s0 = mul1(da, sa_c[d]), s1 = mul1(da, sb_c[d]);
+                        float a;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            a = acc[m][0][i >> 1][i & 1]; fma_c(a, s0, dA[cur][i]); acc[m][0][i >> 1][i & 1] = a;
+                            a = acc[m][1][i >> 1][i & 1]; fma_c(a, s1, dB[cur][i]); acc[m][1][i >> 1][i & 1] = a;
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -489,7 +513,7 @@ __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         float mine0 = 0.f, mine1 = 0.f;
 #pragma unroll
         for (int m = 0; m < MT; m++) {
-            float a0 = acc[m][u][0], a1 = acc[m][u][1], a2 = acc[m][u][2], a3 = acc[m][u][3];
+            float a0 = acc[m][u][0].x, a1 = acc[m][u][0].y, a2 = acc[m][u][1].x, a3 = acc[m][u][1].y;
             a0 = a0 + __shfl_xor(a0, 32); a1 = a1 + __shfl_xor(a1, 32); a2 = a2 + __shfl_xor(a2, 32); a3 = a3 + __shfl_xor(a3, 32);
             a0 = a0 + __shfl_xor(a0, 16); a1 = a1 + __shfl_xor(a1, 16); a2 = a2 + __shfl_xor(a2, 16); a3 = a3 + __shfl_xor(a3, 16);
             const float r = (a0 + a2) + (a1 + a3);
@@ -508,6 +532,150 @@ __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (EPI == EPI_RESID && ok && mrow < p.M) v = v + p.resid[(size_t)mrow * p.ldr + row];   // TransformerBlock.java:185,203
                 if (ok && mrow < p.M) p.out[(size_t)mrow * p.ldc + row] = v;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the same GEMM on v_mfma_f32_32x32x16_f16
+// Why: beside the chains' v_fmac the 16x16x32 MFMA does not hide -- tools/pkfma_lab.hip: one MFMA + 4 v_fmac (one prompt row x one
+// tile x one block) takes 12.9 ns per SIMD at two waves, the sum of its parts (7.0 + 4 x 1.4); one 32x32x16 + 8 v_fmac (TWO such
+// units) takes 19.9.  Same operands in HBM and LDS, other register roles:
+//   A (32 rows x 16 k)  rows 0-15 = the 16 chains t of prompt row m, rows 16-31 = those of row m + 1
+//   B (16 k x 32 cols)  cols 0-15 = weight rows of tile A, 16-31 = tile B
+//   K = 16 holds half a block's 32 elements, so a block takes two MFMAs, the second accumulating onto the first:
+//     MFMA 1: lane group h = lane >> 5 supplies dword h     of the block (elements 4h..4h+3 low nibbles, 16+4h.. high): chains t < 8
+//     MFMA 2: lane group h             supplies dword 2 + h                                                          : chains t >= 8
+//   the selector row of chain t is non-zero in exactly one (MFMA, lane group): lanes read their 16-byte entry for that one and the zero
+//   word for the other.  D register i of lane (col j' = lane & 31, h): prompt row m + (i >> 3), chain t = 8 * ((i >> 2) & 1) + 4h + (i & 3).
+// Per (prompt row, block, tile PAIR): one MFMA issue (was two), ONE scale product (the lane owns one weight row; was two), 8 v_fmac.
+template <int EPI, int MT, int CW>
+__global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_t16x_kernel(GemmT16Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KC = GT16_KC, NT = CW * 64, NP = MT / 2;
+    static_assert(MT == 8, "gemm_t16x_kernel: four row pairs per block (the MFMA / chain schedule below is written out for them)");
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int nblk = p.K / QB, nq = nblk >> 2, nchunks = nblk / KC;   // host: nblk % KC == 0
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int jp = lane & 31, h = lane >> 5, u = jp >> 4, j = jp & 15;
+    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;             // launch order as gemm_t16_kernel: row tiles of a slice are neighbours on one XCD
+    const int rt = kx % p.nrt, slice = (kx / p.nrt) * 8 + xcd;
+    if (slice >= p.nslices) return;
+    const int m0 = rt * MT;
+    int tile = slice * (2 * CW) + 2 * wave + u;                       // the tile of this lane's weight row
+    const bool ok = tile < p.ntiles;
+    tile = ok ? tile : p.ntiles - 1;
+    char* selbuf = smem;                                              // [2][MT][KC][272]
+    float* dabuf = (float*)(smem + (size_t)2 * MT * KC * GT16_ENTRY); // [2][KC][MT]
+    for (int i = threadIdx.x; i < 2 * MT * KC; i += NT) *(i32x4*)(selbuf + (size_t)i * GT16_ENTRY + 256) = i32x4{0, 0, 0, 0};
+    auto stage = [&](int c, int buf) __attribute__((always_inline)) {
+        for (int i = threadIdx.x; i < MT * KC * 16; i += NT) {
+            const int e = i & 15, mb = i >> 4, kb = mb % KC, m = mb / KC;
+            int mm = m0 + m;
+            mm = mm < p.M ? mm : p.M - 1;
+            const i32x4 v = p.asel[((size_t)mm * nblk + (size_t)c * KC + kb) * 16 + e];
+            *(i32x4*)(selbuf + ((size_t)(buf * MT + m) * KC + kb) * GT16_ENTRY + e * 16) = v;
+        }
+        for (int i = threadIdx.x; i < MT * KC; i += NT) {
+            const int m = i % MT, kb = i / MT;
+            int mm = m0 + m;
+            mm = mm < p.M ? mm : p.M - 1;
+            dabuf[(buf * KC + kb) * MT + m] = p.ad[(size_t)(c * KC + kb) * p.ad_stride + mm];
+        }
+    };
+    // as an A supplier the lane is (prompt row m + u, chain t = j, k group h)
+    const int tg = j >> 2;
+    const char* a1_lane = selbuf + (size_t)u * KC * GT16_ENTRY + ((j < 8 && tg == h) ? j * 16 : 256);
+    const char* a2_lane = selbuf + (size_t)u * KC * GT16_ENTRY + ((j >= 8 && (tg & 1) == h) ? j * 16 : 256);
+    const i32x4* w1 = p.w + (size_t)tile * nq * 64 + 16 * h + j;       // dword h of blocks 4q..4q+3 of the lane's weight row
+    const i32x4* w2 = w1 + 32;                                        // dword 2 + h
+    const f32x4t* sw = p.ws + (size_t)tile * nq * 16 + j;
+    float acc[MT][8];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[m][i] = 0.f;
+    stage(0, 0);
+    i32x4 wa = w1[0], wb = w2[0];
+    f32x4t sc = sw[0];
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
+        f16x8 av[2][NP][2];                                           // [set][row pair][MFMA 1 / 2]
+        f32x4t dav[2][MT / 4];
+        auto read_block = [&](int kb, f16x8 (&a)[NP][2], f32x4t (&dv)[MT / 4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pr = 0; pr < NP; pr++) {
+                a[pr][0] = *(const f16x8*)(a1_lane + ((size_t)(buf * MT + 2 * pr) * KC + kb) * GT16_ENTRY);
+                a[pr][1] = *(const f16x8*)(a2_lane + ((size_t)(buf * MT + 2 * pr) * KC + kb) * GT16_ENTRY);
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < MT / 4; q4++) dv[q4] = *(const f32x4t*)(dabuf + (buf * KC + kb) * MT + 4 * q4);
+        };
+        read_block(0, av[0], dav[0]);
+#pragma unroll
+        for (int qq = 0; qq < KC / 4; qq++) {
+            const int q = c * (KC / 4) + qq;
+            const i32x4 wa_c = wa, wb_c = wb;
+            const f32x4t sc_c = sc;
+            const int qn = q + 1 < nq ? q + 1 : q;
+            wa = w1[(size_t)qn * 64]; wb = w2[(size_t)qn * 64];
+            sc = sw[(size_t)qn * 16];
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const int kb = 4 * qq + d, cb = kb & 1;
+                if (kb + 1 < KC) read_block(kb + 1, av[cb ^ 1], dav[cb ^ 1]);
+                const f16x8 b1 = nib8_to_f16(wa_c[d]), b2 = nib8_to_f16(wb_c[d]);
+                const float swd = sc_c[d];
+                f32x16 D[NP];
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                auto mf1 = [&](int pr) __attribute__((always_inline)) { D[pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[cb][pr][0], b1, z, 0, 0, 0); };
+                auto mf2 = [&](int pr) __attribute__((always_inline)) { D[pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[cb][pr][1], b2, D[pr], 0, 0, 0); };
+                auto chains = [&](int pr) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int mm = 0; mm < 2; mm++) {
+                        const int m = 2 * pr + mm;
+                        const float s = dav[cb][m >> 2][m & 3] * swd;          // afr[blk] * bfr[blk] (PTO:819): the reference's own product (-ffp-contract=off)
+#pragma unroll
+                        for (int i = 0; i < 8; i++) fma_c(acc[m][i], s, D[pr][8 * mm + i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // every MFMA 2 waits for its MFMA 1 (the accumulator operand), every chain for its MFMA 2: two other MFMAs in between
+                mf1(0); mf1(1); mf2(0); mf1(2); mf2(1);
+                __builtin_amdgcn_sched_barrier(0);
+                chains(0);
+                mf1(3); mf2(2);
+                __builtin_amdgcn_sched_barrier(0);
+                chains(1);
+                mf2(3);
+                __builtin_amdgcn_sched_barrier(0);
+                chains(2);
+                chains(3);
+            }
+        }
+        __syncthreads();
+    }
+    // halving tree per (prompt row, weight row): (t, t+8) = registers i, i+4; (t, t+4) = lanes l, l^32; registers (i, i+2); (0, 1)
+    float res[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        float a0 = acc[m][0] + acc[m][4], a1 = acc[m][1] + acc[m][5], a2 = acc[m][2] + acc[m][6], a3 = acc[m][3] + acc[m][7];
+        a0 = a0 + __shfl_xor(a0, 32); a1 = a1 + __shfl_xor(a1, 32); a2 = a2 + __shfl_xor(a2, 32); a3 = a3 + __shfl_xor(a3, 32);
+        res[m] = (a0 + a2) + (a1 + a3);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; m++) {                                    // both lane groups hold every sum: group h stores the rows m with m % 2 == h
+        const int mrow = m0 + m;
+        float v = res[m];
+        if (EPI == EPI_SILU_MUL) {
+            const float up = dpp_f<0x128>(v);                         // row_ror:8 (tile = 8 gate + 8 up rows)
+            v = silu_ref(v) * up;                                     // MLPBlock.java:132-142
+            if (ok && mrow < p.M && j < 8 && (m & 1) == h) p.out[(size_t)mrow * p.ldc + (size_t)tile * 8 + j] = v;
+        } else {
+            const int row = tile * 16 + j;
+            if (EPI == EPI_RESID && ok && mrow < p.M && (m & 1) == h) v = v + p.resid[(size_t)mrow * p.ldr + row];   // TransformerBlock.java:185,203
+            if (ok && mrow < p.M && (m & 1) == h) p.out[(size_t)mrow * p.ldc + row] = v;
         }
     }
 }

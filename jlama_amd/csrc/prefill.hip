@@ -379,9 +379,14 @@ int gemm_t16_launch(jh_session* s, const uint8_t* w, const float* ws, int ntiles
     const int nslices = (ntiles + 2 * CW - 1) / (2 * CW), nrt = (rows + MT - 1) / MT;
     GemmT16Params g{(const i32x4*)w, (const f32x4t*)ws, ntiles, K, rows, (const i32x4*)s->pb_sel, s->pb_sad, PB_MAX_ROWS, out, ldc, resid, ldr, nslices, nrt};
     const size_t lds = lds_bytes_gemm_t16(MT);
-    JHCHK(allow_lds((gemm_t16_kernel<EPI, MT, CW>), lds));
     const int grid = ((nslices + 7) / 8) * 8 * nrt;
-    hipLaunchKernelGGL((gemm_t16_kernel<EPI, MT, CW>), dim3(grid), dim3(CW * 64), lds, st, g);
+    if (opt_int("JH_T16_GEMM32", 1)) {                 // the 32x32x16 form (jh_t16.h: one MFMA issue and one scale product per tile pair)
+        JHCHK(allow_lds((gemm_t16x_kernel<EPI, MT, CW>), lds));
+        hipLaunchKernelGGL((gemm_t16x_kernel<EPI, MT, CW>), dim3(grid), dim3(CW * 64), lds, st, g);
+    } else {
+        JHCHK(allow_lds((gemm_t16_kernel<EPI, MT, CW>), lds));
+        hipLaunchKernelGGL((gemm_t16_kernel<EPI, MT, CW>), dim3(grid), dim3(CW * 64), lds, st, g);
+    }
     HIPCHK(hipGetLastError());
     return JH_OK;
 }
@@ -467,19 +472,52 @@ int prefill_p16_operands(jh_session* s) {
     }
     return JH_OK;
 }
+// Rows of a ragged last row tile.  A tile with one valid row costs what a full one costs, and where the full tiles fill the machine
+// exactly (o / down at 128 rows: 32 slices x 16 row tiles = 512 workgroups on 512 slots) it adds a whole second pass: down 279 ->
+// 439 us at 129 rows.  One or two such rows go through the decode GEMVs instead (the same chains, hence the same bits; each does its
+// own prologue from the F32 row): ~35 us per row and layer.  Option JH_T16_TAIL_ROWS (0 = every row through the GEMM).
+static int t16_tail_rows(int rows) {
+    const int r = rows % 8, lim = opt_int("JH_T16_TAIL_ROWS", 2);
+    return (r >= 1 && r <= lim) ? r : 0;
+}
+template <int PRO, int EPI>
+static int tail_gemv_p16(jh_session* s, const JWeight& W, int K, int nrows, const float* x, const float* nw, float eps, float* out, const float* resid,
+                         hipStream_t st) {
+    GemvParams p;
+    memset(&p, 0, sizeof(p));
+    p.w = (const uint8_t*)W.data; p.ws = W.scales; p.nrows = nrows; p.out = out;
+    p.K = K; p.ldb = K / 2; p.ldbf = K / QB;
+    p.x = x; p.nw = nw; p.eps = eps; p.resid = resid;
+    JHCHK(use_p16t(p, W));
+    return launch_gemv_i8q4_p16<PRO, EPI>(p, s->p16_depth, st);
+}
 int prefill_attn_half_p16(jh_session* s, int li, int rows, int start_pos, float* out, const float* resid, hipStream_t st) {
     jh_model* m = s->m;
     const jh_config& c = m->c;
-    const int E = c.embedding_length, hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs;
+    const int E = c.embedding_length, hs = c.head_size, A = c.n_heads * hs, KV = c.n_kv_heads * hs, Q = A + 2 * KV;
     JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     JWeight& F = m->qkv[(size_t)li];
+    const float* n1 = (const float*)W[JH_W_NORM1].data;
+    const int tail = t16_tail_rows(rows), rg = rows - tail;
     JHCHK(prefill_weights_set(s, li));
-    JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, s->pb_x, E, (const float*)W[JH_W_NORM1].data, c.rms_eps, E, rows, st)));
-    JHCHK((gemm_t16_launch<EPI_STORE>(s, F.t16, F.t16_scales, (A + 2 * KV) / 16, E, rows, s->pb_qkv, A + 2 * KV, nullptr, 0, st)));
+    if (rg) {
+        JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, s->pb_x, E, n1, c.rms_eps, E, rg, st)));
+        JHCHK((gemm_t16_launch<EPI_STORE>(s, F.t16, F.t16_scales, Q / 16, E, rg, s->pb_qkv, Q, nullptr, 0, st)));
+    }
+    for (int r = rg; r < rows; r++)
+        JHCHK((tail_gemv_p16<PRO_RMS_Q8, EPI_STORE>(s, F, E, Q, s->pb_x + (size_t)r * E, n1, c.rms_eps, s->pb_qkv + (size_t)r * Q, nullptr, st)));
     JHCHK(prefill_attn_p16_launch(s, li - c.layer_start, rows, start_pos, st));
-    JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_att, A, nullptr, 0.f, A, rows, st)));
-    if (resid) return gemm_t16_launch<EPI_RESID>(s, W[JH_W_O].t16, W[JH_W_O].t16_scales, E / 16, A, rows, out, E, resid, E, st);
-    return gemm_t16_launch<EPI_STORE>(s, W[JH_W_O].t16, W[JH_W_O].t16_scales, E / 16, A, rows, out, E, nullptr, 0, st);
+    if (rg) {
+        JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_att, A, nullptr, 0.f, A, rg, st)));
+        if (resid) JHCHK((gemm_t16_launch<EPI_RESID>(s, W[JH_W_O].t16, W[JH_W_O].t16_scales, E / 16, A, rg, out, E, resid, E, st)));
+        else JHCHK((gemm_t16_launch<EPI_STORE>(s, W[JH_W_O].t16, W[JH_W_O].t16_scales, E / 16, A, rg, out, E, nullptr, 0, st)));
+    }
+    for (int r = rg; r < rows; r++) {
+        const float* xr = s->pb_att + (size_t)r * A;
+        if (resid) JHCHK((tail_gemv_p16<PRO_QUANT_Q8, EPI_RESID>(s, W[JH_W_O], A, E, xr, nullptr, 0.f, out + (size_t)r * E, resid + (size_t)r * E, st)));
+        else JHCHK((tail_gemv_p16<PRO_QUANT_Q8, EPI_STORE>(s, W[JH_W_O], A, E, xr, nullptr, 0.f, out + (size_t)r * E, nullptr, st)));
+    }
+    return JH_OK;
 }
 int prefill_ffn_half_p16(jh_session* s, int li, int rows, const float* x1, float* out, const float* resid, hipStream_t st) {
     jh_model* m = s->m;
@@ -487,11 +525,33 @@ int prefill_ffn_half_p16(jh_session* s, int li, int rows, const float* x1, float
     const int E = c.embedding_length, H = c.hidden_length;
     JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     const JWeight& GU = m->gateup[(size_t)li];
-    JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, x1, E, (const float*)W[JH_W_NORM2].data, c.rms_eps, E, rows, st)));
-    JHCHK((gemm_t16_launch<EPI_SILU_MUL>(s, GU.t16, GU.t16_scales, H / 8, E, rows, s->pb_g, H, nullptr, 0, st)));
-    JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_g, H, nullptr, 0.f, H, rows, st)));
-    if (resid) return gemm_t16_launch<EPI_RESID>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rows, out, E, resid, E, st);
-    return gemm_t16_launch<EPI_STORE>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rows, out, E, nullptr, 0, st);
+    const float* n2 = (const float*)W[JH_W_NORM2].data;
+    const int tail = t16_tail_rows(rows), rg = rows - tail;
+    if (rg) {
+        JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, x1, E, n2, c.rms_eps, E, rg, st)));
+        JHCHK((gemm_t16_launch<EPI_SILU_MUL>(s, GU.t16, GU.t16_scales, H / 8, E, rg, s->pb_g, H, nullptr, 0, st)));
+    }
+    for (int r = rg; r < rows; r++) {   // the decode gate|up GEMV on the same T16 copy (layers.hip)
+        GemvParams p;
+        memset(&p, 0, sizeof(p));
+        if (!GU.t16) return set_err(JH_ERR_INVALID, "reference-order prompt rows: gate|up has no T16 copy (ensure_strict_operands)");
+        p.w = GU.t16; p.ws = GU.t16_scales; p.nrows = H;
+        p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
+        p.x = x1 + (size_t)r * E; p.nw = n2; p.eps = c.rms_eps;
+        p.out = s->pb_g + (size_t)r * H;
+        JHCHK((launch_gemv_t16<PRO_RMS_Q8, EPI_SILU_MUL>(p, st)));
+    }
+    if (rg) {
+        JHCHK((rows_act_t16_launch<PRO_QUANT_Q8>(s, s->pb_g, H, nullptr, 0.f, H, rg, st)));
+        if (resid) JHCHK((gemm_t16_launch<EPI_RESID>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rg, out, E, resid, E, st)));
+        else JHCHK((gemm_t16_launch<EPI_STORE>(s, W[JH_W_DOWN].t16, W[JH_W_DOWN].t16_scales, E / 16, H, rg, out, E, nullptr, 0, st)));
+    }
+    for (int r = rg; r < rows; r++) {
+        const float* xr = s->pb_g + (size_t)r * H;
+        if (resid) JHCHK((tail_gemv_p16<PRO_QUANT_Q8, EPI_RESID>(s, W[JH_W_DOWN], H, E, xr, nullptr, 0.f, out + (size_t)r * E, resid + (size_t)r * E, st)));
+        else JHCHK((tail_gemv_p16<PRO_QUANT_Q8, EPI_STORE>(s, W[JH_W_DOWN], H, E, xr, nullptr, 0.f, out + (size_t)r * E, nullptr, st)));
+    }
+    return JH_OK;
 }
 // ---- the same two halves for a dense BF16 model in reference order (jh_bf16r.h): activation image per projection input, M-row chains
 template <int PRO>

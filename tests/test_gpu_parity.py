@@ -202,17 +202,29 @@ def test_reference_order_prefill_in_batches_is_the_row_path_bit_for_bit(gpu, ora
     a = s_two.forward(prompt[:100], 0)
     b = s_two.forward(prompt[100:], 100)
     np.testing.assert_array_equal(np.concatenate([a, b]).view(np.uint32), rows.view(np.uint32))
+    # one or two rows of a ragged last row tile leave the GEMM for the decode GEMVs (prefill.hip: t16_tail_rows): 129 = 16 tiles + 1,
+    # 170 = 21 tiles + 2, then a single row with no tile at all; JH_T16_TAIL_ROWS=0 keeps every row in the GEMM
+    s_tail = hm.session(512)
+    s_tail.set_strict(True)
+    parts = [s_tail.forward(prompt[:129], 0), s_tail.forward(prompt[129:299], 129), s_tail.forward(prompt[299:], 299)]
+    np.testing.assert_array_equal(np.concatenate(parts).view(np.uint32), rows.view(np.uint32))
+    _N.set_option("JH_T16_TAIL_ROWS", "0")
+    s_gemm = hm.session(512)
+    s_gemm.set_strict(True)
+    np.testing.assert_array_equal(s_gemm.forward(prompt[:129], 0).view(np.uint32), rows[:129].view(np.uint32))
+    s_gemm.close()
+    _N.clear_options()
     want = om.session().forward(prompt[:48], 0)                 # the oracle on the first rows (it is the slow one)
     np.testing.assert_array_equal(bat[:48].view(np.uint32), want.view(np.uint32))
     firsts, logits = [], []
-    for s in (s_row, s_bat, s_two):
+    for s in (s_row, s_bat, s_two, s_tail):
         t, l = s.sample(0.0, 0.5, want_logits=True)
         firsts.append(t); logits.append(l)
-    assert firsts[0] == firsts[1] == firsts[2]
-    np.testing.assert_array_equal(logits[0].view(np.uint32), logits[1].view(np.uint32))
-    np.testing.assert_array_equal(logits[0].view(np.uint32), logits[2].view(np.uint32))
-    ids = [list(s.decode_n(firsts[0], prompt.size, 24)) for s in (s_row, s_bat, s_two)]   # reads the KV pages of all 300 positions
-    assert ids[0] == ids[1] == ids[2]
+    assert firsts[0] == firsts[1] == firsts[2] == firsts[3]
+    for l in logits[1:]:
+        np.testing.assert_array_equal(logits[0].view(np.uint32), l.view(np.uint32))
+    ids = [list(s.decode_n(firsts[0], prompt.size, 24)) for s in (s_row, s_bat, s_two, s_tail)]   # reads the KV pages of all 300 positions
+    assert ids[0] == ids[1] == ids[2] == ids[3]
     np.testing.assert_array_equal(s_row.logits().view(np.uint32), s_bat.logits().view(np.uint32))
 
 

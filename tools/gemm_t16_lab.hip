@@ -7,6 +7,7 @@
 #include "../jlama_amd/csrc/jh_t16.h"
 using namespace jh;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+static int g_x = 0;   // argv[1] = x: the 32x32x16 form (gemm_t16x_kernel)
 template <int EPI, int MT, int CW>
 static void run(const char* tag, int N, int K, int M, int layers) {
     const int nblk = K / 32, ntiles = (EPI == EPI_SILU_MUL) ? N / 8 : N / 16, rowsw = ntiles * 16;
@@ -20,6 +21,7 @@ static void run(const char* tag, int N, int K, int M, int layers) {
     const int nslices = (ntiles + 2 * CW - 1) / (2 * CW), nrt = (M + MT - 1) / MT;
     const size_t lds = lds_bytes_gemm_t16(MT);
     CK(hipFuncSetAttribute((const void*)gemm_t16_kernel<EPI, MT, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)gemm_t16x_kernel<EPI, MT, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = ((nslices + 7) / 8) * 8 * nrt;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 3;
@@ -27,7 +29,7 @@ static void run(const char* tag, int N, int K, int M, int layers) {
         if (it == 0) CK(hipEventRecord(e0));
         for (int l = 0; l < layers; l++) {
             GemmT16Params g{(const i32x4*)((const char*)w + wb * l), (const f32x4t*)((const char*)ws + sb * l), ntiles, K, M, asel, ad, 256, out, N, resid, N, nslices, nrt};
-            gemm_t16_kernel<EPI, MT, CW><<<grid, CW * 64, lds>>>(g);
+            if (g_x) gemm_t16x_kernel<EPI, MT, CW><<<grid, CW * 64, lds>>>(g); else gemm_t16_kernel<EPI, MT, CW><<<grid, CW * 64, lds>>>(g);
         }
     }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -39,7 +41,8 @@ static void run(const char* tag, int N, int K, int M, int layers) {
            us * 1e-6 * 2.1e9 / (mfma / 1024.0));
     CK(hipFree(w)); CK(hipFree(ws)); CK(hipFree(asel)); CK(hipFree(ad)); CK(hipFree(out)); CK(hipFree(resid));
 }
-int main() {
+int main(int argc, char** argv) {
+    g_x = argc > 1 && argv[1][0] == 'x';
     const int M = 129;
     run<EPI_SILU_MUL, 8, 4>("gate|up", 14336, 4096, M, 8);
     run<EPI_RESID, 8, 4>("down", 4096, 14336, M, 8);
