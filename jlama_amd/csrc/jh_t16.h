@@ -537,22 +537,24 @@ __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 // ------------------------------------------------------------------------------------------------ the same GEMM on v_mfma_f32_32x32x16_f16
-// Why: beside the chains' v_fmac the 16x16x32 MFMA does not hide -- tools/pkfma_lab.hip: one MFMA + 4 v_fmac (one prompt row x one
-// tile x one block) takes 12.9 ns per SIMD at two waves, the sum of its parts (7.0 + 4 x 1.4); one 32x32x16 + 8 v_fmac (TWO such
-// units) takes 19.9.  Same operands in HBM and LDS, other register roles:
-//   A (32 rows x 16 k)  rows 0-15 = the 16 chains t of prompt row m, rows 16-31 = those of row m + 1
+// Why: beside the chains' v_fmac the MFMA does not hide on this chip -- tools/pkfma_lab.hip: one 16x16x32 MFMA + 4 v_fmac (one prompt
+// row x one tile x one block) takes 12.9 ns per SIMD at two waves, the sum of its parts (7.0 + 4 x 1.4) -- so the matrix pipe's time
+// per (row, tile, block) counts in full, and the one-hot operand wastes most of it.  The 32x32x16 shape lets FOUR prompt rows share
+// an MFMA: 8 pipe cycles per (row, tile, block) instead of 16.  Same operands in HBM and LDS, other register roles:
+//   A (32 rows x 16 k)  row 8 * mq + t' = chain t' (MFMA 1) or 8 + t' (MFMA 2) of prompt row 4 * quad + mq
 //   B (16 k x 32 cols)  cols 0-15 = weight rows of tile A, 16-31 = tile B
-//   K = 16 holds half a block's 32 elements, so a block takes two MFMAs, the second accumulating onto the first:
+//   K = 16 holds half a block's 32 elements:
 //     MFMA 1: lane group h = lane >> 5 supplies dword h     of the block (elements 4h..4h+3 low nibbles, 16+4h.. high): chains t < 8
 //     MFMA 2: lane group h             supplies dword 2 + h                                                          : chains t >= 8
-//   the selector row of chain t is non-zero in exactly one (MFMA, lane group): lanes read their 16-byte entry for that one and the zero
-//   word for the other.  D register i of lane (col j' = lane & 31, h): prompt row m + (i >> 3), chain t = 8 * ((i >> 2) & 1) + 4h + (i & 3).
-// Per (prompt row, block, tile PAIR): one MFMA issue (was two), ONE scale product (the lane owns one weight row; was two), 8 v_fmac.
+//   chain t' (and 8 + t') is non-zero only in lane group t' >> 2: a lane reads its two 16-byte selector entries there, the zero word
+//   elsewhere -- two LDS reads per (row quad, block), a quarter of the 16x16 form's traffic per row.
+//   D register i of lane (col j' = lane & 31, h): prompt row 4 * quad + (i >> 2), chain t = 4h + (i & 3) (MFMA 1) or 8 + 4h + (i & 3).
+// Per (prompt row, block, tile PAIR): half an MFMA issue (was two), ONE scale product (the lane owns one weight row; was two), 8 v_fmac.
 template <int EPI, int MT, int CW>
 __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_t16x_kernel(GemmT16Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KC = GT16_KC, NT = CW * 64, NP = MT / 2;
-    static_assert(MT == 8, "gemm_t16x_kernel: four row pairs per block (the MFMA / chain schedule below is written out for them)");
+    constexpr int KC = GT16_KC, NT = CW * 64, NQ = MT / 4;
+    static_assert(MT == 8, "gemm_t16x_kernel: two row quads per block (the MFMA / chain schedule below is written out for them)");
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     const int nblk = p.K / QB, nq = nblk >> 2, nchunks = nblk / KC;   // host: nblk % KC == 0
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -582,10 +584,11 @@ __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             dabuf[(buf * KC + kb) * MT + m] = p.ad[(size_t)(c * KC + kb) * p.ad_stride + mm];
         }
     };
-    // as an A supplier the lane is (prompt row m + u, chain t = j, k group h)
-    const int tg = j >> 2;
-    const char* a1_lane = selbuf + (size_t)u * KC * GT16_ENTRY + ((j < 8 && tg == h) ? j * 16 : 256);
-    const char* a2_lane = selbuf + (size_t)u * KC * GT16_ENTRY + ((j >= 8 && (tg & 1) == h) ? j * 16 : 256);
+    // as an A supplier the lane is (prompt row mq of its quad, chain t' or 8 + t', k group h)
+    const int mq = jp >> 3, tq = jp & 7;
+    const bool mine = (tq >> 2) == h;
+    const char* a1_lane = selbuf + (size_t)mq * KC * GT16_ENTRY + (mine ? tq * 16 : 256);
+    const char* a2_lane = selbuf + (size_t)mq * KC * GT16_ENTRY + (mine ? (8 + tq) * 16 : 256);
     const i32x4* w1 = p.w + (size_t)tile * nq * 64 + 16 * h + j;       // dword h of blocks 4q..4q+3 of the lane's weight row
     const i32x4* w2 = w1 + 32;                                        // dword 2 + h
     const f32x4t* sw = p.ws + (size_t)tile * nq * 16 + j;
@@ -601,13 +604,13 @@ __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int c = 0; c < nchunks; c++) {
         const int buf = c & 1;
         if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
-        f16x8 av[2][NP][2];                                           // [set][row pair][MFMA 1 / 2]
+        f16x8 av[2][NQ][2];                                           // [set][row quad][MFMA 1 / 2]
         f32x4t dav[2][MT / 4];
-        auto read_block = [&](int kb, f16x8 (&a)[NP][2], f32x4t (&dv)[MT / 4]) __attribute__((always_inline)) {
+        auto read_block = [&](int kb, f16x8 (&a)[NQ][2], f32x4t (&dv)[MT / 4]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int pr = 0; pr < NP; pr++) {
-                a[pr][0] = *(const f16x8*)(a1_lane + ((size_t)(buf * MT + 2 * pr) * KC + kb) * GT16_ENTRY);
-                a[pr][1] = *(const f16x8*)(a2_lane + ((size_t)(buf * MT + 2 * pr) * KC + kb) * GT16_ENTRY);
+            for (int qd = 0; qd < NQ; qd++) {
+                a[qd][0] = *(const f16x8*)(a1_lane + ((size_t)(buf * MT + 4 * qd) * KC + kb) * GT16_ENTRY);
+                a[qd][1] = *(const f16x8*)(a2_lane + ((size_t)(buf * MT + 4 * qd) * KC + kb) * GT16_ENTRY);
             }
 #pragma unroll
             for (int q4 = 0; q4 < MT / 4; q4++) dv[q4] = *(const f32x4t*)(dabuf + (buf * KC + kb) * MT + 4 * q4);
@@ -627,31 +630,28 @@ __global__ __launch_bounds__(CW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (kb + 1 < KC) read_block(kb + 1, av[cb ^ 1], dav[cb ^ 1]);
                 const f16x8 b1 = nib8_to_f16(wa_c[d]), b2 = nib8_to_f16(wb_c[d]);
                 const float swd = sc_c[d];
-                f32x16 D[NP];
+                f32x16 D1[NQ], D2[NQ];
                 const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                auto mf1 = [&](int pr) __attribute__((always_inline)) { D[pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[cb][pr][0], b1, z, 0, 0, 0); };
-                auto mf2 = [&](int pr) __attribute__((always_inline)) { D[pr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[cb][pr][1], b2, D[pr], 0, 0, 0); };
-                auto chains = [&](int pr) __attribute__((always_inline)) {
+                auto mf = [&](int qd) __attribute__((always_inline)) {
+                    D1[qd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[cb][qd][0], b1, z, 0, 0, 0);
+                    D2[qd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[cb][qd][1], b2, z, 0, 0, 0);
+                };
+                auto chains = [&](int qd) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int mm = 0; mm < 2; mm++) {
-                        const int m = 2 * pr + mm;
-                        const float s = dav[cb][m >> 2][m & 3] * swd;          // afr[blk] * bfr[blk] (PTO:819): the reference's own product (-ffp-contract=off)
+                    for (int mm = 0; mm < 4; mm++) {
+                        const int m = 4 * qd + mm;
+                        const float s = dav[cb][qd][mm] * swd;                 // afr[blk] * bfr[blk] (PTO:819): the reference's own product (-ffp-contract=off)
 #pragma unroll
-                        for (int i = 0; i < 8; i++) fma_c(acc[m][i], s, D[pr][8 * mm + i]);
+                        for (int r = 0; r < 4; r++) fma_c(acc[m][r], s, D1[qd][4 * mm + r]);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) fma_c(acc[m][4 + r], s, D2[qd][4 * mm + r]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                // every MFMA 2 waits for its MFMA 1 (the accumulator operand), every chain for its MFMA 2: two other MFMAs in between
-                mf1(0); mf1(1); mf2(0); mf1(2); mf2(1);
+                mf(0); mf(1);                                                  // the second quad's MFMAs run beside the first quad's chains
                 __builtin_amdgcn_sched_barrier(0);
                 chains(0);
-                mf1(3); mf2(2);
-                __builtin_amdgcn_sched_barrier(0);
                 chains(1);
-                mf2(3);
-                __builtin_amdgcn_sched_barrier(0);
-                chains(2);
-                chains(3);
             }
         }
         __syncthreads();
