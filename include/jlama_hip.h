@@ -241,6 +241,11 @@ int64_t jh_model_weight_bytes(jh_model* m);
 /* Bytes of the SECOND, MFMA-ordered copy of the projection weights the batched prefill keeps resident (0 until the first
  * prefill made it; always 0 with JH_TILED_COPY=transient, where each GEMM's operand is rebuilt in a per-session scratch). */
 int64_t jh_model_tiled_bytes(jh_model* m);
+/* Bytes of row-major projection nibbles (and MFMA-ordered prompt copies) RELEASED because the process option JH_STRICT_ONLY=1 was
+ * set when a reference-order session of this JQ4 model published its T16 / P16T operand copies: those copies are then the only
+ * ones, the model serves reference-order sessions only (order-free use, set_strict(0) and set_weight fail with JH_ERR_UNSUPPORTED).
+ * 0 = the option never took effect.  (No reference counterpart: the Java host keeps one heap copy of a checkpoint.) */
+int64_t jh_model_released_bytes(jh_model* m);
 
 /* One KV buffer (KvBufferCache.getKvBuffer, KvBufferCache.java:58-60): pages of max_page_bytes (0 => 8 MiB)
  * shaped [layersPerPage, 2, ctxPerPage, kvLength] F32, enough pages for positions [0, max_ctx). */

@@ -120,6 +120,8 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
     private static final MethodHandle jh_clear_options = h("jh_clear_options", JAVA_INT, sig(""));
     // int64_t jh_model_tiled_bytes(jh_model* m)
     private static final MethodHandle jh_model_tiled_bytes = h("jh_model_tiled_bytes", JAVA_LONG, sig("p"));
+    // int64_t jh_model_released_bytes(jh_model* m)
+    private static final MethodHandle jh_model_released_bytes = h("jh_model_released_bytes", JAVA_LONG, sig("p"));
     // int jh_pipeline_peer_access(jh_pipeline* p, int32_t* out, int n)
     private static final MethodHandle jh_pipeline_peer_access = h("jh_pipeline_peer_access", JAVA_INT, sig("ppi"));
     // int jh_pipeline_create(jh_session* const* stages, int n_stages, jh_pipeline** out)
@@ -297,6 +299,10 @@ int jh_model_create(const jh_config* cfg, jh_model** out)
 
     public static long jh_model_tiled_bytes(MemorySegment m) {
         try { return (long) jh_model_tiled_bytes.invokeExact(m); } catch (Throwable t) { throw rethrow(t); }
+    }
+
+    public static long jh_model_released_bytes(MemorySegment m) {
+        try { return (long) jh_model_released_bytes.invokeExact(m); } catch (Throwable t) { throw rethrow(t); }
     }
 
     public static int jh_pipeline_peer_access(MemorySegment p, MemorySegment out, int n) {

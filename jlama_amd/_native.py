@@ -208,6 +208,7 @@ _PROTOS = {
     "jh_model_set_weight": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _i]),
     "jh_model_weight_bytes": (_l, [_p]),
     "jh_model_tiled_bytes": (_l, [_p]),
+    "jh_model_released_bytes": (_l, [_p]),
     "jh_session_create": (_i, [_p, _i, _l, _p]),
     "jh_session_destroy": (_i, [_p]),
     "jh_session_page_info": (_i, [_p, _p]),

@@ -88,7 +88,9 @@ struct JWeight {
     uint8_t* t16 = nullptr;          // Q4 only: resident copy in T16 order (jh_t16.h) for the reference-order MFMA GEMV
     float* t16_scales = nullptr;
     uint8_t* p16t = nullptr;         // resident copy for the reference-order GEMVs: Q4 in P16T order (jh_p16.h), BF16 in BF16T order (jh_bf16r.h)
+    bool dropped = false;            // Q4 only: the row-major nibbles were released (JH_STRICT_ONLY); the T16 / P16T copies ARE the weight (scales stay)
 };
+static inline bool w_present(const JWeight& W) { return W.data || W.dropped; }
 struct jh_model {
     jh_config c;
     int device;
@@ -101,6 +103,8 @@ struct jh_model {
     int64_t weight_bytes = 0;
     int kv_head_offset = 0;   // tensor-parallel shard (jh_model_set_kv_head_offset)
     int weights_version = 0;  // bumped by jh_model_set_weight: sessions drop graphs that captured the old device pointers
+    bool strict_only = false; // JH_STRICT_ONLY took effect: row-major projection nibbles released, reference-order sessions only, weights immutable
+    int64_t dropped_bytes = 0;
     int tiled_mode = 0;       // TILED_*: where the prefill GEMM's MFMA-ordered weight operand lives (decided at the first prefill)
     std::mutex op_mu;         // the operand copies (T16 / P16T / BF16T) are per model and shared by its sessions: made under this lock, published packed
 };
@@ -215,6 +219,7 @@ int ensure_t16(JWeight& W, hipStream_t st);
 int ensure_p16t(JWeight& W, hipStream_t st);
 int use_p16t(GemvParams& p, const JWeight& W);
 int ensure_strict_operands(jh_session* s, hipStream_t st);
+int refuse_order_free(const jh_session* s, const char* what);   // JH_STRICT_ONLY models: order-free use fails loudly
 // layers.hip
 int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg = nullptr);
 int tap_copy(jh_session* s, int which, const float* src, int n, hipStream_t st);

@@ -147,7 +147,8 @@ int layer_attn_launch(jh_session* s, int li, hipStream_t st, bool tap, int pos_f
         const JWeight& F = m->qkv[(size_t)li];
         // every slot this half dereferences on the device (a partial checkpoint or a wrong layer range must be an error
         // code, not a GPU fault)
-        if (!F.data || !W[JH_W_Q].data || !W[JH_W_K].data || !W[JH_W_V].data || !W[JH_W_O].data || !W[JH_W_NORM1].data)
+        JHCHK(refuse_order_free(s, "attention half"));
+        if (!w_present(F) || !w_present(W[JH_W_Q]) || !w_present(W[JH_W_K]) || !w_present(W[JH_W_V]) || !w_present(W[JH_W_O]) || !W[JH_W_NORM1].data)
             return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": q/k/v/o/input_layernorm weights not set");
         p.w = (const uint8_t*)F.data; p.ws = F.scales; p.nrows = A + 2 * KV; p.out = s->qkv;
         p.K = E; p.ldb = E / 2; p.ldbf = E / QB;
@@ -212,7 +213,8 @@ int layer_ffn_launch(jh_session* s, int li, hipStream_t st, bool tap, float* out
     const jh_config& c = m->c;
     const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     const int E = c.embedding_length, H = c.hidden_length;
-    if (!W[JH_W_GATE].data || !W[JH_W_UP].data || !W[JH_W_DOWN].data || !W[JH_W_NORM2].data)
+    JHCHK(refuse_order_free(s, "feed-forward half"));
+    if (!w_present(W[JH_W_GATE]) || !w_present(W[JH_W_UP]) || !w_present(W[JH_W_DOWN]) || !W[JH_W_NORM2].data)
         return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": gate/up/down/post_attention_layernorm weights not set");
     {   // gate/up (MLPBlock.java:117-142) with fused preFFNorm + maybeQuantize, SiLU*up + maybeQuantize
         GemvParams p;

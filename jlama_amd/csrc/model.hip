@@ -12,12 +12,13 @@ bool t16_gateup_ok(const jh_model* m, int li) {
     const int enabled = opt_int("JH_T16", 1);
     const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     const JWeight &G = W[JH_W_GATE], &U = W[JH_W_UP];
-    return enabled && G.data && U.data && G.dtype == JH_DT_Q4 && U.dtype == JH_DT_Q4 && G.rows == U.rows && G.cols == U.cols &&
+    return enabled && w_present(G) && w_present(U) && G.dtype == JH_DT_Q4 && U.dtype == JH_DT_Q4 && G.rows == U.rows && G.cols == U.cols &&
            G.rows % 8 == 0 && t16_shape_ok(G.cols);
 }
 int ensure_gateup_t16(jh_model* m, int li, hipStream_t st) {
     JWeight& F = m->gateup[(size_t)li];
     if (F.t16 || !t16_gateup_ok(m, li)) return JH_OK;
+    if (m->strict_only) return set_err(JH_ERR_INVALID, "gate|up T16 copy: the row-major weights of this model were released (JH_STRICT_ONLY)");
     const JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     const JWeight &G = W[JH_W_GATE], &U = W[JH_W_UP];
     const int rows = 2 * G.rows, K = G.cols, nblk = K / QB, ntiles = rows / 16;
@@ -37,9 +38,9 @@ int ensure_gateup_t16(jh_model* m, int li, hipStream_t st) {
     return JH_OK;
 }
 // T16 copy (mode 0: tile u = rows 16u..16u+15) of a Q4 weight: the operand of the reference-order prompt GEMM on the MFMA
-bool t16_weight_ok(const JWeight& W) { return W.data && W.dtype == JH_DT_Q4 && W.rows % 16 == 0 && W.cols % 512 == 0; }
+bool t16_weight_ok(const JWeight& W) { return w_present(W) && W.dtype == JH_DT_Q4 && W.rows % 16 == 0 && W.cols % 512 == 0; }
 int ensure_t16(JWeight& W, hipStream_t st) {
-    if (W.t16 || !t16_weight_ok(W)) return JH_OK;
+    if (W.t16 || !t16_weight_ok(W) || !W.data) return JH_OK;
     const int nblk = W.cols / QB, ntiles = W.rows / 16;
     hipError_t e = hipMalloc((void**)&W.t16, t16_w_bytes(W.rows, W.cols));
     if (e == hipSuccess) e = hipMalloc((void**)&W.t16_scales, t16_s_bytes(W.rows, W.cols));
@@ -88,12 +89,58 @@ static int ensure_strict_operands_locked(jh_session* s, hipStream_t st);
 // The copies belong to the MODEL: every session of it (other streams, other host threads) reads them.  They are created under the
 // model's lock, and the lock is released only once the pack kernels this call queued have FINISHED -- a second session then either
 // waits here or finds complete copies; nobody launches a reference-order GEMV against a half-packed operand.
+// JH_STRICT_ONLY=1: a model that serves reference-order sessions only keeps ONE copy of the projection nibbles per kernel family instead
+// of those plus the checkpoint's row-major ones (70B in reference order held 2.56 x 43 GB).  Once the T16 / P16T
+// copies of a projection are published, its row-major nibbles (and the order-free prompt GEMM's MFMA-ordered copy) are released; the
+// block scales stay (the P16T kernels read them row-major), embedding / LM head / norms stay.  From then on the model refuses
+// order-free sessions and weight replacement, loudly.
+static void release_row_major(jh_model* m, JWeight& W, bool owns) {
+    if (W.dropped || !W.data || W.dtype != JH_DT_Q4) return;
+    if (owns) {
+        m->dropped_bytes += (int64_t)W.rows * W.cols / 2;
+        hipFree(W.data);
+        if (W.tiled) { m->dropped_bytes += (int64_t)(tiled_w_bytes(W) + (W.tiled_scales ? tiled_s_bytes(W) : 0)); hipFree(W.tiled); if (W.tiled_scales) hipFree(W.tiled_scales); }
+        W.tiled = nullptr; W.tiled_scales = nullptr;
+    }
+    W.data = nullptr; W.dropped = true;
+}
+static int drop_row_major_weights(jh_session* s) {
+    jh_model* m = s->m;
+    const bool gemm = prefill_t16_ok(s);
+    for (int li = m->c.layer_start; li < m->c.layer_end; li++) {
+        JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
+        JWeight &F = m->qkv[(size_t)li], &GU = m->gateup[(size_t)li];
+        auto covered = [&](const JWeight& w) { return w.p16t && (w.t16 || !gemm); };   // every reference-order kernel has its operand
+        if (covered(F)) {
+            release_row_major(m, F, true);
+            release_row_major(m, W[JH_W_Q], false); release_row_major(m, W[JH_W_K], false); release_row_major(m, W[JH_W_V], false);   // slices of F
+        }
+        if (covered(W[JH_W_O])) release_row_major(m, W[JH_W_O], true);
+        if (covered(W[JH_W_DOWN])) release_row_major(m, W[JH_W_DOWN], true);
+        if (GU.t16) {   // decode GEMV and prompt GEMM both read the stacked T16 copy
+            release_row_major(m, W[JH_W_GATE], true); release_row_major(m, W[JH_W_UP], true);
+            if (GU.tiled) { m->dropped_bytes += (int64_t)(tiled_w_bytes(GU) + (GU.tiled_scales ? tiled_s_bytes(GU) : 0)); hipFree(GU.tiled); if (GU.tiled_scales) hipFree(GU.tiled_scales); GU.tiled = nullptr; GU.tiled_scales = nullptr; }
+        }
+    }
+    m->strict_only = true;
+    m->weights_version++;   // (no graph may keep a row-major pointer: order-free graphs of other sessions are dropped at their next use -- which now fails)
+    return JH_OK;
+}
 int ensure_strict_operands(jh_session* s, hipStream_t st) {
     std::lock_guard<std::mutex> lk(s->m->op_mu);
     const int before = g_operand_packs;
     const int rc = ensure_strict_operands_locked(s, st);
     if (g_operand_packs != before) HIPCHK(hipStreamSynchronize(st));
+    if (rc == JH_OK && s->strict && s->m->c.weight_dtype == JH_DT_Q4 && !s->m->strict_only && opt_int("JH_STRICT_ONLY", 0)) {
+        HIPCHK(hipDeviceSynchronize());   // nobody is reading the row-major copies (another session's order-free decode would be the caller's bug)
+        return drop_row_major_weights(s);
+    }
     return rc;
+}
+int refuse_order_free(const jh_session* s, const char* what) {
+    if (s->m->strict_only && !s->strict)
+        return set_err(JH_ERR_UNSUPPORTED, std::string(what) + ": this model keeps reference-order operands only (JH_STRICT_ONLY released the row-major weights)");
+    return JH_OK;
 }
 static int ensure_strict_operands_locked(jh_session* s, hipStream_t st) {
     jh_model* m = s->m;
@@ -195,6 +242,7 @@ int jh_model_destroy(jh_model* m) {
 int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void* data, const float* scales, int rows,
                         int cols, int from_device) {
     if (!m || !data || which < 0 || which >= JH_W_COUNT) return set_err(JH_ERR_INVALID, "set_weight: bad argument");
+    if (m->strict_only) return set_err(JH_ERR_UNSUPPORTED, "set_weight: this model released its row-major weights (JH_STRICT_ONLY); its weights are immutable");
     HIPCHK(hipSetDevice(m->device));
     JWeight* w;
     if (layer < 0) {
@@ -301,6 +349,7 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     return JH_OK;
 }
 int64_t jh_model_weight_bytes(jh_model* m) { return m ? m->weight_bytes : 0; }
+int64_t jh_model_released_bytes(jh_model* m) { return m ? m->dropped_bytes : 0; }
 int64_t jh_model_tiled_bytes(jh_model* m) {
     if (!m) return 0;
     int64_t b = 0;
@@ -436,7 +485,7 @@ static int session_init(jh_session* s, jh_model* m, int max_ctx, int64_t max_pag
     HIPCHK(hipMalloc(&s->p16_scores, (size_t)c.n_heads * s->p16_sc_stride * 4));
     if (s->strict && c.weight_dtype != JH_DT_Q4 && c.weight_dtype != JH_DT_BF16) return set_err(JH_ERR_UNSUPPORTED, "JH_STRICT_ORDER: reference-order kernels exist for JQ4 and BF16 models");
     if (s->strict) JHCHK(ensure_strict_operands(s, s->stream));   // a session that STARTS in reference order (JH_STRICT_ORDER=1): same copies as jh_session_set_strict makes
-    if (!s->strict && prefill_batch_ok(s)) {
+    if (!s->strict && !s->m->strict_only && !opt_int("JH_STRICT_ONLY", 0) && prefill_batch_ok(s)) {   // (a reference-order-only model never runs the order-free prompt GEMM)
         // the MFMA-ordered weight copies of the prefill GEMM are made here, once per model, not inside the first prompt
         JHCHK(ensure_all_tiled(s, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -447,6 +496,7 @@ int jh_session_set_strict(jh_session* s, int on) {
     if (!s) return set_err(JH_ERR_INVALID, "set_strict: null");
     if (on && s->m->c.weight_dtype != JH_DT_Q4 && s->m->c.weight_dtype != JH_DT_BF16) return set_err(JH_ERR_UNSUPPORTED, "set_strict: reference-order kernels exist for JQ4 and BF16 models");
     HIPCHK(hipSetDevice(s->m->device));
+    if (!on && s->m->strict_only) return set_err(JH_ERR_UNSUPPORTED, "set_strict(0): this model keeps reference-order operands only (JH_STRICT_ONLY released the row-major weights)");
     if ((on ? 1 : 0) != s->strict) {
         HIPCHK(hipStreamSynchronize(s->stream));
         s->strict = on ? 1 : 0;

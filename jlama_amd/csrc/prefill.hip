@@ -171,6 +171,7 @@ int gateup_operand(jh_session* s, int li, hipStream_t st, const uint8_t** tw, co
 // every weight the prefill GEMMs of this shard will touch (allocation must not happen inside a graph capture): the resident
 // MFMA-ordered copies, or -- TILED_TRANSIENT -- the session's scratch, sized for the largest operand
 int ensure_all_tiled(jh_session* s, hipStream_t st) {
+    JHCHK(refuse_order_free(s, "MFMA-ordered prompt operands"));
     jh_model* m = s->m;
     const jh_config& c = m->c;
     const bool resident = tiled_mode_for(m) == TILED_RESIDENT;
@@ -306,8 +307,9 @@ int prefill_attn_launch(jh_session* s, int rel, int nkeys_bound, int rows, bool 
 int prefill_weights_set(jh_session* s, int li) {
     jh_model* m = s->m;
     JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
-    if (!m->qkv[(size_t)li].data || !W[JH_W_Q].data || !W[JH_W_K].data || !W[JH_W_V].data || !W[JH_W_O].data || !W[JH_W_GATE].data || !W[JH_W_UP].data ||
-        !W[JH_W_DOWN].data || !W[JH_W_NORM1].data || !W[JH_W_NORM2].data)
+    JHCHK(refuse_order_free(s, "prompt chunk"));
+    if (!w_present(m->qkv[(size_t)li]) || !w_present(W[JH_W_Q]) || !w_present(W[JH_W_K]) || !w_present(W[JH_W_V]) || !w_present(W[JH_W_O]) || !w_present(W[JH_W_GATE]) ||
+        !w_present(W[JH_W_UP]) || !w_present(W[JH_W_DOWN]) || !W[JH_W_NORM1].data || !W[JH_W_NORM2].data)
         return set_err(JH_ERR_INVALID, "layer " + std::to_string(li) + ": weights not set");
     return JH_OK;
 }

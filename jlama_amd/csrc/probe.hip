@@ -106,6 +106,7 @@ int jh_kernel_bench(jh_session* s, int which, int iters, double* out_ms, int64_t
     const int A = c.n_heads * hs, KV = c.n_kv_heads * hs;
     const int nl = c.layer_end - c.layer_start;
     JHCHK(ensure_strict_operands(s, st));
+    JHCHK(refuse_order_free(s, "kernel_bench"));
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, s->st, s->max_ctx / 2, 0, 0);
     s->attn_variant = attn_variant_for(s, s->max_ctx / 2);
     const bool p16 = s->strict != 0;   // reference-order kernels (jh_t16.h / jh_p16.h) when the session is in that mode

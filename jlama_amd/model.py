@@ -58,6 +58,10 @@ class HipLlamaModel:
         """bytes of the resident MFMA-ordered second copy the batched prefill made (0 with JH_TILED_COPY=transient)"""
         return N.lib().jh_model_tiled_bytes(self.h)
 
+    def released_bytes(self):
+        """bytes of row-major projection weights released under JH_STRICT_ONLY=1 (reference-order sessions only from then on)"""
+        return N.lib().jh_model_released_bytes(self.h)
+
     def session(self, max_ctx, max_page_bytes=0):
         return HipSession(self, max_ctx, max_page_bytes)
 

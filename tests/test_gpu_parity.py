@@ -228,6 +228,53 @@ def test_reference_order_prefill_in_batches_is_the_row_path_bit_for_bit(gpu, ora
     np.testing.assert_array_equal(s_row.logits().view(np.uint32), s_bat.logits().view(np.uint32))
 
 
+def test_reference_order_only_model_releases_the_row_major_weights(gpu, oracle):
+    """JH_STRICT_ONLY=1: once a reference-order session has published the T16 / P16T operand copies, the row-major
+    projection nibbles are released -- those copies are then the weight.  Same rows, logits and ids bit for bit; HBM really comes
+    back; order-free use, leaving reference order and replacing a weight fail loudly instead of reading freed memory."""
+    from jlama_amd import synthetic as S
+    from jlama_amd.model import HipLlamaModel
+    cfg, hm, om, w = _real("LLAMA3_8B", oracle)                  # whole T16 tiles: the prompt goes through the MFMA GEMM
+    prompt = S.prompt_tokens(cfg, n=41, seed=5)                  # 41 = 5 row tiles + 1 tail row through the decode GEMVs
+    s0 = hm.session(256)
+    s0.set_strict(True)
+    rows0 = s0.forward(prompt, 0)
+    t0, l0 = s0.sample(0.0, 0.5, want_logits=True)
+    ids0 = list(s0.decode_n(t0, prompt.size, 12))
+    s0.close()
+    _N.set_option("JH_STRICT_ONLY", "1")
+    try:
+        m2 = HipLlamaModel(cfg, w)
+        s = m2.session(256)
+        assert m2.released_bytes() == 0
+        s.set_strict(True)                                       # publishes the copies, then releases the row-major nibbles
+        E, H = cfg["embedding_length"], cfg["hidden_length"]
+        A, KV = cfg["n_heads"] * cfg["head_size"], cfg["n_kv_heads"] * cfg["head_size"]
+        nibbles = cfg["n_layers"] * ((A + 2 * KV) * E + E * A + 3 * H * E) // 2
+        assert m2.released_bytes() >= nibbles                    # (+ the MFMA-ordered prompt copies, had an order-free session made them)
+        rows = s.forward(prompt, 0)
+        np.testing.assert_array_equal(rows.view(np.uint32), rows0.view(np.uint32))
+        t, l = s.sample(0.0, 0.5, want_logits=True)
+        assert t == t0
+        np.testing.assert_array_equal(l.view(np.uint32), l0.view(np.uint32))
+        assert list(s.decode_n(t, prompt.size, 12)) == ids0
+        s_other = m2.session(256)                                # sessions are born order-free: using one must fail, not fault
+        with pytest.raises(_N.UnsupportedOperation, match="JH_STRICT_ONLY"):
+            s_other.forward(prompt[:4], 0)
+        with pytest.raises(_N.UnsupportedOperation, match="JH_STRICT_ONLY"):
+            s_other.decode_n(1, 0, 2)
+        s_other.set_strict(True)                                 # ... and entering reference order makes it usable
+        np.testing.assert_array_equal(s_other.forward(prompt, 0).view(np.uint32), rows0.view(np.uint32))
+        with pytest.raises(_N.UnsupportedOperation, match="JH_STRICT_ONLY"):
+            s.set_strict(False)
+        with pytest.raises(_N.UnsupportedOperation, match="immutable"):
+            key = next(k for k in w if k[0] == 0)
+            m2.set_weight(key[0], key[1], w[key])
+        s_other.close(); s.close()
+    finally:
+        _N.clear_options()
+
+
 def test_strict_mode_accepts_bf16_models(gpu):
     """Reference order exists for both weight formats of BASELINE's configs: JQ4 (jh_t16.h / jh_p16.h) and dense BF16
     (jh_bf16r.h; bit-identity asserted in tests/test_gpu_bf16_reference_order.py)."""

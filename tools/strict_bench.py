@@ -51,6 +51,9 @@ def main():
         out[mode] = {"tok_s": round(steps / dt, 1), "event_ms_per_token": round(ev_ms, 4), "kernels_per_token": kernels,
                      "kernels": probe, "first_ids": [int(t) for t in toks[:8]]}
         s.close()
+    free, total = torch.cuda.mem_get_info()
+    out["hbm"] = {"weights_GB": round(model.weight_bytes() / 1e9, 2), "operand_copies_GB": round(model.tiled_bytes() / 1e9, 2),
+                  "released_GB": round(model.released_bytes() / 1e9, 2), "device_used_GB": round((total - free) / 1e9, 2)}   # JH_STRICT_ONLY=1: row-major nibbles released
     print(json.dumps(out))
 
 
