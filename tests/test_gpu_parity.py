@@ -214,6 +214,19 @@ def test_reference_order_prefill_in_batches_is_the_row_path_bit_for_bit(gpu, ora
     np.testing.assert_array_equal(s_gemm.forward(prompt[:129], 0).view(np.uint32), rows[:129].view(np.uint32))
     s_gemm.close()
     _N.clear_options()
+    _N.set_option("JH_T16_GEMM32", "0")                    # the 16x16x32 form of the GEMM (kept for A/B): same bits
+    s_16 = hm.session(512)
+    s_16.set_strict(True)
+    np.testing.assert_array_equal(s_16.forward(prompt[:129], 0).view(np.uint32), rows[:129].view(np.uint32))
+    s_16.close()
+    _N.clear_options()
+    _N.set_option("JH_PREFILL_BATCH_MIN", "1")            # a 2-row chunk in the batched path: tail rows only, no GEMM launch at all
+    s_few = hm.session(512)
+    s_few.set_strict(True)
+    few = [s_few.forward(prompt[:40], 0), s_few.forward(prompt[40:42], 40), s_few.forward(prompt[42:43], 42)]
+    np.testing.assert_array_equal(np.concatenate(few).view(np.uint32), rows[:43].view(np.uint32))
+    s_few.close()
+    _N.clear_options()
     want = om.session().forward(prompt[:48], 0)                 # the oracle on the first rows (it is the slow one)
     np.testing.assert_array_equal(bat[:48].view(np.uint32), want.view(np.uint32))
     firsts, logits = [], []
