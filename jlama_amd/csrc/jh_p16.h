@@ -397,12 +397,6 @@ __device__ __forceinline__ float p16_scale_product(float da16, float sb) {
 // consumed in blocks of D (the host picks D | G, so a pass ends exactly at a block end and the ring needs no bounds checks).
 // `per` = row quads per task wave, `tw` = task waves per workgroup (the host sizes grid x tw x per so that every CU gets the same
 // number of row quads).
-#ifndef P16_RING_DELAY
-#define P16_RING_DELAY 8       // s_sleep units (64 cycles) between the activation loads and the first ring request ...
-#endif
-#ifndef P16_RING_PACE
-#define P16_RING_PACE 2        // ... and between two ring requests of the prologue (see the kernel)
-#endif
 template <int PRO, int EPI, int D, int UM, int NT = P16_THREADS>
 __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per, int tw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -479,6 +473,7 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
         // helper wave: its own copy of the prologue (same barriers).  The two paths must not join: hipcc computes ONE vmcnt per wait
         // and would size the working waves' waits for the path without ring loads, i.e. drain the ring inside the prologue.
         stage_issue_p16<PRO, UM, NT>(p, ar);
+        __builtin_amdgcn_s_barrier();                       // (the working waves' "row requested" barrier, below)
         stage_finish_p16<PRO, UM, NT>(p, a, ar);
         JH_GSTAMP(2);
         if constexpr (EPI == EPI_TP) tp_signal(p);       // every wave of the workgroup passes one tp_signal (its barrier)
@@ -492,16 +487,16 @@ __global__ __launch_bounds__(NT) void gemv_i8q4_p16_kernel(GemvParams p, int per
     // the last of them can end the row: the others are requested without the row-switch branch and with constant group distances
     // (as D generic issue() calls this was ~20 scalar instructions + a branch per group in front of the first weight byte: 0.3 us
     // of a wave that issues one instruction per 4-8 cycles -- tools/gemv_timeline.py "entry -> ring requested")
-    // ... and PACED: requested back to back (16 loads per wave in ~40 instructions) the rings of the first waves fill the CU's
-    // request path in front of the later waves' activation loads, the quantized row -- what every wave waits for at the barrier --
-    // arrives later and the o-projection runs 4.8 -> 5.5 us (664 tok/s against 684).  The old code paced itself by accident (~20
-    // scalar instructions per group).  Same-box A/B of s_sleep in front of / between the groups (x 64 cycles): 0/0 664.7, 0/1 669.6,
-    // 0/2 682.3, 0/4 685.5-689.2, 0/6 681.5, 0/8 670.7, 8/0 683.5, 16/0 686.2, 4/2 686.7-687.4, 8/3 687.6-689.7, 12/2 687.1-689.1,
-    // **8/2 690.1-691.5** against 683.7-684.4 for the generic issue() form.
-    __builtin_amdgcn_s_sleep(P16_RING_DELAY);
+    // ... and they wait until EVERY wave of the workgroup has requested its share of the activation row (a barrier, ~100 cycles).
+    // Requested back to back without it (16 loads per wave in ~40 instructions), the rings of the first waves fill the CU's request
+    // path in front of the later waves' activation loads; the quantized row -- what every wave waits for at the next barrier --
+    // arrives later and the o-projection runs 4.8 -> 5.5 us (664 tok/s against 684).  The generic issue() form had paced itself by
+    // accident (~20 scalar instructions per group).  Same-box A/B, 8B, K = 256 (tools/build_variant.py): generic 683.7-684.4;
+    // compact, unpaced 664.7; s_sleep (x 64 cycles) in front / between the requests 0/2 682.3, 0/4 685.5-689.2, 0/8 670.7, 16/0 686.2,
+    // 8/2 689.8-691.5; **barrier, then the ring at once 698.6-701.0** (barrier + s_sleep 1 / 2 between: 694.5-699.6 / 696.3-696.9).
+    __builtin_amdgcn_s_barrier();
     p16_static_for<D - 1>([&](auto dc) __attribute__((always_inline)) {
         issue_in_row(wq[decltype(dc)::value], sq[decltype(dc)::value]);
-        __builtin_amdgcn_s_sleep(P16_RING_PACE);
         __builtin_amdgcn_sched_barrier(0);                  // request order = consumption order (the loop's vmcnt waits count on it)
     });
     issue(wq[D - 1], sq[D - 1]);

@@ -146,12 +146,6 @@ __device__ __forceinline__ void stage_finish_t16(const GemvParams& p, const ActT
 // D is even and the host picks it as a divisor of K/128.
 // EPI_SILU_MUL: tiles packed in mode 1, nrows = hidden units, out[8u + j] = SiLU(gate_j) * up_j (MLPBlock.java:132-142).
 // EPI_STORE / EPI_RESID: tiles packed in mode 0, out[16u + j] (+ resid).
-#ifndef T16_RING_DELAY
-#define T16_RING_DELAY 0       // s_sleep units in front of / between the prologue's ring requests (jh_p16.h: P16_RING_DELAY / _PACE)
-#endif
-#ifndef T16_RING_PACE
-#define T16_RING_PACE 0
-#endif
 template <int PRO, int EPI, int D, int UM, int NT>
 __global__ __launch_bounds__(NT) void gemv_t16_kernel(GemvParams p, int tiles_per_wave, int aw) {
     static_assert(D % 2 == 0, "the pipelined form alternates two register sets");
@@ -190,15 +184,12 @@ __global__ __launch_bounds__(NT) void gemv_t16_kernel(GemvParams p, int tiles_pe
         s = __builtin_nontemporal_load(sp_ + (size_t)i * 16);
         ++li;
     };
-#if T16_RING_DELAY
-    __builtin_amdgcn_s_sleep(T16_RING_DELAY);
-#endif
+    // (no barrier / pause between the row's requests and the ring's, unlike gemv_i8q4_p16_kernel: this launch is HBM-bound from its
+    // first request on -- same-box A/B on the 8B gate|up: as is 14.1 us / 697.6 tok/s, a workgroup barrier here 14.4 / 693.9,
+    // s_sleep 8 in front 14.5, s_sleep 2 between the requests 14.3)
 #pragma unroll
     for (int d = 0; d < D; d++) {                              // the ring is in flight across the prologue
         issue(wq[d], sq[d]);
-#if T16_RING_PACE
-        __builtin_amdgcn_s_sleep(T16_RING_PACE);
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
     JH_TSTAMP(1);
