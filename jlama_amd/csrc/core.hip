@@ -75,7 +75,7 @@ const char* const JH_KNOWN_OPTIONS[] = {
     "JH_GATEUP_GRIDX", "JH_GATEUP_PIPE", "JH_GATEUP_R", "JH_GATEUP_WAVES", "JH_GEMM_CW", "JH_GEMM_LDS", "JH_GEMM_LDS_CT",
     "JH_GEMM_LDS_CW", "JH_GEMM_LDS_PK", "JH_GEMM_LDS_S", "JH_GEMM_S", "JH_GEMM_Z", "JH_GEMV_PIPE", "JH_GEMV_R", "JH_GEMV_WAVES",
     "JH_LM_GRIDX", "JH_LM_R", "JH_LM_WAVES", "JH_NO_GRAPH", "JH_O_GRIDX", "JH_O_PIPE", "JH_O_R", "JH_O_WAVES",
-    "JH_P16_ATT_FUSED", "JH_P16_ATT_SPLITS", "JH_P16_AV_SEQ_MIN", "JH_P16_D", "JH_P16_PREFILL", "JH_PREFILL_ATTN_MFMA_MIN", "JH_PREFILL_BATCH_MIN", "JH_PREFILL_GRAPH", "JH_T16_GEMM32", "JH_T16_TAIL_ROWS",
+    "JH_P16_ATT_FUSED", "JH_P16_ATT_SPLITS", "JH_P16_AV_SEQ_MIN", "JH_P16_D", "JH_P16_PREFILL", "JH_PREFILL_ATTN_MFMA_MIN", "JH_PREFILL_BATCH_MIN", "JH_PREFILL_GRAPH", "JH_T16_GEMM32", "JH_T16_TAIL_FORCE", "JH_T16_TAIL_ROWS",
     "JH_PREFILL_TILED", "JH_QKV_GRIDX", "JH_QKV_PIPE", "JH_QKV_R", "JH_QKV_WAVES", "JH_STRICT_ONLY", "JH_STRICT_ORDER", "JH_T16",
     "JH_T16_PREFILL", "JH_TIER1_GENERIC", "JH_TOKENS_PER_GRAPH", "JH_TILED_COPY", "JH_TP_CU_MASK", "JH_TP_FUSE", "JH_TP_GRAPH", "JH_TP_LOUD",
     "JH_TRACE",

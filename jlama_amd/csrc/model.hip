@@ -292,6 +292,10 @@ int jh_model_set_weight(jh_model* m, int layer, int which, int dtype, const void
     // ensure_strict_operands / the pack kernels hold.  Replacing a weight while ANOTHER session is decoding with it stays
     // the caller's bug, as in the reference (weights are immutable after load).
     std::lock_guard<std::mutex> op_lock(m->op_mu);
+    if (m->strict_only) {   // (again, under the lock: the release happens under it)
+        if (widened_dev) hipFree(widened_dev);
+        return set_err(JH_ERR_UNSUPPORTED, "set_weight: this model released its row-major weights (JH_STRICT_ONLY); its weights are immutable");
+    }
     if (layer >= 0 && (which == JH_W_Q || which == JH_W_K || which == JH_W_V)) {
         // q|k|v live stacked in one [A+2KV, E] allocation (CausalSelfAttention.java:161-171 issues three GEMVs over the
         // same activation; here they become one)

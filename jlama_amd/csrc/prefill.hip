@@ -474,13 +474,19 @@ int prefill_p16_operands(jh_session* s) {
     }
     return JH_OK;
 }
-// Rows of a ragged last row tile.  A tile with one valid row costs what a full one costs, and where the full tiles fill the machine
-// exactly (o / down at 128 rows: 32 slices x 16 row tiles = 512 workgroups on 512 slots) it adds a whole second pass: down 279 ->
-// 439 us at 129 rows.  One or two such rows go through the decode GEMVs instead (the same chains, hence the same bits; each does its
-// own prologue from the F32 row): ~35 us per row and layer.  Option JH_T16_TAIL_ROWS (0 = every row through the GEMM).
-static int t16_tail_rows(int rows) {
-    const int r = rows % 8, lim = opt_int("JH_T16_TAIL_ROWS", 2);
-    return (r >= 1 && r <= lim) ? r : 0;
+// Rows of a ragged last row tile.  A tile with one valid row costs what a full one costs; that is free while the machine has idle
+// workgroup slots (2 per CU: 512), and a whole extra pass where the full tiles fill them exactly -- o / down of the 8B model at 128
+// rows: 32 slices x 16 row tiles = 512 workgroups; the 17th tile took down from 279 to 439 us.  When the ragged tile would add
+// such a pass to the E-row GEMMs and holds few rows, those rows go through the decode GEMVs instead (the same chains, hence the
+// same bits; each does its own prologue from the F32 row): ~35 us per row and layer against ~180 us for the pass.  Measured on the
+// 8B model (ms per prompt; rows = 129 / 130 / 131 / 132 / 134): all rows in the GEMM 34.7 / 34.9 / 35.0 / 35.1 / 35.2, tail rows
+// 29.2 / 30.3 / 31.3 / 32.4 / 34.6.  Option JH_T16_TAIL_ROWS = most rows to divert (default 4; 0 = never).
+static int t16_tail_rows(const jh_session* s, int rows) {
+    const int r = rows % 8, lim = opt_int("JH_T16_TAIL_ROWS", 4);
+    if (r < 1 || r > lim) return 0;
+    const int nrt = (rows + 7) / 8, nsl = (s->m->c.embedding_length / 16 + 7) / 8, slots = 2 * g_cu_count;
+    const bool extra_pass = (nsl * nrt + slots - 1) / slots > (nsl * (nrt - 1) + slots - 1) / slots;
+    return (extra_pass || opt_int("JH_T16_TAIL_FORCE", 0)) ? r : 0;   // (_FORCE: tests reach the path on small shapes)
 }
 template <int PRO, int EPI>
 static int tail_gemv_p16(jh_session* s, const JWeight& W, int K, int nrows, const float* x, const float* nw, float eps, float* out, const float* resid,
@@ -500,7 +506,7 @@ int prefill_attn_half_p16(jh_session* s, int li, int rows, int start_pos, float*
     JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     JWeight& F = m->qkv[(size_t)li];
     const float* n1 = (const float*)W[JH_W_NORM1].data;
-    const int tail = t16_tail_rows(rows), rg = rows - tail;
+    const int tail = t16_tail_rows(s, rows), rg = rows - tail;
     JHCHK(prefill_weights_set(s, li));
     if (rg) {
         JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, s->pb_x, E, n1, c.rms_eps, E, rg, st)));
@@ -528,7 +534,7 @@ int prefill_ffn_half_p16(jh_session* s, int li, int rows, const float* x1, float
     JWeight* W = &m->layer_w[(size_t)li * JH_W_COUNT];
     const JWeight& GU = m->gateup[(size_t)li];
     const float* n2 = (const float*)W[JH_W_NORM2].data;
-    const int tail = t16_tail_rows(rows), rg = rows - tail;
+    const int tail = t16_tail_rows(s, rows), rg = rows - tail;
     if (rg) {
         JHCHK((rows_act_t16_launch<PRO_RMS_Q8>(s, x1, E, n2, c.rms_eps, E, rg, st)));
         JHCHK((gemm_t16_launch<EPI_SILU_MUL>(s, GU.t16, GU.t16_scales, H / 8, E, rg, s->pb_g, H, nullptr, 0, st)));

@@ -204,10 +204,19 @@ def test_reference_order_prefill_in_batches_is_the_row_path_bit_for_bit(gpu, ora
     np.testing.assert_array_equal(np.concatenate([a, b]).view(np.uint32), rows.view(np.uint32))
     # one or two rows of a ragged last row tile leave the GEMM for the decode GEMVs (prefill.hip: t16_tail_rows): 129 = 16 tiles + 1,
     # 170 = 21 tiles + 2, then a single row with no tile at all; JH_T16_TAIL_ROWS=0 keeps every row in the GEMM
+    # (the library diverts them only where the ragged tile would cost an extra pass over the machine's workgroup slots -- never
+    # on this small shape: JH_T16_TAIL_FORCE)
+    _N.set_option("JH_T16_TAIL_FORCE", "1")
     s_tail = hm.session(512)
     s_tail.set_strict(True)
     parts = [s_tail.forward(prompt[:129], 0), s_tail.forward(prompt[129:299], 129), s_tail.forward(prompt[299:], 299)]
     np.testing.assert_array_equal(np.concatenate(parts).view(np.uint32), rows.view(np.uint32))
+    s_tail4 = hm.session(512)
+    s_tail4.set_strict(True)                                   # 3 and 4 tail rows (the default limit)
+    parts = [s_tail4.forward(prompt[:131], 0), s_tail4.forward(prompt[131:231], 131)]
+    np.testing.assert_array_equal(np.concatenate(parts).view(np.uint32), rows[:231].view(np.uint32))
+    s_tail4.close()
+    _N.clear_options()
     _N.set_option("JH_T16_TAIL_ROWS", "0")
     s_gemm = hm.session(512)
     s_gemm.set_strict(True)
@@ -220,6 +229,7 @@ def test_reference_order_prefill_in_batches_is_the_row_path_bit_for_bit(gpu, ora
     np.testing.assert_array_equal(s_16.forward(prompt[:129], 0).view(np.uint32), rows[:129].view(np.uint32))
     s_16.close()
     _N.clear_options()
+    _N.set_option("JH_T16_TAIL_FORCE", "1")
     _N.set_option("JH_PREFILL_BATCH_MIN", "1")            # a 2-row chunk in the batched path: tail rows only, no GEMM launch at all
     s_few = hm.session(512)
     s_few.set_strict(True)
