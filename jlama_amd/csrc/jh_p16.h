@@ -931,6 +931,15 @@ __device__ __forceinline__ void p16_value_chain_tile(float& acc, const float* vr
 //        double, FLOAT sum in index order by one lane, division), then value[d] = one fma chain per element over positions 0..pos
 //        (saxpy per position, PTO:2648-2698) for its 32 columns; V tiles go through LDS with 16-byte loads.
 constexpr int P16_ATT_THREADS = 256;
+// The one-launch kernel (attn_p16_fused_kernel) runs EIGHT waves: its phases in front of the two sequential chains -- the score
+// passes (a wave issues one instruction per ~5-8 cycles; 128 positions per pass instead of 64), the exponentials (7 waves instead of
+// 3 beside the chain owner), the V tile's transposition -- are instruction-issue bound and split over the waves, and only half of
+// the chip's CUs host an attention workgroup at all.  Same-box A/B (8B, K = 256): 256 threads 697.4-698.0 tok/s, probe 7.24 us;
+// 512 threads 707.5-707.8, 6.86 us.
+#ifndef P16_FUSED_THREADS_N
+#define P16_FUSED_THREADS_N 512
+#endif
+constexpr int P16_FUSED_THREADS = P16_FUSED_THREADS_N;
 template <int HS, int GROUP>
 __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_scores_kernel(AttnParams p, float* scores, int sc_stride) {
     __shared__ float qs[GROUP * HS];
@@ -1150,9 +1159,11 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_av_kernel(AttnParams
 //   16 c + 4 qd + j are ONE 16-byte piece of q and of the K row); the halving tree runs (t, t+8) -> quad_perm xor 2, (t, t+4) ->
 //   quad_perm xor 1, then (0,2)/(1,3) and the last add inside the lane: jo_reduce16's association.
 template <int HS, int RU, bool POW2>   // POW2: ctxPerPage is a power of two (every geometry but the 70B ones): the page split is a shift and a mask, no branch
-__global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnParams p) {
+__global__ __launch_bounds__(P16_FUSED_THREADS) void attn_p16_fused_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = P16_ATT_THREADS, DW = 32, TP = 32 * RU, TPP = TP + 4, half = HS / 2, NC = HS / 16, PPB = NT / 4;   // PPB positions per pass
+    constexpr int NT = P16_FUSED_THREADS, DW = 32, TP = 32 * RU, TPP = TP + 4, half = HS / 2, NC = HS / 16, PPB = NT / 4;   // PPB positions per pass
+    constexpr int VR = NT / 8, RUV = TP / VR;                   // V rows requested per step by the workgroup, steps per tile
+    static_assert(RUV >= 1 && RUV * VR == TP, "a V tile is a whole number of request steps");
     const int group = p.n_heads / p.n_kv_heads;
     const int id = blockIdx.x, kvh = id % p.n_kv_heads, rest = id / p.n_kv_heads, gi = rest % group, colq = rest / group;
     const int h = kvh * group + gi, d0 = colq * DW;
@@ -1229,16 +1240,16 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
     const int vr = tid >> 3, vc = tid & 7;
     const unsigned v_lane = (unsigned)(kvh * HS + d0 + 4 * vc) * 4u;
     const f32x4* v_new = (const f32x4*)(qkv_row + A + KV + (size_t)kvh * HS + d0) + vc;   // the new row: not in the page yet
-    auto load_v = [&](f32x4 (&vreg)[RU], int tile) __attribute__((always_inline)) {
+    auto load_v = [&](f32x4 (&vreg)[RUV], int tile) __attribute__((always_inline)) {
         RowWalk vw = walk_at(tile * TP + vr);
 #pragma unroll
-        for (int u = 0; u < RU; u++) {
-            if (tile * TP + 32 * u < n) {                      // (wave-uniform)
-                const int tt = tile * TP + vr + 32 * u;
+        for (int u = 0; u < RUV; u++) {
+            if (tile * TP + VR * u < n) {                      // (wave-uniform)
+                const int tt = tile * TP + vr + VR * u;
                 const f32x4* vrow = tt >= pos ? v_new : (const f32x4*)(kvb + (walk_off(vw, lrow_v) + v_lane));   // rows past n: clamped copies of the new one
                 vreg[u] = *vrow;
             }
-            walk_step(vw, 32u);
+            walk_step(vw, (unsigned)VR);
         }
     };
     // ---- RoPE of this head's q and of the new k row (table row pos + 2*kvHead: CausalSelfAttention.java:247-286)
@@ -1259,15 +1270,15 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
     }
     if (owner)
         for (int d = tid; d < HS; d += NT) ((float*)(kvb + walk_off(walk_at(pos), lrow_v)) + (size_t)kvh * HS)[d] = qkv_row[A + KV + (size_t)kvh * HS + d];
-    auto file_v = [&](const f32x4 (&vreg)[RU], int tile) __attribute__((always_inline)) {
+    auto file_v = [&](const f32x4 (&vreg)[RUV], int tile) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < RU; u++)
-            if (tile * TP + 32 * u < n) {
-                float* dst = vt + (size_t)(4 * vc) * TPP + vr + 32 * u;
+        for (int u = 0; u < RUV; u++)
+            if (tile * TP + VR * u < n) {
+                float* dst = vt + (size_t)(4 * vc) * TPP + vr + VR * u;
                 dst[0] = vreg[u].x; dst[TPP] = vreg[u].y; dst[2 * TPP] = vreg[u].z; dst[3 * TPP] = vreg[u].w;
             }
     };
-    f32x4 vreg[RU];
+    f32x4 vreg[RUV];
     JH_FSTAMP(1);
     __syncthreads();
     JH_FSTAMP(2);
@@ -1339,7 +1350,7 @@ __global__ __launch_bounds__(P16_ATT_THREADS) void attn_p16_fused_kernel(AttnPar
     for (int tile = 0; tile < ntiles; tile++) {
         if (tile > 0) {
             __syncthreads();
-            f32x4 vnext[RU];
+            f32x4 vnext[RUV];
             load_v(vnext, tile);
             file_v(vnext, tile);
         }

@@ -54,10 +54,10 @@ int attn_launch(jh_session* s, int rel, hipStream_t st, bool tap, long long* dbg
     if (hs == HSV && ru == RV) {                                                                                               \
         if (p.cpp_shift >= 0) {                                                                                                \
             JHCHK(allow_lds((attn_p16_fused_kernel<HSV, RV, true>), lds_f));                                                   \
-            hipLaunchKernelGGL((attn_p16_fused_kernel<HSV, RV, true>), grid_f, dim3(P16_ATT_THREADS), lds_f, st, p);           \
+            hipLaunchKernelGGL((attn_p16_fused_kernel<HSV, RV, true>), grid_f, dim3(P16_FUSED_THREADS), lds_f, st, p);           \
         } else {                                                                                                               \
             JHCHK(allow_lds((attn_p16_fused_kernel<HSV, RV, false>), lds_f));                                                  \
-            hipLaunchKernelGGL((attn_p16_fused_kernel<HSV, RV, false>), grid_f, dim3(P16_ATT_THREADS), lds_f, st, p);          \
+            hipLaunchKernelGGL((attn_p16_fused_kernel<HSV, RV, false>), grid_f, dim3(P16_FUSED_THREADS), lds_f, st, p);          \
         }                                                                                                                      \
         HIPCHK(hipGetLastError());                                                                                             \
         return JH_OK;                                                                                                          \
