@@ -3,6 +3,8 @@ sys.path.insert(0, os.getcwd())
 from jlama_amd import _native as N, synthetic as S, synthetic_torch as ST
 from jlama_amd.model import HipLlamaModel
 cfg = dict(S.LLAMA3_8B); cfg["n_layers"] = 2
+if os.environ.get("JH_LIB"):   # A/B another build of the library on the same box (tools/build_variant.py)
+    N.LIB_PATH = os.path.abspath(os.environ["JH_LIB"])
 N.init(0)
 N.options_from_env()   # tools only: JH_* environment variables become explicit library options
 m = HipLlamaModel(cfg, ST.make_weights(cfg, seed=0, device="cuda"))
